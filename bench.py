@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- projections/sec (fwd+adj) of the Radon projector on synthetic 128x128 foam, 20 sparse angles.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: rotate-and-sum forward (nearest, the reference's
+project_tf_fast) followed by the backward TensorFlow runs for it (tf_compat), on B=50 objects per GPU that are
+already resident in HBM (BASELINE.json configs[1]).  The batch shards over ranks with no data-path collective
+(weak scaling: 50 objects per GPU).  Rank 0 prints ONE JSON line; see DESIGN.md section "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ct_pvae_amd import phantoms  # noqa: E402
+from ct_pvae_amd.forward_functions import RotatePlan, project_tf_fast  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak (spec)
+HBM_COPY_GBS = 6290.0        # same guide: measured float4 copy ceiling
+B_PER_GPU, N_PIX, A_SPARSE = 50, 128, 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--angles", type=int, default=A_SPARSE, help="20 (headline) or 180 (dense evaluation set)")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    return world, rank, local
+
+
+def barrier_sync(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds, world):
+    if world == 1:
+        return seconds
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(imgs, theta, g, budget_s=12.0):
+    """The CPU restatement (oracle/, kind 'port') of the SAME fwd+adj pair, one thread, on a bounded sample of the
+    workload; plus the TomoPy-style (siddon) forward the reference uses on the CPU for dataset generation."""
+    from oracle import radon_oracle as orc
+    orc.build()
+    geom = orc.Geometry(imgs.shape[1], imgs.shape[2], True)
+    T = orc.rotate_transforms(theta, geom.PH, geom.PW)
+    Tinv = orc.invert_transforms(T)
+    A = len(theta)
+    n_obj, t_rot = 0, 0.0
+    while t_rot < budget_s * 0.6 and n_obj < 4 * imgs.shape[0]:
+        k = n_obj % imgs.shape[0]
+        t0 = time.perf_counter()
+        orc.rotate_fwd(imgs[k:k + 1], geom, T, orc.NEAREST)
+        orc.rotate_bwd_tfcompat(g[k:k + 1], geom, Tinv, orc.NEAREST)
+        t_rot += time.perf_counter() - t0
+        n_obj += 1
+    n_sid, t_sid = 0, 0.0
+    while t_sid < budget_s * 0.4 and n_sid < imgs.shape[0]:
+        t0 = time.perf_counter()
+        orc.siddon_project(imgs[n_sid:n_sid + 1], theta, pad=True)
+        t_sid += time.perf_counter() - t0
+        n_sid += 1
+    return {
+        "value": n_obj * A / t_rot, "unit": "projections/s (fwd+adj)", "cores": 1, "kind": "port",
+        "sample": f"{n_obj} objects x {A} angles, rotate nearest fwd + tf_compat bwd, oracle/radon_oracle.c -O2, "
+                  f"1 thread, {t_rot:.1f} s",
+        "siddon_fwd_projections_per_s": n_sid * A / t_sid,
+        "siddon_sample": f"{n_sid} objects x {A} angles, TomoPy project.c restatement (forward only), 1 thread, "
+                         f"{t_sid:.1f} s",
+        "host_cores": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    world, rank, local = dist_setup(args.gpus)
+    dev = torch.device("cuda", local)
+    B, N, A = args.batch, N_PIX, args.angles
+
+    theta_dense = phantoms.dense_theta(180)
+    theta = theta_dense[phantoms.sparse_angle_indices(180, A)] if A < 180 else theta_dense
+    imgs = phantoms.foam_batch(B, N, seed=rank, supersample=2)
+    plan = RotatePlan(theta, N, N, True, dev, interp="nearest", backward="tf_compat")
+    P = plan.PW
+    g_host = np.random.default_rng(1000 + rank).standard_normal((B, A, P)).astype(np.float32)
+    x = torch.from_numpy(imgs).to(dev)
+    g = torch.from_numpy(g_host).to(dev)
+    sino = torch.empty((B, A, P), dtype=torch.float32, device=dev)
+    gimg = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+
+    def step():
+        plan.forward(x, out=sino)
+        plan.backward(g, out=gimg)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+
+    # ---- per-kernel durations, HIP events on the launch stream (torch's current stream) -------------------
+    n_ev = min(args.steps, 200)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_ev)]
+    torch.cuda.synchronize()
+    for e0, e1, e2 in ev:
+        e0.record()
+        plan.forward(x, out=sino)
+        e1.record()
+        plan.backward(g, out=gimg)
+        e2.record()
+    torch.cuda.synchronize()
+    t_fwd = float(np.median([e0.elapsed_time(e1) for e0, e1, _ in ev])) * 1e-3
+    t_bwd = float(np.median([e1.elapsed_time(e2) for _, e1, e2 in ev])) * 1e-3
+
+    # ---- the same step through the public autograd API (secondary) -----------------------------------------
+    x4 = x[..., None].clone().requires_grad_(True)
+    g4 = g[..., None]
+    n_api = min(args.steps, 200)
+
+    def api_step():
+        x4.grad = None
+        out = project_tf_fast(x4, theta, pad=True, dim=2, integrate_vae=True)
+        out.backward(g4)
+
+    for _ in range(10):
+        api_step()
+    torch.cuda.synchronize()
+    ta = time.perf_counter()
+    for _ in range(n_api):
+        api_step()
+    torch.cuda.synchronize()
+    api_elapsed = time.perf_counter() - ta
+
+    if rank != 0:
+        return
+    bytes_dir = 4.0 * B * (N * N + A * P)                 # one direction: read once + write once (fp32)
+    dom = ("rotate_fwd_kernel", t_fwd) if t_fwd >= t_bwd else ("rotate_bwd_tfcompat_kernel", t_bwd)
+    achieved = bytes_dir / dom[1] / 1e9
+    proj_per_s = world * B * A * args.steps / elapsed
+    out = {
+        "metric": "projections/sec (fwd+adj) 128x128 foam, 20 angles; fraction of HBM roofline",
+        "value": proj_per_s, "unit": "projections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"batch={B}/GPU {N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
+                   "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}"},
+        "ray_sums_per_s_per_gpu": proj_per_s * P / world,
+        "hbm_fraction_whole_step": (2 * bytes_dir / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": bytes_dir,
+                     "kernel_us": {"rotate_fwd": t_fwd * 1e6, "rotate_bwd_tfcompat": t_bwd * 1e6},
+                     "note": "object lives in LDS for all angles: LDS-gather/VALU bound, HBM fraction is small by construction"},
+        "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
+        "api": {"value": B * A * n_api / api_elapsed, "unit": "projections/s",
+                "what": "project_tf_fast(...).backward() through torch.autograd, same workload, 1 GPU"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(imgs, theta, g_host)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

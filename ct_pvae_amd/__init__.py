@@ -1,0 +1,12 @@
+"""ct_pvae_amd -- MI355X-native Radon forward/back-projector behind CT_PVAE's physics-decoder call signatures.
+
+Host code is Python + PyTorch-ROCm (device memory, streams, autograd); the operators are hand-written gfx950 HIP
+kernels reached through the C ABI of include/ctpvae_radon.h.  There is no CPU path.
+"""
+from .forward_functions import (RotatePlan, num_proj_pix, pad_amounts, pad_phantom, project_tf_fast,  # noqa: F401
+                                project_tf_low_mem)
+from .helper_functions import (calculate_log_prob_M_given_R, create_sinogram, create_sinograms,  # noqa: F401
+                               gaussian_poisson_log_prob)
+from .fbp import iradon  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,78 @@
+"""ctypes binding of the C ABI in include/ctpvae_radon.h (libctpvae_radon.so, built by csrc/Makefile).
+
+This is the only door between the Python host code and the HIP kernels.  There is no CPU fallback: if the
+shared library is missing, or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
+
+NEAREST, BILINEAR = 0, 1
+BWD_TF_COMPAT, BWD_EXACT = 0, 1
+EINVAL, EHIP, ENODEV = -1, -2, -3
+
+_c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes).  Every symbol the header declares must appear here (tests/test_abi.py
+# checks this table against the header and against the built library).
+SIGNATURES = {
+    "ctpvae_abi_version": (_c_int, []),
+    "ctpvae_last_error": (ctypes.c_char_p, []),
+    "ctpvae_device_count": (_c_int, []),
+    "ctpvae_num_proj_pix": (_c_int, [_c_int, _c_int]),
+    "ctpvae_pad_amounts": (_c_int, [_c_int, _c_int, _ip, _ip]),
+    "ctpvae_rotate_transforms_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
+    "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
+                                       _c_int, _vp, _vp]),
+    "ctpvae_rotate_bwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int,
+                                       _c_int, _c_int, _vp, _vp]),
+    "ctpvae_siddon_dx": (_c_int, [_c_int, _c_int, _c_int]),
+    "ctpvae_siddon_tables_f32": (_c_int, [_vp, _c_int, _vp, _vp, _vp]),
+    "ctpvae_siddon_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp,
+                                       _vp]),
+    "ctpvae_fbp_filter_f64": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp]),
+    "ctpvae_fbp_backproject_f64": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_loglik_fwd_f32": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_float, _vp, _vp]),
+    "ctpvae_loglik_bwd_f32": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_float, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class RadonLibraryError(RuntimeError):
+    """The HIP extension is missing or a HIP call inside it failed."""
+
+
+def load():
+    """Load libctpvae_radon.so (once).  Raises RadonLibraryError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RadonLibraryError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().ctpvae_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """Map a C return code to the reference's error convention: ValueError for bad arguments
+    (the reference raises ValueError on shape mismatches, ctvae/fbp_tensorflow.py:43-45), RuntimeError otherwise."""
+    if rc >= 0:
+        return rc
+    msg = f"{what}: {last_error()}"
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise RadonLibraryError(msg)

@@ -1,0 +1,39 @@
+// common.h -- shared host-side plumbing of the C ABI (include/ctpvae_radon.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/ctpvae_radon.h"
+
+namespace ctpvae {
+
+// thread-local last-error string (the only state of the library)
+char *err_buf();
+int fail(int code, const char *fmt, ...);
+
+#define CTPVAE_REQUIRE(cond, ...)                                   \
+    do {                                                            \
+        if (!(cond)) return ::ctpvae::fail(CTPVAE_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define CTPVAE_HIP(call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ::ctpvae::fail(CTPVAE_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// a launch leaves its error in hipGetLastError(); never synchronises
+#define CTPVAE_LAUNCH_CHECK(name)                                                             \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess)                                                                 \
+            return ::ctpvae::fail(CTPVAE_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950; one workgroup may take all of it
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace ctpvae

@@ -1,0 +1,130 @@
+// core.hip -- error state, size rules (a1) and the transform-table kernel (a3/a4).
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+namespace ctpvae {
+
+char *err_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// 3x3 fp32 inverse by LU with partial pivoting -- the arithmetic TensorFlow's matrix_inverse
+// performs on the flat transform inside the gradient of ImageProjectiveTransformV3.
+__device__ static void inv3x3(const float m[9], float out[9])
+{
+    float a[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[r][c] = m[3 * r + c];
+            a[r][3 + c] = (r == c) ? 1.0f : 0.0f;
+        }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        for (int r = k + 1; r < 3; ++r)
+            if (fabsf(a[r][k]) > fabsf(a[p][k])) p = r;
+        if (p != k)
+            for (int c = 0; c < 6; ++c) {
+                float t = a[k][c];
+                a[k][c] = a[p][c];
+                a[p][c] = t;
+            }
+        for (int r = k + 1; r < 3; ++r) {
+            const float f = a[r][k] / a[k][k];
+            for (int c = k; c < 6; ++c) a[r][c] = a[r][c] - f * a[k][c];
+        }
+    }
+    for (int c = 3; c < 6; ++c)
+        for (int r = 2; r >= 0; --r) {
+            float v = a[r][c];
+            for (int q = r + 1; q < 3; ++q) v = v - a[r][q] * a[q][c];
+            a[r][c] = v / a[r][r];
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[3 * r + c] = a[r][3 + c];
+}
+
+// One thread per angle.  cos/sin are the correctly rounded fp32 values (fp64 evaluation, rounded once).
+__global__ void rotate_transforms_kernel(const float *__restrict__ theta, int A, float hm1, float wm1,
+                                         float *__restrict__ T8, float *__restrict__ Tinv8)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    const float ang = -theta[a];
+    const float c = (float)cos((double)ang);
+    const float s = (float)sin((double)ang);
+    const float cw = c * wm1, sh = s * hm1, sw = s * wm1, ch = c * hm1;
+    const float xo = (wm1 - (cw - sh)) / 2.0f;
+    const float yo = (hm1 - (sw + ch)) / 2.0f;
+    float t[8] = {c, -s, xo, s, c, yo, 0.0f, 0.0f};
+    for (int k = 0; k < 8; ++k) T8[8 * a + k] = t[k];
+    if (Tinv8) {
+        float m[9] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], 1.0f}, inv[9];
+        inv3x3(m, inv);
+        for (int k = 0; k < 8; ++k) Tinv8[8 * a + k] = inv[k] / inv[8];
+    }
+}
+
+}  // namespace ctpvae
+
+using namespace ctpvae;
+
+extern "C" {
+
+int ctpvae_abi_version(void) { return 1000; }
+
+const char *ctpvae_last_error(void) { return err_buf(); }
+
+int ctpvae_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(CTPVAE_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+int ctpvae_num_proj_pix(int nx, int ny)
+{
+    CTPVAE_REQUIRE(nx > 0 && ny > 0, "num_proj_pix: sizes must be positive (got %d, %d)", nx, ny);
+    const double v = std::sqrt((double)((long long)nx * nx + (long long)ny * ny)) + 2.0;
+    return (int)(std::ceil(v / 2.0) * 2.0);
+}
+
+int ctpvae_pad_amounts(int n, int P, int *lo, int *hi)
+{
+    CTPVAE_REQUIRE(lo && hi, "pad_amounts: null output");
+    CTPVAE_REQUIRE(n > 0 && P >= n, "pad_amounts: need 0 < n <= P (got n=%d, P=%d)", n, P);
+    *lo = (P - n) / 2;
+    *hi = *lo + ((P - n) % 2);
+    return CTPVAE_OK;
+}
+
+int ctpvae_rotate_transforms_f32(const float *theta_dev, int A, int H, int W, float *T8_dev,
+                                 float *Tinv8_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(theta_dev && T8_dev, "rotate_transforms: null pointer");
+    CTPVAE_REQUIRE(A > 0 && H > 0 && W > 0, "rotate_transforms: bad sizes A=%d H=%d W=%d", A, H, W);
+    const int block = 64;
+    hipLaunchKernelGGL(rotate_transforms_kernel, dim3(ceil_div(A, block)), dim3(block), 0,
+                       (hipStream_t)stream, theta_dev, A, (float)H - 1.0f, (float)W - 1.0f, T8_dev,
+                       Tinv8_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_transforms_kernel");
+    return CTPVAE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,246 @@
+"""Drop-in replacements for ctvae/forward_functions.py of vganapati/CT_PVAE on MI355X.
+
+Same names, argument order, defaults and tensor layouts as the reference:
+
+    pad_phantom(phantom, dim=3, integrate_vae=False)                        ctvae/forward_functions.py:18-46
+    project_tf_low_mem(phantom, theta, pad=False)                            ctvae/forward_functions.py:49-78
+    project_tf_fast(phantom, theta, pad=False, dim=3, integrate_vae=False)   ctvae/forward_functions.py:80-123
+
+Inputs and outputs are torch tensors on a HIP device; the work is done by hand-written gfx950 kernels behind
+the C ABI of include/ctpvae_radon.h (no TensorFlow, no per-angle image copies, the zero padding is never
+materialised).  Both projectors are differentiable; keyword-only extensions select behaviour the reference
+gets implicitly from TensorFlow:
+
+    interp   = "nearest" | "bilinear"   tfa.image.rotate's interpolation (the reference's fast path uses
+                                        the tfa default "nearest", the low-memory path asks for "bilinear")
+    backward = "tf_compat" | "exact"    "tf_compat" is what tf.GradientTape computes for the reference
+                                        (ctvae/main_ct_vae.py:471-481: the incoming gradient is re-sampled with
+                                        the inverted transform); "exact" is the true transpose of the forward.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["pad_phantom", "project_tf_fast", "project_tf_low_mem", "num_proj_pix", "pad_amounts", "RotatePlan"]
+
+_INTERP = {"nearest": _lib.NEAREST, "bilinear": _lib.BILINEAR}
+_BACKWARD = {"tf_compat": _lib.BWD_TF_COMPAT, "exact": _lib.BWD_EXACT}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a1: size rule of pad_phantom (host arithmetic, ctvae/forward_functions.py:29-36)
+# ---------------------------------------------------------------------------------------------------------
+def num_proj_pix(img_size_x, img_size_y):
+    """P = int(ceil((sqrt(float64(Nx^2 + Ny^2)) + 2) / 2) * 2)."""
+    return int(math.ceil((math.sqrt(float(img_size_x ** 2 + img_size_y ** 2)) + 2.0) / 2.0) * 2)
+
+
+def pad_amounts(n, P):
+    """(lo, hi) with lo = (P-n)//2 and the odd remainder on the high side."""
+    lo = (P - n) // 2
+    return lo, lo + (P - n) % 2
+
+
+def pad_phantom(phantom, dim=3, integrate_vae=False):
+    """Zero-pad the two spatial axes to P x P (materialised, like the reference's tf.pad).
+
+    The projectors below do NOT call this: they fold the padding into their bounds test.
+    """
+    if integrate_vae:
+        nx, ny = phantom.shape[1], phantom.shape[2]
+    else:
+        nx, ny = phantom.shape[0], phantom.shape[1]
+    P = num_proj_pix(nx, ny)
+    (x_lo, x_hi), (y_lo, y_hi) = pad_amounts(nx, P), pad_amounts(ny, P)
+    # torch.nn.functional.pad lists the LAST axis first
+    if integrate_vae:
+        pads = (0, 0, y_lo, y_hi, x_lo, x_hi)
+    elif dim == 3:
+        pads = (0, 0, y_lo, y_hi, x_lo, x_hi)
+    elif dim == 2:
+        pads = (y_lo, y_hi, x_lo, x_hi)
+    else:
+        raise ValueError(f"pad_phantom: dim must be 2 or 3 (got {dim})")
+    return torch.nn.functional.pad(phantom, pads, mode="constant", value=0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Plan: geometry + transform tables on the device + bound C entry points
+# ---------------------------------------------------------------------------------------------------------
+_TABLE_CACHE = {}
+_TABLE_CACHE_MAX = 64
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _theta_to_device(theta, device):
+    """Returns (theta_dev fp32 [A], cache_key or None).  `theta` is anything 1-D with a length: a list, a numpy
+    array (the reference's scripts) or a tensor (the training loop gathers it on the device,
+    ctvae/helper_functions.py:355)."""
+    if isinstance(theta, torch.Tensor):
+        if theta.dim() != 1:
+            raise ValueError(f"theta must be 1-D (got shape {tuple(theta.shape)})")
+        if theta.device.type == "cuda":
+            return theta.detach().to(device=device, dtype=torch.float32).contiguous(), None
+        host = theta.detach().cpu().numpy()
+    else:
+        host = np.asarray(theta)
+    if host.ndim != 1:
+        raise ValueError(f"theta must be 1-D (got shape {host.shape})")
+    host32 = np.ascontiguousarray(host.astype(np.float32))  # tfa converts angles to float32
+    return host32, host32.tobytes()
+
+
+def rotate_tables(theta, H, W, device):
+    """Device tables (T8, Tinv8), each [A][8] fp32, for rotating an H x W canvas by -theta (a3/a4).
+
+    Host-resident angle sets are cached by value; device-resident ones cost one tiny kernel launch."""
+    lib = _lib.load()
+    th, key = _theta_to_device(theta, device)
+    if key is not None:
+        key = (key, H, W, str(device))
+        hit = _TABLE_CACHE.get(key)
+        if hit is not None:
+            return hit
+        th = torch.from_numpy(th).to(device)
+    A = th.numel()
+    if A == 0:
+        raise ValueError("theta is empty")
+    tables = torch.empty((2, A, 8), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.ctpvae_rotate_transforms_f32(th.data_ptr(), A, H, W, tables[0].data_ptr(),
+                                                    tables[1].data_ptr(), _stream_ptr()), "rotate_transforms")
+    out = (tables[0], tables[1])
+    if key is not None:
+        if len(_TABLE_CACHE) >= _TABLE_CACHE_MAX:
+            _TABLE_CACHE.pop(next(iter(_TABLE_CACHE)))
+        _TABLE_CACHE[key] = out
+    return out
+
+
+class RotatePlan:
+    """Geometry and tables of one rotate-and-sum projector: slices [S][H][W] -> sinograms [S][A][PW].
+
+    `forward` / `backward` are the raw operator pair (no autograd bookkeeping); `apply` is differentiable."""
+
+    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat"):
+        if interp not in _INTERP:
+            raise ValueError(f"interp must be one of {sorted(_INTERP)} (got {interp!r})")
+        if backward not in _BACKWARD:
+            raise ValueError(f"backward must be one of {sorted(_BACKWARD)} (got {backward!r})")
+        self.H, self.W = int(H), int(W)
+        if pad:
+            P = num_proj_pix(self.H, self.W)
+            self.PH = self.PW = P
+            self.py, self.px = pad_amounts(self.H, P)[0], pad_amounts(self.W, P)[0]
+        else:
+            self.PH, self.PW, self.py, self.px = self.H, self.W, 0, 0
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.RadonLibraryError(
+                f"the projector runs on a HIP device only (got a tensor on {self.device}); there is no CPU path")
+        self.interp, self.mode = _INTERP[interp], _BACKWARD[backward]
+        self.T8, self.Tinv8 = rotate_tables(theta, self.PH, self.PW, self.device)
+        self.A = self.T8.shape[0]
+        self._lib = _lib.load()
+
+    def forward(self, img, out=None):
+        S = img.shape[0]
+        if out is None:
+            out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+        rc = self._lib.ctpvae_rotate_fwd_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px,
+                                             self.T8.data_ptr(), self.A, self.interp, out.data_ptr(), _stream_ptr())
+        if rc:
+            _lib.check(rc, "rotate_fwd")
+        return out
+
+    def backward(self, gsino, out=None):
+        S = gsino.shape[0]
+        if out is None:
+            out = torch.empty((S, self.H, self.W), dtype=torch.float32, device=gsino.device)
+        tab = self.Tinv8 if self.mode == _lib.BWD_TF_COMPAT else self.T8
+        rc = self._lib.ctpvae_rotate_bwd_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, tab.data_ptr(),
+                                             self.interp, self.mode, self.H, self.W, self.py, self.px,
+                                             out.data_ptr(), _stream_ptr())
+        if rc:
+            _lib.check(rc, "rotate_bwd")
+        return out
+
+    def apply(self, img):
+        return _RotateProject.apply(img, self)
+
+
+class _RotateProject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, plan):
+        ctx.plan = plan
+        return plan.forward(img)
+
+    @staticmethod
+    def backward(ctx, gsino):
+        return ctx.plan.backward(gsino.contiguous()), None
+
+
+def _as_slices(x):
+    """fp32, contiguous [S][H][W] on the current HIP device; returns (slices, original dtype)."""
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"phantom must be a torch.Tensor on a HIP device (got {type(x).__name__})")
+    if x.device.type != "cuda":
+        raise _lib.RadonLibraryError(
+            f"phantom lives on {x.device}: the projector runs on a HIP device only; there is no CPU path")
+    if not x.dtype.is_floating_point:
+        raise TypeError(f"phantom must be floating point (got {x.dtype})")
+    # The reference keeps float64 pixel data (coordinates are fp32 either way); here sums are fp32.
+    return x.to(torch.float32).contiguous(), x.dtype
+
+
+def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
+    if not isinstance(phantom, torch.Tensor):
+        raise TypeError(f"phantom must be a torch.Tensor on a HIP device (got {type(phantom).__name__})")
+    if integrate_vae:
+        if phantom.dim() != 4 or phantom.shape[3] != 1:
+            raise ValueError("integrate_vae=True expects batch_size x img_size_x x img_size_y x 1 "
+                             f"(got {tuple(phantom.shape)})")
+        slices, dt = _as_slices(phantom[..., 0])
+    elif dim == 3:
+        if phantom.dim() != 3:
+            raise ValueError(f"dim=3 expects img_size_x x img_size_y x img_size_z (got {tuple(phantom.shape)})")
+        slices, dt = _as_slices(phantom.permute(2, 0, 1))
+    elif dim == 2:
+        if phantom.dim() != 2:
+            raise ValueError(f"dim=2 expects img_size_x x img_size_y (got {tuple(phantom.shape)})")
+        slices, dt = _as_slices(phantom[None])
+    else:
+        raise ValueError(f"dim must be 2 or 3 (got {dim})")
+    if slices.shape[0] == 0:
+        raise ValueError("phantom holds no slices")
+    plan = RotatePlan(theta, slices.shape[1], slices.shape[2], pad, slices.device, interp=interp, backward=backward)
+    with torch.cuda.device(slices.device):
+        sino = plan.apply(slices)  # [S][A][PW]
+    if integrate_vae:
+        out = sino.unsqueeze(-1)  # batch x angles x P x 1   (ctvae/forward_functions.py:116-121)
+    else:
+        out = sino.permute(1, 2, 0)  # angles x P x Z          (ctvae/forward_functions.py:111-114)
+    return out if dt == torch.float32 else out.to(dt)
+
+
+def project_tf_fast(phantom, theta, pad=False, dim=3, integrate_vae=False, *, interp="nearest",
+                    backward="tf_compat"):
+    """Vectorised Radon forward, ctvae/forward_functions.py:80-123.
+
+    phantom: img_size_x x img_size_y x img_size_z (dim=3), img_size_x x img_size_y (dim=2), or
+    batch_size x img_size_x x img_size_y x 1 (integrate_vae=True).  Returns angles x P x Z, angles x P x 1, or
+    batch_size x angles x P x 1.  Every slice is rotated by -theta (nearest neighbour, zero fill) and summed
+    over image rows."""
+    return _project(phantom, theta, pad, dim, integrate_vae, interp, backward)
+
+
+def project_tf_low_mem(phantom, theta, pad=False, *, interp="bilinear", backward="tf_compat"):
+    """Per-angle Radon forward, ctvae/forward_functions.py:49-78: img_size_x x img_size_y x img_size_z ->
+    angles x img_size_y x img_size_z, bilinear interpolation."""
+    return _project(phantom, theta, pad, 3, False, interp, backward)

@@ -1,0 +1,129 @@
+"""Drop-in replacements for the hot-path pieces of ctvae/helper_functions.py of vganapati/CT_PVAE.
+
+    create_sinogram(img, theta, pad=True)                       ctvae/helper_functions.py:33-38
+    calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise_multiplier, sqrt_reg,
+                                 theta=None, angles_i=None, pad=True)   ctvae/helper_functions.py:336-368
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .forward_functions import _stream_ptr, project_tf_fast
+
+__all__ = ["create_sinogram", "create_sinograms", "calculate_log_prob_M_given_R", "gaussian_poisson_log_prob"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a7: create_sinogram -> tomopy.project(phantom[None], theta, center=None, emission=True, pad=pad,
+#                                       sinogram_order=False), squeezed to [angles][dx]
+# ---------------------------------------------------------------------------------------------------------
+def _siddon_tables(theta, device):
+    lib = _lib.load()
+    th = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
+                                         dtype=np.float32))  # tomopy: dtype.as_float32(theta)
+    if th.ndim != 1 or th.size == 0:
+        raise ValueError(f"theta must be a non-empty 1-D array (got shape {th.shape})")
+    dt = th.size
+    sin_t, cos_t = np.empty(dt, np.float32), np.empty(dt, np.float32)
+    quad = np.empty(dt, np.int32)
+    _lib.check(lib.ctpvae_siddon_tables_f32(th.ctypes.data, dt, sin_t.ctypes.data, cos_t.ctypes.data,
+                                            quad.ctypes.data), "siddon_tables")
+    return (torch.from_numpy(sin_t).to(device), torch.from_numpy(cos_t).to(device),
+            torch.from_numpy(quad).to(device))
+
+
+def create_sinograms(imgs, theta, pad=True, device=None):
+    """Batched create_sinogram: imgs [S][X][Y] -> [S][angles][dx] (fp32), TomoPy's ray-driven projector."""
+    lib = _lib.load()
+    as_numpy = not isinstance(imgs, torch.Tensor)
+    t = torch.as_tensor(np.asarray(imgs, dtype=np.float32)) if as_numpy else imgs
+    if t.dim() != 3:
+        raise ValueError(f"expected slices x X x Y (got shape {tuple(t.shape)})")
+    if t.device.type != "cuda":
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.RadonLibraryError("create_sinogram needs a HIP device; there is no CPU path")
+            device = torch.device("cuda", torch.cuda.current_device())
+        t = t.to(device)
+    t = t.to(torch.float32).contiguous()
+    oy, ox, oz = t.shape
+    dx = lib.ctpvae_siddon_dx(ox, oz, 1 if pad else 0)
+    sin_t, cos_t, quad = _siddon_tables(theta, t.device)
+    dt = sin_t.numel()
+    data = torch.empty((oy, dt, dx), dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        # center=None -> dx / 2 (tomopy.sim.project.get_center)
+        _lib.check(lib.ctpvae_siddon_fwd_f32(t.data_ptr(), oy, ox, oz, sin_t.data_ptr(), cos_t.data_ptr(),
+                                             quad.data_ptr(), dt, dx, ctypes.c_float(dx / 2.0), data.data_ptr(),
+                                             _stream_ptr()), "siddon_fwd")
+    return data.cpu().numpy() if as_numpy else data
+
+
+def create_sinogram(img, theta, pad=True):
+    """img [X][Y] -> sinogram [angles][dx]; numpy in -> numpy out, tensor in -> tensor out."""
+    if isinstance(img, torch.Tensor):
+        return create_sinograms(img[None], theta, pad=pad)[0]
+    return create_sinograms(np.asarray(img)[None], theta, pad=pad)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# a8: log-likelihood of the measured sparse sinogram given a reconstruction
+# ---------------------------------------------------------------------------------------------------------
+class _GaussianPoissonLogProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj, mask, x, pnm, eps):
+        lib = _lib.load()
+        B, A, P = proj.shape
+        out = torch.empty_like(proj)
+        with torch.cuda.device(proj.device):
+            _lib.check(lib.ctpvae_loglik_fwd_f32(proj.data_ptr(), mask.data_ptr(), x.data_ptr(), B, A, P,
+                                                 pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
+                                                 _stream_ptr()), "loglik_fwd")
+        ctx.save_for_backward(proj, mask, x, pnm)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        proj, mask, x, pnm = ctx.saved_tensors
+        B, A, P = proj.shape
+        gout = gout.contiguous()
+        gproj = torch.empty_like(proj)
+        gpnm = torch.empty((), dtype=torch.float32, device=proj.device) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(proj.device):
+            _lib.check(lib.ctpvae_loglik_bwd_f32(proj.data_ptr(), mask.data_ptr(), x.data_ptr(), gout.data_ptr(),
+                                                 B, A, P, pnm.data_ptr(), ctypes.c_float(ctx.eps),
+                                                 gproj.data_ptr(), gpnm.data_ptr() if gpnm is not None else None,
+                                                 _stream_ptr()), "loglik_bwd")
+        return gproj, None, None, (gpnm.reshape(pnm.shape) if gpnm is not None else None), None
+
+
+def gaussian_poisson_log_prob(proj, mask, proj_sample, poisson_noise_multiplier, sqrt_reg):
+    """Normal(loc=proj*mask, scale=sqrt_reg + sqrt(loc/pnm + sqrt_reg)).log_prob(proj_sample), elementwise.
+
+    proj, proj_sample [B][A][P]; mask [B][A]; poisson_noise_multiplier a python number or a 0-d/1-element tensor
+    (it may require grad: --train_pnm)."""
+    dev = proj.device
+    pnm = poisson_noise_multiplier
+    if not isinstance(pnm, torch.Tensor):
+        pnm = torch.tensor(float(pnm), dtype=torch.float32, device=dev)
+    pnm = pnm.to(device=dev, dtype=torch.float32)
+    return _GaussianPoissonLogProb.apply(proj.contiguous(), mask.to(torch.float32).contiguous(),
+                                         proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
+
+
+def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise_multiplier, sqrt_reg,
+                                 theta=None, angles_i=None, pad=True):
+    """ctvae/helper_functions.py:336-368.  output_sample [B][X][Y][1], mask [B][angles], proj_sample
+    [B][angles][P]; returns the log-probabilities [B][angles_used][P][1]."""
+    if angles_i is not None:
+        angles_i = torch.as_tensor(angles_i, device=output_sample.device).long()
+        theta = torch.as_tensor(theta, device=output_sample.device)[angles_i].to(torch.float32)
+        mask = mask[:, angles_i]
+        proj_sample = proj_sample[:, angles_i]
+    proj = project_tf_fast(output_sample, theta, pad=pad, dim=2, integrate_vae=True)
+    logp = gaussian_poisson_log_prob(proj[..., 0], mask, proj_sample, poisson_noise_multiplier, sqrt_reg)
+    return logp.unsqueeze(-1)

@@ -1,0 +1,116 @@
+/*
+ * ctpvae_radon.h -- C ABI of the MI355X-native Radon projector that replaces CT_PVAE's physics
+ * decoder operators.  Plain pointers and sizes only; every pointer named *_dev is a DEVICE pointer
+ * (HIP, gfx950), everything else is host memory.  No allocation of outputs, no host synchronisation,
+ * no global state except a thread-local last-error string.  `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream).
+ *
+ * All functions return 0 on success and a negative CTPVAE_E* code otherwise; the message is
+ * available from ctpvae_last_error().  Nothing is thrown across this boundary.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the vganapati/CT_PVAE root):
+ *   ctpvae_num_proj_pix / ctpvae_pad_amounts   ctvae/forward_functions.py:29-36   (pad_phantom size rule)
+ *   ctpvae_rotate_transforms_f32               tfa.image.rotate's transform table, call sites
+ *                                              ctvae/forward_functions.py:70-74,113; inverse used by
+ *                                              TF's gradient, reached from ctvae/main_ct_vae.py:471-481
+ *   ctpvae_rotate_fwd_f32                      project_tf_fast  ctvae/forward_functions.py:80-123
+ *                                              project_tf_low_mem ctvae/forward_functions.py:49-78
+ *   ctpvae_rotate_bwd_f32                      autodiff of the above (tf.GradientTape,
+ *                                              ctvae/main_ct_vae.py:471-481) and its exact transpose
+ *   ctpvae_siddon_tables_f32 / _fwd_f32        create_sinogram -> tomopy.project
+ *                                              ctvae/helper_functions.py:33-38
+ *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
+ *   ctpvae_loglik_fwd_f32 / _bwd_f32           calculate_log_prob_M_given_R
+ *                                              ctvae/helper_functions.py:360-368
+ */
+#ifndef CTPVAE_RADON_H
+#define CTPVAE_RADON_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTPVAE_OK 0
+#define CTPVAE_EINVAL (-1)   /* bad argument (shape, enum, null pointer) */
+#define CTPVAE_EHIP (-2)     /* a HIP runtime call failed */
+#define CTPVAE_ENODEV (-3)   /* no gfx950 device visible */
+
+#define CTPVAE_NEAREST 0     /* tfa.image.rotate default, project_tf_fast */
+#define CTPVAE_BILINEAR 1    /* project_tf_low_mem */
+
+#define CTPVAE_BWD_TF_COMPAT 0 /* what TensorFlow's registered gradient computes (gather) */
+#define CTPVAE_BWD_EXACT 1     /* true transpose of the forward (scatter) */
+
+typedef void *ctpvae_stream_t;
+
+/* Version of this ABI: major * 1000 + minor. */
+int ctpvae_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *ctpvae_last_error(void);
+/* Number of visible HIP devices, or a negative error code. */
+int ctpvae_device_count(void);
+
+/* ---- a1: pad_phantom size rule (host arithmetic only) ------------------------------------- */
+int ctpvae_num_proj_pix(int nx, int ny);
+int ctpvae_pad_amounts(int n, int P, int *lo, int *hi);
+
+/* ---- a3/a4: transform tables ---------------------------------------------------------------
+ * theta_dev [A] fp32 radians as the caller of project_tf_fast passes them (the kernel negates).
+ * H, W: height (rows) and width (columns) of the image that is rotated (the padded canvas).
+ * T8_dev [A][8]: tfa's flat projective rows; Tinv8_dev [A][8] (may be NULL): the rows TensorFlow's
+ * gradient uses (fp32 3x3 inverse, divided by its [2][2] element). */
+int ctpvae_rotate_transforms_f32(const float *theta_dev, int A, int H, int W, float *T8_dev,
+                                 float *Tinv8_dev, ctpvae_stream_t stream);
+
+/* ---- a2/a5: rotate-and-sum forward ---------------------------------------------------------
+ * img_dev  [S][H][W] fp32, contiguous: the UNPADDED slices.  The PH x PW zero canvas with the
+ *          slice at (py, px) is never materialised.
+ * T8_dev   [A][8] rows applied to the canvas (elements 6, 7 must be 0).
+ * sino_dev [S][A][PW]: sino[s][a][j] = sum_{i<PH} sample(canvas_s, T_a(j, i)), rows added in order. */
+int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                          const float *T8_dev, int A, int interp, float *sino_dev,
+                          ctpvae_stream_t stream);
+
+/* ---- a4: backward of the above -------------------------------------------------------------
+ * gsino_dev [S][A][PW] cotangent.  gimg_dev [S][H][W] (overwritten).
+ * mode CTPVAE_BWD_TF_COMPAT: T8_dev must hold the INVERTED rows (Tinv8 above).
+ * mode CTPVAE_BWD_EXACT:     T8_dev must hold the FORWARD rows. */
+int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev,
+                          int interp, int mode, int H, int W, int py, int px, float *gimg_dev,
+                          ctpvae_stream_t stream);
+
+/* ---- a7: TomoPy-style ray-driven projector --------------------------------------------------
+ * Tables (host side, fp32): theta [dt] -> sin, cos of fmodf(theta, 2*pi) and libtomo's quadrant flag. */
+int ctpvae_siddon_dx(int ox, int oz, int pad);
+int ctpvae_siddon_tables_f32(const float *theta, int dt, float *sin_out, float *cos_out, int *quadrant_out);
+/* obj_dev [oy][ox][oz]; sin_dev/cos_dev [dt] fp32, quad_dev [dt] int32; data_dev [oy][dt][dx]
+ * (libtomo's order; tomopy.project(sinogram_order=False) returns it with axes 0,1 swapped). */
+int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
+                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
+                          float *data_dev, ctpvae_stream_t stream);
+
+/* ---- a6: filtered back-projection (float64, as the reference runs it) -----------------------
+ * filter: circular convolution of every sinogram row with hker_dev [P] = Re(ifft(filter_1d)), which
+ * equals Re(ifft(fft(row) * filter_1d)).  sino_dev, out_dev [R][P].
+ * backproject: filt_dev [B][A][P], cos_dev/sin_dev [A] fp64 of theta, recon_dev [B][X][Y]. */
+int ctpvae_fbp_filter_f64(const double *sino_dev, int R, int P, const double *hker_dev, double *out_dev,
+                          ctpvae_stream_t stream);
+int ctpvae_fbp_backproject_f64(const double *filt_dev, int B, int A, int P, const double *cos_dev,
+                               const double *sin_dev, int X, int Y, double *recon_dev,
+                               ctpvae_stream_t stream);
+
+/* ---- a8: Gaussian-approximated Poisson log-likelihood epilogue ------------------------------
+ * proj_dev, x_dev, out_dev [B][A][P]; mask_dev [B][A]; pnm_dev points at ONE fp32 on the device (the
+ * reference keeps poisson_noise_multiplier in a Variable).
+ *   loc = proj*mask ; scale = eps + sqrt(loc/pnm + eps) ; out = Normal(loc, scale).log_prob(x)
+ * bwd: gproj = gout * d out / d proj  (gpnm_dev, if not NULL, receives sum gout * d out / d pnm). */
+int ctpvae_loglik_fwd_f32(const float *proj_dev, const float *mask_dev, const float *x_dev, int B, int A,
+                          int P, const float *pnm_dev, float eps, float *out_dev, ctpvae_stream_t stream);
+int ctpvae_loglik_bwd_f32(const float *proj_dev, const float *mask_dev, const float *x_dev,
+                          const float *gout_dev, int B, int A, int P, const float *pnm_dev, float eps,
+                          float *gproj_dev, float *gpnm_dev, ctpvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTPVAE_RADON_H */

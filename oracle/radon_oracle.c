@@ -1,0 +1,483 @@
+/*
+ * radon_oracle.c -- CPU restatement of CT_PVAE's Radon hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object; the product path (ct_pvae_amd/) never does.
+ *
+ * PARITY UNPINNED.  The reference (vganapati/CT_PVAE) is pure Python on top of TensorFlow 2.8.1,
+ * tensorflow-addons 0.17.1, tensorflow-probability 0.14.0 and TomoPy 1.11.0.  None of those is
+ * installed (or installable) here and the reference holds no tests, fixtures or golden files
+ * for this path.  The arithmetic below therefore restates the published algorithms of those
+ * pinned third-party versions from their call sites in the reference; what pins it is
+ *   - the 2x2 toy known answers in scripts/images_to_sinograms.py:54-59 with the images of
+ *     scripts/create_toy_images.py:36-40,
+ *   - the size identities of ctvae/forward_functions.py:29-36 and ctvae/main_ct_vae.py:160-161,
+ *   - axis-aligned analytic cases and structural properties (tests/test_oracle.py).
+ *
+ * Every function cites the reference file:line whose behaviour it follows.  All citations are
+ * relative to the reference repo root.  Compile with -ffp-contract=off: the index arithmetic of
+ * the nearest-neighbour projector is only meaningful with separate multiplies and adds.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_NEAREST 0
+#define ORACLE_BILINEAR 1
+
+/* ---------------------------------------------------------------------------------------------
+ * a1: pad_phantom size rule.  ctvae/forward_functions.py:29-36
+ *   num_proj_pix = sqrt(float64(Nx^2 + Ny^2)) + 2 ; P = int(ceil(num_proj_pix / 2) * 2)
+ *   pad_lo = (P - N) // 2 ; pad_hi = pad_lo + (P - N) % 2
+ * ------------------------------------------------------------------------------------------- */
+int oracle_num_proj_pix(int nx, int ny)
+{
+    double v = sqrt((double)((long long)nx * nx + (long long)ny * ny)) + 2.0;
+    return (int)(ceil(v / 2.0) * 2.0);
+}
+
+void oracle_pad_amounts(int n, int P, int *lo, int *hi)
+{
+    *lo = (P - n) / 2;
+    *hi = *lo + ((P - n) % 2);
+}
+
+/* a1: materialised zero padding, [S][H][W] -> [S][PH][PW].  ctvae/forward_functions.py:38-45 */
+void oracle_pad_phantom(const float *img, int S, int H, int W, int py, int px, int PH, int PW,
+                        float *out)
+{
+    memset(out, 0, (size_t)S * PH * PW * sizeof(float));
+    for (int s = 0; s < S; ++s)
+        for (int r = 0; r < H; ++r)
+            memcpy(out + ((size_t)s * PH + (r + py)) * PW + px, img + ((size_t)s * H + r) * W,
+                   (size_t)W * sizeof(float));
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a3: tfa.image.rotate -> angles_to_projective_transforms (tensorflow-addons 0.17.1), called at
+ * ctvae/forward_functions.py:70-74,113 with angles = -theta.
+ *   row = [cos, -sin, x_off, sin, cos, y_off, 0, 0]
+ *   x_off = ((W-1) - (cos*(W-1) - sin*(H-1))) / 2 ; y_off = ((H-1) - (sin*(W-1) + cos*(H-1))) / 2
+ * all in fp32.  `angles` holds the angle handed to rotate (i.e. already -theta, fp32).  cos/sin are
+ * the correctly rounded fp32 values (double libm, then rounded) so that every host agrees.
+ * ------------------------------------------------------------------------------------------- */
+void oracle_rotate_transforms(const float *angles, int A, int H, int W, float *T8)
+{
+    const float wm1 = (float)W - 1.0f, hm1 = (float)H - 1.0f;
+    for (int a = 0; a < A; ++a) {
+        const float c = (float)cos((double)angles[a]);
+        const float s = (float)sin((double)angles[a]);
+        float *t = T8 + 8 * a;
+        const float cw = c * wm1, sh = s * hm1, sw = s * wm1, ch = c * hm1;
+        const float xo = (wm1 - (cw - sh)) / 2.0f;
+        const float yo = (hm1 - (sw + ch)) / 2.0f;
+        t[0] = c;  t[1] = -s; t[2] = xo;
+        t[3] = s;  t[4] = c;  t[5] = yo;
+        t[6] = 0.0f; t[7] = 0.0f;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a4: the transform TensorFlow's registered gradient of ImageProjectiveTransformV3 applies to the
+ * incoming gradient: flat -> 3x3, fp32 matrix_inverse (LU with partial pivoting), 3x3 -> flat with
+ * division by the [2][2] element.  Reached through tf.GradientTape at ctvae/main_ct_vae.py:471-481.
+ * ------------------------------------------------------------------------------------------- */
+static void inv3x3_f32(const float m[9], float out[9])
+{
+    float a[3][6];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            a[r][c] = m[3 * r + c];
+            a[r][3 + c] = (r == c) ? 1.0f : 0.0f;
+        }
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        for (int r = k + 1; r < 3; ++r)
+            if (fabsf(a[r][k]) > fabsf(a[p][k])) p = r;
+        if (p != k)
+            for (int c = 0; c < 6; ++c) { float t = a[k][c]; a[k][c] = a[p][c]; a[p][c] = t; }
+        for (int r = k + 1; r < 3; ++r) {
+            const float f = a[r][k] / a[k][k];
+            for (int c = k; c < 6; ++c) a[r][c] = a[r][c] - f * a[k][c];
+        }
+    }
+    for (int c = 3; c < 6; ++c)
+        for (int r = 2; r >= 0; --r) {
+            float v = a[r][c];
+            for (int q = r + 1; q < 3; ++q) v = v - a[r][q] * a[q][c];
+            a[r][c] = v / a[r][r];
+        }
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[3 * r + c] = a[r][3 + c];
+}
+
+void oracle_invert_transforms(const float *T8, int A, float *Tinv8)
+{
+    for (int a = 0; a < A; ++a) {
+        const float *t = T8 + 8 * a;
+        float m[9] = { t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], 1.0f }, inv[9];
+        inv3x3_f32(m, inv);
+        for (int k = 0; k < 8; ++k) Tinv8[8 * a + k] = inv[k] / inv[8];
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a3: one sample of TensorFlow 2.8.1's ImageProjectiveTransformV3 (ProjectiveGenerator, CPU
+ * functor), fill_mode CONSTANT, fill_value 0.  `img` is the UNPADDED H x W core that sits at
+ * (py, px) inside a PH x PW zero canvas (reading the canvas is the same as reading the zero fill).
+ * ------------------------------------------------------------------------------------------- */
+static inline float canvas_read(const float *img, int H, int W, int py, int px, long iy, long ix)
+{
+    const long r = iy - py, c = ix - px;
+    return (r >= 0 && r < H && c >= 0 && c < W) ? img[r * W + c] : 0.0f;
+}
+
+static inline void map_coord(const float *t, int ox, int oy, float *x, float *y)
+{
+    /* projection = t6*x + t7*y + 1 == 1 for rotations; the division is exact */
+    *x = (t[0] * (float)ox + t[1] * (float)oy) + t[2];
+    *y = (t[3] * (float)ox + t[4] * (float)oy) + t[5];
+}
+
+static inline float sample_canvas(const float *img, int H, int W, int py, int px, float y, float x,
+                                  int interp)
+{
+    if (interp == ORACLE_NEAREST)
+        return canvas_read(img, H, W, py, px, (long)roundf(y), (long)roundf(x));
+    const float yf = floorf(y), xf = floorf(x);
+    const float yc = yf + 1.0f, xc = xf + 1.0f;
+    const float v_yf = (xc - x) * canvas_read(img, H, W, py, px, (long)yf, (long)xf) +
+                       (x - xf) * canvas_read(img, H, W, py, px, (long)yf, (long)xc);
+    const float v_yc = (xc - x) * canvas_read(img, H, W, py, px, (long)yc, (long)xf) +
+                       (x - xf) * canvas_read(img, H, W, py, px, (long)yc, (long)xc);
+    return (yc - y) * v_yf + (y - yf) * v_yc;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a2 / a5: rotate-and-sum forward.  ctvae/forward_functions.py:106-114 (fast, NEAREST by default)
+ * and :69-77 (low_mem, BILINEAR).  sino[s][a][j] = sum_{i=0}^{PH-1} Rot_a(canvas_s)[i][j], rows
+ * summed in order (reduce_sum over axis 1 = image rows).  img [S][H][W], sino [S][A][PW].
+ * ------------------------------------------------------------------------------------------- */
+void oracle_rotate_fwd(const float *img, int S, int H, int W, int PH, int PW, int py, int px,
+                       const float *T8, int A, int interp, float *sino)
+{
+    for (int s = 0; s < S; ++s) {
+        const float *im = img + (size_t)s * H * W;
+        for (int a = 0; a < A; ++a) {
+            const float *t = T8 + 8 * a;
+            float *out = sino + ((size_t)s * A + a) * PW;
+            for (int j = 0; j < PW; ++j) {
+                float acc = 0.0f;
+                for (int i = 0; i < PH; ++i) {
+                    float x, y;
+                    map_coord(t, j, i, &x, &y);
+                    acc += sample_canvas(im, H, W, py, px, y, x, interp);
+                }
+                out[j] = acc;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a4: the backward TensorFlow actually runs for a2 (tf.GradientTape, ctvae/main_ct_vae.py:471-481):
+ *   reduce_sum(axis=1)  <-> broadcast g[a][j] over all rows of a PH x PW image,
+ *   ImageProjectiveTransformV3 <-> the same op on that image with the inverted transform, same
+ *     interpolation, zero fill,
+ *   repeat <-> sum over angles (in order), pad <-> crop of the H x W core.
+ * gsino [S][A][PW], Tinv8 from oracle_invert_transforms, gimg [S][H][W].
+ * ------------------------------------------------------------------------------------------- */
+static inline float bcast_read(const float *grow, int PH, int PW, long iy, long ix)
+{
+    return (iy >= 0 && iy < PH && ix >= 0 && ix < PW) ? grow[ix] : 0.0f;
+}
+
+void oracle_rotate_bwd_tfcompat(const float *gsino, int S, int A, int PH, int PW, const float *Tinv8,
+                                int interp, int H, int W, int py, int px, float *gimg)
+{
+    for (int s = 0; s < S; ++s)
+        for (int r = 0; r < H; ++r)
+            for (int c = 0; c < W; ++c) {
+                float acc = 0.0f;
+                for (int a = 0; a < A; ++a) {
+                    const float *t = Tinv8 + 8 * a;
+                    const float *grow = gsino + ((size_t)s * A + a) * PW;
+                    float x, y, v;
+                    map_coord(t, c + px, r + py, &x, &y);
+                    if (interp == ORACLE_NEAREST) {
+                        v = bcast_read(grow, PH, PW, (long)roundf(y), (long)roundf(x));
+                    } else {
+                        const float yf = floorf(y), xf = floorf(x);
+                        const float yc = yf + 1.0f, xc = xf + 1.0f;
+                        const float v_yf = (xc - x) * bcast_read(grow, PH, PW, (long)yf, (long)xf) +
+                                           (x - xf) * bcast_read(grow, PH, PW, (long)yf, (long)xc);
+                        const float v_yc = (xc - x) * bcast_read(grow, PH, PW, (long)yc, (long)xf) +
+                                           (x - xf) * bcast_read(grow, PH, PW, (long)yc, (long)xc);
+                        v = (yc - y) * v_yf + (y - yf) * v_yc;
+                    }
+                    acc += v;
+                }
+                gimg[((size_t)s * H + r) * W + c] = acc;
+            }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * K2x (not in the reference): the exact transpose of oracle_rotate_fwd, as a scatter in (a, i, j)
+ * order.  <fwd(x), g> == <x, bwd_exact(g)> up to fp32 summation order.
+ * ------------------------------------------------------------------------------------------- */
+static inline void canvas_add(float *gimg, int H, int W, int py, int px, long iy, long ix, float v)
+{
+    const long r = iy - py, c = ix - px;
+    if (r >= 0 && r < H && c >= 0 && c < W) gimg[r * W + c] += v;
+}
+
+void oracle_rotate_bwd_exact(const float *gsino, int S, int A, int PH, int PW, const float *T8,
+                             int interp, int H, int W, int py, int px, float *gimg)
+{
+    memset(gimg, 0, (size_t)S * H * W * sizeof(float));
+    for (int s = 0; s < S; ++s) {
+        float *gi = gimg + (size_t)s * H * W;
+        for (int a = 0; a < A; ++a) {
+            const float *t = T8 + 8 * a;
+            const float *grow = gsino + ((size_t)s * A + a) * PW;
+            for (int i = 0; i < PH; ++i)
+                for (int j = 0; j < PW; ++j) {
+                    float x, y;
+                    map_coord(t, j, i, &x, &y);
+                    const float g = grow[j];
+                    if (interp == ORACLE_NEAREST) {
+                        canvas_add(gi, H, W, py, px, (long)roundf(y), (long)roundf(x), g);
+                    } else {
+                        const float yf = floorf(y), xf = floorf(x);
+                        const float yc = yf + 1.0f, xc = xf + 1.0f;
+                        canvas_add(gi, H, W, py, px, (long)yf, (long)xf, (yc - y) * ((xc - x) * g));
+                        canvas_add(gi, H, W, py, px, (long)yf, (long)xc, (yc - y) * ((x - xf) * g));
+                        canvas_add(gi, H, W, py, px, (long)yc, (long)xf, (y - yf) * ((xc - x) * g));
+                        canvas_add(gi, H, W, py, px, (long)yc, (long)xc, (y - yf) * ((x - xf) * g));
+                    }
+                }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a7: tomopy.project (TomoPy 1.11.0: sim/project.py + libtomo/recon/project.c + utils.c) as called
+ * by create_sinogram, ctvae/helper_functions.py:33-38: center=None, emission=True,
+ * sinogram_order=False.  obj [oy][ox][oz] fp32, data [oy][dt][dx] (libtomo's own order; the Python
+ * wrapper swaps axes 0 and 1 afterwards).  `center` is dx/2 when the caller passes None.
+ * ------------------------------------------------------------------------------------------- */
+int oracle_siddon_dx(int ox, int oz, int pad)
+{
+    /* sim/project.py: dx = _round_to_even(sqrt(ox^2 + oz^2) + 2) if pad else ox */
+    if (!pad) return ox;
+    return (int)(ceil((sqrt((double)ox * ox + (double)oz * oz) + 2.0) / 2.0) * 2.0);
+}
+
+static int siddon_quadrant(float theta_p)
+{
+    /* utils.c calc_quadrant: M_PI is a double there, so the offset and the bounds are doubles */
+    const int32_t ipi_c = 340870420;
+    int32_t theta_i = (int32_t)(theta_p * ipi_c);
+    theta_i += (theta_i < 0) ? (2.0f * M_PI * ipi_c) : 0;
+    return ((theta_i >= 0 && theta_i < 0.5f * M_PI * ipi_c) ||
+            (theta_i >= 1.0f * M_PI * ipi_c && theta_i < 1.5f * M_PI * ipi_c))
+               ? 1 : 0;
+}
+
+void oracle_siddon_project(const float *obj, int oy, int ox, int oz, const float *theta, int dt,
+                           int dx, float center, float *data)
+{
+    float *gridx = (float *)malloc((ox + 1) * sizeof(float));
+    float *gridy = (float *)malloc((oz + 1) * sizeof(float));
+    float *coordx = (float *)malloc((oz + 1) * sizeof(float));
+    float *coordy = (float *)malloc((ox + 1) * sizeof(float));
+    float *ax = (float *)malloc((ox + oz + 2) * sizeof(float));
+    float *ay = (float *)malloc((ox + oz + 2) * sizeof(float));
+    float *bx = (float *)malloc((ox + oz + 2) * sizeof(float));
+    float *by = (float *)malloc((ox + oz + 2) * sizeof(float));
+    float *coorx = (float *)malloc((ox + oz + 2) * sizeof(float));
+    float *coory = (float *)malloc((ox + oz + 2) * sizeof(float));
+    float *dist = (float *)malloc((ox + oz + 1) * sizeof(float));
+    int *indi = (int *)malloc((ox + oz + 1) * sizeof(int));
+
+    memset(data, 0, (size_t)oy * dt * dx * sizeof(float));
+
+    /* utils.c preprocessing */
+    for (int i = 0; i <= ox; ++i) gridx[i] = -ox * 0.5f + i;
+    for (int i = 0; i <= oz; ++i) gridy[i] = -oz * 0.5f + i;
+    float mov = ((float)dx - 1) * 0.5f - center;
+    if (mov - floorf(mov) < 0.01f) mov += 0.01f;
+    mov += 0.5f;
+
+    for (int p = 0; p < dt; ++p) {
+        const float theta_p = fmodf(theta[p], 2.0f * (float)M_PI);
+        const int quadrant = siddon_quadrant(theta_p);
+        const float sin_p = sinf(theta_p), cos_p = cosf(theta_p);
+        for (int d = 0; d < dx; ++d) {
+            const float xi = (float)(-ox - oz);
+            const float yi = (1 - dx) / 2.0f + d + mov;
+            /* calc_coords */
+            const float srcx = xi * cos_p - yi * sin_p, srcy = xi * sin_p + yi * cos_p;
+            const float detx = -xi * cos_p - yi * sin_p, dety = -xi * sin_p + yi * cos_p;
+            const float slope = (srcy - dety) / (srcx - detx);
+            const float islope = (srcx - detx) / (srcy - dety);
+            for (int n = 0; n <= oz; ++n) coordx[n] = islope * (gridy[n] - srcy) + srcx;
+            for (int n = 0; n <= ox; ++n) coordy[n] = slope * (gridx[n] - srcx) + srcy;
+            /* trim_coords */
+            int asize = 0, bsize = 0;
+            const float gx_gt = gridx[0] + 0.01f, gx_le = gridx[ox] - 0.01f;
+            for (int n = 0; n <= oz; ++n)
+                if (coordx[n] >= gx_gt && coordx[n] <= gx_le) {
+                    ax[asize] = coordx[n]; ay[asize] = gridy[n]; ++asize;
+                }
+            const float gy_gt = gridy[0] + 0.01f, gy_le = gridy[oz] - 0.01f;
+            for (int n = 0; n <= ox; ++n)
+                if (coordy[n] >= gy_gt && coordy[n] <= gy_le) {
+                    bx[bsize] = gridx[n]; by[bsize] = coordy[n]; ++bsize;
+                }
+            /* sort_intersections */
+            int i = 0, j = 0, k = 0;
+            while (i < asize && j < bsize) {
+                const int a_ind = quadrant ? i : (asize - 1 - i);
+                if (ax[a_ind] < bx[j]) { coorx[k] = ax[a_ind]; coory[k] = ay[a_ind]; ++i; }
+                else { coorx[k] = bx[j]; coory[k] = by[j]; ++j; }
+                ++k;
+            }
+            while (i < asize) {
+                const int a_ind = quadrant ? i : (asize - 1 - i);
+                coorx[k] = ax[a_ind]; coory[k] = ay[a_ind]; ++i; ++k;
+            }
+            while (j < bsize) { coorx[k] = bx[j]; coory[k] = by[j]; ++j; ++k; }
+            const int csize = asize + bsize;
+            /* calc_dist */
+            for (int n = 0; n < csize - 1; ++n) {
+                const float diffx = coorx[n + 1] - coorx[n], diffy = coory[n + 1] - coory[n];
+                dist[n] = sqrtf(diffx * diffx + diffy * diffy);
+                const float midx = (coorx[n + 1] + coorx[n]) * 0.5f;
+                const float midy = (coory[n + 1] + coory[n]) * 0.5f;
+                const float x1 = midx + ox * 0.5f, x2 = midy + oz * 0.5f;
+                const int i1 = (int)x1, i2 = (int)x2;
+                const int indx = i1 - (i1 > x1), indy = i2 - (i2 > x2);
+                indi[n] = indy + indx * oz;
+            }
+            /* calc_simdata, every slice */
+            for (int s = 0; s < oy; ++s) {
+                const float *model = obj + (size_t)s * ox * oz;
+                float *out = data + ((size_t)s * dt + p) * dx + d;
+                for (int n = 0; n < csize - 1; ++n) *out += model[indi[n]] * dist[n];
+            }
+        }
+    }
+    free(gridx); free(gridy); free(coordx); free(coordy); free(ax); free(ay); free(bx); free(by);
+    free(coorx); free(coory); free(dist); free(indi);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a6: iradon, ctvae/fbp_tensorflow.py:39-74, float64 / complex128 as the reference runs it.
+ *   :49-50  filt = Re(ifft(fft(sino) * filter_1d))        (plain DFT here, O(P^2))
+ *   :52-59  t[x][y][a] = ypr*cos(theta_a) - xpr*sin(theta_a), xpr = i - X/2, ypr = j - Y/2
+ *   :61-70  tfp.math.interp_regular_1d_grid(x=t, x_ref_min=-P/2, x_ref_max=P-1-P/2, y_ref=filt row,
+ *           fill_value='constant_extension')
+ *   :72-74  sum over angles, times pi / (2A)
+ * sino [B][A][P], theta [A], filter [P] (re, im), recon [B][X][Y].
+ * ------------------------------------------------------------------------------------------- */
+void oracle_fbp_filter(const double *sino, int R, int P, const double *filt_re, const double *filt_im,
+                       double *out)
+{
+    double *fr = (double *)malloc(P * sizeof(double)), *fi = (double *)malloc(P * sizeof(double));
+    double *cs = (double *)malloc(P * sizeof(double)), *sn = (double *)malloc(P * sizeof(double));
+    for (int k = 0; k < P; ++k) {
+        cs[k] = cos(2.0 * M_PI * k / P);
+        sn[k] = sin(2.0 * M_PI * k / P);
+    }
+    for (int r = 0; r < R; ++r) {
+        const double *x = sino + (size_t)r * P;
+        for (int k = 0; k < P; ++k) {
+            double re = 0.0, im = 0.0;
+            for (int n = 0; n < P; ++n) {
+                const int m = (int)(((long long)k * n) % P);
+                re += x[n] * cs[m];
+                im -= x[n] * sn[m];
+            }
+            const double hr = filt_re[k], hi = filt_im ? filt_im[k] : 0.0;
+            fr[k] = re * hr - im * hi;
+            fi[k] = re * hi + im * hr;
+        }
+        for (int n = 0; n < P; ++n) {
+            double re = 0.0;
+            for (int k = 0; k < P; ++k) {
+                const int m = (int)(((long long)k * n) % P);
+                re += fr[k] * cs[m] - fi[k] * sn[m];
+            }
+            out[(size_t)r * P + n] = re / P;
+        }
+    }
+    free(fr); free(fi); free(cs); free(sn);
+}
+
+static inline double interp_regular_1d(const double *y_ref, int ny, double x, double x_min, double x_max)
+{
+    /* tensorflow-probability 0.14.0 math/interpolation.py _interp_regular_1d_grid_impl */
+    double idx_unclipped = (x - x_min) / (x_max - x_min) * (double)(ny - 1);
+    double idx = idx_unclipped;
+    if (idx < 0.0) idx = 0.0;
+    if (idx > (double)(ny - 1)) idx = (double)(ny - 1);
+    double below = floor(idx);
+    double above = fmin(below + 1.0, (double)(ny - 1));
+    below = fmax(above - 1.0, 0.0);
+    const double t = idx - below;
+    double y = t * y_ref[(int)above] + (1.0 - t) * y_ref[(int)below];
+    if (idx_unclipped < 0.0) y = y_ref[0];
+    if (idx_unclipped > (double)(ny - 1)) y = y_ref[ny - 1];
+    return y;
+}
+
+void oracle_fbp_backproject(const double *filt, int B, int A, int P, const double *theta, int X, int Y,
+                            double *recon)
+{
+    const double x_min = 0.0 - P / 2.0, x_max = (double)(P - 1) - P / 2.0;
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < X; ++i)
+            for (int j = 0; j < Y; ++j) {
+                const double xpr = (double)i - X / 2.0, ypr = (double)j - Y / 2.0;
+                double acc = 0.0;
+                for (int a = 0; a < A; ++a) {
+                    const double t = ypr * cos(theta[a]) - xpr * sin(theta[a]);
+                    acc += interp_regular_1d(filt + ((size_t)b * A + a) * P, P, t, x_min, x_max);
+                }
+                recon[((size_t)b * X + i) * Y + j] = acc * M_PI / (2.0 * A);
+            }
+}
+
+void oracle_iradon(const double *sino, int B, int A, int P, const double *theta, int X, int Y,
+                   const double *filt_re, const double *filt_im, double *recon)
+{
+    double *filt = (double *)malloc((size_t)B * A * P * sizeof(double));
+    oracle_fbp_filter(sino, B * A, P, filt_re, filt_im, filt);
+    oracle_fbp_backproject(filt, B, A, P, theta, X, Y, recon);
+    free(filt);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * a8: calculate_log_prob_M_given_R, ctvae/helper_functions.py:360-368 (after the projector call):
+ *   loc = proj * mask[b][a] ; scale = eps + sqrt(loc / pnm + eps)
+ *   log_prob = -0.5*(x/scale - loc/scale)^2 - (0.5*log(2*pi) + log(scale))   (tfd.Normal._log_prob)
+ * proj, x [B][A][P], mask [B][A], out [B][A][P], all fp32.
+ * ------------------------------------------------------------------------------------------- */
+void oracle_loglik(const float *proj, const float *mask, const float *x, int B, int A, int P, float pnm,
+                   float eps, float *out)
+{
+    const float half_log_2pi = (float)(0.5 * log(2.0 * M_PI));
+    for (int b = 0; b < B; ++b)
+        for (int a = 0; a < A; ++a) {
+            const float m = mask[(size_t)b * A + a];
+            for (int j = 0; j < P; ++j) {
+                const size_t k = ((size_t)b * A + a) * P + j;
+                const float loc = proj[k] * m;
+                const float scale = eps + sqrtf(loc / pnm + eps);
+                const float z = x[k] / scale - loc / scale;
+                out[k] = -0.5f * (z * z) - (half_log_2pi + logf(scale));
+            }
+        }
+}

@@ -1,0 +1,187 @@
+"""ctypes binding of oracle/radon_oracle.c -- the CPU restatement of CT_PVAE's Radon hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by
+ct_pvae_amd/.  PARITY UNPINNED (see the header of radon_oracle.c): nothing the reference ships pins the
+third-party projectors numerically beyond the 2x2 toy case and analytic identities.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libradon_oracle.so")
+NEAREST, BILINEAR = 0, 1
+
+_lib = None
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i = ctypes.c_int
+
+
+def build(force=False):
+    """Compile the restatement with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "radon_oracle.c")
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = ctypes.CDLL(LIB_PATH)
+        L.oracle_num_proj_pix.restype = _i
+        L.oracle_num_proj_pix.argtypes = [_i, _i]
+        L.oracle_pad_amounts.argtypes = [_i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]
+        L.oracle_pad_phantom.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p]
+        L.oracle_rotate_transforms.argtypes = [_f32p, _i, _i, _i, _f32p]
+        L.oracle_invert_transforms.argtypes = [_f32p, _i, _f32p]
+        L.oracle_rotate_fwd.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _f32p]
+        L.oracle_rotate_bwd_tfcompat.argtypes = [_f32p, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _i, _f32p]
+        L.oracle_rotate_bwd_exact.argtypes = [_f32p, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _i, _f32p]
+        L.oracle_siddon_dx.restype = _i
+        L.oracle_siddon_dx.argtypes = [_i, _i, _i]
+        L.oracle_siddon_project.argtypes = [_f32p, _i, _i, _i, _f32p, _i, _i, ctypes.c_float, _f32p]
+        L.oracle_fbp_filter.argtypes = [_f64p, _i, _i, _f64p, ctypes.c_void_p, _f64p]
+        L.oracle_fbp_backproject.argtypes = [_f64p, _i, _i, _i, _f64p, _i, _i, _f64p]
+        L.oracle_iradon.argtypes = [_f64p, _i, _i, _i, _f64p, _i, _i, _f64p, ctypes.c_void_p, _f64p]
+        L.oracle_loglik.argtypes = [_f32p, _f32p, _f32p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _f32p]
+        _lib = L
+    return _lib
+
+
+def _c32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---- a1 -----------------------------------------------------------------------------------------------
+def num_proj_pix(nx, ny):
+    return lib().oracle_num_proj_pix(nx, ny)
+
+
+def pad_amounts(n, P):
+    lo, hi = _i(), _i()
+    lib().oracle_pad_amounts(n, P, ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+class Geometry:
+    """Canvas geometry of pad_phantom + rotate for slices of H x W (pad=True: square P x P canvas)."""
+
+    def __init__(self, H, W, pad):
+        self.H, self.W = H, W
+        if pad:
+            P = num_proj_pix(H, W)
+            self.PH = self.PW = P
+            self.py, self.px = pad_amounts(H, P)[0], pad_amounts(W, P)[0]
+        else:
+            self.PH, self.PW, self.py, self.px = H, W, 0, 0
+
+
+def pad_phantom(img, geom):
+    img = _c32(img)
+    out = np.empty((img.shape[0], geom.PH, geom.PW), np.float32)
+    lib().oracle_pad_phantom(img, img.shape[0], geom.H, geom.W, geom.py, geom.px, geom.PH, geom.PW, out)
+    return out
+
+
+# ---- a3 / a4 tables -----------------------------------------------------------------------------------
+def rotate_transforms(theta, H, W):
+    """Rows tfa.image.rotate(images, -theta) builds for an H x W image.  theta: radians, cast to fp32 first."""
+    ang = _c32(-_c32(theta))
+    T = np.empty((ang.size, 8), np.float32)
+    lib().oracle_rotate_transforms(ang, ang.size, H, W, T)
+    return T
+
+
+def invert_transforms(T8):
+    T8 = _c32(T8)
+    out = np.empty_like(T8)
+    lib().oracle_invert_transforms(T8, T8.shape[0], out)
+    return out
+
+
+# ---- a2 / a5 / a4 -------------------------------------------------------------------------------------
+def rotate_fwd(img, geom, T8, interp=NEAREST):
+    img, T8 = _c32(img), _c32(T8)
+    S, A = img.shape[0], T8.shape[0]
+    sino = np.empty((S, A, geom.PW), np.float32)
+    lib().oracle_rotate_fwd(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A, interp, sino)
+    return sino
+
+
+def rotate_bwd_tfcompat(gsino, geom, Tinv8, interp=NEAREST):
+    gsino, Tinv8 = _c32(gsino), _c32(Tinv8)
+    S, A = gsino.shape[0], gsino.shape[1]
+    gimg = np.empty((S, geom.H, geom.W), np.float32)
+    lib().oracle_rotate_bwd_tfcompat(gsino, S, A, geom.PH, geom.PW, Tinv8, interp, geom.H, geom.W, geom.py, geom.px,
+                                     gimg)
+    return gimg
+
+
+def rotate_bwd_exact(gsino, geom, T8, interp=NEAREST):
+    gsino, T8 = _c32(gsino), _c32(T8)
+    S, A = gsino.shape[0], gsino.shape[1]
+    gimg = np.empty((S, geom.H, geom.W), np.float32)
+    lib().oracle_rotate_bwd_exact(gsino, S, A, geom.PH, geom.PW, T8, interp, geom.H, geom.W, geom.py, geom.px, gimg)
+    return gimg
+
+
+def project_tf_fast(phantom, theta, pad=False, dim=3, integrate_vae=False, interp=NEAREST):
+    """Reference layouts of ctvae/forward_functions.py:80-123 on numpy arrays."""
+    phantom = np.asarray(phantom, dtype=np.float32)
+    if integrate_vae:
+        slices = phantom[..., 0]
+    elif dim == 3:
+        slices = np.transpose(phantom, (2, 0, 1))
+    else:
+        slices = phantom[None]
+    geom = Geometry(slices.shape[1], slices.shape[2], pad)
+    sino = rotate_fwd(slices, geom, rotate_transforms(theta, geom.PH, geom.PW), interp)
+    return sino[..., None] if integrate_vae else np.transpose(sino, (1, 2, 0))
+
+
+# ---- a7 -----------------------------------------------------------------------------------------------
+def siddon_project(obj, theta, pad=True):
+    """tomopy.project(obj, theta, center=None, emission=True, pad=pad, sinogram_order=False) -> [dt][oy][dx]."""
+    obj, theta = _c32(obj), _c32(theta)
+    oy, ox, oz = obj.shape
+    dx = lib().oracle_siddon_dx(ox, oz, 1 if pad else 0)
+    data = np.empty((oy, theta.size, dx), np.float32)
+    lib().oracle_siddon_project(obj, oy, ox, oz, theta, theta.size, dx, dx / 2.0, data)
+    return np.swapaxes(data, 0, 1).copy()
+
+
+def create_sinogram(img, theta, pad=True):
+    """ctvae/helper_functions.py:33-38."""
+    return np.squeeze(siddon_project(np.asarray(img)[None], theta, pad=pad), axis=1)
+
+
+# ---- a6 -----------------------------------------------------------------------------------------------
+def iradon(sinogram, theta, x_size, y_size, filter_1d):
+    sino, theta = _c64(sinogram), _c64(theta)
+    B, A, P = sino.shape
+    filt = np.asarray(filter_1d).reshape(-1)
+    fre = _c64(filt.real)
+    fim = _c64(filt.imag) if np.iscomplexobj(filt) else None
+    recon = np.empty((B, x_size, y_size), np.float64)
+    lib().oracle_iradon(sino, B, A, P, theta, x_size, y_size, fre,
+                        fim.ctypes.data if fim is not None else None, recon)
+    return recon
+
+
+# ---- a8 -----------------------------------------------------------------------------------------------
+def loglik(proj, mask, x, pnm, eps):
+    proj, mask, x = _c32(proj), _c32(mask), _c32(x)
+    B, A, P = proj.shape
+    out = np.empty_like(proj)
+    lib().oracle_loglik(proj, mask, x, B, A, P, pnm, eps, out)
+    return out

@@ -1,0 +1,83 @@
+"""Regenerates tests/golden/*.npz from the CPU restatement (oracle/radon_oracle.c).
+
+    python tests/golden/make_golden.py
+
+The reference ships no numeric fixtures for this path and TensorFlow / TomoPy cannot be installed here, so these
+vectors are the restatement's own outputs on seeded inputs (PARITY UNPINNED, see oracle/radon_oracle.c).  They
+guard the oracle against regressions and give the HIP path a fixed target on the GPU box."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from ct_pvae_amd import phantoms  # noqa: E402
+from oracle import radon_oracle as orc  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+NEAREST, BILINEAR = 0, 1
+
+
+def rotate_case(name, img, theta, pad, seed):
+    rng = np.random.default_rng(seed)
+    geom = orc.Geometry(img.shape[1], img.shape[2], pad)
+    T = orc.rotate_transforms(theta, geom.PH, geom.PW)
+    Tinv = orc.invert_transforms(T)
+    g = rng.standard_normal((img.shape[0], len(theta), geom.PW)).astype(np.float32)
+    out = dict(img=img, theta=np.asarray(theta, np.float64), pad=np.array(pad), T8=T, Tinv8=Tinv, g=g)
+    for tag, interp in (("nearest", NEAREST), ("bilinear", BILINEAR)):
+        out[f"fwd_{tag}"] = orc.rotate_fwd(img, geom, T, interp)
+        out[f"bwd_tfcompat_{tag}"] = orc.rotate_bwd_tfcompat(g, geom, Tinv, interp)
+        out[f"bwd_exact_{tag}"] = orc.rotate_bwd_exact(g, geom, T, interp)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
+def main():
+    orc.build(force=True)
+    rng = np.random.default_rng(0)
+    # the reference's 2x2 toy set (scripts/create_toy_images.py:36-40), no padding
+    rotate_case("rotate_toy", phantoms.toy_images(), np.array([0, np.pi / 2]), False, 1)
+    rotate_case("rotate_rand8", rng.standard_normal((2, 8, 8)).astype(np.float32), rng.uniform(0, np.pi, 5), True, 2)
+    rotate_case("rotate_rect_nopad", rng.random((3, 16, 12), dtype=np.float32), rng.uniform(0, np.pi, 7), False, 3)
+    rotate_case("rotate_rect_pad", rng.random((2, 10, 15), dtype=np.float32), rng.uniform(-np.pi, 2 * np.pi, 6), True, 4)
+    theta20 = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
+    foam = phantoms.foam_batch(1, 128, seed=0)
+    rotate_case("rotate_foam128_a20", foam, theta20, True, 5)
+
+    # siddon (tomopy.project) cases
+    sid = {}
+    sid["toy_img"] = phantoms.toy_images()
+    sid["toy_theta"] = np.array([0, np.pi / 2])
+    sid["toy_out"] = orc.siddon_project(sid["toy_img"], sid["toy_theta"], pad=False)
+    sid["rand_img"] = rng.random((2, 16, 16), dtype=np.float32)
+    sid["rand_theta"] = rng.uniform(0, 2 * np.pi, 9)
+    sid["rand_out"] = orc.siddon_project(sid["rand_img"], sid["rand_theta"], pad=True)
+    sid["rect_img"] = rng.random((1, 12, 20), dtype=np.float32)
+    sid["rect_theta"] = np.linspace(0, np.pi, 8, endpoint=False)
+    sid["rect_out"] = orc.siddon_project(sid["rect_img"], sid["rect_theta"], pad=True)
+    sid["foam_img"] = foam
+    sid["foam_theta"] = theta20
+    sid["foam_out"] = orc.siddon_project(foam, theta20, pad=True)
+    np.savez_compressed(os.path.join(OUT, "siddon.npz"), **sid)
+
+    # iradon
+    B, A, P, X, Y = 2, 12, 34, 20, 22
+    fbp = dict(sino=rng.random((B, A, P)), theta=np.linspace(0, np.pi, A, endpoint=False),
+               filt=np.abs(np.fft.fftfreq(P)) * 2, x_size=np.array(X), y_size=np.array(Y))
+    fbp["recon"] = orc.iradon(fbp["sino"], fbp["theta"], X, Y, fbp["filt"])
+    np.savez_compressed(os.path.join(OUT, "iradon.npz"), **fbp)
+
+    # log-likelihood epilogue
+    B, A, P = 3, 4, 23
+    proj = (rng.random((B, A, P), dtype=np.float32) * 60).astype(np.float32)
+    mask = np.full((B, A), 1 / 20, np.float32)
+    x = (rng.poisson(proj * mask[..., None] * 1e4) / 1e4).astype(np.float32)
+    eps = float(np.finfo(np.float32).eps)
+    np.savez_compressed(os.path.join(OUT, "loglik.npz"), proj=proj, mask=mask, x=x, pnm=np.array(1e4, np.float32),
+                        eps=np.array(eps, np.float32), out=orc.loglik(proj, mask, x, 1e4, eps))
+    print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""The C-ABI library loads on a GPU-less host and exports exactly what include/ctpvae_radon.h declares."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests.conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "ctpvae_radon.h")
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from ct_pvae_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "ct_pvae_amd", "csrc"), "-s"], check=True)
+    return _lib
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ctpvae_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    names = declared_symbols()
+    for must in ("ctpvae_rotate_fwd_f32", "ctpvae_rotate_bwd_f32", "ctpvae_rotate_transforms_f32",
+                 "ctpvae_siddon_fwd_f32", "ctpvae_fbp_filter_f64", "ctpvae_fbp_backproject_f64",
+                 "ctpvae_loglik_fwd_f32", "ctpvae_loglik_bwd_f32", "ctpvae_num_proj_pix", "ctpvae_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], check=True, capture_output=True,
+                         text=True).stdout
+    exported = set(re.findall(r"\bT (ctpvae_[a-z0-9_]+)", out))
+    assert exported == set(declared_symbols())
+
+
+def test_binding_table_matches_header(built_lib):
+    assert sorted(built_lib.SIGNATURES) == declared_symbols()
+    lib = built_lib.load()
+    assert lib.ctpvae_abi_version() == 1000
+
+
+def test_host_only_entry_points(built_lib):
+    import ctypes
+    lib = built_lib.load()
+    assert lib.ctpvae_num_proj_pix(128, 128) == 184
+    assert lib.ctpvae_num_proj_pix(512, 512) == 728
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    assert lib.ctpvae_pad_amounts(128, 184, ctypes.byref(lo), ctypes.byref(hi)) == 0
+    assert (lo.value, hi.value) == (28, 28)
+    assert lib.ctpvae_siddon_dx(128, 128, 1) == 184 and lib.ctpvae_siddon_dx(128, 128, 0) == 128
+
+
+def test_bad_arguments_are_reported_not_thrown(built_lib):
+    lib = built_lib.load()
+    assert lib.ctpvae_num_proj_pix(0, 5) == built_lib.EINVAL
+    assert "positive" in built_lib.last_error()
+    # null pointers are rejected before any HIP call, so this is safe without a GPU
+    rc = lib.ctpvae_rotate_fwd_f32(None, 1, 8, 8, 8, 8, 0, 0, None, 1, 0, None, None)
+    assert rc == built_lib.EINVAL and "null" in built_lib.last_error()
+    with pytest.raises(ValueError):
+        built_lib.check(rc, "rotate_fwd")
+
+
+def test_siddon_tables_match_oracle(built_lib, oracle):
+    """Host-side table builder of the product (libtomo's fmodf/sinf/cosf/quadrant) vs the oracle's inline one:
+    the oracle's toy and axis-aligned answers depend on these."""
+    import numpy as np
+    lib = built_lib.load()
+    theta = np.concatenate([np.linspace(0, np.pi, 180, endpoint=False), [-0.3, 3.5, 7.0, 2 * np.pi]]).astype(np.float32)
+    s, c = np.empty_like(theta), np.empty_like(theta)
+    q = np.empty(theta.size, np.int32)
+    assert lib.ctpvae_siddon_tables_f32(theta.ctypes.data, theta.size, s.ctypes.data, c.ctypes.data, q.ctypes.data) == 0
+    tp = np.fmod(theta, np.float32(2 * np.pi))
+    np.testing.assert_allclose(s, np.sin(tp.astype(np.float64)), atol=1e-7)
+    np.testing.assert_allclose(c, np.cos(tp.astype(np.float64)), atol=1e-7)
+    want_q = (((tp >= 0) & (tp < np.pi / 2)) | ((tp >= np.pi) & (tp < 1.5 * np.pi)) |
+              ((tp < 0) & (((tp + 2 * np.pi) < np.pi / 2) | (((tp + 2 * np.pi) >= np.pi) & ((tp + 2 * np.pi) < 1.5 * np.pi)))))
+    away = np.abs(np.mod(tp, np.pi / 2)) > 1e-5
+    np.testing.assert_array_equal(q[away], want_q[away].astype(np.int32))

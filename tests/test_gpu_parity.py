@@ -1,0 +1,293 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Bars (north_star: <=1e-5 relative fp32 vs. the reference projector on identical inputs):
+  * rotate forward and TensorFlow-compatible backward: every lane adds in the oracle's order and the index
+    arithmetic is unfused fp32, so NEAREST must be BIT-EXACT (no flipped sample possible) and BILINEAR as well;
+  * exact backward (atomics, order not fixed) and everything compared through a tolerance: max|diff| <= 1e-5 * max|ref|;
+  * siddon: bit-exact (same expressions, correctly rounded / and sqrt);
+  * iradon (fp64): 1e-10 relative (convolution vs. DFT ordering)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ct_pvae_amd as cp
+from ct_pvae_amd import _lib, phantoms
+from ct_pvae_amd.forward_functions import RotatePlan, rotate_tables
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+ROTATE_CASES = ["rotate_toy", "rotate_rand8", "rotate_rect_nopad", "rotate_rect_pad", "rotate_foam128_a20"]
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def rel_err(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_extension_is_loaded_and_sees_the_gpu():
+    lib = _lib.load()
+    assert os.path.samefile(_lib.LIB_PATH, os.path.join(os.path.dirname(cp.__file__), "libctpvae_radon.so"))
+    assert lib.ctpvae_device_count() >= 1
+    name = torch.cuda.get_device_properties(0).gcnArchName
+    assert "gfx950" in name, name
+
+
+def test_device_tables_match_oracle(oracle):
+    theta = np.concatenate([phantoms.dense_theta(180), [-1.0, 4.0, 0.3]])
+    for H, W in ((184, 184), (16, 12), (2, 2)):
+        T, Tinv = rotate_tables(theta, H, W, dev())
+        T0 = oracle.rotate_transforms(theta, H, W)
+        # cos/sin are fp64 evaluations rounded to fp32 on both sides: equal up to one rare double rounding
+        assert np.abs(to_np(T) - T0).max() <= 2e-5 and (to_np(T) != T0).mean() < 0.01
+        np.testing.assert_array_equal(to_np(Tinv), oracle.invert_transforms(to_np(T)))
+        # device-resident theta takes the uncached path and must give the same table
+        T2, _ = rotate_tables(torch.from_numpy(theta.astype(np.float32)).to(dev()), H, W, dev())
+        np.testing.assert_array_equal(to_np(T2), to_np(T))
+
+
+@pytest.mark.parametrize("name", ROTATE_CASES)
+@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
+def test_rotate_against_oracle_and_golden(oracle, golden_dir, name, interp):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    img, pad, theta, g = z["img"], bool(z["pad"]), z["theta"], z["g"]
+    code = 0 if interp == "nearest" else 1
+    plan = RotatePlan(theta, img.shape[1], img.shape[2], pad, dev(), interp=interp, backward="tf_compat")
+    geom = oracle.Geometry(img.shape[1], img.shape[2], pad)
+    T, Tinv = to_np(plan.T8), to_np(plan.Tinv8)   # the oracle sees the very tables the kernel uses
+    x = torch.from_numpy(img).to(dev())
+    gt = torch.from_numpy(g).to(dev())
+
+    fwd = to_np(plan.forward(x))
+    np.testing.assert_array_equal(fwd, oracle.rotate_fwd(img, geom, T, code))       # bit-exact
+    assert rel_err(fwd, z[f"fwd_{interp}"]) <= REL                                  # golden (host-built tables)
+
+    bwd = to_np(plan.backward(gt))
+    np.testing.assert_array_equal(bwd, oracle.rotate_bwd_tfcompat(g, geom, Tinv, code))
+    assert rel_err(bwd, z[f"bwd_tfcompat_{interp}"]) <= REL
+
+    plan_x = RotatePlan(theta, img.shape[1], img.shape[2], pad, dev(), interp=interp, backward="exact")
+    bx = to_np(plan_x.backward(gt))
+    assert rel_err(bx, oracle.rotate_bwd_exact(g, geom, T, code)) <= REL
+    assert rel_err(bx, z[f"bwd_exact_{interp}"]) <= REL
+
+
+def test_toy_known_answers_through_the_public_api():
+    # scripts/images_to_sinograms.py:54-59 / ctvae/toy_mcmc_v2_functions.py:41
+    x = torch.from_numpy(phantoms.toy_images()).to(dev())
+    theta = np.array([0, np.pi / 2])
+    for b, want in enumerate(([[.4, .6], [.7, .3]], [[.4, .6], [.3, .7]])):
+        out = cp.project_tf_fast(x[b], theta, pad=False, dim=2, integrate_vae=False)
+        assert out.shape == (2, 2, 1)
+        np.testing.assert_allclose(to_np(out)[..., 0], want, atol=2e-7)
+    out = cp.project_tf_fast(x[..., None], theta, pad=False, dim=2, integrate_vae=True)
+    assert out.shape == (2, 2, 2, 1)
+    np.testing.assert_allclose(to_np(out)[0, :, :, 0], [[.4, .6], [.7, .3]], atol=2e-7)
+    sid = cp.create_sinogram(phantoms.toy_images()[0], theta, pad=False)
+    np.testing.assert_allclose(sid, [[.4, .6], [.7, .3]], atol=2e-7)
+
+
+def test_public_layouts_match_the_reference(oracle):
+    rng = np.random.default_rng(0)
+    theta = rng.uniform(0, np.pi, 6)
+    d = dev()
+    # (i) integrate_vae: [B][X][Y][1] -> [B][A][P][1]          ctvae/helper_functions.py:359
+    x = rng.random((3, 12, 12, 1), dtype=np.float32)
+    got = cp.project_tf_fast(torch.from_numpy(x).to(d), theta, pad=True, dim=2, integrate_vae=True)
+    want = oracle.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+    assert got.shape == want.shape == (3, 6, 20, 1) and rel_err(to_np(got), want) <= REL
+    # (ii) dim=3: [X][Y][Z] -> [A][P][Z]                        ctvae/tomopy_forward_compare.py:52
+    x = rng.random((12, 10, 2), dtype=np.float32)
+    got = cp.project_tf_fast(torch.from_numpy(x).to(d), theta, pad=True)
+    want = oracle.project_tf_fast(x, theta, pad=True)
+    assert got.shape == want.shape and rel_err(to_np(got), want) <= REL
+    # (iii) dim=2: [X][Y] -> [A][P][1]                          ctvae/main_ct_vae.py:523-524
+    got = cp.project_tf_fast(torch.from_numpy(x[..., 0]).to(d), theta, pad=True, dim=2)
+    want = oracle.project_tf_fast(x[..., 0], theta, pad=True, dim=2)
+    assert got.shape == want.shape and rel_err(to_np(got), want) <= REL
+    # low_mem: bilinear, [X][Y][Z] -> [A][Y][Z]                 ctvae/tomopy_forward_compare.py:56
+    got = cp.project_tf_low_mem(torch.from_numpy(x).to(d), theta, pad=True)
+    want = oracle.project_tf_fast(x, theta, pad=True, interp=1)
+    assert got.shape == want.shape and rel_err(to_np(got), want) <= REL
+    # float64 pixels (the compare script feeds xdesign's float64) come back as float64
+    got64 = cp.project_tf_low_mem(torch.from_numpy(x.astype(np.float64)).to(d), theta, pad=True)
+    assert got64.dtype == torch.float64 and rel_err(to_np(got64), want) <= REL
+    # a theta tensor living on the device (the training loop) gives the same answer
+    got_t = cp.project_tf_fast(torch.from_numpy(x).to(d), torch.from_numpy(theta.astype(np.float32)).to(d), pad=True)
+    assert rel_err(to_np(got_t), oracle.project_tf_fast(x, theta, pad=True)) <= REL
+
+
+@pytest.mark.parametrize("backward", ["tf_compat", "exact"])
+def test_autograd_matches_the_raw_backward(oracle, backward):
+    rng = np.random.default_rng(1)
+    d = dev()
+    theta = rng.uniform(0, np.pi, 5)
+    x = torch.from_numpy(rng.random((2, 16, 16, 1), dtype=np.float32)).to(d).requires_grad_(True)
+    out = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True, backward=backward)
+    g = torch.from_numpy(rng.standard_normal(tuple(out.shape)).astype(np.float32)).to(d)
+    (out * g).sum().backward()
+    geom = oracle.Geometry(16, 16, True)
+    T = oracle.rotate_transforms(theta, geom.PH, geom.PW)
+    if backward == "tf_compat":
+        want = oracle.rotate_bwd_tfcompat(to_np(g)[..., 0], geom, oracle.invert_transforms(T), 0)
+    else:
+        want = oracle.rotate_bwd_exact(to_np(g)[..., 0], geom, T, 0)
+    assert x.grad.shape == x.shape
+    assert rel_err(to_np(x.grad)[..., 0], want) <= REL
+
+
+def test_exact_backward_is_the_transpose_at_full_size():
+    """Size-independent property at BASELINE's headline shape (B=50, 128x128, 20 angles): <Ax, g> == <x, A^T g>."""
+    d = dev()
+    rng = np.random.default_rng(2)
+    theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
+    for interp in ("nearest", "bilinear"):
+        plan = RotatePlan(theta, 128, 128, True, d, interp=interp, backward="exact")
+        x = torch.from_numpy(rng.standard_normal((50, 128, 128)).astype(np.float32)).to(d)
+        g = torch.from_numpy(rng.standard_normal((50, 20, 184)).astype(np.float32)).to(d)
+        lhs = (plan.forward(x).double() * g.double()).sum().item()
+        rhs = (x.double() * plan.backward(g).double()).sum().item()
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+
+
+def test_full_size_properties(oracle):
+    """BASELINE config 2 (B=50, N=128, 20 sparse angles) and the 180-angle evaluation set: linearity, slice
+    independence, axis-aligned analytic answers, and a sampled comparison with the oracle."""
+    d = dev()
+    foam = phantoms.foam_batch(50, 128, seed=0, supersample=2)
+    x = torch.from_numpy(foam).to(d)
+    theta180 = phantoms.dense_theta(180)
+    plan = RotatePlan(theta180, 128, 128, True, d)
+    s = plan.forward(x)
+    assert s.shape == (50, 180, 184)
+    sn = to_np(s)
+    # theta = 0: column sums; theta = pi/2 (index 90): reversed row sums (padded by 28 zeros each side)
+    np.testing.assert_allclose(sn[:, 0, 28:156], foam.sum(axis=1), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(sn[:, 90, 28:156], foam.sum(axis=2)[:, ::-1], rtol=1e-5, atol=1e-5)
+    assert np.all(sn[:, 0, :28] == 0) and np.all(sn[:, 0, 156:] == 0)
+    # slice independence and linearity
+    np.testing.assert_array_equal(to_np(plan.forward(x[7:8])), sn[7:8])
+    y = torch.roll(x, 1, 0)
+    lin = to_np(plan.forward(x + 2 * y))
+    assert rel_err(lin, sn + 2 * np.roll(sn, 1, 0)) <= REL
+    # three whole objects against the oracle, bit for bit
+    geom = oracle.Geometry(128, 128, True)
+    np.testing.assert_array_equal(sn[[0, 23, 49]], oracle.rotate_fwd(foam[[0, 23, 49]], geom, to_np(plan.T8), 0))
+    g = torch.from_numpy(np.random.default_rng(3).standard_normal((50, 180, 184)).astype(np.float32)).to(d)
+    b = to_np(plan.backward(g))
+    np.testing.assert_array_equal(b[[5, 31]], oracle.rotate_bwd_tfcompat(to_np(g)[[5, 31]], geom, to_np(plan.Tinv8), 0))
+
+
+def test_large_image_takes_the_no_lds_path(oracle):
+    """512x512 (BASELINE config 5) does not fit LDS; same numbers either way."""
+    d = dev()
+    rng = np.random.default_rng(4)
+    img = rng.random((1, 512, 512), dtype=np.float32)
+    theta = np.array([0.0, 0.4, np.pi / 2, 2.0])
+    plan = RotatePlan(theta, 512, 512, True, d)
+    assert plan.PW == 728
+    geom = oracle.Geometry(512, 512, True)
+    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
+                                  oracle.rotate_fwd(img, geom, to_np(plan.T8), 0))
+    g = rng.standard_normal((1, 4, 728)).astype(np.float32)
+    np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
+                                  oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0))
+
+
+def test_siddon_against_oracle_and_golden(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "siddon.npz"))
+    for case, pad in (("toy", False), ("rand", True), ("rect", True), ("foam", True)):
+        img, theta = z[case + "_img"], z[case + "_theta"]
+        got = cp.create_sinograms(img, theta, pad=pad)             # [S][A][dx]
+        want = np.swapaxes(z[case + "_out"], 0, 1)
+        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got[0], cp.create_sinogram(img[0], theta, pad=pad))
+    # dense 180-angle dataset geometry, 4 foam images (scripts/images_to_sinograms.py:34,61-68)
+    foam = phantoms.foam_batch(4, 128, seed=1, supersample=2)
+    theta = phantoms.dense_theta(180)
+    got = cp.create_sinograms(foam, theta, pad=True)
+    assert got.shape == (4, 180, 184)
+    np.testing.assert_array_equal(got, np.swapaxes(oracle.siddon_project(foam, theta, pad=True), 0, 1))
+
+
+def test_iradon_against_oracle_and_golden(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "iradon.npz"))
+    d = dev()
+    got = cp.iradon(torch.from_numpy(z["sino"]).to(d), z["theta"], int(z["x_size"]), int(z["y_size"]), z["filt"])
+    assert got.dtype == torch.float64
+    assert rel_err(to_np(got), z["recon"]) <= 1e-10
+    with pytest.raises(ValueError, match="does not match the number of"):
+        cp.iradon(torch.from_numpy(z["sino"]).to(d), z["theta"][:-1], 4, 4, z["filt"])
+    # full size: 128x128 from 180 x 184
+    rng = np.random.default_rng(0)
+    sino = rng.random((2, 180, 184))
+    theta = phantoms.dense_theta(180)
+    filt = np.abs(np.fft.fftfreq(184)) * 2
+    got = cp.iradon(torch.from_numpy(sino).to(d), theta, 128, 128, filt)
+    assert rel_err(to_np(got), oracle.iradon(sino, theta, 128, 128, filt)) <= 1e-10
+
+
+def test_loglik_against_oracle_golden_and_autograd(oracle, golden_dir):
+    z = np.load(os.path.join(golden_dir, "loglik.npz"))
+    d = dev()
+    proj = torch.from_numpy(z["proj"]).to(d).requires_grad_(True)
+    mask, x = torch.from_numpy(z["mask"]).to(d), torch.from_numpy(z["x"]).to(d)
+    pnm = torch.tensor(float(z["pnm"]), device=d, requires_grad=True)
+    eps = float(z["eps"])
+    out = cp.gaussian_poisson_log_prob(proj, mask, x, pnm, eps)
+    assert rel_err(to_np(out), z["out"]) <= 2e-6
+    out.sum().backward()
+    # reference formula in torch (float64, CPU) -> autograd
+    p64 = torch.from_numpy(z["proj"]).double().requires_grad_(True)
+    n64 = torch.tensor(float(z["pnm"]), dtype=torch.float64, requires_grad=True)
+    loc = p64 * torch.from_numpy(z["mask"]).double()[..., None]
+    scale = eps + torch.sqrt(loc / n64 + eps)
+    torch.distributions.Normal(loc, scale).log_prob(torch.from_numpy(z["x"]).double()).sum().backward()
+    assert rel_err(to_np(proj.grad), p64.grad.numpy()) <= 1e-4
+    assert abs(pnm.grad.item() - n64.grad.item()) <= 1e-3 * abs(n64.grad.item())
+
+
+def test_calculate_log_prob_M_given_R(oracle):
+    """The differentiated caller of the path, ctvae/helper_functions.py:336-368, with a random angle subset."""
+    rng = np.random.default_rng(5)
+    d = dev()
+    B, N, A_all, api = 3, 16, 12, 5
+    theta = np.linspace(0, np.pi, A_all, endpoint=False)
+    recon = rng.random((B, N, N, 1), dtype=np.float32)
+    mask = np.zeros((B, A_all), np.float32)
+    mask[:, ::2] = 1 / 6
+    P = cp.num_proj_pix(N, N)
+    meas = rng.random((B, A_all, P), dtype=np.float32)
+    angles_i = rng.permutation(A_all)[:api]
+    eps = float(np.finfo(np.float32).eps)
+    got = cp.calculate_log_prob_M_given_R(torch.from_numpy(recon).to(d), torch.from_numpy(mask).to(d),
+                                          torch.from_numpy(meas).to(d), 1e3, eps,
+                                          theta=torch.from_numpy(theta.astype(np.float32)).to(d),
+                                          angles_i=torch.from_numpy(angles_i).to(d), pad=True)
+    assert got.shape == (B, api, P, 1)
+    proj = oracle.project_tf_fast(recon, theta[angles_i], pad=True, dim=2, integrate_vae=True)[..., 0]
+    want = oracle.loglik(proj, mask[:, angles_i], meas[:, angles_i], 1e3, eps)
+    assert rel_err(to_np(got)[..., 0], want) <= 2e-5
+
+
+def test_bad_shapes_raise():
+    d = dev()
+    with pytest.raises(ValueError):
+        cp.project_tf_fast(torch.zeros(2, 8, 8, 3, device=d), np.array([0.0]), integrate_vae=True)
+    with pytest.raises(ValueError):
+        cp.project_tf_fast(torch.zeros(8, 8, device=d), np.array([0.0]), dim=3)
+    with pytest.raises(ValueError):
+        cp.project_tf_fast(torch.zeros(8, 8, device=d), np.zeros((2, 2)), dim=2)
+    with pytest.raises(ValueError):
+        cp.project_tf_fast(torch.zeros(8, 8, device=d), np.zeros(0), dim=2)

@@ -1,0 +1,75 @@
+"""Host-side logic of the drop-in operators that needs no GPU: size rule, pad_phantom layouts, argument checks,
+and the loud failure when no HIP device / extension is present."""
+import numpy as np
+import pytest
+import torch
+
+import ct_pvae_amd as cp
+from ct_pvae_amd import _lib, forward_functions as ff
+
+
+def test_size_rule_matches_oracle(oracle):
+    for nx, ny in [(2, 2), (128, 128), (512, 512), (100, 37), (1, 1), (33, 33)]:
+        assert cp.num_proj_pix(nx, ny) == oracle.num_proj_pix(nx, ny)
+        P = cp.num_proj_pix(nx, ny)
+        assert cp.pad_amounts(nx, P) == oracle.pad_amounts(nx, P)
+
+
+@pytest.mark.parametrize("shape,kw", [((4, 10, 7, 1), dict(integrate_vae=True)), ((10, 7, 3), dict(dim=3)),
+                                      ((10, 7), dict(dim=2)), ((3, 5, 5, 1), dict(dim=2, integrate_vae=True))])
+def test_pad_phantom_layouts(oracle, shape, kw):
+    # ctvae/forward_functions.py:38-45
+    rng = np.random.default_rng(0)
+    x = rng.random(shape, dtype=np.float32)
+    out = cp.pad_phantom(torch.from_numpy(x), **kw).numpy()
+    if kw.get("integrate_vae"):
+        slices = x[..., 0]
+        got = out[..., 0]
+        assert out.shape[0] == shape[0] and out.shape[3] == 1
+    elif kw.get("dim") == 3:
+        slices = np.transpose(x, (2, 0, 1))
+        got = np.transpose(out, (2, 0, 1))
+    else:
+        slices, got = x[None], out[None]
+    geom = oracle.Geometry(slices.shape[1], slices.shape[2], True)
+    np.testing.assert_array_equal(got, oracle.pad_phantom(slices, geom))
+
+
+def test_no_cpu_fallback():
+    x = torch.zeros(8, 8)
+    with pytest.raises(_lib.RadonLibraryError, match="no CPU path"):
+        cp.project_tf_fast(x, np.array([0.0]), pad=True, dim=2)
+    with pytest.raises(_lib.RadonLibraryError, match="no CPU path"):
+        cp.project_tf_low_mem(torch.zeros(8, 8, 2), np.array([0.0]))
+    with pytest.raises(_lib.RadonLibraryError):
+        cp.iradon(torch.zeros(1, 3, 8), np.zeros(3), 4, 4, np.ones(8))
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.RadonLibraryError):
+            cp.create_sinogram(np.zeros((8, 8), np.float32), np.array([0.0]))
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.RadonLibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_argument_checks():
+    with pytest.raises(ValueError):
+        ff.RotatePlan(np.array([0.0]), 8, 8, True, "cuda", interp="cubic")
+    with pytest.raises(ValueError):
+        ff.RotatePlan(np.array([0.0]), 8, 8, True, "cuda", backward="autodiff")
+    with pytest.raises(TypeError):
+        cp.project_tf_fast(np.zeros((8, 8)), np.array([0.0]), dim=2)
+    with pytest.raises(ValueError):
+        cp.pad_phantom(torch.zeros(4, 4), dim=5)
+
+
+def test_phantoms_are_seeded_and_in_range():
+    from ct_pvae_amd import phantoms
+    a, b = phantoms.foam_batch(2, 32, seed=0, supersample=4), phantoms.foam_batch(2, 32, seed=0, supersample=4)
+    np.testing.assert_array_equal(a, b)
+    assert a.dtype == np.float32 and a.min() >= 0 and a.max() <= 1 and 0.05 < a.mean() < 0.8
+    assert list(phantoms.sparse_angle_indices(180, 20)) == list(range(0, 180, 9))
+    np.testing.assert_allclose(phantoms.dense_theta(180), np.pi * np.arange(180) / 180)

@@ -1,0 +1,228 @@
+"""CPU tests of the oracle (oracle/radon_oracle.c): the known answers the reference's own code holds, the size
+identities, analytic axis-aligned cases, structural properties, and agreement with a literal numpy restatement
+of the TensorFlow op chain.  PARITY UNPINNED beyond these: the reference ships no numeric fixtures."""
+import math
+
+import numpy as np
+import pytest
+
+from ct_pvae_amd import phantoms
+from tests import np_twin
+
+NEAREST, BILINEAR = 0, 1
+
+
+# ---- what the reference itself pins ---------------------------------------------------------------------
+def test_size_identities(oracle):
+    # ctvae/forward_functions.py:29-36 ; ctvae/main_ct_vae.py:160-161 inverts it
+    assert oracle.num_proj_pix(128, 128) == 184
+    assert oracle.num_proj_pix(512, 512) == 728
+    assert oracle.pad_amounts(128, 184) == (28, 28)
+    assert oracle.pad_amounts(512, 728) == (108, 108)
+    assert oracle.pad_amounts(5, 10) == (2, 3)  # odd remainder on the high side
+    for n in (2, 3, 64, 100, 128, 200, 512):
+        P = oracle.num_proj_pix(n, n)
+        assert P % 2 == 0 and P >= math.sqrt(2) * n + 2
+    assert math.floor(184 / math.sqrt(2) - 2) == 128  # the one size the reference uses it for
+    assert math.floor(728 / math.sqrt(2) - 2) == 512
+    assert oracle.lib().oracle_siddon_dx(128, 128, 1) == 184
+    assert oracle.lib().oracle_siddon_dx(2, 2, 0) == 2
+
+
+def test_toy_known_answers_rotate(oracle):
+    # scripts/images_to_sinograms.py:54-59 with the images of scripts/create_toy_images.py:36-40
+    x = phantoms.toy_images()
+    theta = np.array([0, np.pi / 2])
+    for interp in (NEAREST, BILINEAR):
+        for b, want in enumerate(([[.4, .6], [.7, .3]], [[.4, .6], [.3, .7]])):
+            got = oracle.project_tf_fast(x[b], theta, pad=False, dim=2, interp=interp)  # ctvae/toy_mcmc_v2_functions.py:41
+            assert got.shape == (2, 2, 1)
+            np.testing.assert_allclose(got[..., 0], want, rtol=0, atol=2e-7)
+    # the script's vectorised form
+    proj_0 = np.sum(x, axis=1)
+    proj_1 = np.sum(x, axis=2)[::-1]
+    want = np.stack((proj_0, proj_1), axis=1)
+    got = oracle.project_tf_fast(x[..., None], theta, pad=False, dim=2, integrate_vae=True)[..., 0]
+    np.testing.assert_allclose(got, want, atol=2e-7)
+
+
+def test_toy_known_answers_siddon(oracle):
+    x = phantoms.toy_images()
+    theta = np.array([0, np.pi / 2])
+    np.testing.assert_allclose(oracle.create_sinogram(x[0], theta, pad=False), [[.4, .6], [.7, .3]], atol=2e-7)
+    np.testing.assert_allclose(oracle.create_sinogram(x[1], theta, pad=False), [[.4, .6], [.3, .7]], atol=2e-7)
+
+
+# ---- analytic axis-aligned cases --------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 5, 8, 16, 33])
+@pytest.mark.parametrize("pad", [False, True])
+def test_axis_aligned_rotate(oracle, n, pad):
+    rng = np.random.default_rng(n)
+    img = rng.random((n, n), dtype=np.float32)
+    for interp in (NEAREST, BILINEAR):
+        got = oracle.project_tf_fast(img, np.array([0.0, np.pi / 2]), pad=pad, dim=2, interp=interp)[..., 0]
+        P = got.shape[1]
+        lo = (P - n) // 2
+        col = np.zeros(P, np.float32)
+        col[lo:lo + n] = np_twin.seq_sum(img, 0)
+        row = np.zeros(P, np.float32)
+        row[lo:lo + n] = np_twin.seq_sum(img, 1)
+        tol = dict(rtol=0, atol=0) if interp == NEAREST else dict(rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got[0], col, **tol)          # theta = 0: column sums
+        np.testing.assert_allclose(got[1], row[::-1], **tol)    # theta = pi/2: reversed row sums
+
+
+@pytest.mark.parametrize("n", [2, 8, 16])
+def test_axis_aligned_siddon(oracle, n):
+    # even sizes only: with an odd side and libtomo's even detector the rays run ON the pixel boundaries
+    rng = np.random.default_rng(n)
+    img = rng.random((n, n), dtype=np.float32)
+    got = oracle.create_sinogram(img, np.array([0.0, np.pi / 2]), pad=True)
+    P = got.shape[1]
+    lo = (P - n) // 2
+    np.testing.assert_allclose(got[0, lo:lo + n], img.sum(0), rtol=2e-6)
+    np.testing.assert_allclose(got[1, lo:lo + n], img.sum(1)[::-1], rtol=2e-5)
+    assert np.all(got[:, :lo] == 0) and np.all(got[:, lo + n:] == 0)
+
+
+# ---- the fused formulas mean the literal TF op chain ------------------------------------------------------
+@pytest.mark.parametrize("interp", [NEAREST, BILINEAR])
+@pytest.mark.parametrize("shape,pad", [((9, 9), True), ((16, 16), True), ((12, 7), True), ((10, 10), False),
+                                       ((6, 11), False)])
+def test_oracle_equals_literal_chain(oracle, interp, shape, pad):
+    rng = np.random.default_rng(7)
+    S, A = 2, 7
+    img = rng.standard_normal((S,) + shape).astype(np.float32)
+    theta = rng.uniform(0, np.pi, A)
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    T = oracle.rotate_transforms(theta, geom.PH, geom.PW)
+    Tinv = oracle.invert_transforms(T)
+    canvas = oracle.pad_phantom(img, geom)
+    assert canvas.shape == (S, geom.PH, geom.PW)
+    fwd = oracle.rotate_fwd(img, geom, T, interp)
+    np.testing.assert_array_equal(fwd, np_twin.project_chain(canvas, T, interp))
+    g = rng.standard_normal(fwd.shape).astype(np.float32)
+    bwd = oracle.rotate_bwd_tfcompat(g, geom, Tinv, interp)
+    full = np_twin.project_chain_grad(g, Tinv, interp, geom.PH)
+    crop = full[:, geom.py:geom.py + geom.H, geom.px:geom.px + geom.W]
+    np.testing.assert_array_equal(bwd, crop)
+
+
+def test_inverse_transform_is_rotation_back(oracle):
+    theta = np.linspace(0, np.pi, 20, endpoint=False)
+    T = oracle.rotate_transforms(theta, 184, 184)
+    Tinv = oracle.invert_transforms(T)
+    Tback = oracle.rotate_transforms(-theta, 184, 184)  # analytic inverse: rotation by +theta about the centre
+    np.testing.assert_allclose(Tinv[:, :6], Tback[:, :6], atol=3e-5)
+    np.testing.assert_array_equal(T[:, 6:], 0)
+    # tables follow tfa's formula with correctly rounded cos/sin
+    ang = (-theta.astype(np.float32)).astype(np.float64)
+    np.testing.assert_array_equal(T[:, 0], np.cos(ang).astype(np.float32))
+    np.testing.assert_array_equal(T[:, 3], np.sin(ang).astype(np.float32))
+    np.testing.assert_array_equal(T[:, 1], -T[:, 3])
+
+
+# ---- structural properties --------------------------------------------------------------------------------
+@pytest.mark.parametrize("interp", [NEAREST, BILINEAR])
+def test_linearity_and_slice_independence(oracle, interp):
+    rng = np.random.default_rng(3)
+    geom = oracle.Geometry(16, 16, True)
+    T = oracle.rotate_transforms(rng.uniform(0, np.pi, 5), geom.PH, geom.PW)
+    x, y = rng.random((2, 3, 16, 16), dtype=np.float32)
+    fx, fy = oracle.rotate_fwd(x, geom, T, interp), oracle.rotate_fwd(y, geom, T, interp)
+    np.testing.assert_allclose(oracle.rotate_fwd(x + 2 * y, geom, T, interp), fx + 2 * fy, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(oracle.rotate_fwd(x[1:2], geom, T, interp), fx[1:2])
+
+
+@pytest.mark.parametrize("interp", [NEAREST, BILINEAR])
+@pytest.mark.parametrize("pad", [True, False])
+def test_exact_backward_is_the_transpose(oracle, interp, pad):
+    rng = np.random.default_rng(11)
+    geom = oracle.Geometry(14, 14, pad)
+    T = oracle.rotate_transforms(rng.uniform(0, np.pi, 6), geom.PH, geom.PW)
+    x = rng.standard_normal((2, 14, 14)).astype(np.float32)
+    g = rng.standard_normal((2, 6, geom.PW)).astype(np.float32)
+    lhs = np.vdot(oracle.rotate_fwd(x, geom, T, interp).astype(np.float64), g.astype(np.float64))
+    rhs = np.vdot(x.astype(np.float64), oracle.rotate_bwd_exact(g, geom, T, interp).astype(np.float64))
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
+def test_mass_is_conserved_by_bilinear_and_siddon(oracle):
+    img = phantoms.foam_batch(1, 32, seed=5, supersample=4)[0]
+    theta = np.linspace(0, np.pi, 12, endpoint=False)
+    total = img.sum(dtype=np.float64)
+    bil = oracle.project_tf_fast(img, theta, pad=True, dim=2, interp=BILINEAR)[..., 0]
+    np.testing.assert_allclose(bil.sum(axis=1, dtype=np.float64), total, rtol=2e-2)
+    sid = oracle.create_sinogram(img, theta, pad=True)
+    np.testing.assert_allclose(sid.sum(axis=1, dtype=np.float64), total, rtol=2e-3)
+    near = oracle.project_tf_fast(img, theta, pad=True, dim=2, interp=NEAREST)[..., 0]
+    np.testing.assert_allclose(near.sum(axis=1, dtype=np.float64), total, rtol=5e-2)
+    # the two discretisations see the same object (loose: they are different operators)
+    assert np.abs(sid - bil).max() < 0.15 * bil.max()
+
+
+def test_siddon_layouts(oracle):
+    rng = np.random.default_rng(2)
+    obj = rng.random((3, 9, 9), dtype=np.float32)
+    theta = np.linspace(0, np.pi, 5, endpoint=False)
+    out = oracle.siddon_project(obj, theta, pad=True)
+    assert out.shape == (5, 3, oracle.lib().oracle_siddon_dx(9, 9, 1))
+    for s in range(3):
+        np.testing.assert_array_equal(out[:, s], oracle.create_sinogram(obj[s], theta, pad=True))
+
+
+# ---- a6: iradon -------------------------------------------------------------------------------------------
+def _ramp(P):
+    # skimage.transform.radon_transform._get_fourier_filter(P, 'ramp') (scikit-image 0.18), squeezed
+    n = np.concatenate((np.arange(1, P / 2 + 1, 2, dtype=int), np.arange(P / 2 - 1, 0, -2, dtype=int)))
+    f = np.zeros(P)
+    f[0] = 0.25
+    f[1::2] = -1 / (np.pi * n) ** 2
+    return 2 * np.real(np.fft.fft(f))
+
+
+def test_iradon_matches_numpy_restatement(oracle):
+    rng = np.random.default_rng(0)
+    B, A, P, X, Y = 2, 9, 24, 10, 12
+    sino = rng.random((B, A, P))
+    theta = np.linspace(0, np.pi, A, endpoint=False)
+    filt = _ramp(P)
+    got = oracle.iradon(sino, theta, X, Y, filt)
+    # ctvae/fbp_tensorflow.py:49-74 literally
+    radon_filtered = np.real(np.fft.ifft(np.fft.fft(sino.astype(np.complex128)) * filt))
+    xpr, ypr = np.meshgrid(np.arange(X) - X / 2, np.arange(Y) - Y / 2, indexing="ij")
+    coords = np.arange(P) - P / 2
+    want = np.zeros((B, X, Y))
+    for a in range(A):
+        t = ypr * np.cos(theta[a]) - xpr * np.sin(theta[a])
+        for b in range(B):
+            want[b] += np.interp(t, coords, radon_filtered[b, a])  # constant extension outside the grid
+    want *= np.pi / (2 * A)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+
+
+def test_iradon_reconstructs_a_disc(oracle):
+    n = 32
+    P = oracle.num_proj_pix(n, n)
+    yy, xx = np.mgrid[:n, :n]
+    img = (((xx - n / 2 + .5) ** 2 + (yy - n / 2 + .5) ** 2) < (n / 4) ** 2).astype(np.float32)
+    theta = np.linspace(0, np.pi, 60, endpoint=False)
+    sino = oracle.project_tf_fast(img, theta, pad=True, dim=2, interp=BILINEAR)[..., 0][None]
+    rec = oracle.iradon(sino, theta, n, n, _ramp(P))[0]
+    inside, outside = rec[img > 0.5].mean(), rec[img < 0.5].mean()
+    assert inside > 0.8 and abs(outside) < 0.1
+
+
+# ---- a8 ---------------------------------------------------------------------------------------------------
+def test_loglik_matches_scipy(oracle):
+    from scipy.stats import norm
+    rng = np.random.default_rng(1)
+    B, A, P = 2, 3, 17
+    proj = rng.random((B, A, P), dtype=np.float32) * 40
+    mask = np.full((B, A), 1 / 20, np.float32)
+    x = (proj * mask[..., None] + rng.standard_normal((B, A, P)).astype(np.float32) * 0.02).astype(np.float32)
+    eps = float(np.finfo(np.float32).eps)
+    got = oracle.loglik(proj, mask, x, 1e4, eps)
+    loc = proj.astype(np.float64) * mask[..., None]
+    want = norm.logpdf(x, loc=loc, scale=eps + np.sqrt(loc / 1e4 + eps))
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
