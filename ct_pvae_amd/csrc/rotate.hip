@@ -11,6 +11,9 @@
 // bank) and every lane owns one ray (angle a, detector bin j), walking the canvas rows i = 0..PH-1 in
 // order -- the same summation order as reduce_sum(axis=1) on the reference, so results are
 // reproducible bit for bit against the CPU restatement.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ctpvae {
@@ -85,6 +88,216 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float *__restrict
     }
 }
 
+// ---- forward, fast path: zero-bordered LDS image, clipped row range, no per-sample bounds test ----
+//
+// The slice is staged with a zero border of BORDER pixels (1 for NEAREST, 2 for BILINEAR) and an odd
+// row pitch.  A sample's integer tap is clamped onto that border with one v_med3_i32 per coordinate, so
+// a tap outside the core reads an exact 0 without a compare/select.  Each lane first clips its ray
+// against the core (conservatively, in floats), then all lanes of a wave walk the same NUMBER of rows
+// from their own first row -- rows outside the clipped range only ever contribute +0.0f, and a lane
+// whose range is short is shifted so that it stays inside [0, PH): every visited row is a legitimate
+// term of the sum, taken in ascending order, so the result is still bit-identical to the oracle.
+//
+// Rounding: v_cvt_rpi_i32_f32 is floor(x + 0.5) evaluated exactly (tools/probe_rpi.hip).  It differs
+// from round-half-away-from-zero only at negative ties; of those only x == -0.5 can reach a live
+// pixel, and only when the canvas has no padding on that side (TIE_FIX).
+__device__ __forceinline__ int cvt_rpi(float v)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ int cvt_flr(float v)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ int med3i(int v, int lo, int hi)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// an opaque copy in a VGPR: keeps loop-invariant operands of the asm helpers out of the loop body
+__device__ __forceinline__ int pin_vgpr(int v)
+{
+    int r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+    return r;
+}
+typedef const __attribute__((address_space(3))) float *lds_cptr;
+
+// LDS byte address (absolute, the LDS base is folded into off4) of the clamped NEAREST tap of (x, y):
+//   rpi both coordinates, clamp onto the zero border, row * pitch4 + col * 4 + off4.
+// One asm block: hipcc pads every asm statement with s_nop, so the six dependent VALU ops stay together.
+__device__ __forceinline__ int nearest_tap_addr(float x, float y, int xlo, int xhi, int ylo, int yhi, int pitch4,
+                                                int off4)
+{
+    int col, row;
+    asm("v_cvt_rpi_i32_f32 %0, %2\n\t"
+        "v_cvt_rpi_i32_f32 %1, %3\n\t"
+        "v_med3_i32 %0, %0, %4, %5\n\t"
+        "v_med3_i32 %1, %1, %6, %7\n\t"
+        "v_mad_i32_i24 %1, %1, %8, %9\n\t"
+        "v_lshl_add_u32 %0, %0, 2, %1"
+        : "=&v"(col), "=&v"(row)
+        : "v"(x), "v"(y), "v"(xlo), "v"(xhi), "v"(ylo), "v"(yhi), "s"(pitch4), "v"(off4));
+    return col;
+}
+// same for the top-left BILINEAR tap: floor instead of round
+__device__ __forceinline__ int floor_tap_addr(float x, float y, int xlo, int xhi, int ylo, int yhi, int pitch4,
+                                              int off4)
+{
+    int col, row;
+    asm("v_cvt_flr_i32_f32 %0, %2\n\t"
+        "v_cvt_flr_i32_f32 %1, %3\n\t"
+        "v_med3_i32 %0, %0, %4, %5\n\t"
+        "v_med3_i32 %1, %1, %6, %7\n\t"
+        "v_mad_i32_i24 %1, %1, %8, %9\n\t"
+        "v_lshl_add_u32 %0, %0, 2, %1"
+        : "=&v"(col), "=&v"(row)
+        : "v"(x), "v"(y), "v"(xlo), "v"(xhi), "v"(ylo), "v"(yhi), "s"(pitch4), "v"(off4));
+    return col;
+}
+__device__ __forceinline__ float lds_abs(int byte_addr) { return *(lds_cptr)(uintptr_t)(unsigned)byte_addr; }
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// rows [lo, hi) of the canvas on which base + slope*i may fall inside [L, U]
+__device__ __forceinline__ void clip_rows(float base, float slope, float L, float U, float &lo, float &hi)
+{
+    if (fabsf(slope) < 1e-6f) {
+        // |slope * i| < 1e-6 * 2^24: treat as constant, with a margin far above that drift
+        if (base < L - 1.0f || base > U + 1.0f) hi = -1.0f;
+    } else {
+        const float inv = 1.0f / slope;
+        const float i1 = (L - base) * inv, i2 = (U - base) * inv;
+        lo = fmaxf(lo, fminf(i1, i2));
+        hi = fminf(hi, fmaxf(i1, i2));
+    }
+}
+
+template <int INTERP, bool TIE_FIX>
+__global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom g,
+                                                               const float *__restrict__ T8, int rays_per_blk,
+                                                               float *__restrict__ sino)
+{
+    constexpr int BORDER = (INTERP == CTPVAE_NEAREST) ? 1 : 2;
+    extern __shared__ float lds[];
+    const int s = blockIdx.y;
+    const float *im = img + (size_t)s * g.H * g.W;
+    const int wb = g.W + 2 * BORDER;
+    const int pitch = wb | 1;  // odd pitch: a wave walking a column touches 32 different banks
+    const int hb = g.H + 2 * BORDER;
+
+    // zero border (top/bottom rows, left/right columns), then the core
+    for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
+        const int r = p / pitch, c = p - r * pitch;
+        lds[(r < BORDER ? r : hb - 2 * BORDER + r) * pitch + c] = 0.0f;
+    }
+    for (int p = threadIdx.x; p < g.H * (pitch - g.W); p += blockDim.x) {
+        const int r = p / (pitch - g.W), c = p - r * (pitch - g.W);
+        lds[(r + BORDER) * pitch + (c < BORDER ? c : g.W + c)] = 0.0f;
+    }
+    if ((g.W & 3) == 0) {
+        const int w4 = g.W >> 2;
+        const float4 *im4 = reinterpret_cast<const float4 *>(im);
+        for (int p = threadIdx.x; p < g.H * w4; p += blockDim.x) {
+            const int r = p / w4, c = (p - r * w4) << 2;
+            const float4 v = im4[p];
+            float *dst = lds + (r + BORDER) * pitch + BORDER + c;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    } else {
+        for (int p = threadIdx.x; p < g.H * g.W; p += blockDim.x) {
+            const int r = p / g.W, c = p - r * g.W;
+            lds[(r + BORDER) * pitch + BORDER + c] = im[p];
+        }
+    }
+    __syncthreads();
+
+    const int nrays = g.A * g.PW;
+    const int ray0 = blockIdx.x * rays_per_blk;
+    const int ray_end = min(ray0 + rays_per_blk, nrays);
+    // clamp bounds in canvas coordinates and the matching LDS offset
+    const int xlo = g.px - BORDER, xhi = g.px + g.W + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
+    const int ylo = g.py - BORDER, yhi = g.py + g.H + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
+    // clamp bounds pinned in VGPRs (v_med3_i32 takes them as is), byte pitch, byte offset of canvas (0, 0)
+    const int xlo_v = pin_vgpr(xlo), xhi_v = pin_vgpr(xhi), ylo_v = pin_vgpr(ylo), yhi_v = pin_vgpr(yhi);
+    const int pitch4 = pitch * 4;
+    const int off4_v = pin_vgpr(-(ylo * pitch + xlo) * 4 + (int)(uintptr_t)(lds_cptr)lds);
+
+    for (int rbase = ray0; rbase < ray_end; rbase += blockDim.x) {
+        const int ray = rbase + threadIdx.x;
+        const bool live = ray < ray_end;
+        const int rr = live ? ray : ray_end - 1;
+        const int a = rr / g.PW;
+        const int j = rr - a * g.PW;
+        const float *t = T8 + 8 * a;
+        const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+        const float xj = t0 * (float)j, yj = t3 * (float)j;
+
+        // conservative row range of this ray through the core (margins of >= 1.5 px, fp error << that)
+        float lo = 0.0f, hi = (float)g.PH;
+        clip_rows(xj + t2, t1, (float)(g.px - 2), (float)(g.px + g.W + 1), lo, hi);
+        clip_rows(yj + t5, t4, (float)(g.py - 2), (float)(g.py + g.H + 1), lo, hi);
+        lo = fminf(fmaxf(lo, 0.0f), (float)g.PH);
+        hi = fminf(fmaxf(hi, -1.0f), (float)g.PH);
+        int ilo = max((int)floorf(lo) - 1, 0);
+        const int ihi = min((int)ceilf(hi) + 2, g.PH);
+        const int cnt = live ? max(ihi - ilo, 0) : 0;
+        const int kmax = __builtin_amdgcn_readfirstlane(wave_max(cnt));  // wave-uniform trip count (SGPR)
+        ilo = max(min(ilo, g.PH - kmax), 0);     // keep ilo + kmax <= PH: only legitimate rows are visited
+
+        // packed fp32 coordinate math: (x, y) = ((xj, yj) + (t1, t4) * i) + (t2, t5) -- v_pk_mul_f32 / v_pk_add_f32,
+        // separate multiply and adds exactly as the scalar expression
+        const f32x2 base = {xj, yj}, step = {t1, t4}, shift = {t2, t5};
+        f32x2 fi2 = {(float)ilo, (float)ilo};
+        const f32x2 one2 = {1.0f, 1.0f};
+        float acc = 0.0f;
+        auto sample = [&]() -> float {
+            const f32x2 xy = (base + step * fi2) + shift;
+            fi2 += one2;
+            const float x = xy.x, y = xy.y;
+            if (INTERP == CTPVAE_NEAREST) {
+                if (TIE_FIX) {
+                    // x == -0.5 must round to -1 (dead); steer it below the clamp range instead of to pixel 0
+                    const float xs = (x == -0.5f) ? -1.0f : x, ys = (y == -0.5f) ? -1.0f : y;
+                    return lds_abs(nearest_tap_addr(xs, ys, xlo_v, xhi_v, ylo_v, yhi_v, pitch4, off4_v));
+                }
+                return lds_abs(nearest_tap_addr(x, y, xlo_v, xhi_v, ylo_v, yhi_v, pitch4, off4_v));
+            } else {
+                const float xf = floorf(x), yf = floorf(y);
+                const float xc = xf + 1.0f, yc = yf + 1.0f;
+                const int ad = floor_tap_addr(x, y, xlo_v, xhi_v, ylo_v, yhi_v, pitch4, off4_v);
+                const float v00 = lds_abs(ad), v01 = lds_abs(ad + 4);
+                const float v10 = lds_abs(ad + pitch4), v11 = lds_abs(ad + pitch4 + 4);
+                const float v_yf = (xc - x) * v00 + (x - xf) * v01;
+                const float v_yc = (xc - x) * v10 + (x - xf) * v11;
+                return (yc - y) * v_yf + (y - yf) * v_yc;
+            }
+        };
+        int k = 0;
+        for (; k + 4 <= kmax; k += 4) {   // four independent gathers in flight, added in row order
+            const float v0 = sample(), v1 = sample(), v2 = sample(), v3 = sample();
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+        }
+        for (; k < kmax; ++k) acc += sample();
+        if (live) sino[(size_t)s * nrays + ray] = acc;
+    }
+}
+
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
 // G_a[y][x] = sample(row-broadcast image of g[a][:], Tinv_a(x, y)); gimg = crop(sum_a G_a).
 __device__ __forceinline__ float bcast_read(const float *grow, int PH, int PW, int iy, int ix)
@@ -150,6 +363,87 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_kernel(const float *_
         if (k >= px_per_thread) break;
         const int p = base + k * blockDim.x + threadIdx.x;
         if (p < npix) gimg[(size_t)s * npix + p] = acc[k];
+    }
+}
+
+// ---- backward, TensorFlow-compatible, fast path ---------------------------------------------------
+//
+// One wave owns 64 consecutive columns of one image row at a time; a thread keeps PPT pixels of ONE
+// column (rows r0, r0+RS, ...) in registers, so t0*x and t3*x are computed once per angle and thread.
+// The cotangent rows of a chunk of angles sit in LDS with zero cells on both sides; a tap that TensorFlow
+// would zero-fill is steered to a zero cell with one select, so the gather needs no branch.  Transform
+// rows are wave-uniform and come through scalar loads.  Every pixel adds its angles in ascending order
+// (bit-identical to the oracle).
+//
+// NEAREST: a tap is live iff -0.5 < x' < PW-0.5 and -0.5 < y' < PH-0.5 (round half away from zero lands in
+// [0, P)); inside that interval v_cvt_rpi_i32_f32 equals the reference rounding exactly.
+template <int INTERP, int PPT>
+__global__ __launch_bounds__(256) void rotate_bwd_tfcompat_fast_kernel(const float *__restrict__ gsino, RotGeom g,
+                                                                       const float *__restrict__ Tinv8, int chunk_a,
+                                                                       float *__restrict__ gimg)
+{
+    constexpr int ZL = (INTERP == CTPVAE_NEAREST) ? 0 : 2;   // zero cells in front of a cotangent row
+    constexpr int ZR = (INTERP == CTPVAE_NEAREST) ? 1 : 2;   // ... and behind it
+    extern __shared__ float lds[];
+    const int pitchg = g.PW + ZL + ZR;
+    const int s = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + lane;                     // column of this thread
+    const int r0 = blockIdx.y * (nwaves * PPT) + wave;        // first row; rows step by nwaves
+    const bool col_ok = c < g.W;
+    const float fx = (float)(c + g.px);
+    const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
+
+    float acc[PPT];
+    float fy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        acc[k] = 0.0f;
+        fy[k] = (float)(r0 + k * nwaves + g.py);
+    }
+
+    for (int ac = 0; ac < g.A; ac += chunk_a) {
+        const int na = min(chunk_a, g.A - ac);
+        __syncthreads();
+        const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
+        for (int p = threadIdx.x; p < na * pitchg; p += blockDim.x) {
+            const int al = p / pitchg, q = p - al * pitchg - ZL;
+            lds[p] = ((unsigned)q < (unsigned)g.PW) ? src[(size_t)al * g.PW + q] : 0.0f;
+        }
+        __syncthreads();
+        for (int al = 0; al < na; ++al) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);   // wave-uniform: scalar loads
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+            const float *grow = lds + al * pitchg + ZL;
+            const float xa = t0 * fx, ya = t3 * fx;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const float x = (xa + t1 * fy[k]) + t2;
+                const float y = (ya + t4 * fy[k]) + t5;
+                if (INTERP == CTPVAE_NEAREST) {
+                    const bool ok = (x > -0.5f) & (x < x_hi) & (y > -0.5f) & (y < y_hi);
+                    const int ixr = cvt_rpi(x);                // unconditional: no branch around the gather
+                    const int ix = ok ? ixr : g.PW;            // g.PW is the zero cell
+                    acc[k] += grow[ix];
+                } else {
+                    const float xf = floorf(x), yf = floorf(y);
+                    const float xc = xf + 1.0f, yc = yf + 1.0f;
+                    const int ix = med3i(cvt_flr(x), -2, g.PW);
+                    const float h = (xc - x) * grow[ix] + (x - xf) * grow[ix + 1];
+                    // row taps: yf and yf+1 must lie in [0, PH)
+                    const float v_yf = ((yf >= 0.0f) & (yf < (float)g.PH)) ? h : 0.0f;
+                    const float v_yc = ((yc >= 0.0f) & (yc < (float)g.PH)) ? h : 0.0f;
+                    acc[k] += (yc - y) * v_yf + (y - yf) * v_yc;
+                }
+            }
+        }
+    }
+    if (col_ok) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int r = r0 + k * nwaves;
+            if (r < g.H) gimg[((size_t)s * g.H + r) * g.W + c] = acc[k];
+        }
     }
 }
 
@@ -257,6 +551,37 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
     CTPVAE_REQUIRE(img_dev && T8_dev && sino_dev, "rotate_fwd: null pointer");
     if (int rc = check_geom("rotate_fwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     const RotGeom g{S, H, W, PH, PW, py, px, A};
+
+    // fast path: the zero-bordered slice must fit LDS
+    const int border = interp == CTPVAE_NEAREST ? 1 : 2;
+    const size_t fast_lds = (size_t)(H + 2 * border) * ((W + 2 * border) | 1) * sizeof(float);
+    if (fast_lds <= (size_t)kMaxLdsBytes && getenv("CTPVAE_FORCE_GENERIC") == nullptr) {
+        // rays per workgroup: about two workgroups per CU over the whole launch, whole waves, <= 1024
+        const long long nrays = (long long)A * PW;
+        long long rpb = ceil_div((int)std::min<long long>(nrays * S, 1ll << 30), 512);
+        rpb = std::max<long long>(64, std::min<long long>(rpb, nrays));
+        rpb = (rpb + 63) / 64 * 64;
+        const int block = (int)std::min<long long>(rpb, fast_lds > 80 * 1024 ? 1024 : 512);
+        const dim3 grid((unsigned)((nrays + rpb - 1) / rpb), S);
+        const bool tie_fix = (px == 0 || py == 0);
+        auto launch = [&](auto kernel) -> int {
+            static bool attr_set = false;  // one flag per instantiation (the lambda is instantiated per kernel)
+            if (!attr_set) {
+                CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               kMaxLdsBytes));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(kernel, grid, dim3(block), fast_lds, (hipStream_t)stream, img_dev, g, T8_dev,
+                               (int)rpb, sino_dev);
+            CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel");
+            return CTPVAE_OK;
+        };
+        if (interp == CTPVAE_NEAREST)
+            return tie_fix ? launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true>)
+                           : launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false>);
+        return launch(rotate_fwd_fast_kernel<CTPVAE_BILINEAR, false>);
+    }
+
     const size_t lds_bytes = (size_t)H * (W + 1) * sizeof(float);
     const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
     const int apb = pick_angles_per_block(S, A, PW);
@@ -283,6 +608,24 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
     if (int rc = check_geom("rotate_bwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     CTPVAE_REQUIRE(mode == CTPVAE_BWD_TF_COMPAT || mode == CTPVAE_BWD_EXACT, "rotate_bwd: unknown mode %d", mode);
     const RotGeom g{S, H, W, PH, PW, py, px, A};
+    if (mode == CTPVAE_BWD_TF_COMPAT && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
+        // fast path: 64-column x (4 waves x PPT rows) tiles; cotangent rows in LDS, <= 48 KiB per chunk
+        constexpr int kPpt = 8;
+        const int pitchg = PW + (interp == CTPVAE_NEAREST ? 1 : 4);
+        int chunk_a = (48 * 1024) / (pitchg * (int)sizeof(float));
+        CTPVAE_REQUIRE(chunk_a >= 1, "rotate_bwd: a detector row of %d bins does not fit LDS", PW);
+        chunk_a = std::min(chunk_a, A);
+        const size_t shmem = (size_t)chunk_a * pitchg * sizeof(float);
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * kPpt), S), block(256);
+        auto launch = [&](auto kernel) -> int {
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev, chunk_a,
+                               gimg_dev);
+            CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_fast_kernel");
+            return CTPVAE_OK;
+        };
+        return interp == CTPVAE_NEAREST ? launch(rotate_bwd_tfcompat_fast_kernel<CTPVAE_NEAREST, kPpt>)
+                                        : launch(rotate_bwd_tfcompat_fast_kernel<CTPVAE_BILINEAR, kPpt>);
+    }
     if (mode == CTPVAE_BWD_TF_COMPAT) {
         // cotangent rows staged in LDS in chunks of angles (<= 32 KiB per chunk)
         int chunk_a = (32 * 1024) / ((PW + 8) * (int)sizeof(float));
