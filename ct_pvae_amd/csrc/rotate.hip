@@ -90,17 +90,24 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float *__restrict
 
 // ---- forward, fast path: zero-bordered LDS image, clipped row range, no per-sample bounds test ----
 //
-// The slice is staged with a zero border of BORDER pixels (1 for NEAREST, 2 for BILINEAR) and an odd
-// row pitch.  A sample's integer tap is clamped onto that border with one v_med3_i32 per coordinate, so
-// a tap outside the core reads an exact 0 without a compare/select.  Each lane first clips its ray
-// against the core (conservatively, in floats), then all lanes of a wave walk the same NUMBER of rows
-// from their own first row -- rows outside the clipped range only ever contribute +0.0f, and a lane
-// whose range is short is shifted so that it stays inside [0, PH): every visited row is a legitimate
-// term of the sum, taken in ascending order, so the result is still bit-identical to the oracle.
+// The slice is staged with a zero border of BORDER pixels (1 for NEAREST, 2 for BILINEAR).  A sample's
+// integer tap is clamped onto that border with one v_med3_i32 per coordinate, so a tap outside the core
+// reads an exact 0 without a compare/select.  Each lane first clips its ray against the core
+// (conservatively, in floats), then all lanes of a wave walk the same NUMBER of rows from their own first
+// row -- rows outside the clipped range only ever contribute +0.0f, and a lane whose range is short is
+// shifted so that it stays inside [0, PH): every visited row is a legitimate term of the sum, taken in
+// ascending order, so the result is still bit-identical to the oracle.
 //
 // Rounding: v_cvt_rpi_i32_f32 is floor(x + 0.5) evaluated exactly (tools/probe_rpi.hip).  It differs
 // from round-half-away-from-zero only at negative ties; of those only x == -0.5 can reach a live
 // pixel, and only when the canvas has no padding on that side (TIE_FIX).
+//
+// What the measurements say (tools/tune_rotate.hip, tools/probe_valu.hip, profiles/): at the reference's
+// batch sizes there are only ~12 waves of rays per CU, one wave issues a VALU op every ~4.4 cycles, and the
+// SIMD saturates near 0.5 op/cycle for this mix -- the loop is VALU-issue bound, LDS bandwidth and HBM are
+// idle.  So the per-sample instruction count is what is minimised here: packed fp32 for the coordinates of
+// TWO consecutive rows at once, one asm block per pair (hipcc pads every asm statement and every packed-op
+// consumer with s_nop), gathers software-pipelined two groups deep with one s_waitcnt per group.
 __device__ __forceinline__ int cvt_rpi(float v)
 {
     int r;
@@ -120,6 +127,16 @@ __device__ __forceinline__ int med3i(int v, int lo, int hi)
     return r;
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) float *lds_cptr;
+typedef __attribute__((address_space(3))) float *lds_ptr;
+typedef const __attribute__((address_space(1))) float *glb_cptr;
+
+// smallest pitch >= wb with pitch == +1 (mod 32) if want_plus else == -1 (mod 32)
+__host__ __device__ __forceinline__ int pitch_for(int wb, bool want_plus)
+{
+    const int r = want_plus ? 1 : 31;
+    return wb + ((r - (wb & 31)) & 31);
+}
 
 // an opaque copy in a VGPR: keeps loop-invariant operands of the asm helpers out of the loop body
 __device__ __forceinline__ int pin_vgpr(int v)
@@ -128,47 +145,55 @@ __device__ __forceinline__ int pin_vgpr(int v)
     asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
     return r;
 }
-typedef const __attribute__((address_space(3))) float *lds_cptr;
 
-// LDS byte address (absolute, the LDS base is folded into off4) of the clamped NEAREST tap of (x, y):
-//   rpi both coordinates, clamp onto the zero border, row * pitch4 + col * 4 + off4.
-// One asm block: hipcc pads every asm statement with s_nop, so the six dependent VALU ops stay together.
-__device__ __forceinline__ int nearest_tap_addr(float x, float y, int xlo, int xhi, int ylo, int yhi, int pitch4,
-                                                int off4)
+// Two consecutive rows (i, i+1) of one ray, NEAREST: LDS byte addresses (absolute: the LDS base is folded
+// into off4) of the two clamped taps.
+//   (x_i, x_i+1) = ((xj, xj) + (t1, t1) * (i, i+1)) + (t2, t2), same for y with (yj, t4, t5): v_pk_mul_f32 and
+//   v_pk_add_f32 round every lane like the scalar ops, so this is the reference's expression bit for bit;
+//   then v_cvt_rpi, clamp onto the zero border, row * pitch4 + col * 4 + off4.
+// A packed op cannot forward its result to the next instruction on gfx950 (the compiler pads with s_nop);
+// the x and y chains are interleaved so every consumer is at least one instruction behind its producer.
+// v60..v63 are scratch inside the block.
+__device__ __forceinline__ void nearest_pair_addr(f32x2 &fi, f32x2 basex, f32x2 basey, f32x2 stepx, f32x2 stepy,
+                                                  f32x2 shiftx, f32x2 shifty, int xlo, int xhi, int ylo, int yhi,
+                                                  int pitch4, int off4, int &addr0, int &addr1)
 {
-    int col, row;
-    asm("v_cvt_rpi_i32_f32 %0, %2\n\t"
-        "v_cvt_rpi_i32_f32 %1, %3\n\t"
-        "v_med3_i32 %0, %0, %4, %5\n\t"
-        "v_med3_i32 %1, %1, %6, %7\n\t"
-        "v_mad_i32_i24 %1, %1, %8, %9\n\t"
-        "v_lshl_add_u32 %0, %0, 2, %1"
-        : "=&v"(col), "=&v"(row)
-        : "v"(x), "v"(y), "v"(xlo), "v"(xhi), "v"(ylo), "v"(yhi), "s"(pitch4), "v"(off4));
-    return col;
-}
-// same for the top-left BILINEAR tap: floor instead of round
-__device__ __forceinline__ int floor_tap_addr(float x, float y, int xlo, int xhi, int ylo, int yhi, int pitch4,
-                                              int off4)
-{
-    int col, row;
-    asm("v_cvt_flr_i32_f32 %0, %2\n\t"
-        "v_cvt_flr_i32_f32 %1, %3\n\t"
-        "v_med3_i32 %0, %0, %4, %5\n\t"
-        "v_med3_i32 %1, %1, %6, %7\n\t"
-        "v_mad_i32_i24 %1, %1, %8, %9\n\t"
-        "v_lshl_add_u32 %0, %0, 2, %1"
-        : "=&v"(col), "=&v"(row)
-        : "v"(x), "v"(y), "v"(xlo), "v"(xhi), "v"(ylo), "v"(yhi), "s"(pitch4), "v"(off4));
-    return col;
+    asm("v_pk_mul_f32 v[60:61], %[sx], %[fi]\n\t"
+        "v_pk_mul_f32 v[62:63], %[sy], %[fi]\n\t"
+        "v_pk_add_f32 v[60:61], %[bx], v[60:61]\n\t"
+        "v_pk_add_f32 v[62:63], %[by], v[62:63]\n\t"
+        "v_pk_add_f32 v[60:61], v[60:61], %[hx]\n\t"
+        "v_pk_add_f32 v[62:63], v[62:63], %[hy]\n\t"
+        "v_pk_add_f32 %[fi], %[fi], 2.0 op_sel_hi:[1,0]\n\t"
+        "v_cvt_rpi_i32_f32 %[a0], v60\n\t"
+        "v_cvt_rpi_i32_f32 %[a1], v61\n\t"
+        "v_cvt_rpi_i32_f32 v62, v62\n\t"
+        "v_cvt_rpi_i32_f32 v63, v63\n\t"
+        "v_med3_i32 %[a0], %[a0], %[xlo], %[xhi]\n\t"
+        "v_med3_i32 %[a1], %[a1], %[xlo], %[xhi]\n\t"
+        "v_med3_i32 v62, v62, %[ylo], %[yhi]\n\t"
+        "v_med3_i32 v63, v63, %[ylo], %[yhi]\n\t"
+        "v_mad_i32_i24 v62, v62, %[p4], %[o4]\n\t"
+        "v_mad_i32_i24 v63, v63, %[p4], %[o4]\n\t"
+        "v_lshl_add_u32 %[a0], %[a0], 2, v62\n\t"
+        "v_lshl_add_u32 %[a1], %[a1], 2, v63"
+        : [fi] "+v"(fi), [a0] "=&v"(addr0), [a1] "=&v"(addr1)
+        : [sx] "v"(stepx), [sy] "v"(stepy), [bx] "v"(basex), [by] "v"(basey), [hx] "v"(shiftx), [hy] "v"(shifty),
+          [xlo] "v"(xlo), [xhi] "v"(xhi), [ylo] "v"(ylo), [yhi] "v"(yhi), [p4] "s"(pitch4), [o4] "v"(off4)
+        : "v60", "v61", "v62", "v63");
 }
 __device__ __forceinline__ float lds_abs(int byte_addr) { return *(lds_cptr)(uintptr_t)(unsigned)byte_addr; }
 
-__device__ __forceinline__ int wave_max(int v)
+// max over the 64 lanes of a wave of a non-negative int, as an SGPR value (DPP row shifts + row broadcasts)
+__device__ __forceinline__ int wave_max_nonneg(int v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // rows [lo, hi) of the canvas on which base + slope*i may fall inside [L, U]
@@ -178,12 +203,25 @@ __device__ __forceinline__ void clip_rows(float base, float slope, float L, floa
         // |slope * i| < 1e-6 * 2^24: treat as constant, with a margin far above that drift
         if (base < L - 1.0f || base > U + 1.0f) hi = -1.0f;
     } else {
-        const float inv = 1.0f / slope;
+        const float inv = __builtin_amdgcn_rcpf(slope);   // 1 ulp is ample: the range is widened by whole rows
         const float i1 = (L - base) * inv, i2 = (U - base) * inv;
         lo = fmaxf(lo, fminf(i1, i2));
         hi = fminf(hi, fmaxf(i1, i2));
     }
 }
+
+#ifdef CTPVAE_TUNE_STAMPS
+__device__ long long g_stamps[8 * 65536];
+#define CTPVAE_STAMP(slot)                                                                                   \
+    do {                                                                                                     \
+        long long t_;                                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+        if ((threadIdx.x & 63) == 0)                                                                         \
+            g_stamps[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) + (slot)] = t_; \
+    } while (0)
+#else
+#define CTPVAE_STAMP(slot)
+#endif
 
 template <int INTERP, bool TIE_FIX>
 __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom g,
@@ -191,38 +229,48 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
                                                                float *__restrict__ sino)
 {
     constexpr int BORDER = (INTERP == CTPVAE_NEAREST) ? 1 : 2;
+    constexpr bool PAIRS = (INTERP == CTPVAE_NEAREST) && !TIE_FIX;   // the asm pair path
     extern __shared__ float lds[];
+    CTPVAE_STAMP(0);
     const int s = blockIdx.y;
     const float *im = img + (size_t)s * g.H * g.W;
     const int wb = g.W + 2 * BORDER;
-    const int pitch = wb | 1;  // odd pitch: a wave walking a column touches 32 different banks
     const int hb = g.H + 2 * BORDER;
+    // Row pitch == +1 or -1 (mod 32), chosen per workgroup from the direction its rays' lanes walk: consecutive
+    // detector bins step by (t0, t3) pixels, i.e. by t3*pitch + t0 dwords ~ +-t3 + t0 banks.  Picking the sign that
+    // makes the two terms add keeps |step| in [1, 1.42] banks per lane: at most 2 lanes of a 32-lane group share a
+    // bank at any angle.
+    int pitch;
+    {
+        const int ray_mid = min(blockIdx.x * rays_per_blk + rays_per_blk / 2, g.A * g.PW - 1);
+        const float *tm = T8 + 8 * (ray_mid / g.PW);
+        const bool same_sign = (tm[0] >= 0.0f) == (tm[3] >= 0.0f);
+        pitch = pitch_for(wb, same_sign);
+    }
 
-    // zero border (top/bottom rows, left/right columns), then the core
-    for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
-        const int r = p / pitch, c = p - r * pitch;
-        lds[(r < BORDER ? r : hb - 2 * BORDER + r) * pitch + c] = 0.0f;
-    }
-    for (int p = threadIdx.x; p < g.H * (pitch - g.W); p += blockDim.x) {
-        const int r = p / (pitch - g.W), c = p - r * (pitch - g.W);
-        lds[(r + BORDER) * pitch + (c < BORDER ? c : g.W + c)] = 0.0f;
-    }
-    if ((g.W & 3) == 0) {
-        const int w4 = g.W >> 2;
-        const float4 *im4 = reinterpret_cast<const float4 *>(im);
-        for (int p = threadIdx.x; p < g.H * w4; p += blockDim.x) {
-            const int r = p / w4, c = (p - r * w4) << 2;
-            const float4 v = im4[p];
-            float *dst = lds + (r + BORDER) * pitch + BORDER + c;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+#ifndef CTPVAE_TUNE_NOFILL
+    // Stage the slice: LDS-DMA (global_load_lds_dword), one wave-instruction per 64-pixel row segment, no VGPRs and
+    // no ds_write; the zero border goes in with ordinary stores.  Everything is asynchronous until the barrier below.
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        const int nseg = (g.W + 63) >> 6;
+        for (int t = wave; t < g.H * nseg; t += nwaves) {
+            const int r = t / nseg, c0 = (t - r * nseg) << 6;
+            if (c0 + lane < g.W)
+                __builtin_amdgcn_global_load_lds((glb_cptr)(im + (size_t)r * g.W + c0 + lane),
+                                                 (lds_ptr)(lds + (r + BORDER) * pitch + BORDER + c0), 4, 0, 0);
         }
-    } else {
-        for (int p = threadIdx.x; p < g.H * g.W; p += blockDim.x) {
-            const int r = p / g.W, c = p - r * g.W;
-            lds[(r + BORDER) * pitch + BORDER + c] = im[p];
+        for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
+            const int r = p / pitch, c = p - r * pitch;
+            lds[(r < BORDER ? r : hb - 2 * BORDER + r) * pitch + c] = 0.0f;
+        }
+        for (int p = threadIdx.x; p < g.H * (pitch - g.W); p += blockDim.x) {
+            const int r = p / (pitch - g.W), c = p - r * (pitch - g.W);
+            lds[(r + BORDER) * pitch + (c < BORDER ? c : g.W + c)] = 0.0f;
         }
     }
-    __syncthreads();
+#endif
+    CTPVAE_STAMP(1);
 
     const int nrays = g.A * g.PW;
     const int ray0 = blockIdx.x * rays_per_blk;
@@ -230,72 +278,157 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     // clamp bounds in canvas coordinates and the matching LDS offset
     const int xlo = g.px - BORDER, xhi = g.px + g.W + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
     const int ylo = g.py - BORDER, yhi = g.py + g.H + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
-    // clamp bounds pinned in VGPRs (v_med3_i32 takes them as is), byte pitch, byte offset of canvas (0, 0)
+    // clamp bounds pinned in VGPRs (v_med3_i32 takes them as is), byte pitch, absolute byte offset of canvas (0, 0)
     const int xlo_v = pin_vgpr(xlo), xhi_v = pin_vgpr(xhi), ylo_v = pin_vgpr(ylo), yhi_v = pin_vgpr(yhi);
     const int pitch4 = pitch * 4;
     const int off4_v = pin_vgpr(-(ylo * pitch + xlo) * 4 + (int)(uintptr_t)(lds_cptr)lds);
 
-    for (int rbase = ray0; rbase < ray_end; rbase += blockDim.x) {
-        const int ray = rbase + threadIdx.x;
-        const bool live = ray < ray_end;
-        const int rr = live ? ray : ray_end - 1;
+    // per-ray setup: transform row, conservative row range through the core, wave-uniform trip count
+    struct Ray {
+        float t1, t2, t4, t5, xj, yj;
+        int ray, ilo, kmax;
+        bool live;
+    };
+    auto setup = [&](int rbase) -> Ray {
+        Ray q;
+        q.ray = rbase + threadIdx.x;
+        q.live = q.ray < ray_end;
+        const int rr = q.live ? q.ray : ray_end - 1;
         const int a = rr / g.PW;
         const int j = rr - a * g.PW;
         const float *t = T8 + 8 * a;
-        const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
-        const float xj = t0 * (float)j, yj = t3 * (float)j;
-
-        // conservative row range of this ray through the core (margins of >= 1.5 px, fp error << that)
+        const float t0 = t[0], t3 = t[3];
+        q.t1 = t[1]; q.t2 = t[2]; q.t4 = t[4]; q.t5 = t[5];
+        q.xj = t0 * (float)j;
+        q.yj = t3 * (float)j;
+        // margins of >= 1.5 px around the live zone; fp error of this estimate is far below that
         float lo = 0.0f, hi = (float)g.PH;
-        clip_rows(xj + t2, t1, (float)(g.px - 2), (float)(g.px + g.W + 1), lo, hi);
-        clip_rows(yj + t5, t4, (float)(g.py - 2), (float)(g.py + g.H + 1), lo, hi);
+        clip_rows(q.xj + q.t2, q.t1, (float)(g.px - 2), (float)(g.px + g.W + 1), lo, hi);
+        clip_rows(q.yj + q.t5, q.t4, (float)(g.py - 2), (float)(g.py + g.H + 1), lo, hi);
         lo = fminf(fmaxf(lo, 0.0f), (float)g.PH);
         hi = fminf(fmaxf(hi, -1.0f), (float)g.PH);
-        int ilo = max((int)floorf(lo) - 1, 0);
+        const int ilo = max((int)floorf(lo) - 1, 0);
         const int ihi = min((int)ceilf(hi) + 2, g.PH);
-        const int cnt = live ? max(ihi - ilo, 0) : 0;
-        const int kmax = __builtin_amdgcn_readfirstlane(wave_max(cnt));  // wave-uniform trip count (SGPR)
-        ilo = max(min(ilo, g.PH - kmax), 0);     // keep ilo + kmax <= PH: only legitimate rows are visited
+        const int cnt = q.live ? max(ihi - ilo, 0) : 0;
+#ifdef CTPVAE_TUNE_KMAX
+        q.kmax = min(wave_max_nonneg(cnt) * CTPVAE_TUNE_KMAX, g.PH);  // timing only
+#else
+        q.kmax = wave_max_nonneg(cnt);            // wave-uniform trip count (SGPR)
+#endif
+        q.ilo = max(min(ilo, g.PH - q.kmax), 0);  // keep ilo + kmax <= PH: only legitimate rows are visited
+        return q;
+    };
 
-        // packed fp32 coordinate math: (x, y) = ((xj, yj) + (t1, t4) * i) + (t2, t5) -- v_pk_mul_f32 / v_pk_add_f32,
-        // separate multiply and adds exactly as the scalar expression
-        const f32x2 base = {xj, yj}, step = {t1, t4}, shift = {t2, t5};
-        f32x2 fi2 = {(float)ilo, (float)ilo};
-        const f32x2 one2 = {1.0f, 1.0f};
+    Ray q = setup(ray0);   // runs under the LDS-DMA
+    CTPVAE_STAMP(2);
+    __syncthreads();       // (an unconditional barrier: a barrier inside the ray loop makes hipcc wait lgkmcnt(0) in it)
+    for (int rbase = ray0; rbase < ray_end; rbase += blockDim.x) {
+        if (rbase != ray0) q = setup(rbase);
+        const float t1 = q.t1, t2 = q.t2, t4 = q.t4, t5 = q.t5, xj = q.xj, yj = q.yj;
+        const int ray = q.ray, ilo = q.ilo, kmax = q.kmax;
+        const bool live = q.live;
+        CTPVAE_STAMP(3);
+
         float acc = 0.0f;
-        auto sample = [&]() -> float {
-            const f32x2 xy = (base + step * fi2) + shift;
-            fi2 += one2;
-            const float x = xy.x, y = xy.y;
-            if (INTERP == CTPVAE_NEAREST) {
-                if (TIE_FIX) {
-                    // x == -0.5 must round to -1 (dead); steer it below the clamp range instead of to pixel 0
-                    const float xs = (x == -0.5f) ? -1.0f : x, ys = (y == -0.5f) ? -1.0f : y;
-                    return lds_abs(nearest_tap_addr(xs, ys, xlo_v, xhi_v, ylo_v, yhi_v, pitch4, off4_v));
-                }
-                return lds_abs(nearest_tap_addr(x, y, xlo_v, xhi_v, ylo_v, yhi_v, pitch4, off4_v));
-            } else {
-                const float xf = floorf(x), yf = floorf(y);
-                const float xc = xf + 1.0f, yc = yf + 1.0f;
-                const int ad = floor_tap_addr(x, y, xlo_v, xhi_v, ylo_v, yhi_v, pitch4, off4_v);
-                const float v00 = lds_abs(ad), v01 = lds_abs(ad + 4);
-                const float v10 = lds_abs(ad + pitch4), v11 = lds_abs(ad + pitch4 + 4);
-                const float v_yf = (xc - x) * v00 + (x - xf) * v01;
-                const float v_yc = (xc - x) * v10 + (x - xf) * v11;
-                return (yc - y) * v_yf + (y - yf) * v_yc;
-            }
-        };
         int k = 0;
-        for (; k + 4 <= kmax; k += 4) {   // four independent gathers in flight, added in row order
-            const float v0 = sample(), v1 = sample(), v2 = sample(), v3 = sample();
-            acc += v0;
-            acc += v1;
-            acc += v2;
-            acc += v3;
+#ifdef CTPVAE_TUNE_NOLOOP
+        k = kmax;
+#endif
+        if (PAIRS) {
+            // ---- NEAREST: two rows per asm block, groups of U gathers, two groups in flight --------------------
+            constexpr int U = 6;
+            const f32x2 basex = {xj, xj}, basey = {yj, yj}, stepx = {t1, t1}, stepy = {t4, t4};
+            const f32x2 shiftx = {t2, t2}, shifty = {t5, t5};
+            f32x2 fi = {(float)ilo, (float)ilo + 1.0f};
+            const int nblk = (kmax - k) / U;
+            if (nblk > 0) {
+                float bx[U], by[U];   // ping-pong groups: X holds even blocks, Y odd blocks
+                auto issue = [&](float (&buf)[U]) {
+#pragma unroll
+                    for (int u = 0; u < U; u += 2) {
+                        int a0, a1;
+                        nearest_pair_addr(fi, basex, basey, stepx, stepy, shiftx, shifty, xlo_v, xhi_v, ylo_v, yhi_v,
+                                          pitch4, off4_v, a0, a1);
+#ifdef CTPVAE_TUNE_NOLDS
+                        buf[u] = __int_as_float(a0 & 0x3fffff);
+                        buf[u + 1] = __int_as_float(a1 & 0x3fffff);
+#else
+                        buf[u] = lds_abs(a0);
+                        buf[u + 1] = lds_abs(a1);
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the adds of the older group behind these gathers
+                };
+                auto consume = [&](float (&buf)[U], bool newer_in_flight) {
+                    (void)newer_in_flight;   // hipcc counts the in-order LDS returns itself: lgkmcnt(2U-1 .. U)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc += buf[u];
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                issue(bx);
+                int b = 1;
+                for (; b + 1 < nblk; b += 2) {
+                    issue(by);
+                    consume(bx, true);
+                    issue(bx);
+                    consume(by, true);
+                }
+                if (b < nblk) {
+                    issue(by);
+                    consume(bx, true);
+                    consume(by, false);
+                } else {
+                    consume(bx, false);
+                }
+                k += nblk * U;
+            }
+            // remainder rows, one at a time (fi.x is the next row)
+            float fr = fi.x;
+            for (; k < kmax; ++k) {
+                const float x = (xj + t1 * fr) + t2, y = (yj + t4 * fr) + t5;
+                fr += 1.0f;
+                const int idx = __mul24(med3i(cvt_rpi(y), ylo_v, yhi_v), pitch4) + (med3i(cvt_rpi(x), xlo_v, xhi_v) << 2);
+                acc += lds_abs(idx + off4_v);
+            }
+        } else {
+            // ---- BILINEAR, and NEAREST on an unpadded canvas (TIE_FIX): one row at a time, U in flight ------------
+            constexpr int U = (INTERP == CTPVAE_NEAREST) ? 4 : 2;
+            float fr = (float)ilo;
+            auto sample = [&]() -> float {
+                const float x = (xj + t1 * fr) + t2, y = (yj + t4 * fr) + t5;
+                fr += 1.0f;
+                if (INTERP == CTPVAE_NEAREST) {
+                    // x == -0.5 must round to -1 (dead): steer it below the clamp range instead of to pixel 0
+                    const float xs = (x == -0.5f) ? -1.0f : x, ys = (y == -0.5f) ? -1.0f : y;
+                    const int idx = __mul24(med3i(cvt_rpi(ys), ylo_v, yhi_v), pitch4) + (med3i(cvt_rpi(xs), xlo_v, xhi_v) << 2);
+                    return lds_abs(idx + off4_v);
+                } else {
+                    const float xf = floorf(x), yf = floorf(y);
+                    const float xc = xf + 1.0f, yc = yf + 1.0f;
+                    const int ad = __mul24(med3i(cvt_flr(y), ylo_v, yhi_v), pitch4) + (med3i(cvt_flr(x), xlo_v, xhi_v) << 2) + off4_v;
+                    const float v00 = lds_abs(ad), v01 = lds_abs(ad + 4);
+                    const float v10 = lds_abs(ad + pitch4), v11 = lds_abs(ad + pitch4 + 4);
+                    const float v_yf = (xc - x) * v00 + (x - xf) * v01;
+                    const float v_yc = (xc - x) * v10 + (x - xf) * v11;
+                    return (yc - y) * v_yf + (y - yf) * v_yc;
+                }
+            };
+            for (; k + U <= kmax; k += U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = sample();
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc += v[u];
+            }
+            for (; k < kmax; ++k) acc += sample();
         }
-        for (; k < kmax; ++k) acc += sample();
+        CTPVAE_STAMP(4);
+#ifdef CTPVAE_TUNE_STAMPS
+        if ((threadIdx.x & 63) == 0) g_stamps[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 6] = kmax;
+#endif
         if (live) sino[(size_t)s * nrays + ray] = acc;
     }
+    CTPVAE_STAMP(5);
 }
 
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
@@ -552,16 +685,22 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
     if (int rc = check_geom("rotate_fwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     const RotGeom g{S, H, W, PH, PW, py, px, A};
 
-    // fast path: the zero-bordered slice must fit LDS
+    // fast path: the zero-bordered slice must fit LDS (row pitch == +-1 mod 32, see the kernel)
     const int border = interp == CTPVAE_NEAREST ? 1 : 2;
-    const size_t fast_lds = (size_t)(H + 2 * border) * ((W + 2 * border) | 1) * sizeof(float);
+    const int wb = W + 2 * border;
+    const size_t fast_lds = (size_t)(H + 2 * border) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
     if (fast_lds <= (size_t)kMaxLdsBytes && getenv("CTPVAE_FORCE_GENERIC") == nullptr) {
-        // rays per workgroup: about two workgroups per CU over the whole launch, whole waves, <= 1024
+        // rays per workgroup: whole waves, <= 1024, about one workgroup per CU when the launch is small (every
+        // workgroup re-stages its slice, and a wave needs its CU's LDS bandwidth more than it needs neighbours)
         const long long nrays = (long long)A * PW;
-        long long rpb = ceil_div((int)std::min<long long>(nrays * S, 1ll << 30), 512);
-        rpb = std::max<long long>(64, std::min<long long>(rpb, nrays));
+        const int wgs_per_cu = fast_lds * 2 <= (size_t)kMaxLdsBytes ? 2 : 1;
+        long long rpb = (nrays * S + 256 * wgs_per_cu - 1) / (256 * wgs_per_cu);
+        rpb = std::max<long long>(64, std::min<long long>(rpb, std::min<long long>(nrays, 1024)));
         rpb = (rpb + 63) / 64 * 64;
-        const int block = (int)std::min<long long>(rpb, fast_lds > 80 * 1024 ? 1024 : 512);
+#ifdef CTPVAE_TUNE_STAMPS
+        if (const char *e = getenv("CTPVAE_TUNE_RPB")) rpb = atoi(e);
+#endif
+        const int block = (int)rpb;
         const dim3 grid((unsigned)((nrays + rpb - 1) / rpb), S);
         const bool tie_fix = (px == 0 || py == 0);
         auto launch = [&](auto kernel) -> int {

@@ -1,0 +1,565 @@
+// rotate_plan.hip -- gather plans for the NEAREST rotate-and-sum projector and its TensorFlow-compatible
+// backward, and the kernels that execute them (gfx950).
+//
+// Why a plan.  The tap a sample reads depends on (angle, canvas row, detector bin) only -- not on the object.
+// CT_PVAE projects batches (50 objects per step in the README recipe), so evaluating TensorFlow's index
+// arithmetic per object repeats the same ~20 VALU ops per sample 50 times, and on gfx950 everything except a
+// plain fp32 add/mul (conversions, VOP3, packed ops) issues at a quarter of the lane rate: the direct kernels
+// in rotate.hip are VALU-issue bound with HBM and LDS nearly idle (tools/probe_valu.hip, profiles/).  A plan is
+// the table of LDS tap indices (u16), written ONCE per geometry by a kernel that evaluates the reference
+// arithmetic exactly (unfused fp32, round half away from zero, zero fill); the per-object kernels then only
+// stream indices (16 B per lane per load, coalesced, L2-resident), gather from LDS and add in row order.  The
+// result is bit-identical to the direct kernels and to the oracle, because the same indices are used and every
+// ray still adds its rows in ascending order (skipped rows and dead taps contribute exactly +0.0f).
+//
+// Forward plan   idx[a][g][j] : uint4 = the 8 taps of rows 8g..8g+7 of ray (a, j), each a dword index into the
+//                               staged slice (row pitch == 1 mod 32), or `zero` (a cell holding 0.0f) if the tap
+//                               is outside the H x W core or the row is past the canvas.
+//                rng[a][jb]   : first row-group and group count (multiple of 4) that any of the 64 rays of bin
+//                               block jb needs -- the kernel's wave-uniform loop bounds.
+//                cls[a]       : 1 if lanes walk the slice with column and row moving the same way, else 0; for
+//                               class 0 the slice is staged (and indexed) column-mirrored, so that consecutive
+//                               detector bins always advance by |dx| + |dy| in [1, 1.42] LDS banks: at most two
+//                               lanes of a 32-lane group share a bank at any angle.
+// Backward plan  idx[a8][y][x]: uint4 = for angles 8*a8..8*a8+7, the dword index of the cotangent cell
+//                               (a * pitchg + bin) that TensorFlow's gradient op reads for pixel (y, x), or `zero`.
+#include <algorithm>
+#include <climits>
+#include <cstdlib>
+
+#include "common.h"
+
+namespace ctpvae {
+
+struct PlanGeom {
+    int H, W, PH, PW, py, px, A;
+};
+
+struct FwdLayout {
+    int nJB, PWpad, NG, Galloc, pitch, zero;
+    long long off_cls, off_rng, off_idx, bytes;
+};
+struct BwdLayout {
+    int nXB, Wpad, NA8, pitchg, zero;
+    long long bytes;
+};
+
+__host__ __device__ inline int pitch_mod32_is_1(int w) { return w + ((1 - (w & 31)) & 31); }
+
+static FwdLayout fwd_layout(const PlanGeom &g)
+{
+    FwdLayout L;
+    L.nJB = ceil_div(g.PW, 64);
+    L.PWpad = L.nJB * 64;
+    L.NG = ceil_div(g.PH, 8);
+    L.Galloc = L.NG + 8;  // dead groups behind the canvas: the kernel prefetches up to 7 groups past a range
+    L.pitch = pitch_mod32_is_1(g.W);
+    L.zero = g.H * L.pitch;
+    L.off_cls = 0;
+    L.off_rng = ((long long)g.A * 4 + 255) / 256 * 256;
+    L.off_idx = (L.off_rng + (long long)g.A * L.nJB * 8 + 255) / 256 * 256;
+    L.bytes = L.off_idx + (long long)g.A * L.Galloc * L.PWpad * 16;
+    return L;
+}
+static BwdLayout bwd_layout(const PlanGeom &g)
+{
+    BwdLayout L;
+    L.nXB = ceil_div(g.W, 64);
+    L.Wpad = L.nXB * 64;
+    L.NA8 = ceil_div(g.A, 8);
+    L.pitchg = pitch_mod32_is_1(g.PW);
+    L.zero = g.A * L.pitchg;
+    L.bytes = (long long)L.NA8 * g.H * L.Wpad * 16;
+    return L;
+}
+static bool fwd_plan_fits(const PlanGeom &g)
+{
+    const FwdLayout L = fwd_layout(g);
+    return L.zero < 65535 && (size_t)(L.zero + 1) * 4 <= (size_t)kMaxLdsBytes;
+}
+static bool bwd_plan_fits(const PlanGeom &g)
+{
+    const BwdLayout L = bwd_layout(g);
+    return L.zero < 65535 && (size_t)(L.zero + 1) * 4 <= (size_t)kMaxLdsBytes;
+}
+
+typedef const __attribute__((address_space(3))) float *lds_cptr;
+typedef __attribute__((address_space(3))) float *lds_ptr;
+typedef const __attribute__((address_space(1))) float *glb_cptr;
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- plan builders: the reference arithmetic, evaluated exactly, once per geometry ---------------------------
+__global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const float *__restrict__ T8, FwdLayout L,
+                                                             char *__restrict__ plan)
+{
+    const int a = blockIdx.y, jb = blockIdx.x, lane = threadIdx.x;
+    const int j = jb * 64 + lane;
+    const float *t = T8 + 8 * a;
+    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
+    int *cls = reinterpret_cast<int *>(plan + L.off_cls);
+    int *rng = reinterpret_cast<int *>(plan + L.off_rng);
+    uint4 *idx = reinterpret_cast<uint4 *>(plan + L.off_idx);
+    if (jb == 0 && lane == 0) cls[a] = plus ? 1 : 0;
+    const float xj = t0 * (float)j, yj = t3 * (float)j;
+    int first = INT_MAX, last = -1;
+    for (int gq = 0; gq < L.Galloc; ++gq) {
+        unsigned e16[8];
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = 8 * gq + e;
+            unsigned v = (unsigned)L.zero;
+            if (i < g.PH && j < g.PW) {
+                // ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round, zero fill
+                const float fi = (float)i;
+                const float x = (xj + t1 * fi) + t2;
+                const float y = (yj + t4 * fi) + t5;
+                const int ix = (int)__builtin_roundf(x) - g.px;
+                const int iy = (int)__builtin_roundf(y) - g.py;
+                if ((unsigned)ix < (unsigned)g.W && (unsigned)iy < (unsigned)g.H) {
+                    v = (unsigned)(iy * L.pitch + (plus ? ix : g.W - 1 - ix));
+                    any = true;
+                }
+            }
+            e16[e] = v;
+        }
+        uint4 q;
+        q.x = e16[0] | (e16[1] << 16);
+        q.y = e16[2] | (e16[3] << 16);
+        q.z = e16[4] | (e16[5] << 16);
+        q.w = e16[6] | (e16[7] << 16);
+        idx[((size_t)a * L.Galloc + gq) * L.PWpad + j] = q;
+        if (any) {
+            first = min(first, gq);
+            last = gq;
+        }
+    }
+    first = wave_min_i(first);
+    last = wave_max_i(last);
+    if (lane == 0) {
+        const int ng = last >= 0 ? last - first + 1 : 0;
+        rng[(a * L.nJB + jb) * 2 + 0] = last >= 0 ? first : 0;
+        rng[(a * L.nJB + jb) * 2 + 1] = (ng + 3) / 4 * 4;
+    }
+}
+
+__global__ __launch_bounds__(64) void rotate_bwd_plan_kernel(PlanGeom g, const float *__restrict__ Tinv8, BwdLayout L,
+                                                             uint4 *__restrict__ idx)
+{
+    const int xb = blockIdx.x, yrow = blockIdx.y, a8 = blockIdx.z, lane = threadIdx.x;
+    const int xcol = xb * 64 + lane;
+    const float fx = (float)(xcol + g.px), fy = (float)(yrow + g.py);
+    unsigned e16[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int a = 8 * a8 + e;
+        unsigned v = (unsigned)L.zero;
+        if (a < g.A && xcol < g.W) {
+            // the gradient op re-samples the row-broadcast cotangent with the inverted transform (same arithmetic)
+            const float *t = Tinv8 + 8 * a;
+            const float x = (t[0] * fx + t[1] * fy) + t[2];
+            const float y = (t[3] * fx + t[4] * fy) + t[5];
+            const int ix = (int)__builtin_roundf(x), iy = (int)__builtin_roundf(y);
+            if ((unsigned)ix < (unsigned)g.PW && (unsigned)iy < (unsigned)g.PH) v = (unsigned)(a * L.pitchg + ix);
+        }
+        e16[e] = v;
+    }
+    uint4 q;
+    q.x = e16[0] | (e16[1] << 16);
+    q.y = e16[2] | (e16[3] << 16);
+    q.z = e16[4] | (e16[5] << 16);
+    q.w = e16[6] | (e16[7] << 16);
+    idx[((size_t)a8 * g.H + yrow) * L.Wpad + xcol] = q;
+}
+
+// ---- executing a plan -------------------------------------------------------------------------------------------
+// LDS byte addresses of the two u16 dword indices packed in `pk`: one SDWA op each (select a 16-bit half, shift by 2)
+__device__ __forceinline__ void unpack2(unsigned pk, int &lo4, int &hi4)
+{
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(lo4)
+        : "v"(pk));
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(hi4)
+        : "v"(pk));
+}
+__device__ __forceinline__ float lds_at(const float *lds, int byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + byte_off);
+}
+__device__ __forceinline__ void gather8(const float *lds, const uint4 q, float (&v)[8])
+{
+    int a0, a1, a2, a3, a4, a5, a6, a7;
+    unpack2(q.x, a0, a1);
+    unpack2(q.y, a2, a3);
+    unpack2(q.z, a4, a5);
+    unpack2(q.w, a6, a7);
+    v[0] = lds_at(lds, a0);
+    v[1] = lds_at(lds, a1);
+    v[2] = lds_at(lds, a2);
+    v[3] = lds_at(lds, a3);
+    v[4] = lds_at(lds, a4);
+    v[5] = lds_at(lds, a5);
+    v[6] = lds_at(lds, a6);
+    v[7] = lds_at(lds, a7);
+}
+
+// rows x cols floats from global (row stride src_stride) into LDS (row stride pitch == 1 mod 32), optionally
+// column-mirrored.  16-byte global loads, and a lane arrangement that makes the four ds_write_b32 of a float4
+// conflict-free: inside a 32-lane group, lane l takes row (l >> 3) and float4 number (l & 7) of a 4-row x 32-column
+// block (8 consecutive lanes read one 128-B line), so for component e the group writes dword (k*pitch + 4m + e), k = 0..3, m = 0..7 -- and with pitch == 1
+// (mod 32) the bank k + 4m + e runs over all 32 banks exactly once.  The two halves of a wave take adjacent blocks.
+// (LDS-DMA was measured here and lost: its dword form costs ~47 cycles per 256-B instruction per CU, and the odd
+// pitch rules out its 16-byte form.  Plain dword loads also lost: 4x the requests of float4 loads.)
+// Requires cols % 4 == 0 and 16-byte aligned rows; stage_rows_scalar covers everything else.
+__device__ __forceinline__ void stage_rows_v4(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
+                                              int pitch, bool mirror, int lane, int wave, int nwaves)
+{
+    const int ncb = (cols + 31) >> 5, npc = (ncb + 1) >> 1, nrq = (rows + 3) >> 2;
+    const int npairs = nrq * npc;
+    const int h = lane >> 5, k = (lane & 31) >> 3, m = lane & 7;   // 8 consecutive lanes = one 128-B line of one row
+    constexpr int NB = 8;   // float4 loads in flight per lane: 64 KiB lands in one batch with >= 8 waves
+    // pair index pp = wave, wave + nwaves, ... -> (rq, pc) = (pp / npc, pp % npc), advanced without dividing
+    const int d_rq = nwaves / npc, d_pc = nwaves - d_rq * npc;
+    int rq = wave / npc, pc = wave - rq * npc;
+    for (int p0 = wave; p0 < npairs; p0 += NB * nwaves) {
+        float4 v[NB];
+        int r_[NB], c_[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            r_[u] = 4 * rq + k;
+            c_[u] = 32 * (2 * pc + h) + 4 * m;
+            const bool ok = rq < nrq && r_[u] < rows && c_[u] < cols;
+            // The load itself is UNCONDITIONAL (address clamped into the slice): a select between a load and a
+            // constant makes hipcc branch around every load and wait vmcnt(0) after each.
+            const int rl = min(r_[u], rows - 1), cl = min(c_[u], cols - 4);
+            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)rl * src_stride + (mirror ? cols - 4 - cl : cl));
+            if (!ok) r_[u] = -1;
+            rq += d_rq;
+            pc += d_pc;
+            if (pc >= npc) {
+                pc -= npc;
+                ++rq;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (r_[u] < 0) continue;
+            float *d = lds + r_[u] * pitch + c_[u];
+            d[0] = mirror ? v[u].w : v[u].x;
+            d[1] = mirror ? v[u].z : v[u].y;
+            d[2] = mirror ? v[u].y : v[u].z;
+            d[3] = mirror ? v[u].x : v[u].w;
+        }
+    }
+}
+__device__ __forceinline__ void stage_rows_scalar(float *lds, const float *__restrict__ src, int rows, int cols,
+                                                  int src_stride, int pitch, bool mirror, int tid, int nthreads)
+{
+    for (int p = tid; p < rows * cols; p += nthreads) {
+        const int r = p / cols, c = p - r * cols;
+        lds[r * pitch + c] = src[(size_t)r * src_stride + (mirror ? cols - 1 - c : c)];
+    }
+}
+__device__ __forceinline__ void stage_rows(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
+                                           int pitch, bool mirror, int lane, int wave, int nwaves)
+{
+    if ((cols & 3) == 0 && (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+        stage_rows_v4(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves);
+    else
+        stage_rows_scalar(lds, src, rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64);
+}
+
+// Forward.  Workgroup = (slice s, class c, group gi): stages the slice once (LDS-DMA, mirrored for class 0), then each
+// wave takes the (angle, bin block) tasks of its class round-robin.  A task streams its index groups four loads deep,
+// gathers the previous group's eight taps while the next indices are in flight, and adds in row order.
+#ifdef CTPVAE_TUNE_STAMPS
+__device__ long long g_pstamps[8 * 65536];
+#define CTPVAE_PSTAMP(slot)                                                                                  \
+    do {                                                                                                     \
+        long long t_;                                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
+        if ((threadIdx.x & 63) == 0) g_pstamps[8 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + (slot)] = t_; \
+    } while (0)
+#else
+#define CTPVAE_PSTAMP(slot)
+#endif
+
+__global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *__restrict__ img, PlanGeom g, FwdLayout L,
+                                                                  const char *__restrict__ plan, int wgs_per_slice,
+                                                                  int g_S, float *__restrict__ sino)
+{
+    extern __shared__ float lds[];
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only).  Slices are dealt to the 8 XCDs so that
+    // all workgroups of one slice read it through the same L2: block = (s / 8) * 8 * wgs + wg * 8 + s % 8.
+    int s, wg;
+    {
+        const int per8 = 8 * wgs_per_slice, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
+        if ((octet + 1) * 8 <= g_S) {
+            wg = rem >> 3;
+            s = octet * 8 + (rem & 7);
+        } else {   // the last, partial octet (S % 8 slices) is laid out slice-major
+            s = octet * 8 + rem / wgs_per_slice;
+            wg = rem % wgs_per_slice;
+        }
+    }
+    const int c = wg & 1, gi = wg >> 1, G = wgs_per_slice >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const float *im = img + (size_t)s * g.H * g.W;
+    CTPVAE_PSTAMP(0);
+
+    // Stage the slice: coalesced dword loads (one 256-B row segment per wave-instruction, all of a wave's loads in
+    // flight together), then conflict-free ds_write_b32.  (LDS-DMA in its dword form measured ~47 cycles per
+    // instruction per CU here, several times slower than this; the odd pitch rules out its 16-byte form.)
+    stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+    if (threadIdx.x == 0) lds[L.zero] = 0.0f;
+    CTPVAE_PSTAMP(1);
+    __syncthreads();
+    CTPVAE_PSTAMP(2);
+
+    const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
+    const int *rng = reinterpret_cast<const int *>(plan + L.off_rng);
+    const uint4 *idx = reinterpret_cast<const uint4 *>(plan + L.off_idx);
+    const int T = g.A * L.nJB;
+    int matched = 0;
+    // tasks t = gi, gi + G, ... with (a, jb) = (t / nJB, t % nJB), advanced without dividing
+    const int da = G / L.nJB, djb = G - da * L.nJB;
+    int a = gi / L.nJB, jb = gi - a * L.nJB;
+    for (int t = gi; t < T; t += G, a += da, jb += djb) {
+        if (jb >= L.nJB) {
+            jb -= L.nJB;
+            ++a;
+        }
+        if (cls[a] != c) continue;
+        const bool mine = (matched % nwaves) == wave;
+        ++matched;
+        if (!mine) continue;
+
+        const int g0 = rng[(a * L.nJB + jb) * 2], ng4 = rng[(a * L.nJB + jb) * 2 + 1];
+        const int j = jb * 64 + lane;
+        const uint4 *p = idx + ((size_t)a * L.Galloc + g0) * L.PWpad + j;
+        const size_t st = (size_t)L.PWpad;
+        float acc = 0.0f;
+        if (ng4 > 0) {
+            uint4 q0 = p[0], q1 = p[st], q2 = p[2 * st], q3 = p[3 * st];
+            p += 4 * st;
+            float va[8], vb[8];
+            gather8(lds, q0, va);
+            q0 = p[0];
+            for (int gq = 0; gq < ng4; gq += 4) {
+                // invariant: va holds the gathers of group gq (in flight), q1..q3 groups gq+1..gq+3, q0 group gq+4
+                gather8(lds, q1, vb);
+                q1 = p[st];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += va[e];
+                gather8(lds, q2, va);
+                q2 = p[2 * st];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += vb[e];
+                gather8(lds, q3, vb);
+                q3 = p[3 * st];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += va[e];
+                gather8(lds, q0, va);   // group gq+4: the next iteration's first group (dead taps past the range)
+                p += 4 * st;
+                q0 = p[0];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += vb[e];
+            }
+            // va (group ng4) was gathered only to keep the pipeline uniform; it is not part of the sum
+        }
+        if (j < g.PW) sino[((size_t)s * g.A + a) * g.PW + j] = acc;
+    }
+    CTPVAE_PSTAMP(3);
+}
+
+// Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x ROWS-row tile): stages the slice's cotangent
+// block [A][pitchg] (LDS-DMA), then every lane owns one column and PPT rows; for each group of eight angles it loads
+// the PPT index vectors, gathers and adds in angle order.
+template <int PPT>
+__global__ __launch_bounds__(256) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
+                                                                 const uint4 *__restrict__ idx, int tiles_y,
+                                                                 float *__restrict__ gimg)
+{
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tiles = L.nXB * tiles_y;
+    const int s = blockIdx.x / tiles;
+    const int tile = blockIdx.x - s * tiles;
+    const int xb = tile % L.nXB, ty = tile / L.nXB;
+    const float *gs = gsino + (size_t)s * g.A * g.PW;
+
+    stage_rows(lds, gs, g.A, g.PW, g.PW, L.pitchg, false, lane, wave, nwaves);
+    if (threadIdx.x == 0) lds[L.zero] = 0.0f;
+
+    const int xcol = xb * 64 + lane;
+    const int y0 = ty * (nwaves * PPT) + wave;   // this wave's rows: y0, y0 + nwaves, ...
+    float acc[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) acc[k] = 0.0f;
+    const uint4 *p = idx + (size_t)xcol;
+    uint4 q[PPT];
+    auto load_group = [&](int a8) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int y = min(y0 + k * nwaves, g.H - 1);   // rows past the slice re-read the last row, never stored
+            q[k] = p[((size_t)a8 * g.H + y) * L.Wpad];
+        }
+    };
+    load_group(0);       // index loads fly while the cotangent block lands
+    __syncthreads();
+    for (int a8 = 0; a8 < L.NA8; ++a8) {
+        float v[PPT][8];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) gather8(lds, q[k], v[k]);
+        if (a8 + 1 < L.NA8) load_group(a8 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[k] += v[k][e];
+    }
+    if (xcol < g.W) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int y = y0 + k * nwaves;
+            if (y < g.H) gimg[((size_t)s * g.H + y) * g.W + xcol] = acc[k];
+        }
+    }
+}
+
+static int check_plan_geom(const char *who, int H, int W, int PH, int PW, int py, int px, int A)
+{
+    CTPVAE_REQUIRE(H > 0 && W > 0 && A > 0, "%s: sizes must be positive (H=%d W=%d A=%d)", who, H, W, A);
+    CTPVAE_REQUIRE(py >= 0 && px >= 0 && PH >= H + py && PW >= W + px,
+                   "%s: the %dx%d slice at (%d,%d) does not fit the %dx%d canvas", who, H, W, py, px, PH, PW);
+    CTPVAE_REQUIRE((long long)PH * PW < (1ll << 24), "%s: canvas too large for fp32 index arithmetic", who);
+    return CTPVAE_OK;
+}
+
+}  // namespace ctpvae
+
+using namespace ctpvae;
+
+extern "C" {
+
+int ctpvae_rotate_plan_supported(int H, int W, int PH, int PW, int A, int interp, int which)
+{
+    if (interp != CTPVAE_NEAREST || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return 0;
+    if (getenv("CTPVAE_NO_PLAN") != nullptr) return 0;
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    return which == 0 ? (fwd_plan_fits(g) ? 1 : 0) : (bwd_plan_fits(g) ? 1 : 0);
+}
+
+long long ctpvae_rotate_plan_bytes(int H, int W, int PH, int PW, int A, int which)
+{
+    if (H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_plan_bytes: bad sizes");
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    return which == 0 ? fwd_layout(g).bytes : bwd_layout(g).bytes;
+}
+
+int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py,
+                                 int px, void *fwd_plan_dev, void *bwd_plan_dev, ctpvae_stream_t stream)
+{
+    if (int rc = check_plan_geom("rotate_plan_build", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(fwd_plan_dev || bwd_plan_dev, "rotate_plan_build: no plan buffer given");
+    const PlanGeom g{H, W, PH, PW, py, px, A};
+    if (fwd_plan_dev) {
+        CTPVAE_REQUIRE(T8_dev, "rotate_plan_build: forward plan needs the forward transforms");
+        CTPVAE_REQUIRE(fwd_plan_fits(g), "rotate_plan_build: a %dx%d slice does not fit the forward plan's LDS image", H, W);
+        CTPVAE_REQUIRE(A <= 65535, "rotate_plan_build: at most 65535 angles");
+        const FwdLayout L = fwd_layout(g);
+        hipLaunchKernelGGL(rotate_fwd_plan_kernel, dim3(L.nJB, A), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L,
+                           (char *)fwd_plan_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_plan_kernel");
+    }
+    if (bwd_plan_dev) {
+        CTPVAE_REQUIRE(Tinv8_dev, "rotate_plan_build: backward plan needs the inverted transforms");
+        CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_plan_build: %d angles x %d bins do not fit the backward plan's LDS block", A, PW);
+        CTPVAE_REQUIRE(H <= 65535, "rotate_plan_build: at most 65535 rows");
+        const BwdLayout L = bwd_layout(g);
+        hipLaunchKernelGGL(rotate_bwd_plan_kernel, dim3(L.nXB, H, L.NA8), dim3(64), 0, (hipStream_t)stream, g, Tinv8_dev, L,
+                           (uint4 *)bwd_plan_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_bwd_plan_kernel");
+    }
+    return CTPVAE_OK;
+}
+
+int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
+                                  float *sino_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(img_dev && fwd_plan_dev && sino_dev, "rotate_fwd_planned: null pointer");
+    CTPVAE_REQUIRE(S > 0, "rotate_fwd_planned: need at least one slice");
+    if (int rc = check_plan_geom("rotate_fwd_planned", H, W, PH, PW, 0, 0, A)) return rc;
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    CTPVAE_REQUIRE(fwd_plan_fits(g), "rotate_fwd_planned: a %dx%d slice does not fit the plan's LDS image", H, W);
+    const FwdLayout L = fwd_layout(g);
+    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float);
+    // (angle, bin block) tasks of one slice are dealt to G groups per class; about two workgroups per CU chip-wide,
+    // at most 16 waves each
+    const int T = A * L.nJB;
+    const int wgs_per_cu = shmem * 2 <= (size_t)kMaxLdsBytes ? 2 : 1;
+    int G = (int)std::max<long long>(1, (256ll * wgs_per_cu) / (2ll * S));
+    G = std::min(G, std::max(1, T / 2));
+    while ((T + 2 * G - 1) / (2 * G) > 16) ++G;
+    if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
+    const int waves = std::min(16, std::max(1, (T + 2 * G - 1) / (2 * G)));
+    const int wgs_per_slice = 2 * G;
+    CTPVAE_REQUIRE((long long)S * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTPVAE_HIP(hipFuncSetAttribute((const void *)rotate_fwd_planned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kMaxLdsBytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rotate_fwd_planned_kernel, dim3((unsigned)(S * wgs_per_slice)), dim3(64 * waves), shmem,
+                       (hipStream_t)stream, img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
+    return CTPVAE_OK;
+}
+
+int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A, const void *bwd_plan_dev,
+                                  float *gimg_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(gsino_dev && bwd_plan_dev && gimg_dev, "rotate_bwd_planned: null pointer");
+    CTPVAE_REQUIRE(S > 0, "rotate_bwd_planned: need at least one slice");
+    if (int rc = check_plan_geom("rotate_bwd_planned", H, W, PH, PW, 0, 0, A)) return rc;
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd_planned: %d angles x %d bins do not fit the plan's LDS block", A, PW);
+    const BwdLayout L = bwd_layout(g);
+    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float);
+    constexpr int kPpt = 4;
+    const int rows_per_wg = 4 * kPpt;
+    const int tiles_y = ceil_div(H, rows_per_wg);
+    const long long nblk = (long long)S * L.nXB * tiles_y;
+    CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CTPVAE_HIP(hipFuncSetAttribute((const void *)rotate_bwd_planned_kernel<kPpt>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(rotate_bwd_planned_kernel<kPpt>, dim3((unsigned)nblk), dim3(256), shmem, (hipStream_t)stream,
+                       gsino_dev, g, L, (const uint4 *)bwd_plan_dev, tiles_y, gimg_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_bwd_planned_kernel");
+    return CTPVAE_OK;
+}
+
+}  // extern "C"

@@ -128,7 +128,7 @@ class RotatePlan:
 
     `forward` / `backward` are the raw operator pair (no autograd bookkeeping); `apply` is differentiable."""
 
-    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat"):
+    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True):
         if interp not in _INTERP:
             raise ValueError(f"interp must be one of {sorted(_INTERP)} (got {interp!r})")
         if backward not in _BACKWARD:
@@ -148,13 +148,44 @@ class RotatePlan:
         self.T8, self.Tinv8 = rotate_tables(theta, self.PH, self.PW, self.device)
         self.A = self.T8.shape[0]
         self._lib = _lib.load()
+        # Gather plans (NEAREST): tap indices computed once for this geometry, shared by every slice of every call.
+        # The forward plan is built now, the backward plan on the first backward.
+        self._fwd_plan = self._bwd_plan = None
+        self._want_bwd_plan = False
+        if use_plan:
+            geo = (self.H, self.W, self.PH, self.PW, self.A, self.interp)
+            if self._lib.ctpvae_rotate_plan_supported(*geo, 0):
+                self._fwd_plan = self._build_plan(0)
+            self._want_bwd_plan = bool(self.mode == _lib.BWD_TF_COMPAT and
+                                       self._lib.ctpvae_rotate_plan_supported(*geo, 1))
+
+    def _build_plan(self, which):
+        nbytes = self._lib.ctpvae_rotate_plan_bytes(self.H, self.W, self.PH, self.PW, self.A, which)
+        _lib.check(nbytes, "rotate_plan_bytes")
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctpvae_rotate_plan_build_f32(
+                self.T8.data_ptr(), self.Tinv8.data_ptr(), self.A, self.H, self.W, self.PH, self.PW, self.py, self.px,
+                buf.data_ptr() if which == 0 else None, buf.data_ptr() if which == 1 else None, _stream_ptr()),
+                "rotate_plan_build")
+        return buf
+
+    @property
+    def planned(self):
+        """(forward uses a plan, backward uses / will use a plan)"""
+        return self._fwd_plan is not None, self._want_bwd_plan
 
     def forward(self, img, out=None):
         S = img.shape[0]
         if out is None:
             out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
-        rc = self._lib.ctpvae_rotate_fwd_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px,
-                                             self.T8.data_ptr(), self.A, self.interp, out.data_ptr(), _stream_ptr())
+        if self._fwd_plan is not None:
+            rc = self._lib.ctpvae_rotate_fwd_planned_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                         self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr())
+        else:
+            rc = self._lib.ctpvae_rotate_fwd_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
+                                                 self.px, self.T8.data_ptr(), self.A, self.interp, out.data_ptr(),
+                                                 _stream_ptr())
         if rc:
             _lib.check(rc, "rotate_fwd")
         return out
@@ -163,10 +194,16 @@ class RotatePlan:
         S = gsino.shape[0]
         if out is None:
             out = torch.empty((S, self.H, self.W), dtype=torch.float32, device=gsino.device)
-        tab = self.Tinv8 if self.mode == _lib.BWD_TF_COMPAT else self.T8
-        rc = self._lib.ctpvae_rotate_bwd_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, tab.data_ptr(),
-                                             self.interp, self.mode, self.H, self.W, self.py, self.px,
-                                             out.data_ptr(), _stream_ptr())
+        if self._want_bwd_plan:
+            if self._bwd_plan is None:
+                self._bwd_plan = self._build_plan(1)
+            rc = self._lib.ctpvae_rotate_bwd_planned_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                         self._bwd_plan.data_ptr(), out.data_ptr(), _stream_ptr())
+        else:
+            tab = self.Tinv8 if self.mode == _lib.BWD_TF_COMPAT else self.T8
+            rc = self._lib.ctpvae_rotate_bwd_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, tab.data_ptr(),
+                                                 self.interp, self.mode, self.H, self.W, self.py, self.px,
+                                                 out.data_ptr(), _stream_ptr())
         if rc:
             _lib.check(rc, "rotate_bwd")
         return out

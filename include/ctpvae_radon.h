@@ -17,6 +17,8 @@
  *                                              project_tf_low_mem ctvae/forward_functions.py:49-78
  *   ctpvae_rotate_bwd_f32                      autodiff of the above (tf.GradientTape,
  *                                              ctvae/main_ct_vae.py:471-481) and its exact transpose
+ *   ctpvae_rotate_plan_* / _planned_f32        the same two operators, batched: index arithmetic hoisted
+ *                                              out of the per-object work (no counterpart in the reference)
  *   ctpvae_siddon_tables_f32 / _fwd_f32        create_sinogram -> tomopy.project
  *                                              ctvae/helper_functions.py:33-38
  *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
@@ -78,6 +80,25 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
 int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev,
                           int interp, int mode, int H, int W, int py, int px, float *gimg_dev,
                           ctpvae_stream_t stream);
+
+/* ---- gather plans (NEAREST): the tap indices of a geometry, computed once, reused for every slice ----------
+ * The tap a sample reads depends on (angle, canvas row, detector bin) only, so for batched projection the index
+ * arithmetic of a3/a4 is evaluated ONCE by ctpvae_rotate_plan_build_f32 (exactly as the direct kernels do) and
+ * stored as u16 LDS indices; ctpvae_rotate_{fwd,bwd}_planned_f32 then compute the SAME sums, bit for bit, as
+ * ctpvae_rotate_fwd_f32 / ctpvae_rotate_bwd_f32(mode TF_COMPAT) with interp NEAREST.
+ * which: 0 = forward plan, 1 = backward (TF_COMPAT) plan.  _supported returns 1 if the geometry fits the planned
+ * kernels (slice / cotangent block must fit LDS), else 0 -- use the direct entry points then.
+ * Plan buffers are caller-owned device memory of ctpvae_rotate_plan_bytes() bytes, 256-byte aligned. */
+int ctpvae_rotate_plan_supported(int H, int W, int PH, int PW, int A, int interp, int which);
+long long ctpvae_rotate_plan_bytes(int H, int W, int PH, int PW, int A, int which);
+/* T8_dev: forward rows (needed for the forward plan); Tinv8_dev: inverted rows (needed for the backward plan);
+ * either plan pointer may be NULL to skip it. */
+int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
+                                 int py, int px, void *fwd_plan_dev, void *bwd_plan_dev, ctpvae_stream_t stream);
+int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                  const void *fwd_plan_dev, float *sino_dev, ctpvae_stream_t stream);
+int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                  const void *bwd_plan_dev, float *gimg_dev, ctpvae_stream_t stream);
 
 /* ---- a7: TomoPy-style ray-driven projector --------------------------------------------------
  * Tables (host side, fp32): theta [dt] -> sin, cos of fmodf(theta, 2*pi) and libtomo's quadrant flag. */

@@ -58,12 +58,15 @@ def test_device_tables_match_oracle(oracle):
 
 
 @pytest.mark.parametrize("name", ROTATE_CASES)
-@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
-def test_rotate_against_oracle_and_golden(oracle, golden_dir, name, interp):
+@pytest.mark.parametrize("interp,use_plan", [("nearest", True), ("nearest", False), ("bilinear", False)])
+def test_rotate_against_oracle_and_golden(oracle, golden_dir, name, interp, use_plan):
+    """use_plan=True: the gather-plan kernels (csrc/rotate_plan.hip); False: the direct kernels (csrc/rotate.hip)."""
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     img, pad, theta, g = z["img"], bool(z["pad"]), z["theta"], z["g"]
     code = 0 if interp == "nearest" else 1
-    plan = RotatePlan(theta, img.shape[1], img.shape[2], pad, dev(), interp=interp, backward="tf_compat")
+    plan = RotatePlan(theta, img.shape[1], img.shape[2], pad, dev(), interp=interp, backward="tf_compat",
+                      use_plan=use_plan)
+    assert plan.planned == (use_plan, use_plan)
     geom = oracle.Geometry(img.shape[1], img.shape[2], pad)
     T, Tinv = to_np(plan.T8), to_np(plan.Tinv8)   # the oracle sees the very tables the kernel uses
     x = torch.from_numpy(img).to(dev())
@@ -161,14 +164,16 @@ def test_exact_backward_is_the_transpose_at_full_size():
         assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
 
 
-def test_full_size_properties(oracle):
+@pytest.mark.parametrize("use_plan", [True, False])
+def test_full_size_properties(oracle, use_plan):
     """BASELINE config 2 (B=50, N=128, 20 sparse angles) and the 180-angle evaluation set: linearity, slice
     independence, axis-aligned analytic answers, and a sampled comparison with the oracle."""
     d = dev()
     foam = phantoms.foam_batch(50, 128, seed=0, supersample=2)
     x = torch.from_numpy(foam).to(d)
     theta180 = phantoms.dense_theta(180)
-    plan = RotatePlan(theta180, 128, 128, True, d)
+    plan = RotatePlan(theta180, 128, 128, True, d, use_plan=use_plan)
+    assert plan.planned == (use_plan, use_plan)
     s = plan.forward(x)
     assert s.shape == (50, 180, 184)
     sn = to_np(s)
@@ -189,6 +194,27 @@ def test_full_size_properties(oracle):
     np.testing.assert_array_equal(b[[5, 31]], oracle.rotate_bwd_tfcompat(to_np(g)[[5, 31]], geom, to_np(plan.Tinv8), 0))
 
 
+@pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 5), ((128, 128), True, 7, 1), ((40, 100), True, 33, 3),
+                                          ((65, 31), False, 9, 2), ((2, 2), False, 2, 2), ((130, 70), True, 181, 2)])
+def test_planned_equals_direct(oracle, shape, pad, A, S):
+    """The gather-plan kernels and the direct kernels are the same operator, bit for bit, on ragged shapes, odd angle
+    counts (the plans pack rows by 8 and angles by 8), unpadded canvases (negative-tie rounding) and tiny batches."""
+    d = dev()
+    rng = np.random.default_rng(A)
+    theta = rng.uniform(-1.0, 4.0, A)
+    x = torch.from_numpy(rng.standard_normal((S,) + shape).astype(np.float32)).to(d)
+    pa = RotatePlan(theta, shape[0], shape[1], pad, d, use_plan=True)
+    pb = RotatePlan(theta, shape[0], shape[1], pad, d, use_plan=False)
+    assert pa.planned == (True, True) and pb.planned == (False, False)
+    fa, fb = pa.forward(x), pb.forward(x)
+    assert torch.equal(fa, fb)
+    g = torch.from_numpy(rng.standard_normal(tuple(fa.shape)).astype(np.float32)).to(d)
+    assert torch.equal(pa.backward(g), pb.backward(g))
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    np.testing.assert_array_equal(to_np(fa[:1]), oracle.rotate_fwd(to_np(x[:1]), geom, to_np(pa.T8), 0))
+    np.testing.assert_array_equal(to_np(pa.backward(g)[:1]), oracle.rotate_bwd_tfcompat(to_np(g[:1]), geom, to_np(pa.Tinv8), 0))
+
+
 def test_large_image_takes_the_no_lds_path(oracle):
     """512x512 (BASELINE config 5) does not fit LDS; same numbers either way."""
     d = dev()
@@ -196,7 +222,7 @@ def test_large_image_takes_the_no_lds_path(oracle):
     img = rng.random((1, 512, 512), dtype=np.float32)
     theta = np.array([0.0, 0.4, np.pi / 2, 2.0])
     plan = RotatePlan(theta, 512, 512, True, d)
-    assert plan.PW == 728
+    assert plan.PW == 728 and plan.planned[0] is False
     geom = oracle.Geometry(512, 512, True)
     np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
                                   oracle.rotate_fwd(img, geom, to_np(plan.T8), 0))
