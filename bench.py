@@ -83,7 +83,7 @@ def cpu_baseline(imgs, theta, g, budget_s=12.0):
     Tinv = orc.invert_transforms(T)
     A = len(theta)
     n_obj, t_rot = 0, 0.0
-    while t_rot < budget_s * 0.6 and n_obj < 4 * imgs.shape[0]:
+    while t_rot < budget_s * 0.6:
         k = n_obj % imgs.shape[0]
         t0 = time.perf_counter()
         orc.rotate_fwd(imgs[k:k + 1], geom, T, orc.NEAREST)
@@ -91,9 +91,10 @@ def cpu_baseline(imgs, theta, g, budget_s=12.0):
         t_rot += time.perf_counter() - t0
         n_obj += 1
     n_sid, t_sid = 0, 0.0
-    while t_sid < budget_s * 0.4 and n_sid < imgs.shape[0]:
+    while t_sid < budget_s * 0.4:
+        k = n_sid % imgs.shape[0]
         t0 = time.perf_counter()
-        orc.siddon_project(imgs[n_sid:n_sid + 1], theta, pad=True)
+        orc.siddon_project(imgs[k:k + 1], theta, pad=True)
         t_sid += time.perf_counter() - t0
         n_sid += 1
     return {
@@ -173,7 +174,9 @@ def main():
     if rank != 0:
         return
     bytes_dir = 4.0 * B * (N * N + A * P)                 # one direction: read once + write once (fp32)
-    dom = ("rotate_fwd_kernel", t_fwd) if t_fwd >= t_bwd else ("rotate_bwd_tfcompat_kernel", t_bwd)
+    fwd_name = "rotate_fwd_planned_kernel" if plan.planned[0] else "rotate_fwd_fast_kernel"
+    bwd_name = "rotate_bwd_planned_kernel" if plan.planned[1] else "rotate_bwd_tfcompat_fast_kernel"
+    dom = (fwd_name, t_fwd) if t_fwd >= t_bwd else (bwd_name, t_bwd)
     achieved = bytes_dir / dom[1] / 1e9
     proj_per_s = world * B * A * args.steps / elapsed
     out = {

@@ -101,10 +101,13 @@ __device__ __forceinline__ int wave_max_i(int v)
 }
 
 // ---- plan builders: the reference arithmetic, evaluated exactly, once per geometry ---------------------------
+// One wave per (bin block, angle, row group).  rng[a][jb] = {first live group, kRngBias - last live group}, both
+// reduced with atomicMin over the groups (the buffer is preset to 0x7f7f7f7f by the host-side memset).
+constexpr int kRngBias = 0x7f7f7f7f;
 __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const float *__restrict__ T8, FwdLayout L,
                                                              char *__restrict__ plan)
 {
-    const int a = blockIdx.y, jb = blockIdx.x, lane = threadIdx.x;
+    const int a = blockIdx.y, jb = blockIdx.x, gq = blockIdx.z, lane = threadIdx.x;
     const int j = jb * 64 + lane;
     const float *t = T8 + 8 * a;
     const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
@@ -112,47 +115,37 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
     int *cls = reinterpret_cast<int *>(plan + L.off_cls);
     int *rng = reinterpret_cast<int *>(plan + L.off_rng);
     uint4 *idx = reinterpret_cast<uint4 *>(plan + L.off_idx);
-    if (jb == 0 && lane == 0) cls[a] = plus ? 1 : 0;
+    if (jb == 0 && gq == 0 && lane == 0) cls[a] = plus ? 1 : 0;
     const float xj = t0 * (float)j, yj = t3 * (float)j;
-    int first = INT_MAX, last = -1;
-    for (int gq = 0; gq < L.Galloc; ++gq) {
-        unsigned e16[8];
-        bool any = false;
+    unsigned e16[8];
+    bool any = false;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int i = 8 * gq + e;
-            unsigned v = (unsigned)L.zero;
-            if (i < g.PH && j < g.PW) {
-                // ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round, zero fill
-                const float fi = (float)i;
-                const float x = (xj + t1 * fi) + t2;
-                const float y = (yj + t4 * fi) + t5;
-                const int ix = (int)__builtin_roundf(x) - g.px;
-                const int iy = (int)__builtin_roundf(y) - g.py;
-                if ((unsigned)ix < (unsigned)g.W && (unsigned)iy < (unsigned)g.H) {
-                    v = (unsigned)(iy * L.pitch + (plus ? ix : g.W - 1 - ix));
-                    any = true;
-                }
+    for (int e = 0; e < 8; ++e) {
+        const int i = 8 * gq + e;
+        unsigned v = (unsigned)L.zero;
+        if (i < g.PH && j < g.PW) {
+            // ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round, zero fill
+            const float fi = (float)i;
+            const float x = (xj + t1 * fi) + t2;
+            const float y = (yj + t4 * fi) + t5;
+            const int ix = (int)__builtin_roundf(x) - g.px;
+            const int iy = (int)__builtin_roundf(y) - g.py;
+            if ((unsigned)ix < (unsigned)g.W && (unsigned)iy < (unsigned)g.H) {
+                v = (unsigned)(iy * L.pitch + (plus ? ix : g.W - 1 - ix));
+                any = true;
             }
-            e16[e] = v;
         }
-        uint4 q;
-        q.x = e16[0] | (e16[1] << 16);
-        q.y = e16[2] | (e16[3] << 16);
-        q.z = e16[4] | (e16[5] << 16);
-        q.w = e16[6] | (e16[7] << 16);
-        idx[((size_t)a * L.Galloc + gq) * L.PWpad + j] = q;
-        if (any) {
-            first = min(first, gq);
-            last = gq;
-        }
+        e16[e] = v;
     }
-    first = wave_min_i(first);
-    last = wave_max_i(last);
-    if (lane == 0) {
-        const int ng = last >= 0 ? last - first + 1 : 0;
-        rng[(a * L.nJB + jb) * 2 + 0] = last >= 0 ? first : 0;
-        rng[(a * L.nJB + jb) * 2 + 1] = (ng + 3) / 4 * 4;
+    uint4 q;
+    q.x = e16[0] | (e16[1] << 16);
+    q.y = e16[2] | (e16[3] << 16);
+    q.z = e16[4] | (e16[5] << 16);
+    q.w = e16[6] | (e16[7] << 16);
+    idx[((size_t)a * L.Galloc + gq) * L.PWpad + j] = q;
+    if (__any(any) && lane == 0) {
+        atomicMin(&rng[(a * L.nJB + jb) * 2 + 0], gq);
+        atomicMin(&rng[(a * L.nJB + jb) * 2 + 1], kRngBias - gq);
     }
 }
 
@@ -348,7 +341,9 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
         ++matched;
         if (!mine) continue;
 
-        const int g0 = rng[(a * L.nJB + jb) * 2], ng4 = rng[(a * L.nJB + jb) * 2 + 1];
+        const int first = rng[(a * L.nJB + jb) * 2], last = kRngBias - rng[(a * L.nJB + jb) * 2 + 1];
+        const int g0 = last >= first ? first : 0;
+        const int ng4 = last >= first ? (last - first + 4) / 4 * 4 : 0;   // group count, rounded up to 4
         const int j = jb * 64 + lane;
         const uint4 *p = idx + ((size_t)a * L.Galloc + g0) * L.PWpad + j;
         const size_t st = (size_t)L.PWpad;
@@ -486,7 +481,9 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
         CTPVAE_REQUIRE(fwd_plan_fits(g), "rotate_plan_build: a %dx%d slice does not fit the forward plan's LDS image", H, W);
         CTPVAE_REQUIRE(A <= 65535, "rotate_plan_build: at most 65535 angles");
         const FwdLayout L = fwd_layout(g);
-        hipLaunchKernelGGL(rotate_fwd_plan_kernel, dim3(L.nJB, A), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L,
+        CTPVAE_REQUIRE(L.Galloc <= 65535, "rotate_plan_build: canvas too tall");
+        CTPVAE_HIP(hipMemsetAsync((char *)fwd_plan_dev + L.off_rng, 0x7f, (size_t)A * L.nJB * 8, (hipStream_t)stream));
+        hipLaunchKernelGGL(rotate_fwd_plan_kernel, dim3(L.nJB, A, L.Galloc), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L,
                            (char *)fwd_plan_dev);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_plan_kernel");
     }

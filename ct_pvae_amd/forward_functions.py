@@ -223,6 +223,28 @@ class _RotateProject(torch.autograd.Function):
         return ctx.plan.backward(gsino.contiguous()), None
 
 
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 16
+
+
+def _cached_plan(theta, H, W, pad, device, interp, backward):
+    """RotatePlan for this call.  A host-resident angle set (list / numpy / CPU tensor) is keyed by value, so the
+    scripts that project with a fixed theta build their tables and gather plans once; a device-resident theta (the
+    training loop's per-step subset) is rebuilt -- three small launches -- because reading it back would synchronise."""
+    if isinstance(theta, torch.Tensor) and theta.device.type == "cuda":
+        return RotatePlan(theta, H, W, pad, device, interp=interp, backward=backward)
+    host = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
+                                           dtype=np.float32))
+    key = (host.tobytes(), H, W, bool(pad), str(device), interp, backward)
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        plan = RotatePlan(host, H, W, pad, device, interp=interp, backward=backward)
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE[key] = plan
+    return plan
+
+
 def _as_slices(x):
     """fp32, contiguous [S][H][W] on the current HIP device; returns (slices, original dtype)."""
     if not isinstance(x, torch.Tensor):
@@ -256,7 +278,7 @@ def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
         raise ValueError(f"dim must be 2 or 3 (got {dim})")
     if slices.shape[0] == 0:
         raise ValueError("phantom holds no slices")
-    plan = RotatePlan(theta, slices.shape[1], slices.shape[2], pad, slices.device, interp=interp, backward=backward)
+    plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, interp, backward)
     with torch.cuda.device(slices.device):
         sino = plan.apply(slices)  # [S][A][PW]
     if integrate_vae:
