@@ -46,10 +46,22 @@ struct BwdLayout {
 
 __host__ __device__ inline int pitch_mod32_is_1(int w) { return w + ((1 - (w & 31)) & 31); }
 
+// Detector bins are dealt to 64-lane blocks in two 32-bin bands mirrored about the detector centre: block k holds
+// bins [c - 32(k+1), c - 32k) in lanes 0..31 and [c + 32k, c + 32(k+1)) in lanes 32..63, c = PW / 2.  Rays at equal
+// distance from the centre have equal chords through the slice, so a wave's 64 rays need nearly the same rows
+// (a contiguous 64-bin block mixes long central chords with short outer ones: 147 vs 134 visited rows per task at
+// N = 128).  Each 32-lane half is still a contiguous run of bins, which is what the LDS bank argument needs.
+__host__ __device__ inline int lane_to_bin(int PW, int jb, int lane)
+{
+    const int c = PW >> 1;
+    return lane < 32 ? c - 32 * (jb + 1) + lane : c + 32 * jb + (lane - 32);   // may fall outside [0, PW): dead lane
+}
+__host__ __device__ inline int num_bin_blocks(int PW) { return (PW - (PW >> 1) + 31) / 32; }
+
 static FwdLayout fwd_layout(const PlanGeom &g)
 {
     FwdLayout L;
-    L.nJB = ceil_div(g.PW, 64);
+    L.nJB = num_bin_blocks(g.PW);
     L.PWpad = L.nJB * 64;
     L.NG = ceil_div(g.PH, 8);
     L.Galloc = L.NG + 8;  // dead groups behind the canvas: the kernel prefetches up to 7 groups past a range
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
                                                              char *__restrict__ plan)
 {
     const int a = blockIdx.y, jb = blockIdx.x, gq = blockIdx.z, lane = threadIdx.x;
-    const int j = jb * 64 + lane;
+    const int j = lane_to_bin(g.PW, jb, lane);
     const float *t = T8 + 8 * a;
     const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
     const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
     for (int e = 0; e < 8; ++e) {
         const int i = 8 * gq + e;
         unsigned v = (unsigned)L.zero;
-        if (i < g.PH && j < g.PW) {
+        if (i < g.PH && (unsigned)j < (unsigned)g.PW) {
             // ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round, zero fill
             const float fi = (float)i;
             const float x = (xj + t1 * fi) + t2;
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
     q.y = e16[2] | (e16[3] << 16);
     q.z = e16[4] | (e16[5] << 16);
     q.w = e16[6] | (e16[7] << 16);
-    idx[((size_t)a * L.Galloc + gq) * L.PWpad + j] = q;
+    idx[((size_t)a * L.Galloc + gq) * L.PWpad + jb * 64 + lane] = q;
     if (__any(any) && lane == 0) {
         atomicMin(&rng[(a * L.nJB + jb) * 2 + 0], gq);
         atomicMin(&rng[(a * L.nJB + jb) * 2 + 1], kRngBias - gq);
@@ -286,6 +298,8 @@ __device__ long long g_pstamps[8 * 65536];
         long long t_;                                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
         if ((threadIdx.x & 63) == 0) g_pstamps[8 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + (slot)] = t_; \
+        if ((threadIdx.x & 63) == 0 && ((slot) == 0 || (slot) == 3))                                         \
+            g_pstamps[8 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define CTPVAE_PSTAMP(slot)
@@ -343,44 +357,52 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 
         const int first = rng[(a * L.nJB + jb) * 2], last = kRngBias - rng[(a * L.nJB + jb) * 2 + 1];
         const int g0 = last >= first ? first : 0;
-        const int ng4 = last >= first ? (last - first + 4) / 4 * 4 : 0;   // group count, rounded up to 4
-        const int j = jb * 64 + lane;
-        const uint4 *p = idx + ((size_t)a * L.Galloc + g0) * L.PWpad + j;
+        const int ng = last >= first ? last - first + 1 : 0;   // row groups any of this block's rays needs
+        const int j = lane_to_bin(g.PW, jb, lane);
+        const uint4 *p = idx + ((size_t)a * L.Galloc + g0) * L.PWpad + jb * 64 + lane;
+#ifdef CTPVAE_TUNE_NOIDX
+        const size_t st = 0;   // timing only: every group re-reads the first index vector (no index streaming)
+#else
         const size_t st = (size_t)L.PWpad;
+#endif
         float acc = 0.0f;
-        if (ng4 > 0) {
+        if (ng > 0) {
+            // q0..q3: index vectors of groups n..n+3 (loads in flight); va/vb: gathers of group n / n+1 in flight.
+            // Loads and gathers run up to four groups past `ng`: the table keeps 8 dead groups behind the canvas.
             uint4 q0 = p[0], q1 = p[st], q2 = p[2 * st], q3 = p[3 * st];
             p += 4 * st;
             float va[8], vb[8];
             gather8(lds, q0, va);
             q0 = p[0];
-            for (int gq = 0; gq < ng4; gq += 4) {
-                // invariant: va holds the gathers of group gq (in flight), q1..q3 groups gq+1..gq+3, q0 group gq+4
+            for (int n = 0;; n += 4) {
                 gather8(lds, q1, vb);
                 q1 = p[st];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += va[e];
+                for (int e = 0; e < 8; ++e) acc += va[e];          // group n
+                if (n + 1 >= ng) break;
                 gather8(lds, q2, va);
                 q2 = p[2 * st];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += vb[e];
+                for (int e = 0; e < 8; ++e) acc += vb[e];          // group n + 1
+                if (n + 2 >= ng) break;
                 gather8(lds, q3, vb);
                 q3 = p[3 * st];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += va[e];
-                gather8(lds, q0, va);   // group gq+4: the next iteration's first group (dead taps past the range)
+                for (int e = 0; e < 8; ++e) acc += va[e];          // group n + 2
+                if (n + 3 >= ng) break;
+                gather8(lds, q0, va);
                 p += 4 * st;
                 q0 = p[0];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += vb[e];
+                for (int e = 0; e < 8; ++e) acc += vb[e];          // group n + 3
+                if (n + 4 >= ng) break;
             }
-            // va (group ng4) was gathered only to keep the pipeline uniform; it is not part of the sum
         }
-        if (j < g.PW) sino[((size_t)s * g.A + a) * g.PW + j] = acc;
+        if ((unsigned)j < (unsigned)g.PW) sino[((size_t)s * g.A + a) * g.PW + j] = acc;
     }
     CTPVAE_PSTAMP(3);
 }
@@ -513,9 +535,8 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
     // at most 16 waves each
     const int T = A * L.nJB;
     const int wgs_per_cu = shmem * 2 <= (size_t)kMaxLdsBytes ? 2 : 1;
-    int G = (int)std::max<long long>(1, (256ll * wgs_per_cu) / (2ll * S));
+    int G = (int)std::max<long long>(1, (long long)(256 * (wgs_per_cu == 2 ? 1.6 : 1.0) / (2.0 * S) + 0.5));
     G = std::min(G, std::max(1, T / 2));
-    while ((T + 2 * G - 1) / (2 * G) > 16) ++G;
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, (T + 2 * G - 1) / (2 * G)));
     const int wgs_per_slice = 2 * G;

@@ -88,6 +88,15 @@ int main(int argc, char **argv)
         double seg[3] = {0, 0, 0};
         for (int w = 0; w < nw; ++w) for (int q = 0; q < 3; ++q) seg[q] += (double)(st[8 * w + q + 1] - st[8 * w + q]);
         printf("planned fwd stamps over %d waves (cycles): fill-issue %.0f | barrier wait %.0f | tasks %.0f\n", nw, seg[0] / nw, seg[1] / nw, seg[2] / nw);
+        {   // global timeline in 10 ns ticks (s_memrealtime, 100 MHz)
+            long long t0 = st[4], t1 = 0; std::vector<long long> starts, ends;
+            for (int w = 0; w < nw; ++w) { t0 = std::min(t0, st[8 * w + 4]); t1 = std::max(t1, st[8 * w + 5]); }
+            for (int w = 0; w < nw; ++w) { starts.push_back(st[8 * w + 4] - t0); ends.push_back(st[8 * w + 5] - t0); }
+            std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
+            printf("  timeline (us): span %.2f | wave starts p0 %.2f p50 %.2f p90 %.2f p100 %.2f | wave ends p0 %.2f p10 %.2f p50 %.2f p90 %.2f p100 %.2f\n",
+                   (t1 - t0) * 0.01, starts[0] * 0.01, starts[nw / 2] * 0.01, starts[nw * 9 / 10] * 0.01, starts[nw - 1] * 0.01,
+                   ends[0] * 0.01, ends[nw / 10] * 0.01, ends[nw / 2] * 0.01, ends[nw * 9 / 10] * 0.01, ends[nw - 1] * 0.01);
+        }
     }
     {
         ctpvae_rotate_fwd_f32(d_img, S, N, N, P, P, pad, pad, d_T, A, 0, d_sino, nullptr);
