@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from ct_pvae_amd import phantoms  # noqa: E402
+from ct_pvae_amd import phantoms, sharding  # noqa: E402
 from ct_pvae_amd.forward_functions import RotatePlan, project_tf_fast  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak (spec)
@@ -39,19 +39,13 @@ def parse():
     ap.add_argument("--angles", type=int, default=A_SPARSE, help="20 (headline) or 180 (dense evaluation set)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["projector", "train"], default="projector",
+                    help="projector: the headline fwd+adj metric (default); train: BASELINE config 3, P-VAE steps/s")
     return ap.parse_args()
 
 
 def dist_setup(n_gpus):
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+    world, rank, local = sharding.init_from_env()      # one process per GPU; "nccl" = RCCL
     if world != n_gpus:
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     return world, rank, local
@@ -65,12 +59,7 @@ def barrier_sync(world):
 
 
 def max_over_ranks(seconds, world):
-    if world == 1:
-        return seconds
-    import torch.distributed as dist
-    t = torch.tensor([seconds], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return sharding.max_over_ranks(seconds)
 
 
 def cpu_baseline(imgs, theta, g, budget_s=12.0):
@@ -108,10 +97,50 @@ def cpu_baseline(imgs, theta, g, budget_s=12.0):
     }
 
 
+def train_mode(args, world, rank, dev):
+    """BASELINE config 3: main_ct_vae.py --nsa 20 --td 50 -b 5 --ns 2 --api 20 (README.md:80), HIP projector decoder."""
+    from ct_pvae_amd import trainer as tr
+    targs = tr.get_args(f"--nsa 20 --td 50 -b {5 * world} --ns 2 --api 20 --pnm 1e4 --pnm_start 1e3 --random --normal "
+                        f"-i {args.steps + args.warmup} --train".split())
+    t = tr.PVAETrainer(targs, dev)
+    for _ in range(args.warmup):
+        t.train_step()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t.train_step()
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    # projector share: the same 2 x (fwd + bwd) on 5 objects x 20 angles per step, timed alone
+    from ct_pvae_amd.forward_functions import RotatePlan as RP
+    theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
+    plan = RP(theta, 128, 128, True, dev)
+    x = torch.rand((5, 128, 128), device=dev)
+    g = torch.rand((5, 20, plan.PW), device=dev)
+    for _ in range(20):
+        plan.backward(g); plan.forward(x)
+    torch.cuda.synchronize()
+    tp = time.perf_counter()
+    for _ in range(200):
+        plan.forward(x); plan.backward(g); plan.forward(x); plan.backward(g)
+    torch.cuda.synchronize()
+    proj_s = (time.perf_counter() - tp) / 200
+    if rank == 0:
+        print(json.dumps({"metric": "P-VAE training steps/sec (main_ct_vae.py --nsa 20 --td 50 -b 5 --ns 2 --api 20)",
+                          "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "P-VAE step: encoder + 2 x (decoder, TruncatedNormal sample, HIP "
+                                                 "projector fwd, log-likelihood) + backward + Adam; 5 objects/GPU, 20 of 180 angles"},
+                          "projector_ms_per_step": proj_s * 1e3, "projector_share": proj_s / (elapsed / args.steps)}))
+
+
 def main():
     args = parse()
     world, rank, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
+    if args.mode == "train":
+        return train_mode(args, world, rank, dev)
     B, N, A = args.batch, N_PIX, args.angles
 
     theta_dense = phantoms.dense_theta(180)

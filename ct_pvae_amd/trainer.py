@@ -1,0 +1,408 @@
+"""P-VAE training harness around the HIP projector (BASELINE config 3/4).
+
+The reference's driver is ctvae/main_ct_vae.py (CT_VAE.train / train_step, :375-486) with the ELBO of
+ctvae/helper_functions.py:204-332 and the nets of ctvae/models.py.  The nets and the driver are host code: here they
+are plain PyTorch-ROCm (MIOpen convs); the physics decoder -- calculate_log_prob_M_given_R, the only differentiated
+caller of the projector -- runs on the hand-written kernels.  What is reproduced from the reference, line by line:
+
+  * `ns` decoder samples per step, each projected through `api` angles drawn per step from a shuffled stream of
+    0..A-1 (ctvae/helper_functions.py:104-107, :263-295)
+  * TruncatedNormal(positive_range(alpha), positive_range(beta), low=0, high=1e10) output distribution (:273)
+  * log p(M|R): Normal(loc=proj*mask, scale=eps+sqrt(loc/pnm+eps)) (:360-368); pnm annealed as
+    pnm * factor**iter with factor = exp(log(pnm/pnm_start)/num_iter) (ctvae/main_ct_vae.py:146-149, :392 -- the
+    variable already holds the FINAL pnm, so the effective multiplier runs pnm .. pnm^2/pnm_start; kept as is)
+  * loss = mean over the batch / 1e5 (:478); NaN gradients zeroed, per-tensor clip_by_norm(100), Adam(1e-4, eps 1e-7)
+    (:353, :482-485); encoder input scaled by 1/300 (ctvae/helper_functions.py:239)
+  * NaN loss stops the run (:401-402); checkpoint every save_interval and at the end (:409-415)
+
+Data parallelism is new (the reference is single-device): every rank trains on its shard of the batch and the flat
+gradient bucket (~0.7 M fp32) is summed with ONE all-reduce per step (RCCL over xGMI; gloo in the CPU tests).
+
+Synthetic data stands in for the reference's dataset files: foam phantoms (phantoms.py) -> dense sinograms with the
+TomoPy-style projector on the GPU (create_sinograms) -> dose masks and Poisson noise (ctvae/create_masks.py:45-63,
+:94-95) -> initial reconstructions for the encoder by FBP on the GPU (iradon) in place of tomopy.recon
+(ctvae/helper_functions.py:477-529): one ramp-filtered channel plus the unfiltered back-projection of the mask.
+"""
+import argparse
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import phantoms, sharding
+from .fbp import iradon
+from .forward_functions import num_proj_pix
+from .helper_functions import calculate_log_prob_M_given_R, create_sinograms
+
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# nets (ctvae/models.py), channels-first
+# ---------------------------------------------------------------------------------------------------------
+def positive_range(x, offset=EPS32):
+    """ctvae/helper_functions.py:198-201"""
+    x = x - 1
+    neg = (x < 0).to(x.dtype)
+    return (torch.exp(torch.clamp(x, -1e10, 10)) + offset) * neg + (x + 1) * (1 - neg)
+
+
+class ConvBlock(nn.Module):
+    """Conv2D => maxout of two convolutions (ctvae/models.py:267-342); 'periodic' padding for the strided/plain
+    convolutions (:219-263), Conv2DTranspose(padding='same') for up-sampling."""
+
+    def __init__(self, cin, cout, k, stride, transpose):
+        super().__init__()
+        self.k, self.stride, self.transpose = k, stride, transpose
+        if transpose:
+            pad = (k - stride + 1) // 2
+            opad = stride + 2 * pad - k
+            mk = lambda: nn.ConvTranspose2d(cin, cout, k, stride=stride, padding=pad, output_padding=opad)
+        else:
+            mk = lambda: nn.Conv2d(cin, cout, k, stride=stride, padding=0)
+        self.a, self.b = mk(), mk()
+        for m in (self.a, self.b):
+            nn.init.xavier_uniform_(m.weight)      # GlorotUniform
+            nn.init.zeros_(m.bias)
+
+    def forward(self, x):
+        if not self.transpose:
+            pads = []
+            for n in (x.shape[-1], x.shape[-2]):   # F.pad wants the last axis first
+                p = self.k - (n % self.stride if n % self.stride else self.stride)
+                pads += [p // 2 + p % 2, p // 2]
+            x = F.pad(x, pads, mode="circular")
+        return torch.maximum(self.a(x), self.b(x))
+
+
+class EncodeNet(nn.Module):
+    """create_encode_net, ctvae/models.py:23-108: returns the list of skips (the first one is the repeated input)."""
+
+    def __init__(self, cin, feature_maps, fmm, kernel, stride, inter_layers, inter_kernel):
+        super().__init__()
+        self.fmm = fmm
+        c = cin * fmm
+        self.channels = [c]
+        self.blocks = nn.ModuleList()
+        for f in feature_maps:
+            layers = [ConvBlock(c, c, inter_kernel, 1, False) for _ in range(inter_layers)]
+            layers.append(ConvBlock(c, f * fmm, kernel, stride, False))
+            self.blocks.append(nn.Sequential(*layers))
+            c = f * fmm
+            self.channels.append(c)
+
+    def forward(self, x):
+        x = x.repeat_interleave(self.fmm, dim=1)   # tf.repeat(output, feature_maps_multiplier, axis=-1)
+        skips = [x]
+        for blk in self.blocks:
+            x = blk(x)
+            skips.append(x)
+        return skips
+
+
+class DecodeNet(nn.Module):
+    """create_decode_net, ctvae/models.py:112-215 (the code concatenates every skip, including the input level)."""
+
+    def __init__(self, enc_channels, fmm, out_channels, kernel, stride, inter_layers, inter_kernel):
+        super().__init__()
+        lat = [c // fmm for c in enc_channels]     # channels of the sampled latents
+        self.ups = nn.ModuleList()
+        c = lat[-1]
+        for lvl in range(len(enc_channels) - 2, -1, -1):
+            layers = [ConvBlock(c, enc_channels[lvl], kernel, stride, True)]
+            layers += [ConvBlock(enc_channels[lvl], enc_channels[lvl], inter_kernel, 1, False) for _ in range(inter_layers)]
+            self.ups.append(nn.Sequential(*layers))
+            c = enc_channels[lvl] + lat[lvl]
+        self.head = ConvBlock(c, 2 * out_channels, kernel, 1, False)
+
+    def forward(self, latents):
+        x = latents[-1]
+        for up, skip in zip(self.ups, reversed(latents[:-1])):
+            x = up(x)
+            dx, dy = x.shape[-2] - skip.shape[-2], x.shape[-1] - skip.shape[-1]
+            x0, y0 = dx // 2 + dx % 2, dy // 2 + dy % 2
+            x = x[..., x0:x0 + skip.shape[-2], y0:y0 + skip.shape[-1]]
+            x = torch.cat([x, skip], dim=1)
+        alpha, beta = self.head(x).chunk(2, dim=1)
+        return alpha, beta
+
+
+# ---------------------------------------------------------------------------------------------------------
+# distributions
+# ---------------------------------------------------------------------------------------------------------
+_SQRT2 = math.sqrt(2.0)
+
+
+def _ncdf(z):
+    return 0.5 * (1 + torch.erf(z / _SQRT2))
+
+
+class TruncatedNormal:
+    """tfd.TruncatedNormal(loc, scale, low, high): reparameterised sample by inverse CDF, log_prob."""
+
+    def __init__(self, loc, scale, low=0.0, high=1e10):
+        self.loc, self.scale = loc, scale
+        self.a, self.b = (low - loc) / scale, (high - loc) / scale
+        self.cdf_a, self.cdf_b = _ncdf(self.a), _ncdf(self.b)
+        self.Z = (self.cdf_b - self.cdf_a).clamp_min(1e-30)
+
+    def rsample(self):
+        u = torch.rand_like(self.loc)
+        p = (self.cdf_a + u * self.Z).clamp(1e-7, 1 - 1e-7)
+        z = torch.special.ndtri(p)
+        return (self.loc + self.scale * z).clamp_min(0.0)
+
+    def log_prob(self, x):
+        z = (x - self.loc) / self.scale
+        return -0.5 * z * z - 0.5 * math.log(2 * math.pi) - torch.log(self.scale) - torch.log(self.Z)
+
+
+def kl_normal_std(loc, scale):
+    """KL(N(loc, scale) || N(0, 1)), elementwise."""
+    return 0.5 * (scale * scale + loc * loc - 1.0) - torch.log(scale)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ELBO (ctvae/helper_functions.py:204-332, use_normal path)
+# ---------------------------------------------------------------------------------------------------------
+def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_decode, poisson_noise_multiplier, sqrt_reg,
+                        kl_anneal, kl_multiplier, num_samples=2, theta=None, angles_i=None, pad=True, deterministic=False):
+    skips = model_encode(input_encode / 300)
+    q = None
+    if not deterministic:
+        q = []
+        for sk in skips:
+            loc, log_scale = sk.chunk(2, dim=1)
+            q.append((loc, positive_range(log_scale) + sqrt_reg))
+    log_prob_M, recon = [], None
+    for _ in range(num_samples):
+        if deterministic:
+            q_sample = skips
+        else:
+            q_sample = [loc + scale * torch.randn_like(loc) for loc, scale in q]
+        alpha, beta = model_decode(q_sample)
+        dist = TruncatedNormal(positive_range(alpha), positive_range(beta), low=0.0, high=1e10)
+        output_sample = dist.rsample()                                   # [B][1][X][Y]
+        log_prob_R_given_z = dist.log_prob(output_sample)
+        lp = calculate_log_prob_M_given_R(output_sample.permute(0, 2, 3, 1), mask, proj_sample,
+                                          poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad)
+        log_prob_M.append(lp.sum(dim=(1, 2, 3)) + log_prob_R_given_z.sum(dim=(1, 2, 3)))
+        recon = output_sample
+    if deterministic:
+        kl = torch.zeros_like(log_prob_M[0])
+    else:
+        kl = sum(kl_normal_std(loc, scale).sum(dim=(1, 2, 3)) for loc, scale in q[1:])   # the input level is unused
+    loglik = torch.stack(log_prob_M).mean(dim=0)
+    return kl_anneal * kl_multiplier * kl - loglik, kl, loglik, recon
+
+
+# ---------------------------------------------------------------------------------------------------------
+# driver
+# ---------------------------------------------------------------------------------------------------------
+def ramp_filter(P):
+    """skimage.transform.radon_transform._get_fourier_filter(P, 'ramp') squeezed (scikit-image 0.18), even P."""
+    n = np.concatenate((np.arange(1, P / 2 + 1, 2, dtype=int), np.arange(P / 2 - 1, 0, -2, dtype=int)))
+    f = np.zeros(P)
+    f[0] = 0.25
+    f[1::2] = -1 / (np.pi * n) ** 2
+    return 2 * np.real(np.fft.fft(f))
+
+
+class AngleStream:
+    """Shuffled, repeating stream of 0..A-1 in chunks of `api` (ctvae/helper_functions.py:104-107)."""
+
+    def __init__(self, num_angles, api, seed):
+        self.n, self.api, self.rng, self.buf = num_angles, api, np.random.default_rng(seed), np.empty(0, np.int64)
+
+    def next(self):
+        while self.buf.size < self.api:
+            self.buf = np.concatenate([self.buf, self.rng.permutation(self.n)])
+        out, self.buf = self.buf[:self.api], self.buf[self.api:]
+        return out
+
+
+class PVAETrainer:
+    def __init__(self, args, device):
+        self.args, self.dev = args, device
+        self.world, self.rank, _ = sharding.env_world()
+        self.sqrt_reg = EPS32
+        torch.manual_seed(1234 + self.rank)
+        a = args
+        self.pnm_anneal = math.exp(math.log(a.pnm / a.pnm_start) / max(a.num_iter, 1)) if a.pnm_start else 1.0
+        self._make_data()
+        fm = [int(a.nfm * a.nfmm ** i) for i in range(a.num_blocks)]
+        fmm = 1 if a.deterministic else 2
+        self.enc = EncodeNet(2, fm, fmm, a.kernel_size, a.stride_encode, a.il, a.ik).to(device)
+        self.dec = DecodeNet(self.enc.channels, fmm, 1, a.kernel_size, a.stride_encode, a.il, a.ik).to(device)
+        if self.world > 1:   # identical initial weights on every rank
+            for p in list(self.enc.parameters()) + list(self.dec.parameters()):
+                torch.distributed.broadcast(p.data, 0)
+        self.params = list(self.enc.parameters()) + list(self.dec.parameters())
+        self.pnm = torch.tensor(float(a.pnm), device=device, requires_grad=bool(a.train_pnm))
+        self.opt = torch.optim.Adam(self.params + ([self.pnm] if a.train_pnm else []), lr=a.lr, eps=a.adam_epsilon)
+        self.kl_anneal = 1.0
+        self.angles = AngleStream(self.num_angles, a.api, seed=7)     # same stream on every rank
+        self.iter = 0
+
+    # -- synthetic dataset (stands in for dataset_foam/*.npy) ------------------------------------------------
+    def _make_data(self):
+        a, dev = self.args, self.dev
+        N = a.n_pixel
+        self.theta_np = phantoms.dense_theta(a.num_angles)
+        self.num_angles = a.num_angles
+        self.P = num_proj_pix(N, N)
+        self.x_size = self.y_size = int(math.floor(self.P / math.sqrt(2) - 2))      # ctvae/main_ct_vae.py:160-161
+        imgs = phantoms.foam_batch(a.td, N, seed=0, supersample=2)
+        sino = create_sinograms(torch.from_numpy(imgs).to(dev), self.theta_np, pad=True).clamp_min(0)   # [td][A][P]
+        # dose masks, ctvae/create_masks.py:45-63
+        masks = torch.zeros((a.td, a.num_angles), device=dev)
+        rng = np.random.default_rng(0)
+        for k in range(a.td):
+            idx = rng.permutation(a.num_angles)[:a.nsa] if a.random else phantoms.sparse_angle_indices(a.num_angles, a.nsa)
+            masks[k, torch.as_tensor(idx, device=dev)] = 1.0 / a.nsa
+        # sparse noisy measurements, ctvae/create_masks.py:94-95 (the data is simulated at the FINAL pnm)
+        g = torch.Generator(device=dev).manual_seed(0)
+        proj_masked = sino * masks[..., None]
+        self.proj_samples = torch.poisson(proj_masked * a.pnm, generator=g) / a.pnm
+        self.masks, self.truth = masks, torch.from_numpy(imgs).to(dev)
+        # initial reconstructions for the encoder, ctvae/helper_functions.py:490-520 with FBP on the GPU
+        m_exp = masks[..., None].expand(-1, -1, self.P)
+        expand = torch.where(m_exp > self.sqrt_reg, self.proj_samples / m_exp.clamp_min(1e-30), self.proj_samples)
+        rec = iradon(expand, self.theta_np, self.x_size, self.y_size, ramp_filter(self.P))
+        rec_mask = iradon(m_exp.contiguous(), self.theta_np, self.x_size, self.y_size, np.ones(self.P))
+        self.input_encode = torch.stack([rec, rec_mask], dim=1).to(torch.float32)          # [td][2][X][Y]
+        self.theta = torch.from_numpy(self.theta_np.astype(np.float32)).to(dev)
+        self.order = np.random.default_rng(11)
+
+    def _batch(self):
+        """Global batch of `-b` examples, the same on every rank; each rank keeps its shard."""
+        idx = self.order.choice(self.args.td, size=self.args.batch_size, replace=False)
+        lo, hi = sharding.shard_range(len(idx), self.rank, self.world)
+        idx = torch.as_tensor(idx[lo:hi], device=self.dev)
+        return self.proj_samples[idx], self.masks[idx], self.input_encode[idx]
+
+    # -- one step (CT_VAE.train_step, ctvae/main_ct_vae.py:463-486) -------------------------------------------
+    def train_step(self):
+        a = self.args
+        proj_sample, mask, input_encode = self._batch()
+        angles_i = torch.as_tensor(self.angles.next(), device=self.dev)
+        pnm_i = self.pnm * (self.pnm_anneal ** self.iter)
+        self.kl_anneal = min(max(self.kl_anneal * a.klaf, 0.0), 100.0)
+        loss_vec, kl, loglik, _ = find_loss_vae_unsup(proj_sample, mask, input_encode, self.enc, self.dec, pnm_i,
+                                                      self.sqrt_reg, self.kl_anneal, a.klm, num_samples=a.ns,
+                                                      theta=self.theta, angles_i=angles_i, pad=True,
+                                                      deterministic=a.deterministic)
+        # mean over the GLOBAL batch: each rank contributes sum/global_B, gradients are then summed over ranks
+        loss = loss_vec.sum() / a.batch_size / 1e5
+        self.opt.zero_grad(set_to_none=True)
+        loss.backward()
+        grads = [p.grad for p in self.opt.param_groups[0]["params"] if p.grad is not None]
+        sharding.allreduce_flat_(grads, average=False)                     # ONE bucket, one all-reduce
+        for gr in grads:
+            torch.nan_to_num_(gr, nan=0.0)                                 # tf.where(is_nan, 0, grad)
+            n = gr.norm()
+            if n > a.norm:                                                 # tf.clip_by_norm(g, norm), per tensor
+                gr.mul_(a.norm / n)
+        self.opt.step()
+        self.iter += 1
+        return float(loss.item()) if self.world == 1 else self._global_loss(loss)
+
+    def _global_loss(self, loss):
+        t = loss.detach().clone()
+        torch.distributed.all_reduce(t)
+        return float(t.item())
+
+    def train(self):
+        a = self.args
+        losses, t0 = [], time.time()
+        for it in range(a.num_iter):
+            loss = self.train_step()
+            losses.append(loss)
+            if self.rank == 0 and (it % max(a.num_iter // 10, 1) == 0 or it == a.num_iter - 1):
+                print(f"Iteration number: {it}  Training loss_M_VAE: {loss:.6f}", flush=True)
+            if math.isnan(loss):
+                raise SystemExit("loss is NaN")                            # ctvae/main_ct_vae.py:401-402
+            if a.save_path and self.rank == 0 and (it % a.si == 0 or it == a.num_iter - 1):
+                self.save(os.path.join(a.save_path, "training_checkpoints", f"ckpt-{it}.pt"), losses)
+        return losses, time.time() - t0
+
+    def save(self, path, losses):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"enc": self.enc.state_dict(), "dec": self.dec.state_dict(), "opt": self.opt.state_dict(),
+                    "kl_anneal": self.kl_anneal, "pnm": self.pnm.detach().cpu(), "iter": self.iter, "losses": losses}, path)
+
+    def restore(self, path):
+        ck = torch.load(path, map_location=self.dev)
+        self.enc.load_state_dict(ck["enc"])
+        self.dec.load_state_dict(ck["dec"])
+        self.opt.load_state_dict(ck["opt"])
+        self.kl_anneal, self.iter = ck["kl_anneal"], ck["iter"]
+        with torch.no_grad():
+            self.pnm.copy_(ck["pnm"].to(self.dev))
+
+    @torch.no_grad()
+    def evaluate(self, n=None):
+        """Mean decoder output on the first n examples vs. the phantoms (MSE), and the FBP input's MSE."""
+        n = n or min(self.args.td, 16)
+        skips = self.enc(self.input_encode[:n] / 300)
+        lat = [s.chunk(2, dim=1)[0] for s in skips] if not self.args.deterministic else skips
+        alpha, _ = self.dec(lat)
+        rec = positive_range(alpha)[:, 0]
+        return float(((rec - self.truth[:n]) ** 2).mean()), float(((self.input_encode[:n, 0] - self.truth[:n]) ** 2).mean())
+
+
+def get_args(argv=None):
+    """The reference's flags that reach the path (ctvae/main_ct_vae.py:30-116), same spellings and defaults."""
+    p = argparse.ArgumentParser(description="P-VAE training with the MI355X projector")
+    p.add_argument("--ae", type=float, dest="adam_epsilon", default=1e-7)
+    p.add_argument("-b", type=int, dest="batch_size", default=4)
+    p.add_argument("--ns", type=int, dest="ns", default=2)
+    p.add_argument("--det", action="store_true", dest="deterministic")
+    p.add_argument("-i", type=int, dest="num_iter", default=100)
+    p.add_argument("--ik", type=int, dest="ik", default=4)
+    p.add_argument("--il", type=int, dest="il", default=2)
+    p.add_argument("--klaf", type=float, dest="klaf", default=1.0)
+    p.add_argument("--klm", type=float, dest="klm", default=1.0)
+    p.add_argument("--ks", type=int, dest="kernel_size", default=4)
+    p.add_argument("--lr", type=float, dest="lr", default=1e-4)
+    p.add_argument("--nb", type=int, dest="num_blocks", default=3)
+    p.add_argument("--nfm", type=int, dest="nfm", default=20)
+    p.add_argument("--nfmm", type=float, dest="nfmm", default=1.1)
+    p.add_argument("--norm", type=float, dest="norm", default=100.0)
+    p.add_argument("--normal", action="store_true", dest="use_normal", help="accepted; the normal path is the only one built")
+    p.add_argument("--nsa", type=int, dest="nsa", default=10)
+    p.add_argument("--api", type=int, dest="api", default=5)
+    p.add_argument("--pnm", type=float, dest="pnm", default=(2 ** 16 - 1) * 0.41)
+    p.add_argument("--pnm_start", type=float, dest="pnm_start", default=None)
+    p.add_argument("--train_pnm", action="store_true")
+    p.add_argument("--random", action="store_true")
+    p.add_argument("--save_path", default=None)
+    p.add_argument("--se", type=int, dest="stride_encode", default=2)
+    p.add_argument("--si", type=int, dest="si", default=100000)
+    p.add_argument("--td", type=int, dest="td", default=100)
+    p.add_argument("--train", action="store_true")
+    # synthetic-data knobs (the reference reads these from its dataset folder)
+    p.add_argument("--n_pixel", type=int, default=128)
+    p.add_argument("--num_angles", type=int, default=180)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = get_args(argv)
+    world, rank, local = sharding.init_from_env()
+    dev = torch.device("cuda", local)
+    tr = PVAETrainer(args, dev)
+    losses, secs = tr.train()
+    if rank == 0:
+        mse, mse_fbp = tr.evaluate()
+        print(f"{len(losses)} iterations in {secs:.1f} s ({len(losses) / secs:.2f} it/s); loss {losses[0]:.5f} -> {losses[-1]:.5f}; "
+              f"MSE reconstruction {mse:.5f} (FBP input {mse_fbp:.5f})")
+    return losses
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""The P-VAE training step with the HIP projector as physics decoder (README quick-check recipe, scaled down)."""
+import math
+
+import pytest
+import torch
+
+from ct_pvae_amd import trainer as tr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_quick_check_recipe_trains():
+    # README.md:80: --nsa 20 --td 50 -b 5 --ns 2 --api 20 --pnm 1e4 --pnm_start 1e3 --random --normal
+    # (without --pnm_start: the reference's annealing multiplies pnm by a factor > 1 every iteration, which by itself
+    # raises the loss -- checked separately below)
+    args = tr.get_args("--nsa 20 --td 10 -b 5 --ns 2 --api 20 --pnm 1e4 --random --normal -i 60 --lr 1e-3 --train".split())
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    assert t.P == 184 and t.x_size == 128 and tuple(t.proj_samples.shape) == (10, 180, 184)
+    assert tuple(t.input_encode.shape) == (10, 2, 128, 128)
+    assert abs(t.masks.sum(dim=1) - 1).max() < 1e-6 and int((t.masks[0] > 0).sum()) == 20
+    before = [p.detach().clone() for p in t.params[:3]]
+    losses, _ = t.train()
+    assert len(losses) == 60 and all(math.isfinite(x) for x in losses)
+    assert any(not torch.equal(a, b) for a, b in zip(before, t.params[:3]))      # the optimiser moved the nets
+    assert sum(losses[-10:]) < sum(losses[:10])                                   # and the ELBO improves
+    # gradients flow through the projector into the decoder
+    t.opt.zero_grad(set_to_none=True)
+    ps, m, ie = t._batch()
+    loss_vec, _, _, recon = tr.find_loss_vae_unsup(ps, m, ie, t.enc, t.dec, t.pnm, t.sqrt_reg, 1.0, 1.0, num_samples=1,
+                                                   theta=t.theta, angles_i=torch.arange(0, 180, 9, device=t.dev))
+    loss_vec.mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in t.dec.parameters())
+    assert recon.shape == (5, 1, 128, 128)
+
+
+def test_pnm_annealing_follows_the_reference_quirk():
+    # ctvae/main_ct_vae.py:146-149,352,392: the variable holds the FINAL pnm and is multiplied by factor**iter
+    args = tr.get_args("--nsa 20 --td 6 -b 3 --ns 1 --api 10 --pnm 1e4 --pnm_start 1e3 --normal -i 10 --train".split())
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    assert math.isclose(t.pnm_anneal ** 10, 10.0, rel_tol=1e-9)
+    t.train()
+    assert math.isclose(float(t.pnm) * t.pnm_anneal ** (t.iter - 1), 1e4 * 10 ** 0.9, rel_tol=1e-5)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    args = tr.get_args("--nsa 20 --td 6 -b 3 --ns 1 --api 10 --pnm 1e4 --normal -i 2 --train".split())
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    t.train()
+    path = str(tmp_path / "training_checkpoints" / "ckpt-1.pt")
+    t.save(path, [1.0, 2.0])
+    t2 = tr.PVAETrainer(args, torch.device("cuda", 0))
+    t2.restore(path)
+    assert t2.iter == 2
+    for a, b in zip(t.params, t2.params):
+        assert torch.equal(a, b)
