@@ -207,6 +207,12 @@ def main():
     bwd_name = "rotate_bwd_planned_kernel" if plan.planned[1] else "rotate_bwd_tfcompat_fast_kernel"
     dom = (fwd_name, t_fwd) if t_fwd >= t_bwd else (bwd_name, t_bwd)
     achieved = bytes_dir / dom[1] / 1e9
+    traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))["kernels"]
+        traffic = next(v["traffic_bytes_per_launch"] for k, v in pmc.items() if dom[0] in k)
+    except Exception:
+        pass
     proj_per_s = world * B * A * args.steps / elapsed
     out = {
         "metric": "projections/sec (fwd+adj) 128x128 foam, 20 angles; fraction of HBM roofline",
@@ -219,7 +225,7 @@ def main():
         "hbm_fraction_whole_step": (2 * bytes_dir / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": bytes_dir,
+                     "traffic": traffic, "algorithmic_bytes_per_launch": bytes_dir,
                      "kernel_us": {"rotate_fwd": t_fwd * 1e6, "rotate_bwd_tfcompat": t_bwd * 1e6},
                      "note": "object lives in LDS for all angles: LDS-gather/VALU bound, HBM fraction is small by construction"},
         "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
