@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--angles", type=int, default=A_SPARSE, help="20 (headline) or 180 (dense evaluation set)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=["projector", "train"], default="projector",
-                    help="projector: the headline fwd+adj metric (default); train: BASELINE config 3, P-VAE steps/s")
+    ap.add_argument("--mode", choices=["projector", "train", "siddon", "n512"], default="projector",
+                    help="projector: the headline fwd+adj metric, BASELINE config 2 (default; --angles 180 = config 4's "
+                         "per-GPU share); train: config 3, P-VAE steps/s; siddon: config 1, TomoPy-style forward; "
+                         "n512: config 5, 512x512 x 90 angles fwd + log-likelihood + adj")
     return ap.parse_args()
 
 
@@ -135,12 +137,100 @@ def train_mode(args, world, rank, dev):
                           "projector_ms_per_step": proj_s * 1e3, "projector_share": proj_s / (elapsed / args.steps)}))
 
 
+def _time_loop(fn, steps, warmup, world):
+    for _ in range(warmup):
+        fn()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier_sync(world)
+    return max_over_ranks(time.perf_counter() - t0, world)
+
+
+def siddon_mode(args, world, rank, dev):
+    """BASELINE config 1: scripts/images_to_sinograms.py's inner call -- tomopy.project on one 128x128 slice, 180 angles
+    (one slice per call as the script does, and 50 slices per call), next to the CPU restatement on one host thread."""
+    from ct_pvae_amd.helper_functions import create_sinograms
+    imgs = phantoms.foam_batch(50, N_PIX, seed=rank, supersample=2)
+    x = torch.from_numpy(imgs).to(dev)
+    theta = phantoms.dense_theta(180)
+    t1 = _time_loop(lambda: create_sinograms(x[:1], theta), args.steps, args.warmup, world) / args.steps
+    t50 = _time_loop(lambda: create_sinograms(x, theta), max(args.steps // 10, 5), 3, world) / max(args.steps // 10, 5)
+    if rank != 0:
+        return
+    from oracle import radon_oracle as orc
+    orc.build()
+    n, tc = 0, 0.0
+    while tc < 8.0:
+        t0 = time.perf_counter()
+        orc.siddon_project(imgs[n % 50:n % 50 + 1], theta, pad=True)
+        tc += time.perf_counter() - t0
+        n += 1
+    P = orc.num_proj_pix(N_PIX, N_PIX)
+    print(json.dumps({"metric": "projections/sec, TomoPy-style forward (create_sinogram), 128x128 foam, 180 angles",
+                      "value": world * 50 * 180 / t50, "unit": "projections/s", "n_gpus": world, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": t50 * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "create_sinograms: 50 slices x 180 angles x 184 bins per call (siddon_fwd_kernel)"},
+                      "single_slice_call_us": t1 * 1e6, "single_slice_projections_per_s": 180 / t1,
+                      "ray_sums_per_s_per_gpu": 50 * 180 * P / t50,
+                      "cpu_baseline": {"value": n * 180 / tc, "unit": "projections/s", "cores": 1, "kind": "port",
+                                       "sample": f"{n} slices x 180 angles, oracle/radon_oracle.c (TomoPy project.c "
+                                                 f"restatement), 1 thread, {tc:.1f} s"}}))
+
+
+def n512_mode(args, world, rank, dev):
+    """BASELINE config 5: 512x512 phantoms, 90 angles, Poisson-noise forward model (pnm 1e4): forward + Gaussian-Poisson
+    log-likelihood + backward.  The slice (1 MiB) does not fit LDS: direct kernels."""
+    from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
+    B, N, A = 8, 512, 90
+    theta = np.pi * np.arange(A) / A
+    plan = RotatePlan(theta, N, N, True, dev)
+    x = torch.rand((B, N, N), device=dev)
+    mask = torch.full((B, A), 1.0 / A, device=dev)
+    meas = torch.poisson(plan.forward(x) * mask[..., None] * 1e4) / 1e4
+    pnm = torch.tensor(1e4, device=dev)
+    eps = float(np.finfo(np.float32).eps)
+    from ct_pvae_amd import _lib
+    from ct_pvae_amd.forward_functions import _stream_ptr
+    import ctypes
+    lib = _lib.load()
+    sino = torch.empty((B, A, plan.PW), device=dev)
+    lp, gp, gx = torch.empty_like(sino), torch.empty_like(sino), torch.empty_like(x)
+    ones = torch.ones_like(sino)
+
+    def step():
+        plan.forward(x, out=sino)
+        lib.ctpvae_loglik_fwd_f32(sino.data_ptr(), mask.data_ptr(), meas.data_ptr(), B, A, plan.PW, pnm.data_ptr(),
+                                  ctypes.c_float(eps), lp.data_ptr(), _stream_ptr())
+        lib.ctpvae_loglik_bwd_f32(sino.data_ptr(), mask.data_ptr(), meas.data_ptr(), ones.data_ptr(), B, A, plan.PW,
+                                  pnm.data_ptr(), ctypes.c_float(eps), gp.data_ptr(), None, _stream_ptr())
+        plan.backward(gp, out=gx)
+
+    steps = max(args.steps // 10, 10)
+    el = _time_loop(step, steps, 3, world)
+    if rank == 0:
+        bytes_step = 8.0 * B * (N * N + A * plan.PW)
+        print(json.dumps({"metric": "projections/sec (fwd + log-lik + adj), 512x512, 90 angles, pnm 1e4",
+                          "value": world * B * A * steps / el, "unit": "projections/s", "n_gpus": world, "steps": steps,
+                          "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"batch={B}/GPU 512x512, 90 angles, P={plan.PW}, nearest fwd + "
+                                                 "Gaussian-Poisson log-likelihood fwd/bwd + tf_compat adj (direct kernels)"},
+                          "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS}))
+
+
 def main():
     args = parse()
     world, rank, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     if args.mode == "train":
         return train_mode(args, world, rank, dev)
+    if args.mode == "siddon":
+        return siddon_mode(args, world, rank, dev)
+    if args.mode == "n512":
+        return n512_mode(args, world, rank, dev)
     B, N, A = args.batch, N_PIX, args.angles
 
     theta_dense = phantoms.dense_theta(180)

@@ -279,8 +279,11 @@ def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
     if slices.shape[0] == 0:
         raise ValueError("phantom holds no slices")
     plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, interp, backward)
-    with torch.cuda.device(slices.device):
+    if slices.device.index == torch.cuda.current_device():
         sino = plan.apply(slices)  # [S][A][PW]
+    else:
+        with torch.cuda.device(slices.device):
+            sino = plan.apply(slices)
     if integrate_vae:
         out = sino.unsqueeze(-1)  # batch x angles x P x 1   (ctvae/forward_functions.py:116-121)
     else:

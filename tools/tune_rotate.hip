@@ -69,6 +69,12 @@ int main(int argc, char **argv)
             char b[16]; snprintf(b, 16, "%d", G); setenv("CTPVAE_TUNE_G", b, 1);
             printf("planned fwd G=%d: %.2f us\n", G, time_us([&] { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); }, 100));
         }
+        for (int lds_kb : {0, 90}) for (int G : {2, 3}) {
+            char b[16]; snprintf(b, 16, "%d", G); setenv("CTPVAE_TUNE_G", b, 1);
+            snprintf(b, 16, "%d", lds_kb); setenv("CTPVAE_TUNE_LDS", b, 1);
+            printf("planned fwd G=%d LDS>=%dKB: %.2f us\n", G, lds_kb, time_us([&] { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); }, 100));
+        }
+        unsetenv("CTPVAE_TUNE_LDS");
         unsetenv("CTPVAE_TUNE_G");
     }
     printf("product fwd bilinear: %.2f us\n", time_us([&] { ctpvae_rotate_fwd_f32(d_img, S, N, N, P, P, pad, pad, d_T, A, 1, d_sino, nullptr); }));
