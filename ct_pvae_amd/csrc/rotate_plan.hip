@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -39,8 +40,10 @@ struct FwdLayout {
     int nJB, PWpad, NG, Galloc, pitch, zero;
     long long off_cls, off_rng, off_idx, bytes;
 };
+constexpr int kBwdPitch = 257;   // dwords per staged cotangent row (== 1 mod 32; bins, then zeros up to cell 256)
+constexpr int kBwdChunk = 64;    // angles staged per pass: row offsets (<= 63 * 1028 B) fit ds_read's 16-bit immediate
 struct BwdLayout {
-    int nXB, Wpad, NA8, pitchg, zero;
+    int nXB, Wpad, NA16, pitchg, chunkA;   // chunkA: angles staged per pass (multiple of 16)
     long long bytes;
 };
 
@@ -73,15 +76,17 @@ static FwdLayout fwd_layout(const PlanGeom &g)
     L.bytes = L.off_idx + (long long)g.A * L.Galloc * L.PWpad * 16;
     return L;
 }
+// Backward taps are detector bins: one BYTE per (angle, pixel), 255 = dead.  A cotangent row is staged as 257 dwords
+// (== 1 mod 32): bins 0..PW-1, then zeros up to cell 256, so a dead tap reads row cell 255 = 0.0f and needs no select.
 static BwdLayout bwd_layout(const PlanGeom &g)
 {
     BwdLayout L;
     L.nXB = ceil_div(g.W, 64);
     L.Wpad = L.nXB * 64;
-    L.NA8 = ceil_div(g.A, 8);
-    L.pitchg = pitch_mod32_is_1(g.PW);
-    L.zero = g.A * L.pitchg;
-    L.bytes = (long long)L.NA8 * g.H * L.Wpad * 16;
+    L.NA16 = ceil_div(g.A, 16);
+    L.pitchg = kBwdPitch;
+    L.chunkA = std::min(L.NA16 * 16, kBwdChunk);
+    L.bytes = (long long)L.NA16 * g.H * L.Wpad * 16;
     return L;
 }
 static bool fwd_plan_fits(const PlanGeom &g)
@@ -89,11 +94,7 @@ static bool fwd_plan_fits(const PlanGeom &g)
     const FwdLayout L = fwd_layout(g);
     return L.zero < 65535 && (size_t)(L.zero + 1) * 4 <= (size_t)kMaxLdsBytes;
 }
-static bool bwd_plan_fits(const PlanGeom &g)
-{
-    const BwdLayout L = bwd_layout(g);
-    return L.zero < 65535 && (size_t)(L.zero + 1) * 4 <= (size_t)kMaxLdsBytes;
-}
+static bool bwd_plan_fits(const PlanGeom &g) { return g.PW <= 255; }
 
 typedef const __attribute__((address_space(3))) float *lds_cptr;
 typedef __attribute__((address_space(3))) float *lds_ptr;
@@ -164,30 +165,25 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
 __global__ __launch_bounds__(64) void rotate_bwd_plan_kernel(PlanGeom g, const float *__restrict__ Tinv8, BwdLayout L,
                                                              uint4 *__restrict__ idx)
 {
-    const int xb = blockIdx.x, yrow = blockIdx.y, a8 = blockIdx.z, lane = threadIdx.x;
+    const int xb = blockIdx.x, yrow = blockIdx.y, a16 = blockIdx.z, lane = threadIdx.x;
     const int xcol = xb * 64 + lane;
     const float fx = (float)(xcol + g.px), fy = (float)(yrow + g.py);
-    unsigned e16[8];
+    unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int a = 8 * a8 + e;
-        unsigned v = (unsigned)L.zero;
+    for (int e = 0; e < 16; ++e) {
+        const int a = 16 * a16 + e;
+        unsigned v = 255u;
         if (a < g.A && xcol < g.W) {
             // the gradient op re-samples the row-broadcast cotangent with the inverted transform (same arithmetic)
             const float *t = Tinv8 + 8 * a;
             const float x = (t[0] * fx + t[1] * fy) + t[2];
             const float y = (t[3] * fx + t[4] * fy) + t[5];
             const int ix = (int)__builtin_roundf(x), iy = (int)__builtin_roundf(y);
-            if ((unsigned)ix < (unsigned)g.PW && (unsigned)iy < (unsigned)g.PH) v = (unsigned)(a * L.pitchg + ix);
+            if ((unsigned)ix < (unsigned)g.PW && (unsigned)iy < (unsigned)g.PH) v = (unsigned)ix;
         }
-        e16[e] = v;
+        w[e >> 2] |= v << (8 * (e & 3));
     }
-    uint4 q;
-    q.x = e16[0] | (e16[1] << 16);
-    q.y = e16[2] | (e16[3] << 16);
-    q.z = e16[4] | (e16[5] << 16);
-    q.w = e16[6] | (e16[7] << 16);
-    idx[((size_t)a8 * g.H + yrow) * L.Wpad + xcol] = q;
+    idx[((size_t)a16 * g.H + yrow) * L.Wpad + xcol] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---- executing a plan -------------------------------------------------------------------------------------------
@@ -407,9 +403,39 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     CTPVAE_PSTAMP(3);
 }
 
-// Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x ROWS-row tile): stages the slice's cotangent
-// block [A][pitchg] (LDS-DMA), then every lane owns one column and PPT rows; for each group of eight angles it loads
-// the PPT index vectors, gathers and adds in angle order.
+// four byte taps of one dword -> four LDS byte offsets inside a cotangent row (SDWA: select a byte, shift by 2)
+__device__ __forceinline__ void unpack4(unsigned pk, int &b0, int &b1, int &b2, int &b3)
+{
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(b0) : "v"(pk));
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(b1) : "v"(pk));
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(b2) : "v"(pk));
+    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(b3) : "v"(pk));
+}
+// the 16 taps of `q` are staged rows AL0 .. AL0+15: the row offset is a compile-time ds_read immediate, the address
+// VGPR is just the SDWA-extracted bin * 4 -- no address arithmetic per tap
+template <int AL0>
+__device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_live, float (&v)[16])
+{
+    // n_live (wave-uniform): staged rows AL0 .. AL0+n_live-1 exist; a partial last group skips whole dwords of taps
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        if (4 * d < n_live) {
+            int b0, b1, b2, b3;
+            unpack4(w[d], b0, b1, b2, b3);
+            v[4 * d + 0] = lds_at(lds, b0 + (AL0 + 4 * d + 0) * kBwdPitch * 4);
+            v[4 * d + 1] = lds_at(lds, b1 + (AL0 + 4 * d + 1) * kBwdPitch * 4);
+            v[4 * d + 2] = lds_at(lds, b2 + (AL0 + 4 * d + 2) * kBwdPitch * 4);
+            v[4 * d + 3] = lds_at(lds, b3 + (AL0 + 4 * d + 3) * kBwdPitch * 4);
+        } else {
+            v[4 * d + 0] = v[4 * d + 1] = v[4 * d + 2] = v[4 * d + 3] = 0.0f;
+        }
+    }
+}
+
+// Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x (4 x PPT)-row tile): stages a chunk of the
+// slice's cotangent rows (257-dword rows, zeros behind the bins), then every lane owns one column and PPT rows; for
+// each group of sixteen angles it loads the PPT index vectors (16 B = 16 taps), gathers and adds in angle order.
 template <int PPT>
 __global__ __launch_bounds__(256) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y,
@@ -422,10 +448,6 @@ __global__ __launch_bounds__(256) void rotate_bwd_planned_kernel(const float *__
     const int tile = blockIdx.x - s * tiles;
     const int xb = tile % L.nXB, ty = tile / L.nXB;
     const float *gs = gsino + (size_t)s * g.A * g.PW;
-
-    stage_rows(lds, gs, g.A, g.PW, g.PW, L.pitchg, false, lane, wave, nwaves);
-    if (threadIdx.x == 0) lds[L.zero] = 0.0f;
-
     const int xcol = xb * 64 + lane;
     const int y0 = ty * (nwaves * PPT) + wave;   // this wave's rows: y0, y0 + nwaves, ...
     float acc[PPT];
@@ -433,25 +455,43 @@ __global__ __launch_bounds__(256) void rotate_bwd_planned_kernel(const float *__
     for (int k = 0; k < PPT; ++k) acc[k] = 0.0f;
     const uint4 *p = idx + (size_t)xcol;
     uint4 q[PPT];
-    auto load_group = [&](int a8) {
+    auto load_group = [&](int a16) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int y = min(y0 + k * nwaves, g.H - 1);   // rows past the slice re-read the last row, never stored
-            q[k] = p[((size_t)a8 * g.H + y) * L.Wpad];
+            q[k] = p[((size_t)a16 * g.H + y) * L.Wpad];
         }
     };
-    load_group(0);       // index loads fly while the cotangent block lands
-    __syncthreads();
-    for (int a8 = 0; a8 < L.NA8; ++a8) {
-        float v[PPT][8];
+    load_group(0);       // index loads fly while the cotangent rows land
+
+    for (int ac = 0; ac < g.A; ac += L.chunkA) {
+        const int na = min(L.chunkA, g.A - ac);
+        const int na4 = (na + 3) & ~3;              // taps are consumed a dword (4 angles) at a time
+        if (ac > 0) __syncthreads();
+        // a dead tap is byte 255: only cell 255 of every row (never a bin: PW <= 255) must hold 0.0f
+        for (int t = threadIdx.x; t < na4; t += blockDim.x) lds[t * kBwdPitch + 255] = 0.0f;
+        stage_rows(lds, gs + (size_t)ac * g.PW, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        __syncthreads();
+        // up to four groups of sixteen staged angles, unrolled so that every row offset is an immediate
+        auto group = [&](auto al_tag) {
+            constexpr int AL = decltype(al_tag)::value;
+            if (AL >= na4) return;                       // wave-uniform
+            const int n_live = min(16, na4 - AL);
+            float v[PPT][16];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) gather8(lds, q[k], v[k]);
-        if (a8 + 1 < L.NA8) load_group(a8 + 1);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < PPT; ++k) gather16<AL>(lds, q[k], n_live, v[k]);
+            const int next = (ac + AL) / 16 + 1;         // all index vectors of this group consumed: prefetch the next
+            if (next < L.NA16) load_group(next);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k)
+            for (int k = 0; k < PPT; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[k] += v[k][e];
+                for (int e = 0; e < 16; ++e) acc[k] += v[k][e];   // skipped taps hold +0.0f
+        };
+        group(std::integral_constant<int, 0>{});
+        group(std::integral_constant<int, 16>{});
+        group(std::integral_constant<int, 32>{});
+        group(std::integral_constant<int, 48>{});
     }
     if (xcol < g.W) {
 #pragma unroll
@@ -511,10 +551,10 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
     }
     if (bwd_plan_dev) {
         CTPVAE_REQUIRE(Tinv8_dev, "rotate_plan_build: backward plan needs the inverted transforms");
-        CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_plan_build: %d angles x %d bins do not fit the backward plan's LDS block", A, PW);
+        CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_plan_build: the backward plan stores bins as bytes (PW=%d > 255)", PW);
         CTPVAE_REQUIRE(H <= 65535, "rotate_plan_build: at most 65535 rows");
         const BwdLayout L = bwd_layout(g);
-        hipLaunchKernelGGL(rotate_bwd_plan_kernel, dim3(L.nXB, H, L.NA8), dim3(64), 0, (hipStream_t)stream, g, Tinv8_dev, L,
+        hipLaunchKernelGGL(rotate_bwd_plan_kernel, dim3(L.nXB, H, L.NA16), dim3(64), 0, (hipStream_t)stream, g, Tinv8_dev, L,
                            (uint4 *)bwd_plan_dev);
         CTPVAE_LAUNCH_CHECK("rotate_bwd_plan_kernel");
     }
@@ -560,9 +600,9 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
     CTPVAE_REQUIRE(S > 0, "rotate_bwd_planned: need at least one slice");
     if (int rc = check_plan_geom("rotate_bwd_planned", H, W, PH, PW, 0, 0, A)) return rc;
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
-    CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd_planned: %d angles x %d bins do not fit the plan's LDS block", A, PW);
+    CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd_planned: the backward plan stores bins as bytes (PW=%d > 255)", PW);
     const BwdLayout L = bwd_layout(g);
-    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float);
+    const size_t shmem = (size_t)L.chunkA * L.pitchg * sizeof(float);
     constexpr int kPpt = 4;
     const int rows_per_wg = 4 * kPpt;
     const int tiles_y = ceil_div(H, rows_per_wg);
