@@ -215,6 +215,42 @@ def test_planned_equals_direct(oracle, shape, pad, A, S):
     np.testing.assert_array_equal(to_np(pa.backward(g)[:1]), oracle.rotate_bwd_tfcompat(to_np(g[:1]), geom, to_np(pa.Tinv8), 0))
 
 
+def test_mixed_planned_forward_direct_backward(oracle):
+    """192x192: the slice still fits the forward plan's LDS image (148 KiB), but P = 274 bins do not fit the backward
+    plan's byte taps -- forward planned, backward direct, both bit-exact."""
+    d = dev()
+    rng = np.random.default_rng(8)
+    img = rng.random((2, 192, 192), dtype=np.float32)
+    theta = rng.uniform(0, np.pi, 5)
+    plan = RotatePlan(theta, 192, 192, True, d)
+    assert plan.PW == 274 and plan.planned == (True, False)
+    geom = oracle.Geometry(192, 192, True)
+    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))), oracle.rotate_fwd(img, geom, to_np(plan.T8), 0))
+    g = rng.standard_normal((2, 5, 274)).astype(np.float32)
+    np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
+                                  oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0))
+
+
+def test_inputs_in_other_forms(oracle):
+    """theta as a python list / CPU tensor; a non-contiguous phantom; a single slice; many angles for one tiny image."""
+    d = dev()
+    rng = np.random.default_rng(9)
+    x = rng.random((12, 10, 4), dtype=np.float32)
+    theta = [0.1, 0.9, 2.0]
+    want = oracle.project_tf_fast(x, np.array(theta), pad=True)
+    got = cp.project_tf_fast(torch.from_numpy(x).to(d), theta, pad=True)
+    assert rel_err(to_np(got), want) <= REL
+    got = cp.project_tf_fast(torch.from_numpy(x).to(d), torch.tensor(theta, dtype=torch.float64), pad=True)
+    assert rel_err(to_np(got), want) <= REL
+    xt = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 0, 2)))).to(d).permute(1, 0, 2)   # non-contiguous view
+    assert not xt.is_contiguous()
+    assert rel_err(to_np(cp.project_tf_fast(xt, theta, pad=True)), want) <= REL
+    th = np.linspace(0, 2 * np.pi, 300)
+    one = rng.random((1, 4, 4, 1), dtype=np.float32)
+    got = cp.project_tf_fast(torch.from_numpy(one).to(d), th, pad=True, dim=2, integrate_vae=True)
+    assert rel_err(to_np(got), oracle.project_tf_fast(one, th, pad=True, dim=2, integrate_vae=True)) <= REL
+
+
 def test_large_image_takes_the_no_lds_path(oracle):
     """512x512 (BASELINE config 5) does not fit LDS; same numbers either way."""
     d = dev()
