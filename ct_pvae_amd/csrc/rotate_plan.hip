@@ -201,6 +201,29 @@ __device__ __forceinline__ float lds_at(const float *lds, int byte_off)
 {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + byte_off);
 }
+// NS slices interleaved in LDS (float or float2 per pixel): byte offset = index * 4 * NS, one ds_read_b32 / _b64 per tap
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NS> struct SliceVec { typedef float type; };
+template <> struct SliceVec<2> { typedef f32x2 type; };
+__device__ __forceinline__ void unpack2x8(unsigned pk, int &lo8, int &hi8)
+{
+    asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(lo8)
+        : "v"(pk));
+    asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+        : "=v"(hi8)
+        : "v"(pk));
+}
+__device__ __forceinline__ void gather8(const float *lds, const uint4 q, f32x2 (&v)[8])
+{
+    int a[8];
+    unpack2x8(q.x, a[0], a[1]);
+    unpack2x8(q.y, a[2], a[3]);
+    unpack2x8(q.z, a[4], a[5]);
+    unpack2x8(q.w, a[6], a[7]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(lds) + a[e]);
+}
 __device__ __forceinline__ void gather8(const float *lds, const uint4 q, float (&v)[8])
 {
     int a0, a1, a2, a3, a4, a5, a6, a7;
@@ -227,8 +250,8 @@ __device__ __forceinline__ void gather8(const float *lds, const uint4 q, float (
 // pitch rules out its 16-byte form.  Plain dword loads also lost: 4x the requests of float4 loads.)
 // Requires cols % 4 == 0 and 16-byte aligned rows; stage_rows_scalar covers everything else.
 __device__ __forceinline__ void stage_rows_v4(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
-                                              int pitch, bool mirror, int lane, int wave, int nwaves)
-{
+                                              int pitch, bool mirror, int lane, int wave, int nwaves, int es = 1)
+{   // es: element stride in dwords (2 when two slices are interleaved as float2; `lds` then points at the slice's lane)
     const int ncb = (cols + 31) >> 5, npc = (ncb + 1) >> 1, nrq = (rows + 3) >> 2;
     const int npairs = nrq * npc;
     const int h = lane >> 5, k = (lane & 31) >> 3, m = lane & 7;   // 8 consecutive lanes = one 128-B line of one row
@@ -259,29 +282,29 @@ __device__ __forceinline__ void stage_rows_v4(float *lds, const float *__restric
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             if (r_[u] < 0) continue;
-            float *d = lds + r_[u] * pitch + c_[u];
+            float *d = lds + (r_[u] * pitch + c_[u]) * es;
             d[0] = mirror ? v[u].w : v[u].x;
-            d[1] = mirror ? v[u].z : v[u].y;
-            d[2] = mirror ? v[u].y : v[u].z;
-            d[3] = mirror ? v[u].x : v[u].w;
+            d[es] = mirror ? v[u].z : v[u].y;
+            d[2 * es] = mirror ? v[u].y : v[u].z;
+            d[3 * es] = mirror ? v[u].x : v[u].w;
         }
     }
 }
 __device__ __forceinline__ void stage_rows_scalar(float *lds, const float *__restrict__ src, int rows, int cols,
-                                                  int src_stride, int pitch, bool mirror, int tid, int nthreads)
+                                                  int src_stride, int pitch, bool mirror, int tid, int nthreads, int es = 1)
 {
     for (int p = tid; p < rows * cols; p += nthreads) {
         const int r = p / cols, c = p - r * cols;
-        lds[r * pitch + c] = src[(size_t)r * src_stride + (mirror ? cols - 1 - c : c)];
+        lds[(r * pitch + c) * es] = src[(size_t)r * src_stride + (mirror ? cols - 1 - c : c)];
     }
 }
 __device__ __forceinline__ void stage_rows(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
-                                           int pitch, bool mirror, int lane, int wave, int nwaves)
+                                           int pitch, bool mirror, int lane, int wave, int nwaves, int es = 1)
 {
     if ((cols & 3) == 0 && (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
-        stage_rows_v4(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves);
+        stage_rows_v4(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves, es);
     else
-        stage_rows_scalar(lds, src, rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64);
+        stage_rows_scalar(lds, src, rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64, es);
 }
 
 // Forward.  Workgroup = (slice s, class c, group gi): stages the slice once (LDS-DMA, mirrored for class 0), then each
@@ -301,34 +324,41 @@ __device__ long long g_pstamps[8 * 65536];
 #define CTPVAE_PSTAMP(slot)
 #endif
 
+// NS = 2: two slices per workgroup, interleaved as float2 in LDS -- ONE index stream and ONE ds_read_b64 per tap serve
+// both slices (the index stream is what binds the kernel, section 6 of DESIGN.md).  Used when a launch has enough
+// tasks to keep every CU busy with half as many workgroups.
+template <int NS>
 __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *__restrict__ img, PlanGeom g, FwdLayout L,
                                                                   const char *__restrict__ plan, int wgs_per_slice,
                                                                   int g_S, float *__restrict__ sino)
 {
+    typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
-    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only).  Slices are dealt to the 8 XCDs so that
-    // all workgroups of one slice read it through the same L2: block = (s / 8) * 8 * wgs + wg * 8 + s % 8.
-    int s, wg;
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only).  Slices (slice pairs) are dealt to the 8
+    // XCDs so that all workgroups of one slice read it through the same L2: block = (u / 8) * 8 * wgs + wg * 8 + u % 8.
+    const int units = (g_S + NS - 1) / NS;
+    int u, wg;
     {
         const int per8 = 8 * wgs_per_slice, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
-        if ((octet + 1) * 8 <= g_S) {
+        if ((octet + 1) * 8 <= units) {
             wg = rem >> 3;
-            s = octet * 8 + (rem & 7);
-        } else {   // the last, partial octet (S % 8 slices) is laid out slice-major
-            s = octet * 8 + rem / wgs_per_slice;
+            u = octet * 8 + (rem & 7);
+        } else {   // the last, partial octet is laid out unit-major
+            u = octet * 8 + rem / wgs_per_slice;
             wg = rem % wgs_per_slice;
         }
     }
+    const int s = u * NS;
+    const bool has2 = NS == 2 && s + 1 < g_S;     // an odd batch ends with a half-empty pair (slice s staged twice)
     const int c = wg & 1, gi = wg >> 1, G = wgs_per_slice >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const float *im = img + (size_t)s * g.H * g.W;
     CTPVAE_PSTAMP(0);
 
-    // Stage the slice: coalesced dword loads (one 256-B row segment per wave-instruction, all of a wave's loads in
-    // flight together), then conflict-free ds_write_b32.  (LDS-DMA in its dword form measured ~47 cycles per
-    // instruction per CU here, several times slower than this; the odd pitch rules out its 16-byte form.)
-    stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
-    if (threadIdx.x == 0) lds[L.zero] = 0.0f;
+    // Stage the slice(s): 16-byte loads, conflict-free ds_write_b32 (see stage_rows_v4).
+    stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves, NS);
+    if (NS == 2) stage_rows(lds + 1, im + (has2 ? (size_t)g.H * g.W : 0), g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves, NS);
+    if (threadIdx.x < NS) lds[L.zero * NS + threadIdx.x] = 0.0f;
     CTPVAE_PSTAMP(1);
     __syncthreads();
     CTPVAE_PSTAMP(2);
@@ -361,13 +391,13 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 #else
         const size_t st = (size_t)L.PWpad;
 #endif
-        float acc = 0.0f;
+        vec_t acc = 0.0f;
         if (ng > 0) {
             // q0..q3: index vectors of groups n..n+3 (loads in flight); va/vb: gathers of group n / n+1 in flight.
             // Loads and gathers run up to four groups past `ng`: the table keeps 8 dead groups behind the canvas.
             uint4 q0 = p[0], q1 = p[st], q2 = p[2 * st], q3 = p[3 * st];
             p += 4 * st;
-            float va[8], vb[8];
+            vec_t va[8], vb[8];
             gather8(lds, q0, va);
             q0 = p[0];
             for (int n = 0;; n += 4) {
@@ -398,7 +428,14 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
                 if (n + 4 >= ng) break;
             }
         }
-        if ((unsigned)j < (unsigned)g.PW) sino[((size_t)s * g.A + a) * g.PW + j] = acc;
+        if ((unsigned)j < (unsigned)g.PW) {
+            if constexpr (NS == 1) {
+                sino[((size_t)s * g.A + a) * g.PW + j] = acc;
+            } else {
+                sino[((size_t)s * g.A + a) * g.PW + j] = acc.x;
+                if (has2) sino[((size_t)(s + 1) * g.A + a) * g.PW + j] = acc.y;
+            }
+        }
     }
     CTPVAE_PSTAMP(3);
 }
@@ -436,8 +473,8 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
 // Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x (4 x PPT)-row tile): stages a chunk of the
 // slice's cotangent rows (257-dword rows, zeros behind the bins), then every lane owns one column and PPT rows; for
 // each group of sixteen angles it loads the PPT index vectors (16 B = 16 taps), gathers and adds in angle order.
-template <int PPT>
-__global__ __launch_bounds__(256) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
+template <int PPT, int MAXT>
+__global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y,
                                                                  float *__restrict__ gimg)
 {
@@ -570,27 +607,34 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     CTPVAE_REQUIRE(fwd_plan_fits(g), "rotate_fwd_planned: a %dx%d slice does not fit the plan's LDS image", H, W);
     const FwdLayout L = fwd_layout(g);
-    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float);
-    // (angle, bin block) tasks of one slice are dealt to G groups per class; about two workgroups per CU chip-wide,
-    // at most 16 waves each
-    const int T = A * L.nJB;
+    const int T = A * L.nJB;   // (angle, bin block) tasks per slice
+    // Two slices per workgroup (one index stream serves both) when the interleaved pair fits LDS and the launch has
+    // enough tasks that pairing still leaves >= ~8 tasks for every CU; otherwise one slice per workgroup.
+    int ns = ((size_t)(L.zero + 1) * 8 <= (size_t)kMaxLdsBytes && (long long)S * T >= 2ll * 256 * 8) ? 2 : 1;
+    if (const char *e = getenv("CTPVAE_TUNE_NS")) ns = atoi(e) == 2 ? 2 : 1;
+    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns;
+    const int units = (S + ns - 1) / ns;
+    // the tasks of one unit are dealt to G groups per mirror class; about 1.6 workgroups per CU chip-wide when two fit
+    // a CU, one otherwise; at most 16 waves each
     const int wgs_per_cu = shmem * 2 <= (size_t)kMaxLdsBytes ? 2 : 1;
-    int G = (int)std::max<long long>(1, (long long)(256 * (wgs_per_cu == 2 ? 1.6 : 1.0) / (2.0 * S) + 0.5));
+    int G = (int)std::max<long long>(1, (long long)(256 * (wgs_per_cu == 2 ? 1.6 : 1.0) / (2.0 * units) + 0.5));
     G = std::min(G, std::max(1, T / 2));
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, (T + 2 * G - 1) / (2 * G)));
     const int wgs_per_slice = 2 * G;
-    CTPVAE_REQUIRE((long long)S * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
-    static bool attr_set = false;
-    if (!attr_set) {
-        CTPVAE_HIP(hipFuncSetAttribute((const void *)rotate_fwd_planned_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kMaxLdsBytes));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(rotate_fwd_planned_kernel, dim3((unsigned)(S * wgs_per_slice)), dim3(64 * waves), shmem,
-                       (hipStream_t)stream, img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev);
-    CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
-    return CTPVAE_OK;
+    CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
+    auto launch = [&](auto kernel) -> int {
+        static bool attr_set = false;   // one flag per instantiation
+        if (!attr_set) {
+            CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
+        return CTPVAE_OK;
+    };
+    return ns == 2 ? launch(rotate_fwd_planned_kernel<2>) : launch(rotate_fwd_planned_kernel<1>);
 }
 
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A, const void *bwd_plan_dev,
@@ -604,18 +648,29 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
     const BwdLayout L = bwd_layout(g);
     const size_t shmem = (size_t)L.chunkA * L.pitchg * sizeof(float);
     constexpr int kPpt = 4;
-    const int rows_per_wg = 4 * kPpt;
+    // Tile = 64 columns x (waves x 4) rows.  Every workgroup of a slice stages ALL the slice's cotangent rows: with many
+    // angles taller tiles amortise that staging (measured, B=50 A=180: 44 -> 28 us from 4 to 16 waves); with few angles
+    // the staging is small and short tiles win, because four small workgroups per CU overlap each other's staging and
+    // barrier waits while one 16-wave workgroup (114 VGPRs: one per CU) cannot (B=400 A=20: 34 us vs 45 us).
+    int waves = 4;
+    if (A >= 32)
+        while (waves < 16 && (long long)S * L.nXB * ceil_div(H, 2 * waves * kPpt) >= 200 && waves * kPpt < H) waves *= 2;
+    if (const char *e = getenv("CTPVAE_TUNE_BW")) waves = std::min(16, std::max(1, atoi(e)));
+    const int rows_per_wg = waves * kPpt;
     const int tiles_y = ceil_div(H, rows_per_wg);
     const long long nblk = (long long)S * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
-    static bool attr_set = false;
-    if (!attr_set) {
-        CTPVAE_HIP(hipFuncSetAttribute((const void *)rotate_bwd_planned_kernel<kPpt>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(rotate_bwd_planned_kernel<kPpt>, dim3((unsigned)nblk), dim3(256), shmem, (hipStream_t)stream,
-                       gsino_dev, g, L, (const uint4 *)bwd_plan_dev, tiles_y, gimg_dev);
+    auto launch = [&](auto kernel) -> int {
+        static bool attr_set = false;   // one flag per instantiation
+        if (!attr_set) {
+            CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
+                           (const uint4 *)bwd_plan_dev, tiles_y, gimg_dev);
+        return CTPVAE_OK;
+    };
+    if (int rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<kPpt, 256>) : launch(rotate_bwd_planned_kernel<kPpt, 1024>)) return rc;
     CTPVAE_LAUNCH_CHECK("rotate_bwd_planned_kernel");
     return CTPVAE_OK;
 }

@@ -215,6 +215,28 @@ def test_planned_equals_direct(oracle, shape, pad, A, S):
     np.testing.assert_array_equal(to_np(pa.backward(g)[:1]), oracle.rotate_bwd_tfcompat(to_np(g[:1]), geom, to_np(pa.Tinv8), 0))
 
 
+@pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 5), ((128, 128), True, 180, 51), ((40, 100), True, 33, 3),
+                                          ((65, 31), False, 9, 1), ((2, 2), False, 2, 2), ((128, 128), True, 20, 17)])
+def test_paired_slices_equal_single_slices(oracle, shape, pad, A, S, monkeypatch):
+    """The planned forward runs one or two slices per workgroup (two: float2-interleaved in LDS behind one index stream);
+    both forms are the same operator bit for bit -- odd batches (half-empty last pair), one slice, ragged shapes."""
+    d = dev()
+    rng = np.random.default_rng(A + S)
+    theta = rng.uniform(-1.0, 4.0, A)
+    x = torch.from_numpy(rng.standard_normal((S,) + shape).astype(np.float32)).to(d)
+    plan = RotatePlan(theta, shape[0], shape[1], pad, d)
+    assert plan.planned[0]
+    monkeypatch.setenv("CTPVAE_TUNE_NS", "1")
+    one = plan.forward(x)
+    monkeypatch.setenv("CTPVAE_TUNE_NS", "2")
+    two = plan.forward(x)
+    monkeypatch.delenv("CTPVAE_TUNE_NS")
+    auto = plan.forward(x)
+    assert torch.equal(one, two) and torch.equal(one, auto)
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    np.testing.assert_array_equal(to_np(two[-1:]), oracle.rotate_fwd(to_np(x[-1:]), geom, to_np(plan.T8), 0))
+
+
 def test_mixed_planned_forward_direct_backward(oracle):
     """192x192: the slice still fits the forward plan's LDS image (148 KiB), but P = 274 bins do not fit the backward
     plan's byte taps -- forward planned, backward direct, both bit-exact."""

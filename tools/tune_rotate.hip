@@ -65,15 +65,18 @@ int main(int argc, char **argv)
         printf("plan build (fwd+bwd): %.2f us\n", time_us([&] { ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, fp, bp, nullptr); }));
         printf("planned fwd : %.2f us\n", time_us([&] { if (ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); } }));
         printf("planned bwd : %.2f us\n", time_us([&] { if (ctpvae_rotate_bwd_planned_f32(d_g, S, N, N, P, P, A, bp, d_gimg, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); } }));
-        for (int G : {1, 2, 3, 4, 5, 6, 8, 10}) {
+        for (int ns : {1, 2}) for (int G : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
             char b[16]; snprintf(b, 16, "%d", G); setenv("CTPVAE_TUNE_G", b, 1);
-            printf("planned fwd G=%d: %.2f us\n", G, time_us([&] { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); }, 100));
+            snprintf(b, 16, "%d", ns); setenv("CTPVAE_TUNE_NS", b, 1);
+            printf("planned fwd NS=%d G=%d: %.2f us\n", ns, G, time_us([&] { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); }, 100));
         }
-        for (int lds_kb : {0, 90}) for (int G : {2, 3}) {
-            char b[16]; snprintf(b, 16, "%d", G); setenv("CTPVAE_TUNE_G", b, 1);
-            snprintf(b, 16, "%d", lds_kb); setenv("CTPVAE_TUNE_LDS", b, 1);
-            printf("planned fwd G=%d LDS>=%dKB: %.2f us\n", G, lds_kb, time_us([&] { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); }, 100));
+        unsetenv("CTPVAE_TUNE_NS");
+        unsetenv("CTPVAE_TUNE_G");
+        for (int bw : {2, 4, 8, 16}) {
+            char b[16]; snprintf(b, 16, "%d", bw); setenv("CTPVAE_TUNE_BW", b, 1);
+            printf("planned bwd waves=%d: %.2f us\n", bw, time_us([&] { ctpvae_rotate_bwd_planned_f32(d_g, S, N, N, P, P, A, bp, d_gimg, nullptr); }, 100));
         }
+        unsetenv("CTPVAE_TUNE_BW");
         unsetenv("CTPVAE_TUNE_LDS");
         unsetenv("CTPVAE_TUNE_G");
     }
