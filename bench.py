@@ -182,7 +182,8 @@ def siddon_mode(args, world, rank, dev):
 
 def n512_mode(args, world, rank, dev):
     """BASELINE config 5: 512x512 phantoms, 90 angles, Poisson-noise forward model (pnm 1e4): forward + Gaussian-Poisson
-    log-likelihood + backward.  The slice (1 MiB) does not fit LDS: direct kernels."""
+    log-likelihood + backward.  The slice (1 MiB) does not fit LDS: the forward cuts it into 128x128 tiles, each staged
+    once for all angles; the backward stages cotangent rows in angle chunks."""
     from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
     B, N, A = 8, 512, 90
     theta = np.pi * np.arange(A) / A
@@ -217,7 +218,7 @@ def n512_mode(args, world, rank, dev):
                           "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"batch={B}/GPU 512x512, 90 angles, P={plan.PW}, nearest fwd + "
-                                                 "Gaussian-Poisson log-likelihood fwd/bwd + tf_compat adj (direct kernels)"},
+                                                 "Gaussian-Poisson log-likelihood fwd/bwd + tf_compat adj (tiled fwd, chunked adj)"},
                           "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS}))
 
 

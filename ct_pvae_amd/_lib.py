@@ -27,6 +27,9 @@ SIGNATURES = {
     "ctpvae_rotate_transforms_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
     "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                        _c_int, _vp, _vp]),
+    "ctpvae_rotate_fwd_tiled_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_rotate_fwd_tiled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp,
+                                             _vp, _vp]),
     "ctpvae_rotate_bwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int,
                                        _c_int, _c_int, _vp, _vp]),
     "ctpvae_rotate_plan_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),

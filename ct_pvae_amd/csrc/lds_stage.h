@@ -1,0 +1,74 @@
+// lds_stage.h -- staging rows of fp32 from global memory into LDS, shared by the rotate kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace ctpvae {
+
+// rows x cols floats from global (row stride src_stride) into LDS (row stride pitch == +-1 mod 32), optionally
+// column-mirrored.  16-byte global loads, and a lane arrangement that makes the four ds_write_b32 of a float4
+// conflict-free: inside a 32-lane group, lane l takes row (l >> 3) and float4 number (l & 7) of a 4-row x 32-column
+// block (8 consecutive lanes read one 128-B line), so for component e the group writes dword (k*pitch + 4m + e), k = 0..3, m = 0..7 -- and with pitch == 1
+// (mod 32) the bank k + 4m + e runs over all 32 banks exactly once.  The two halves of a wave take adjacent blocks.
+// (LDS-DMA was measured here and lost: its dword form costs ~47 cycles per 256-B instruction per CU, and the odd
+// pitch rules out its 16-byte form.  Plain dword loads also lost: 4x the requests of float4 loads.)
+// Requires cols % 4 == 0 and 16-byte aligned rows; stage_rows_scalar covers everything else.
+__device__ __forceinline__ void stage_rows_v4(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
+                                              int pitch, bool mirror, int lane, int wave, int nwaves, int es = 1)
+{   // es: element stride in dwords (2 when two slices are interleaved as float2; `lds` then points at the slice's lane)
+    const int ncb = (cols + 31) >> 5, npc = (ncb + 1) >> 1, nrq = (rows + 3) >> 2;
+    const int npairs = nrq * npc;
+    const int h = lane >> 5, k = (lane & 31) >> 3, m = lane & 7;   // 8 consecutive lanes = one 128-B line of one row
+    constexpr int NB = 8;   // float4 loads in flight per lane: 64 KiB lands in one batch with >= 8 waves
+    // pair index pp = wave, wave + nwaves, ... -> (rq, pc) = (pp / npc, pp % npc), advanced without dividing
+    const int d_rq = nwaves / npc, d_pc = nwaves - d_rq * npc;
+    int rq = wave / npc, pc = wave - rq * npc;
+    for (int p0 = wave; p0 < npairs; p0 += NB * nwaves) {
+        float4 v[NB];
+        int r_[NB], c_[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            r_[u] = 4 * rq + k;
+            c_[u] = 32 * (2 * pc + h) + 4 * m;
+            const bool ok = rq < nrq && r_[u] < rows && c_[u] < cols;
+            // The load itself is UNCONDITIONAL (address clamped into the slice): a select between a load and a
+            // constant makes hipcc branch around every load and wait vmcnt(0) after each.
+            const int rl = min(r_[u], rows - 1), cl = min(c_[u], cols - 4);
+            v[u] = *reinterpret_cast<const float4 *>(src + (size_t)rl * src_stride + (mirror ? cols - 4 - cl : cl));
+            if (!ok) r_[u] = -1;
+            rq += d_rq;
+            pc += d_pc;
+            if (pc >= npc) {
+                pc -= npc;
+                ++rq;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (r_[u] < 0) continue;
+            float *d = lds + (r_[u] * pitch + c_[u]) * es;
+            d[0] = mirror ? v[u].w : v[u].x;
+            d[es] = mirror ? v[u].z : v[u].y;
+            d[2 * es] = mirror ? v[u].y : v[u].z;
+            d[3 * es] = mirror ? v[u].x : v[u].w;
+        }
+    }
+}
+__device__ __forceinline__ void stage_rows_scalar(float *lds, const float *__restrict__ src, int rows, int cols,
+                                                  int src_stride, int pitch, bool mirror, int tid, int nthreads, int es = 1)
+{
+    for (int p = tid; p < rows * cols; p += nthreads) {
+        const int r = p / cols, c = p - r * cols;
+        lds[(r * pitch + c) * es] = src[(size_t)r * src_stride + (mirror ? cols - 1 - c : c)];
+    }
+}
+__device__ __forceinline__ void stage_rows(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
+                                           int pitch, bool mirror, int lane, int wave, int nwaves, int es = 1)
+{
+    if ((cols & 3) == 0 && (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+        stage_rows_v4(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves, es);
+    else
+        stage_rows_scalar(lds, src, rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64, es);
+}
+
+}  // namespace ctpvae

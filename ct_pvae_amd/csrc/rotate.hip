@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "lds_stage.h"
 
 namespace ctpvae {
 
@@ -223,8 +224,38 @@ __device__ long long g_stamps[8 * 65536];
 #define CTPVAE_STAMP(slot)
 #endif
 
-template <int INTERP, bool TIE_FIX>
-__global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom g,
+// Slices that do not fit LDS (512 x 512 = 1 MiB) are cut into tiles.  A tile is an ordinary slice that sits at its own
+// (py, px) of the SAME canvas, read through the slice's row stride -- the transform, the rounding and therefore every
+// tap index are unchanged -- and the projector is linear, so the sinogram is the sum of the tiles' sinograms.  Each
+// tile is staged ONCE and serves all angles.  A ray of angle a can hit tile t only if its bin lies within `radius` of
+// the bin the tile's centre projects to, so a tile owns nb ray slots per angle starting at tile_first_bin(); its
+// partial sums go to a workspace [S][tiles][A][nb] and rotate_tile_reduce_kernel adds them in ascending tile order:
+//     sino[s][a][j] = ((0 + p_0) + p_1) + ... ,   p_t = sum over canvas rows, ascending, of the taps inside tile t.
+// (A different association of the same terms than the row-sequential sum of a slice that fits LDS; the CPU
+// restatement has the same tiled mode, oracle_rotate_fwd_tiled.)
+struct TileSpec {
+    int ntx, nty;   // tiles per slice
+    int tw, th;     // nominal tile size (edge tiles are smaller)
+    int nb;         // ray slots per (tile, angle), a multiple of 64
+    float radius;   // half the tile diagonal + 3 px
+};
+__host__ __device__ __forceinline__ void tile_rect(const RotGeom &g, const TileSpec &ts, int t, int &y0, int &x0, int &h, int &w)
+{
+    const int ty = t / ts.ntx, tx = t - ty * ts.ntx;
+    y0 = ty * ts.th;
+    x0 = tx * ts.tw;
+    h = min(ts.th, g.H - y0);
+    w = min(ts.tw, g.W - x0);
+}
+// first ray slot's bin: the orthonormal transform maps canvas (x, y) to bin t0*(x - t2) + t3*(y - t5)
+__device__ __forceinline__ int tile_first_bin(const float *__restrict__ t, float cx, float cy, float radius)
+{
+    const float jc = t[0] * (cx - t[2]) + t[3] * (cy - t[5]);
+    return (int)floorf(jc - radius);
+}
+
+template <int INTERP, bool TIE_FIX, bool TILED>
+__global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                const float *__restrict__ T8, int rays_per_blk,
                                                                float *__restrict__ sino)
 {
@@ -232,16 +263,36 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     constexpr bool PAIRS = (INTERP == CTPVAE_NEAREST) && !TIE_FIX;   // the asm pair path
     extern __shared__ float lds[];
     CTPVAE_STAMP(0);
-    const int s = blockIdx.y;
-    const float *im = img + (size_t)s * g.H * g.W;
+    // g: the geometry this workgroup works in -- the slice itself, or one tile of it as a slice of its own
+    RotGeom g = gfull;
+    int s = blockIdx.y;
+    const float *im;
+    float tile_cx = 0.0f, tile_cy = 0.0f;
+    if (TILED) {
+        const int nt = ts.ntx * ts.nty, v = blockIdx.y;
+        s = v / nt;
+        int y0, x0;
+        tile_rect(gfull, ts, v - s * nt, y0, x0, g.H, g.W);
+        g.py = gfull.py + y0;
+        g.px = gfull.px + x0;
+        im = img + ((size_t)s * gfull.H + y0) * gfull.W + x0;
+        tile_cx = (float)g.px + 0.5f * (float)(g.W - 1);
+        tile_cy = (float)g.py + 0.5f * (float)(g.H - 1);
+    } else {
+        im = img + (size_t)s * g.H * g.W;
+    }
+    const int nb = TILED ? ts.nb : g.PW;   // ray slots per angle
     const int wb = g.W + 2 * BORDER;
     const int hb = g.H + 2 * BORDER;
     // Row pitch == +1 or -1 (mod 32), chosen per workgroup from the direction its rays' lanes walk: consecutive
     // detector bins step by (t0, t3) pixels, i.e. by t3*pitch + t0 dwords ~ +-t3 + t0 banks.  Picking the sign that
     // makes the two terms add keeps |step| in [1, 1.42] banks per lane: at most 2 lanes of a 32-lane group share a
     // bank at any angle.
+    // A tiled launch deals whole classes to workgroups instead: blockIdx.x = 2 * group + class.
     int pitch;
-    {
+    if (TILED) {
+        pitch = pitch_for(wb, (blockIdx.x & 1) != 0);
+    } else {
         const int ray_mid = min(blockIdx.x * rays_per_blk + rays_per_blk / 2, g.A * g.PW - 1);
         const float *tm = T8 + 8 * (ray_mid / g.PW);
         const bool same_sign = (tm[0] >= 0.0f) == (tm[3] >= 0.0f);
@@ -249,17 +300,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     }
 
 #ifndef CTPVAE_TUNE_NOFILL
-    // Stage the slice: LDS-DMA (global_load_lds_dword), one wave-instruction per 64-pixel row segment, no VGPRs and
-    // no ds_write; the zero border goes in with ordinary stores.  Everything is asynchronous until the barrier below.
+    // Stage the slice (16-byte loads, conflict-free ds_write_b32: lds_stage.h), then its zero border.
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-        const int nseg = (g.W + 63) >> 6;
-        for (int t = wave; t < g.H * nseg; t += nwaves) {
-            const int r = t / nseg, c0 = (t - r * nseg) << 6;
-            if (c0 + lane < g.W)
-                __builtin_amdgcn_global_load_lds((glb_cptr)(im + (size_t)r * g.W + c0 + lane),
-                                                 (lds_ptr)(lds + (r + BORDER) * pitch + BORDER + c0), 4, 0, 0);
-        }
+        stage_rows(lds + BORDER * pitch + BORDER, im, g.H, g.W, gfull.W, pitch, false, lane, wave, nwaves);
         for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
             const int r = p / pitch, c = p - r * pitch;
             lds[(r < BORDER ? r : hb - 2 * BORDER + r) * pitch + c] = 0.0f;
@@ -272,9 +316,9 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 #endif
     CTPVAE_STAMP(1);
 
-    const int nrays = g.A * g.PW;
-    const int ray0 = blockIdx.x * rays_per_blk;
-    const int ray_end = min(ray0 + rays_per_blk, nrays);
+    const int nrays = g.A * nb;
+    const int ray0 = TILED ? 0 : blockIdx.x * rays_per_blk;
+    const int ray_end = TILED ? nrays : min(ray0 + rays_per_blk, nrays);
     // clamp bounds in canvas coordinates and the matching LDS offset
     const int xlo = g.px - BORDER, xhi = g.px + g.W + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
     const int ylo = g.py - BORDER, yhi = g.py + g.H + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
@@ -289,14 +333,18 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
         int ray, ilo, kmax;
         bool live;
     };
-    auto setup = [&](int rbase) -> Ray {
+    auto setup = [&](int first_ray) -> Ray {
         Ray q;
-        q.ray = rbase + threadIdx.x;
+        q.ray = first_ray;
         q.live = q.ray < ray_end;
         const int rr = q.live ? q.ray : ray_end - 1;
-        const int a = rr / g.PW;
-        const int j = rr - a * g.PW;
+        const int a = rr / nb;
+        int j = rr - a * nb;
         const float *t = T8 + 8 * a;
+        if (TILED) {
+            j += tile_first_bin(t, tile_cx, tile_cy, ts.radius);
+            q.live = q.live && (unsigned)j < (unsigned)g.PW;   // slots off the detector are never read back
+        }
         const float t0 = t[0], t3 = t[3];
         q.t1 = t[1]; q.t2 = t[2]; q.t4 = t[4]; q.t5 = t[5];
         q.xj = t0 * (float)j;
@@ -319,11 +367,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
         return q;
     };
 
-    Ray q = setup(ray0);   // runs under the LDS-DMA
-    CTPVAE_STAMP(2);
-    __syncthreads();       // (an unconditional barrier: a barrier inside the ray loop makes hipcc wait lgkmcnt(0) in it)
-    for (int rbase = ray0; rbase < ray_end; rbase += blockDim.x) {
-        if (rbase != ray0) q = setup(rbase);
+    // one ray per lane: walk its rows, store its sum
+    auto walk = [&](const Ray &q) {
         const float t1 = q.t1, t2 = q.t2, t4 = q.t4, t5 = q.t5, xj = q.xj, yj = q.yj;
         const int ray = q.ray, ilo = q.ilo, kmax = q.kmax;
         const bool live = q.live;
@@ -426,9 +471,63 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 #ifdef CTPVAE_TUNE_STAMPS
         if ((threadIdx.x & 63) == 0) g_stamps[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 6] = kmax;
 #endif
-        if (live) sino[(size_t)s * nrays + ray] = acc;
+        if (live) sino[(size_t)blockIdx.y * nrays + ray] = acc;
+    };
+
+    if (TILED) {
+        // (angle, 64-slot block) tasks of this workgroup's bank class, dealt to its waves round-robin
+        __syncthreads();
+        const int cls = blockIdx.x & 1, gi = blockIdx.x >> 1, G = gridDim.x >> 1;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        const int nbk = nb >> 6, T = g.A * nbk;
+        int matched = 0;
+        for (int t = gi; t < T; t += G) {
+            const int a = t / nbk, blk = t - a * nbk;
+            const float *tm = T8 + 8 * a;
+            if ((((tm[0] >= 0.0f) == (tm[3] >= 0.0f)) ? 1 : 0) != cls) continue;
+            const bool mine = (matched % nwaves) == wave;
+            ++matched;
+            if (mine) walk(setup(a * nb + blk * 64 + lane));
+        }
+    } else {
+        Ray q = setup(ray0 + threadIdx.x);   // runs while the staging loads are in flight
+        CTPVAE_STAMP(2);
+        __syncthreads();   // (an unconditional barrier: a barrier inside the ray loop makes hipcc wait lgkmcnt(0) in it)
+        for (int rbase = ray0; rbase < ray_end; rbase += blockDim.x) {
+            if (rbase != ray0) q = setup(rbase + threadIdx.x);
+            walk(q);
+        }
     }
     CTPVAE_STAMP(5);
+}
+
+// sino[s][a][j] = sum over tiles, ascending, of the partial sums of the tiles whose slot range holds bin j
+__global__ __launch_bounds__(256) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
+                                                                 const float *__restrict__ T8, float *__restrict__ sino)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y, s = blockIdx.z;
+    if (j >= g.PW) return;
+    const float *t = T8 + 8 * a;
+    const int nt = ts.ntx * ts.nty;
+    float acc = 0.0f;
+    constexpr int U = 8;   // loads in flight; unconditional (index clamped to a valid cell), the select comes after
+    for (int t0 = 0; t0 < nt; t0 += U) {
+        float v[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tile = min(t0 + u, nt - 1);
+            int y0, x0, h, w;
+            tile_rect(g, ts, tile, y0, x0, h, w);
+            const float cx = (float)(g.px + x0) + 0.5f * (float)(w - 1), cy = (float)(g.py + y0) + 0.5f * (float)(h - 1);
+            const int slot = j - tile_first_bin(t, cx, cy, ts.radius);
+            ok[u] = t0 + u < nt && (unsigned)slot < (unsigned)ts.nb;
+            v[u] = partial[(((size_t)s * nt + tile) * g.A + a) * ts.nb + (ok[u] ? slot : 0)];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += ok[u] ? v[u] : 0.0f;   // + 0.0f leaves the sum unchanged
+    }
+    sino[((size_t)s * g.A + a) * g.PW + j] = acc;
 }
 
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
@@ -672,6 +771,25 @@ static int pick_angles_per_block(int S, int A, int PW)
     return apb;
 }
 
+// Tiling of a slice that does not fit LDS: 128 x 128 tiles (84 KiB with the zero border at the +-1 (mod 32) pitch: one
+// 16-wave workgroup per CU, which already saturates the VALU).  ntx == 0: no tiling needed / possible.
+static TileSpec pick_tiles(int H, int W, int interp)
+{
+    TileSpec ts{};
+    if (interp != CTPVAE_NEAREST) return ts;   // a bilinear sample straddles tiles: it stays on the generic kernel
+    const int wb = W + 2;
+    const size_t whole = (size_t)(H + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
+    if (whole <= (size_t)kMaxLdsBytes) return ts;
+    ts.tw = std::min(W, 128);
+    ts.th = std::min(H, 128);
+    ts.ntx = ceil_div(W, ts.tw);
+    ts.nty = ceil_div(H, ts.th);
+    const float diag = sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th));
+    ts.radius = 0.5f * diag + 3.0f;
+    ts.nb = ((int)ceilf(2.0f * ts.radius) + 2 + 63) / 64 * 64;
+    return ts;
+}
+
 }  // namespace ctpvae
 
 using namespace ctpvae;
@@ -710,15 +828,15 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
                                                kMaxLdsBytes));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(kernel, grid, dim3(block), fast_lds, (hipStream_t)stream, img_dev, g, T8_dev,
+            hipLaunchKernelGGL(kernel, grid, dim3(block), fast_lds, (hipStream_t)stream, img_dev, g, TileSpec{}, T8_dev,
                                (int)rpb, sino_dev);
             CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel");
             return CTPVAE_OK;
         };
         if (interp == CTPVAE_NEAREST)
-            return tie_fix ? launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true>)
-                           : launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false>);
-        return launch(rotate_fwd_fast_kernel<CTPVAE_BILINEAR, false>);
+            return tie_fix ? launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, false>)
+                           : launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, false>);
+        return launch(rotate_fwd_fast_kernel<CTPVAE_BILINEAR, false, false>);
     }
 
     const size_t lds_bytes = (size_t)H * (W + 1) * sizeof(float);
@@ -738,6 +856,53 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
                        : launch(rotate_fwd_kernel<CTPVAE_NEAREST, false>, 0);
     return use_lds ? launch(rotate_fwd_kernel<CTPVAE_BILINEAR, true>, lds_bytes)
                    : launch(rotate_fwd_kernel<CTPVAE_BILINEAR, false>, 0);
+}
+
+long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, int PW, int A, int interp)
+{
+    if (S <= 0 || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_fwd_tiled_workspace_bytes: bad sizes");
+    const TileSpec ts = pick_tiles(H, W, interp);
+    if (ts.ntx == 0 || getenv("CTPVAE_FORCE_GENERIC") != nullptr) return 0;
+    return (long long)S * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
+}
+
+int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                const float *T8_dev, int A, void *workspace_dev, float *sino_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev, "rotate_fwd_tiled: null pointer");
+    if (int rc = check_geom("rotate_fwd_tiled", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
+    const RotGeom g{S, H, W, PH, PW, py, px, A};
+    const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
+    CTPVAE_REQUIRE(ts.ntx > 0, "rotate_fwd_tiled: a %dx%d slice fits LDS whole; call ctpvae_rotate_fwd_f32", H, W);
+    const int nt = ts.ntx * ts.nty;
+    CTPVAE_REQUIRE((long long)S * nt <= 65535, "rotate_fwd_tiled: at most 65535 tiles per call (got %lld)", (long long)S * nt);
+    const int wb = ts.tw + 2;
+    const size_t lds_bytes = (size_t)(ts.th + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
+    // about one 16-wave workgroup per CU: groups per bank class so that tiles x 2 classes x groups covers the chip
+    const int tasks = A * (ts.nb / 64);
+    int G = std::max(1, (int)(256.0 / (2.0 * S * nt) + 0.5));
+    G = std::min(G, std::max(1, tasks / 2));
+    if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
+    const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
+    const bool tie_fix = (px == 0 || py == 0);
+    auto launch = [&](auto kernel) -> int {
+        static bool attr_set = false;  // one flag per instantiation
+        if (!attr_set) {
+            CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(2 * G, S * nt), dim3(64 * waves), lds_bytes, (hipStream_t)stream, img_dev, g, ts,
+                           T8_dev, 0, (float *)workspace_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel (tiled)");
+        return CTPVAE_OK;
+    };
+    if (int rc = tie_fix ? launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, true>)
+                         : launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true>))
+        return rc;
+    hipLaunchKernelGGL(rotate_tile_reduce_kernel, dim3(ceil_div(PW, 256), A, S), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace_dev, g, ts, T8_dev, sino_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
+    return CTPVAE_OK;
 }
 
 int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,

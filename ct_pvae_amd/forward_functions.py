@@ -158,6 +158,8 @@ class RotatePlan:
         # The forward plan is built now, the backward plan on the first backward.
         self._fwd_plan = self._bwd_plan = None
         self._want_bwd_plan = False
+        self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
+        self._tile_ws = None
         if use_plan:
             geo = (self.H, self.W, self.PH, self.PW, self.A, self.interp)
             if self._lib.ctpvae_rotate_plan_supported(*geo, 0):
@@ -181,13 +183,36 @@ class RotatePlan:
         """(forward uses a plan, backward uses / will use a plan)"""
         return self._fwd_plan is not None, self._want_bwd_plan
 
+    def _tile_workspace(self, S):
+        """Device workspace of the tiled forward for S slices, or None when this geometry is not tiled."""
+        if not self._use_tiles or self._fwd_plan is not None:
+            return None
+        need = self._lib.ctpvae_rotate_fwd_tiled_workspace_bytes(S, self.H, self.W, self.PH, self.PW, self.A, self.interp)
+        _lib.check(need, "rotate_fwd_tiled_workspace_bytes")
+        if need == 0:
+            self._use_tiles = False
+            return None
+        if self._tile_ws is None or self._tile_ws.numel() < need:
+            self._tile_ws = torch.empty(int(need), dtype=torch.uint8, device=self.device)
+        return self._tile_ws
+
+    @property
+    def tiled(self):
+        """True if the forward cuts slices into LDS-sized tiles (slices larger than LDS, nearest)."""
+        return self._tile_workspace(1) is not None
+
     def forward(self, img, out=None):
         S = img.shape[0]
         if out is None:
             out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+        ws = self._tile_workspace(S)
         if self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                          self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+        elif ws is not None:
+            rc = self._lib.ctpvae_rotate_fwd_tiled_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
+                                                       self.px, self.T8.data_ptr(), self.A, ws.data_ptr(), out.data_ptr(),
+                                                       _stream_ptr(self._dev_index))
         else:
             rc = self._lib.ctpvae_rotate_fwd_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
                                                  self.px, self.T8.data_ptr(), self.A, self.interp, out.data_ptr(),

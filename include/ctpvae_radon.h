@@ -15,6 +15,7 @@
  *                                              TF's gradient, reached from ctvae/main_ct_vae.py:471-481
  *   ctpvae_rotate_fwd_f32                      project_tf_fast  ctvae/forward_functions.py:80-123
  *                                              project_tf_low_mem ctvae/forward_functions.py:49-78
+ *   ctpvae_rotate_fwd_tiled_f32                the same operator for slices larger than LDS (config 5, 512 x 512)
  *   ctpvae_rotate_bwd_f32                      autodiff of the above (tf.GradientTape,
  *                                              ctvae/main_ct_vae.py:471-481) and its exact transpose
  *   ctpvae_rotate_plan_* / _planned_f32        the same two operators, batched: index arithmetic hoisted
@@ -72,6 +73,18 @@ int ctpvae_rotate_transforms_f32(const float *theta_dev, int A, int H, int W, fl
 int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                           const float *T8_dev, int A, int interp, float *sino_dev,
                           ctpvae_stream_t stream);
+
+/* ---- a2 for slices larger than LDS (512 x 512): tiled forward, NEAREST -----------------------
+ * The slice is cut into 128 x 128 tiles; every tile is staged once and serves all angles, the tiles' partial sums
+ * (workspace) are then added in ascending tile order (row-major over the slice):
+ *     sino[s][a][j] = ((0 + p_0) + p_1) + ...,  p_t = sum over canvas rows i, ascending, of the taps inside tile t.
+ * Tap indices are exactly those of ctpvae_rotate_fwd_f32; only the association of the fp32 sum differs.
+ * _workspace_bytes returns 0 when the slice fits LDS whole or interp is not NEAREST (use ctpvae_rotate_fwd_f32),
+ * otherwise the size of the caller-owned device workspace (contents undefined on return). */
+long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, int PW, int A, int interp);
+int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                const float *T8_dev, int A, void *workspace_dev, float *sino_dev,
+                                ctpvae_stream_t stream);
 
 /* ---- a4: backward of the above -------------------------------------------------------------
  * gsino_dev [S][A][PW] cotangent.  gimg_dev [S][H][W] (overwritten).

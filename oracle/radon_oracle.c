@@ -181,6 +181,44 @@ void oracle_rotate_fwd(const float *img, int S, int H, int W, int PH, int PW, in
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * a2 with the tile-blocked association of the row sum (NEAREST).  reduce_sum(axis=1)
+ * (ctvae/forward_functions.py:108,114) fixes the terms, not the order in which fp32 adds them; the
+ * build's kernels for slices larger than LDS add the taps of each th x tw tile of the slice first
+ * (rows ascending) and then the tile sums in ascending row-major tile order:
+ *   sino[s][a][j] = ((0 + p_0) + p_1) + ...,   p_t = sum_{i ascending, tap in tile t} canvas[tap].
+ * Same taps as oracle_rotate_fwd; the two differ by fp32 rounding of the sum only.
+ * ------------------------------------------------------------------------------------------- */
+int oracle_rotate_fwd_tiled(const float *img, int S, int H, int W, int PH, int PW, int py, int px,
+                            const float *T8, int A, int th, int tw, float *sino)
+{
+    if (th <= 0 || tw <= 0) return -1;
+    const int ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th, nt = ntx * nty;
+    float *part = (float *)malloc((size_t)nt * sizeof(float));
+    if (!part) return -1;
+    for (int s = 0; s < S; ++s) {
+        const float *im = img + (size_t)s * H * W;
+        for (int a = 0; a < A; ++a) {
+            const float *t = T8 + 8 * a;
+            float *out = sino + ((size_t)s * A + a) * PW;
+            for (int j = 0; j < PW; ++j) {
+                for (int k = 0; k < nt; ++k) part[k] = 0.0f;
+                for (int i = 0; i < PH; ++i) {
+                    float x, y;
+                    map_coord(t, j, i, &x, &y);
+                    const long r = (long)roundf(y) - py, c = (long)roundf(x) - px;
+                    if (r >= 0 && r < H && c >= 0 && c < W) part[(r / th) * ntx + c / tw] += im[r * W + c];
+                }
+                float acc = 0.0f;
+                for (int k = 0; k < nt; ++k) acc += part[k];
+                out[j] = acc;
+            }
+        }
+    }
+    free(part);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * a4: the backward TensorFlow actually runs for a2 (tf.GradientTape, ctvae/main_ct_vae.py:471-481):
  *   reduce_sum(axis=1)  <-> broadcast g[a][j] over all rows of a PH x PW image,
  *   ImageProjectiveTransformV3 <-> the same op on that image with the inverted transform, same

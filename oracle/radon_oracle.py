@@ -41,6 +41,8 @@ def lib():
         L.oracle_rotate_transforms.argtypes = [_f32p, _i, _i, _i, _f32p]
         L.oracle_invert_transforms.argtypes = [_f32p, _i, _f32p]
         L.oracle_rotate_fwd.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _f32p]
+        L.oracle_rotate_fwd_tiled.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _i, _f32p]
+        L.oracle_rotate_fwd_tiled.restype = _i
         L.oracle_rotate_bwd_tfcompat.argtypes = [_f32p, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _i, _f32p]
         L.oracle_rotate_bwd_exact.argtypes = [_f32p, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _i, _f32p]
         L.oracle_siddon_dx.restype = _i
@@ -115,6 +117,18 @@ def rotate_fwd(img, geom, T8, interp=NEAREST):
     S, A = img.shape[0], T8.shape[0]
     sino = np.empty((S, A, geom.PW), np.float32)
     lib().oracle_rotate_fwd(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A, interp, sino)
+    return sino
+
+
+def rotate_fwd_tiled(img, geom, T8, tile=(128, 128)):
+    """Same taps as rotate_fwd (NEAREST), summed tile by tile (the association the build uses for slices > LDS)."""
+    img, T8 = _c32(img), _c32(T8)
+    S, A = img.shape[0], T8.shape[0]
+    sino = np.empty((S, A, geom.PW), np.float32)
+    rc = lib().oracle_rotate_fwd_tiled(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A,
+                                       int(tile[0]), int(tile[1]), sino)
+    if rc:
+        raise ValueError("rotate_fwd_tiled: bad tile size")
     return sino
 
 

@@ -273,20 +273,43 @@ def test_inputs_in_other_forms(oracle):
     assert rel_err(to_np(got), oracle.project_tf_fast(one, th, pad=True, dim=2, integrate_vae=True)) <= REL
 
 
-def test_large_image_takes_the_no_lds_path(oracle):
-    """512x512 (BASELINE config 5) does not fit LDS; same numbers either way."""
+def test_large_image_is_tiled(oracle):
+    """512x512 (BASELINE config 5) does not fit LDS: the forward cuts the slice into 128x128 tiles, every tile staged
+    once for all angles.  Same taps as the whole-slice kernels; the sum is associated tile by tile, which the oracle
+    restates (rotate_fwd_tiled) -- bit-exact against that, within REL of the row-sequential sum, and bit-exact against
+    the row-sequential oracle when tiling is switched off (generic kernel)."""
     d = dev()
     rng = np.random.default_rng(4)
-    img = rng.random((1, 512, 512), dtype=np.float32)
-    theta = np.array([0.0, 0.4, np.pi / 2, 2.0])
+    img = rng.random((3, 512, 512), dtype=np.float32)
+    theta = np.array([0.0, 0.4, np.pi / 4, np.pi / 2, 2.0, 3.0])
     plan = RotatePlan(theta, 512, 512, True, d)
-    assert plan.PW == 728 and plan.planned[0] is False
+    assert plan.PW == 728 and plan.planned[0] is False and plan.tiled
     geom = oracle.Geometry(512, 512, True)
-    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
-                                  oracle.rotate_fwd(img, geom, to_np(plan.T8), 0))
-    g = rng.standard_normal((1, 4, 728)).astype(np.float32)
+    x = torch.from_numpy(img).to(d)
+    got = to_np(plan.forward(x))
+    np.testing.assert_array_equal(got[[0, 2]], oracle.rotate_fwd_tiled(img[[0, 2]], geom, to_np(plan.T8), (128, 128)))
+    seq = oracle.rotate_fwd(img[:1], geom, to_np(plan.T8), 0)
+    assert rel_err(got[:1], seq) <= REL
+    untiled = RotatePlan(theta, 512, 512, True, d, use_plan=False)
+    assert not untiled.tiled
+    np.testing.assert_array_equal(to_np(untiled.forward(x[:1])), seq)
+    g = rng.standard_normal((1, 6, 728)).astype(np.float32)
     np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
                                   oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0))
+
+
+@pytest.mark.parametrize("shape,pad,A,S", [((300, 200), True, 7, 2), ((129, 385), False, 5, 1), ((256, 256), True, 33, 4)])
+def test_tiled_forward_ragged(oracle, shape, pad, A, S):
+    """Edge tiles smaller than 128, unpadded canvases (negative-tie rounding at the canvas edge), odd angle counts."""
+    d = dev()
+    rng = np.random.default_rng(A)
+    theta = rng.uniform(-1.0, 4.0, A)
+    img = rng.standard_normal((S,) + shape).astype(np.float32)
+    plan = RotatePlan(theta, shape[0], shape[1], pad, d)
+    assert plan.tiled
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
+                                  oracle.rotate_fwd_tiled(img, geom, to_np(plan.T8), (128, 128)))
 
 
 def test_siddon_against_oracle_and_golden(oracle, golden_dir):
