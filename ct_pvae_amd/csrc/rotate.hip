@@ -679,6 +679,136 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_fast_kernel(const flo
     }
 }
 
+// ---- backward, TensorFlow-compatible, NEAREST: cotangent SEGMENTS in LDS ---------------------------------------
+//
+// A 64-column x 32-row pixel tile reads, for one angle, only the bins its rectangle projects to: at most
+// sqrt(64^2 + 32^2) = 71.6 bins for a rotation.  So the workgroup stages an 80-bin segment per angle (320 B instead of
+// the whole detector row: 2.9 KiB at 728 bins) -- all angles of a launch in one chunk, three barriers in total -- and
+// classifies every angle once from the tile's corners:
+//   0  the whole tile maps inside the canvas (always, on a padded canvas): the tap needs no bounds test, and the
+//      second coordinate is not needed at all -- 6 VALU ops per tap;
+//   1  some pixel may map outside: the reference's zero fill, by steering the tap to the segment's zero cell;
+//   2  the segment would not hold the span (the table row is not a rotation): bounds-tested reads from global memory.
+// Every pixel adds its angles in ascending order (bit-identical to the oracle), whatever the class.
+constexpr int kSegBins = 80, kSegPitch = kSegBins + 1;   // cell kSegBins of every segment is 0.0f
+template <int PPT>
+__global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const float *__restrict__ gsino, RotGeom g,
+                                                                      const float *__restrict__ Tinv8, int chunk_a,
+                                                                      float *__restrict__ gimg)
+{
+    extern __shared__ float lds[];   // [chunk_a][kSegPitch] segments, then [chunk_a][2] ints (first bin, class)
+    int *meta = reinterpret_cast<int *>(lds + chunk_a * kSegPitch);
+    const int s = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
+    const float fx = (float)(c + g.px);
+    // the tile's rectangle in canvas coordinates
+    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + 63.0f;
+    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)(nwaves * PPT - 1);
+    const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
+    const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
+
+    float acc[PPT], fy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        acc[k] = 0.0f;
+        fy[k] = (float)(r0 + k * nwaves + g.py);
+    }
+
+    for (int ac = 0; ac < g.A; ac += chunk_a) {
+        const int na = min(chunk_a, g.A - ac);
+        if (ac > 0) __syncthreads();
+        for (int al = threadIdx.x; al < na; al += blockDim.x) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+            const float xa = (t0 * X0 + t1 * Y0) + t2, xb = (t0 * X1 + t1 * Y0) + t2;
+            const float xc = (t0 * X0 + t1 * Y1) + t2, xd = (t0 * X1 + t1 * Y1) + t2;
+            const float ya = (t3 * X0 + t4 * Y0) + t5, yb = (t3 * X1 + t4 * Y0) + t5;
+            const float yc = (t3 * X0 + t4 * Y1) + t5, yd = (t3 * X1 + t4 * Y1) + t5;
+            const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+            const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
+            int cls = 0, first = 0;
+            if (!(xmax - xmin <= (float)(kSegBins - 6)) || !(fabsf(xmin) < 1.0e6f)) {
+                cls = 2;   // (also NaN / absurd rows)
+            } else {
+                first = (int)floorf(xmin) - 2;
+                if (!(xmin > 0.5f && xmax < x_hi - 1.0f && ymin > 0.5f && ymax < y_hi - 1.0f)) cls = 1;
+            }
+            meta[2 * al] = first;
+            meta[2 * al + 1] = cls;
+        }
+        __syncthreads();
+        const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
+        {
+            constexpr int U = 8;   // loads in flight per thread; unconditional (clamped), the select comes after
+            const int ncell = na * kSegPitch;
+            for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
+                float v[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = min(p0 + u * (int)blockDim.x, ncell - 1);
+                    const int al = p / kSegPitch, q = p - al * kSegPitch;
+                    const int j = meta[2 * al] + q;
+                    ok[u] = q < kSegBins && (unsigned)j < (unsigned)g.PW;
+                    v[u] = src[al * g.PW + min(max(j, 0), g.PW - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * (int)blockDim.x;
+                    if (p < ncell) lds[p] = ok[u] ? v[u] : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+
+        for (int al = 0; al < na; ++al) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);   // wave-uniform: scalar loads
+            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            const int first = __builtin_amdgcn_readfirstlane(meta[2 * al]);
+            const int cls = __builtin_amdgcn_readfirstlane(meta[2 * al + 1]);
+            const float xa = t0 * fx;
+            if (cls == 0) {
+                const int k4 = __builtin_amdgcn_readfirstlane((al * kSegPitch - first) * 4 + lds_base);
+                float v[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const float x = (xa + t1 * fy[k]) + t2;
+                    int addr;   // (round(x) - first) * 4 + segment base: one convert, one shift-add
+                    asm("v_cvt_rpi_i32_f32 %0, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(addr) : "v"(x), "s"(k4));
+                    v[k] = lds_abs(addr);
+                }
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += v[k];
+            } else {
+                const float t3 = t[3], t4 = t[4], t5 = t[5];
+                const float ya = t3 * fx;
+                const float *seg = lds + al * kSegPitch;
+                const float *grow = src + (size_t)al * g.PW;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const float x = (xa + t1 * fy[k]) + t2;
+                    const float y = (ya + t4 * fy[k]) + t5;
+                    const bool ok = (x > -0.5f) & (x < x_hi) & (y > -0.5f) & (y < y_hi);
+                    const int ix = ok ? cvt_rpi(x) : 0;
+                    if (cls == 1)
+                        acc[k] += seg[ok ? ix - first : kSegBins];
+                    else
+                        acc[k] += ok ? grow[ix] : 0.0f;
+                }
+            }
+        }
+    }
+    if (c < g.W) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int r = r0 + k * nwaves;
+            if (r < g.H) gimg[((size_t)s * g.H + r) * g.W + c] = acc[k];
+        }
+    }
+}
+
 // ---- backward, exact transpose (scatter) -------------------------------------------------------
 // Mirrors the forward's decomposition; every ray adds its cotangent into an LDS copy of the slice
 // (ds_add_f32), and the workgroup then adds its tile into gimg (global_atomic_add_f32; gimg is zeroed
@@ -912,23 +1042,30 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
     if (int rc = check_geom("rotate_bwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     CTPVAE_REQUIRE(mode == CTPVAE_BWD_TF_COMPAT || mode == CTPVAE_BWD_EXACT, "rotate_bwd: unknown mode %d", mode);
     const RotGeom g{S, H, W, PH, PW, py, px, A};
-    if (mode == CTPVAE_BWD_TF_COMPAT && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
-        // fast path: 64-column x (4 waves x PPT rows) tiles; cotangent rows in LDS, <= 48 KiB per chunk
+    if (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
+        // 64-column x 32-row tiles, an 80-bin cotangent segment per angle in LDS (<= 31 KiB per chunk of angles)
         constexpr int kPpt = 8;
-        const int pitchg = PW + (interp == CTPVAE_NEAREST ? 1 : 4);
+        const int chunk_a = std::min(A, 96);
+        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) + 2 * sizeof(int));
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * kPpt), S), block(256);
+        hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<kPpt>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g,
+                           T8_dev, chunk_a, gimg_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_seg_kernel");
+        return CTPVAE_OK;
+    }
+    if (mode == CTPVAE_BWD_TF_COMPAT && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
+        // BILINEAR: 64-column x (4 waves x PPT rows) tiles; whole cotangent rows in LDS, <= 48 KiB per chunk
+        constexpr int kPpt = 8;
+        const int pitchg = PW + 4;
         int chunk_a = (48 * 1024) / (pitchg * (int)sizeof(float));
         CTPVAE_REQUIRE(chunk_a >= 1, "rotate_bwd: a detector row of %d bins does not fit LDS", PW);
         chunk_a = std::min(chunk_a, A);
         const size_t shmem = (size_t)chunk_a * pitchg * sizeof(float);
         const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * kPpt), S), block(256);
-        auto launch = [&](auto kernel) -> int {
-            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev, chunk_a,
-                               gimg_dev);
-            CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_fast_kernel");
-            return CTPVAE_OK;
-        };
-        return interp == CTPVAE_NEAREST ? launch(rotate_bwd_tfcompat_fast_kernel<CTPVAE_NEAREST, kPpt>)
-                                        : launch(rotate_bwd_tfcompat_fast_kernel<CTPVAE_BILINEAR, kPpt>);
+        hipLaunchKernelGGL((rotate_bwd_tfcompat_fast_kernel<CTPVAE_BILINEAR, kPpt>), grid, block, shmem, (hipStream_t)stream,
+                           gsino_dev, g, T8_dev, chunk_a, gimg_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_fast_kernel");
+        return CTPVAE_OK;
     }
     if (mode == CTPVAE_BWD_TF_COMPAT) {
         // cotangent rows staged in LDS in chunks of angles (<= 32 KiB per chunk)
