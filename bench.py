@@ -218,7 +218,7 @@ def n512_mode(args, world, rank, dev):
                           "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"batch={B}/GPU 512x512, 90 angles, P={plan.PW}, nearest fwd + "
-                                                 "Gaussian-Poisson log-likelihood fwd/bwd + tf_compat adj (tiled fwd, chunked adj)"},
+                                                 "Gaussian-Poisson log-likelihood fwd/bwd + tf_compat adj (tiled fwd, 4 slices per workgroup; segment-staged adj)"},
                           "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS}))
 
 

@@ -155,6 +155,7 @@ __device__ __forceinline__ int pin_vgpr(int v)
 // A packed op cannot forward its result to the next instruction on gfx950 (the compiler pads with s_nop);
 // the x and y chains are interleaved so every consumer is at least one instruction behind its producer.
 // v60..v63 are scratch inside the block.
+template <int SHIFT>   // log2 of the bytes per LDS pixel: 2, or 3 / 4 when 2 / 4 slices are interleaved
 __device__ __forceinline__ void nearest_pair_addr(f32x2 &fi, f32x2 basex, f32x2 basey, f32x2 stepx, f32x2 stepy,
                                                   f32x2 shiftx, f32x2 shifty, int xlo, int xhi, int ylo, int yhi,
                                                   int pitch4, int off4, int &addr0, int &addr1)
@@ -176,14 +177,25 @@ __device__ __forceinline__ void nearest_pair_addr(f32x2 &fi, f32x2 basex, f32x2 
         "v_med3_i32 v63, v63, %[ylo], %[yhi]\n\t"
         "v_mad_i32_i24 v62, v62, %[p4], %[o4]\n\t"
         "v_mad_i32_i24 v63, v63, %[p4], %[o4]\n\t"
-        "v_lshl_add_u32 %[a0], %[a0], 2, v62\n\t"
-        "v_lshl_add_u32 %[a1], %[a1], 2, v63"
+        "v_lshl_add_u32 %[a0], %[a0], %[sh], v62\n\t"
+        "v_lshl_add_u32 %[a1], %[a1], %[sh], v63"
         : [fi] "+v"(fi), [a0] "=&v"(addr0), [a1] "=&v"(addr1)
         : [sx] "v"(stepx), [sy] "v"(stepy), [bx] "v"(basex), [by] "v"(basey), [hx] "v"(shiftx), [hy] "v"(shifty),
-          [xlo] "v"(xlo), [xhi] "v"(xhi), [ylo] "v"(ylo), [yhi] "v"(yhi), [p4] "s"(pitch4), [o4] "v"(off4)
+          [xlo] "v"(xlo), [xhi] "v"(xhi), [ylo] "v"(ylo), [yhi] "v"(yhi), [p4] "s"(pitch4), [o4] "v"(off4),
+          [sh] "i"(SHIFT)
         : "v60", "v61", "v62", "v63");
 }
 __device__ __forceinline__ float lds_abs(int byte_addr) { return *(lds_cptr)(uintptr_t)(unsigned)byte_addr; }
+// NS interleaved slices per LDS pixel: one ds_read_b32 / _b64 / _b128 per tap
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NS> struct PixVec { typedef float type; };
+template <> struct PixVec<2> { typedef f32x2 type; };
+template <> struct PixVec<4> { typedef f32x4 type; };
+template <int NS> __device__ __forceinline__ typename PixVec<NS>::type lds_abs_vec(int byte_addr)
+{
+    typedef const __attribute__((address_space(3))) typename PixVec<NS>::type *vptr;
+    return *(vptr)(uintptr_t)(unsigned)byte_addr;
+}
 
 // max over the 64 lanes of a wave of a non-negative int, as an SGPR value (DPP row shifts + row broadcasts)
 __device__ __forceinline__ int wave_max_nonneg(int v)
@@ -248,19 +260,23 @@ __host__ __device__ __forceinline__ void tile_rect(const RotGeom &g, const TileS
     w = min(ts.tw, g.W - x0);
 }
 // first ray slot's bin: the orthonormal transform maps canvas (x, y) to bin t0*(x - t2) + t3*(y - t5)
-__device__ __forceinline__ int tile_first_bin(const float *__restrict__ t, float cx, float cy, float radius)
+__device__ __forceinline__ int tile_first_bin(const float *t, float cx, float cy, float radius)
 {
     const float jc = t[0] * (cx - t[2]) + t[3] * (cy - t[5]);
     return (int)floorf(jc - radius);
 }
 
-template <int INTERP, bool TIE_FIX, bool TILED>
+template <int INTERP, bool TIE_FIX, bool TILED, int NS = 1>
 __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                const float *__restrict__ T8, int rays_per_blk,
                                                                float *__restrict__ sino)
 {
     constexpr int BORDER = (INTERP == CTPVAE_NEAREST) ? 1 : 2;
     constexpr bool PAIRS = (INTERP == CTPVAE_NEAREST) && !TIE_FIX;   // the asm pair path
+    // NS > 1 (tiled launches): NS slices interleaved per LDS pixel share every address computation
+    static_assert(NS == 1 || (TILED && PAIRS && (NS == 2 || NS == 4)), "interleaved slices: tiled NEAREST only");
+    constexpr int SHIFT = NS == 1 ? 2 : (NS == 2 ? 3 : 4);
+    typedef typename PixVec<NS>::type vec_t;
     extern __shared__ float lds[];
     CTPVAE_STAMP(0);
     // g: the geometry this workgroup works in -- the slice itself, or one tile of it as a slice of its own
@@ -270,9 +286,9 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     float tile_cx = 0.0f, tile_cy = 0.0f;
     if (TILED) {
         const int nt = ts.ntx * ts.nty, v = blockIdx.y;
-        s = v / nt;
+        s = (v / nt) * NS;   // first slice of this workgroup's group of NS
         int y0, x0;
-        tile_rect(gfull, ts, v - s * nt, y0, x0, g.H, g.W);
+        tile_rect(gfull, ts, v % nt, y0, x0, g.H, g.W);
         g.py = gfull.py + y0;
         g.px = gfull.px + x0;
         im = img + ((size_t)s * gfull.H + y0) * gfull.W + x0;
@@ -300,17 +316,25 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     }
 
 #ifndef CTPVAE_TUNE_NOFILL
-    // Stage the slice (16-byte loads, conflict-free ds_write_b32: lds_stage.h), then its zero border.
+    // Stage the slice (16-byte loads, conflict-free ds_write_b32: lds_stage.h), then its zero border.  With NS > 1 the
+    // LDS pixel (r, c) is NS consecutive floats, one per slice of the group (a short last group repeats its last slice).
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-        stage_rows(lds + BORDER * pitch + BORDER, im, g.H, g.W, gfull.W, pitch, false, lane, wave, nwaves);
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            const int sn = min(s + n, gfull.S - 1) - s;
+            stage_rows(lds + (BORDER * pitch + BORDER) * NS + n, im + (size_t)sn * gfull.H * gfull.W, g.H, g.W, gfull.W, pitch,
+                       false, lane, wave, nwaves, NS);
+        }
         for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
             const int r = p / pitch, c = p - r * pitch;
-            lds[(r < BORDER ? r : hb - 2 * BORDER + r) * pitch + c] = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) lds[((r < BORDER ? r : hb - 2 * BORDER + r) * pitch + c) * NS + n] = 0.0f;
         }
         for (int p = threadIdx.x; p < g.H * (pitch - g.W); p += blockDim.x) {
             const int r = p / (pitch - g.W), c = p - r * (pitch - g.W);
-            lds[(r + BORDER) * pitch + (c < BORDER ? c : g.W + c)] = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) lds[((r + BORDER) * pitch + (c < BORDER ? c : g.W + c)) * NS + n] = 0.0f;
         }
     }
 #endif
@@ -324,8 +348,31 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     const int ylo = g.py - BORDER, yhi = g.py + g.H + BORDER - 1 - (INTERP == CTPVAE_BILINEAR ? 1 : 0);
     // clamp bounds pinned in VGPRs (v_med3_i32 takes them as is), byte pitch, absolute byte offset of canvas (0, 0)
     const int xlo_v = pin_vgpr(xlo), xhi_v = pin_vgpr(xhi), ylo_v = pin_vgpr(ylo), yhi_v = pin_vgpr(yhi);
-    const int pitch4 = pitch * 4;
-    const int off4_v = pin_vgpr(-(ylo * pitch + xlo) * 4 + (int)(uintptr_t)(lds_cptr)lds);
+    const int pitch4 = pitch * 4 * NS;
+    const int off4_v = pin_vgpr(-(ylo * pitch + xlo) * 4 * NS + (int)(uintptr_t)(lds_cptr)lds);
+
+    // Tiled launches keep, behind the tile: a copy of T8 (float offset rays_per_blk; 0: none, for very many angles) and
+    // then the ascending list of the angles of this workgroup's bank class ([0] = their count) and a task counter.
+    const int t8_lds_off = TILED ? rays_per_blk : 0;
+    int *cls_list = reinterpret_cast<int *>(lds + t8_lds_off + 8 * g.A);
+    if (TILED && t8_lds_off > 0) {
+        for (int p = threadIdx.x; p < 8 * g.A; p += blockDim.x) lds[t8_lds_off + p] = T8[p];
+        if (threadIdx.x < 64) {   // wave 0: classes of 64 angles at a time from one vector load + ballot
+            const int lane = threadIdx.x, cls = blockIdx.x & 1;
+            int n = 0;
+            for (int a0 = 0; a0 < g.A; a0 += 64) {
+                const float *tm = T8 + 8 * min(a0 + lane, g.A - 1);
+                const bool in_cls = a0 + lane < g.A && ((((tm[0] >= 0.0f) == (tm[3] >= 0.0f)) ? 1 : 0) == cls);
+                const unsigned long long m = __ballot(in_cls);
+                if (in_cls) cls_list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
+                n += __popcll(m);
+            }
+            if (lane == 0) {
+                cls_list[0] = n;
+                cls_list[1 + g.A] = 0;   // the task counter
+            }
+        }
+    }
 
     // per-ray setup: transform row, conservative row range through the core, wave-uniform trip count
     struct Ray {
@@ -333,20 +380,32 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
         int ray, ilo, kmax;
         bool live;
     };
-    auto setup = [&](int first_ray) -> Ray {
+    auto setup = [&](int first_ray, int tiled_a = 0) -> Ray {
         Ray q;
         q.ray = first_ray;
         q.live = q.ray < ray_end;
         const int rr = q.live ? q.ray : ray_end - 1;
-        const int a = rr / nb;
+        const int a = TILED ? tiled_a : rr / nb;
         int j = rr - a * nb;
-        const float *t = T8 + 8 * a;
+        // Tiled: the transform rows were copied behind the tile and are read with ds_read (an explicit LDS address:
+        // a global / flat load here would make every task wait, through vmcnt, for the previous task's stores).
+        float t6[6];
+        if (TILED && t8_lds_off > 0) {
+            const int ad = (t8_lds_off + 8 * a) * 4 + (int)(uintptr_t)(lds_cptr)lds;
+            const f32x4 u = lds_abs_vec<4>(ad);
+            const f32x2 w = lds_abs_vec<2>(ad + 16);
+            t6[0] = u.x; t6[1] = u.y; t6[2] = u.z; t6[3] = u.w; t6[4] = w.x; t6[5] = w.y;
+        } else {
+            const float *t = T8 + 8 * a;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) t6[e] = t[e];
+        }
         if (TILED) {
-            j += tile_first_bin(t, tile_cx, tile_cy, ts.radius);
+            j += tile_first_bin(t6, tile_cx, tile_cy, ts.radius);
             q.live = q.live && (unsigned)j < (unsigned)g.PW;   // slots off the detector are never read back
         }
-        const float t0 = t[0], t3 = t[3];
-        q.t1 = t[1]; q.t2 = t[2]; q.t4 = t[4]; q.t5 = t[5];
+        const float t0 = t6[0], t3 = t6[3];
+        q.t1 = t6[1]; q.t2 = t6[2]; q.t4 = t6[4]; q.t5 = t6[5];
         q.xj = t0 * (float)j;
         q.yj = t3 * (float)j;
         // margins of >= 1.5 px around the live zone; fp error of this estimate is far below that
@@ -374,12 +433,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
         const bool live = q.live;
         CTPVAE_STAMP(3);
 
-        float acc = 0.0f;
+        vec_t acc = 0.0f;
         int k = 0;
 #ifdef CTPVAE_TUNE_NOLOOP
         k = kmax;
 #endif
-        if (PAIRS) {
+        if constexpr (PAIRS) {
             // ---- NEAREST: two rows per asm block, groups of U gathers, two groups in flight --------------------
             constexpr int U = 6;
             const f32x2 basex = {xj, xj}, basey = {yj, yj}, stepx = {t1, t1}, stepy = {t4, t4};
@@ -387,24 +446,24 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
             f32x2 fi = {(float)ilo, (float)ilo + 1.0f};
             const int nblk = (kmax - k) / U;
             if (nblk > 0) {
-                float bx[U], by[U];   // ping-pong groups: X holds even blocks, Y odd blocks
-                auto issue = [&](float (&buf)[U]) {
+                vec_t bx[U], by[U];   // ping-pong groups: X holds even blocks, Y odd blocks
+                auto issue = [&](vec_t (&buf)[U]) {
 #pragma unroll
                     for (int u = 0; u < U; u += 2) {
                         int a0, a1;
-                        nearest_pair_addr(fi, basex, basey, stepx, stepy, shiftx, shifty, xlo_v, xhi_v, ylo_v, yhi_v,
+                        nearest_pair_addr<SHIFT>(fi, basex, basey, stepx, stepy, shiftx, shifty, xlo_v, xhi_v, ylo_v, yhi_v,
                                           pitch4, off4_v, a0, a1);
 #ifdef CTPVAE_TUNE_NOLDS
                         buf[u] = __int_as_float(a0 & 0x3fffff);
                         buf[u + 1] = __int_as_float(a1 & 0x3fffff);
 #else
-                        buf[u] = lds_abs(a0);
-                        buf[u + 1] = lds_abs(a1);
+                        buf[u] = lds_abs_vec<NS>(a0);
+                        buf[u + 1] = lds_abs_vec<NS>(a1);
 #endif
                     }
                     __builtin_amdgcn_sched_barrier(0);   // keep the adds of the older group behind these gathers
                 };
-                auto consume = [&](float (&buf)[U], bool newer_in_flight) {
+                auto consume = [&](vec_t (&buf)[U], bool newer_in_flight) {
                     (void)newer_in_flight;   // hipcc counts the in-order LDS returns itself: lgkmcnt(2U-1 .. U)
 #pragma unroll
                     for (int u = 0; u < U; ++u) acc += buf[u];
@@ -432,8 +491,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
             for (; k < kmax; ++k) {
                 const float x = (xj + t1 * fr) + t2, y = (yj + t4 * fr) + t5;
                 fr += 1.0f;
-                const int idx = __mul24(med3i(cvt_rpi(y), ylo_v, yhi_v), pitch4) + (med3i(cvt_rpi(x), xlo_v, xhi_v) << 2);
-                acc += lds_abs(idx + off4_v);
+                const int idx = __mul24(med3i(cvt_rpi(y), ylo_v, yhi_v), pitch4) + (med3i(cvt_rpi(x), xlo_v, xhi_v) << SHIFT);
+                acc += lds_abs_vec<NS>(idx + off4_v);
             }
         } else {
             // ---- BILINEAR, and NEAREST on an unpadded canvas (TIE_FIX): one row at a time, U in flight ------------
@@ -471,23 +530,62 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 #ifdef CTPVAE_TUNE_STAMPS
         if ((threadIdx.x & 63) == 0) g_stamps[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 6] = kmax;
 #endif
-        if (live) sino[(size_t)blockIdx.y * nrays + ray] = acc;
+        if constexpr (NS == 1) {
+            if (live) sino[(size_t)blockIdx.y * nrays + ray] = acc;
+        } else if (live) {
+            // partial sums of slice s + n, tile t: workspace row (s + n) * nt + t
+            const int nt = ts.ntx * ts.nty, t = blockIdx.y % nt;
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+                if (s + n < gfull.S) sino[((size_t)(s + n) * nt + t) * nrays + ray] = acc[n];
+        }
     };
 
     if (TILED) {
-        // (angle, 64-slot block) tasks of this workgroup's bank class, dealt to its waves round-robin
-        __syncthreads();
+        // (angle, 64-slot block) tasks of this workgroup's bank class: task m = (m / nbk)-th angle of the class list,
+        // block m % nbk; group gi of G takes m = gi, gi + G, ..., dealt to its waves round-robin.
         const int cls = blockIdx.x & 1, gi = blockIdx.x >> 1, G = gridDim.x >> 1;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-        const int nbk = nb >> 6, T = g.A * nbk;
-        int matched = 0;
-        for (int t = gi; t < T; t += G) {
-            const int a = t / nbk, blk = t - a * nbk;
-            const float *tm = T8 + 8 * a;
-            if ((((tm[0] >= 0.0f) == (tm[3] >= 0.0f)) ? 1 : 0) != cls) continue;
-            const bool mine = (matched % nwaves) == wave;
-            ++matched;
-            if (mine) walk(setup(a * nb + blk * 64 + lane));
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+        const int nbk = nb >> 6;
+        CTPVAE_STAMP(1);
+        __syncthreads();
+        CTPVAE_STAMP(2);
+        auto task = [&](int a, int blk) {
+            CTPVAE_STAMP(7);
+            // A wave takes two MIRRORED 32-slot runs of the angle's slot range: a tile's chord lengths are symmetric
+            // about its centre's bin, so both runs have the same trip count (the outermost waves walk short rays only,
+            // instead of every wave carrying a piece of the longest ones).
+            const int slot = lane < 32 ? blk * 32 + lane : nb - 32 * (blk + 1) + (lane - 32);
+            walk(setup(a * nb + slot, a));
+        };
+        if (t8_lds_off > 0) {
+            // Tasks are handed out dynamically (an LDS counter), the long ones first: m counts blocks from the
+            // innermost (longest rays) outwards, angles within a block; group gi of G takes every G-th task.
+            const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
+            int *next_task = cls_list + 1 + g.A;
+            const int ntask = ncls * nbk;
+            for (;;) {
+                int m = 0;
+                if (lane == 0) m = atomicAdd(next_task, 1);
+                m = __builtin_amdgcn_readfirstlane(m) * G + gi;
+                if (m >= ntask) break;
+                const int bi = m / ncls, ai = m - bi * ncls;
+                task(__builtin_amdgcn_readfirstlane(cls_list[1 + ai]), nbk - 1 - bi);
+            }
+        } else {   // no room for the list: scan the angles (a scalar load per angle)
+            int mg = 0, mw = 0;
+            for (int a = 0; a < g.A; ++a) {
+                const float *tm = T8 + 8 * a;
+                if ((((tm[0] >= 0.0f) == (tm[3] >= 0.0f)) ? 1 : 0) != cls) continue;
+                for (int blk = 0; blk < nbk; ++blk) {
+                    const bool mine = mg == gi && mw == wave;
+                    if (++mg == G) {
+                        mg = 0;
+                        if (++mw == nwaves) mw = 0;
+                    }
+                    if (mine) task(a, blk);
+                }
+            }
         }
     } else {
         Ray q = setup(ray0 + threadIdx.x);   // runs while the staging loads are in flight
@@ -501,28 +599,52 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     CTPVAE_STAMP(5);
 }
 
-// sino[s][a][j] = sum over tiles, ascending, of the partial sums of the tiles whose slot range holds bin j
-__global__ __launch_bounds__(256) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
-                                                                 const float *__restrict__ T8, float *__restrict__ sino)
+// sino[s][a][j] = sum over tiles, ascending, of the partial sums of the tiles whose slot range holds bin j.
+// One wave = 64 consecutive bins of one (slice, angle): it first lists, in ascending order, the tiles whose slot range
+// touches its bins (about a quarter of them), then adds their partial sums.
+constexpr int kMaxTiles = 1024;
+__global__ __launch_bounds__(64) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
+                                                                const float *__restrict__ T8, float *__restrict__ sino)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y, s = blockIdx.z;
-    if (j >= g.PW) return;
+    __shared__ int list_tile[kMaxTiles], list_first[kMaxTiles];
+    const int lane = threadIdx.x, j0 = blockIdx.x * 64, j = j0 + lane, a = blockIdx.y, s = blockIdx.z;
     const float *t = T8 + 8 * a;
     const int nt = ts.ntx * ts.nty;
+    int n = 0;
+    for (int base = 0; base < nt; base += 64) {
+        const int tile = base + lane;
+        bool rel = false;
+        int fb = 0;
+        if (tile < nt) {
+            int y0, x0, h, w;
+            tile_rect(g, ts, tile, y0, x0, h, w);
+            const float cx = (float)(g.px + x0) + 0.5f * (float)(w - 1), cy = (float)(g.py + y0) + 0.5f * (float)(h - 1);
+            fb = tile_first_bin(t, cx, cy, ts.radius);   // the same expression as the tile kernel's
+            rel = fb <= j0 + 63 && fb + ts.nb > j0;
+        }
+        const unsigned long long m = __ballot(rel);
+        if (rel) {
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            list_tile[pos] = tile;
+            list_first[pos] = fb;
+        }
+        n += __popcll(m);
+    }
+    __syncthreads();
+    if (j >= g.PW) return;
+    const float *pa = partial + ((size_t)s * nt * g.A + a) * ts.nb;   // tile stride: A * nb
+    const size_t tstride = (size_t)g.A * ts.nb;
     float acc = 0.0f;
-    constexpr int U = 8;   // loads in flight; unconditional (index clamped to a valid cell), the select comes after
-    for (int t0 = 0; t0 < nt; t0 += U) {
+    constexpr int U = 8;   // loads in flight; unconditional (slot clamped to a valid cell), the select comes after
+    for (int i0 = 0; i0 < n; i0 += U) {
         float v[U];
         bool ok[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int tile = min(t0 + u, nt - 1);
-            int y0, x0, h, w;
-            tile_rect(g, ts, tile, y0, x0, h, w);
-            const float cx = (float)(g.px + x0) + 0.5f * (float)(w - 1), cy = (float)(g.py + y0) + 0.5f * (float)(h - 1);
-            const int slot = j - tile_first_bin(t, cx, cy, ts.radius);
-            ok[u] = t0 + u < nt && (unsigned)slot < (unsigned)ts.nb;
-            v[u] = partial[(((size_t)s * nt + tile) * g.A + a) * ts.nb + (ok[u] ? slot : 0)];
+            const int i = min(i0 + u, n - 1);
+            const int slot = j - list_first[i];
+            ok[u] = i0 + u < n && (unsigned)slot < (unsigned)ts.nb;
+            v[u] = pa[list_tile[i] * tstride + (ok[u] ? slot : 0)];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) acc += ok[u] ? v[u] : 0.0f;   // + 0.0f leaves the sum unchanged
@@ -901,8 +1023,20 @@ static int pick_angles_per_block(int S, int A, int PW)
     return apb;
 }
 
-// Tiling of a slice that does not fit LDS: 128 x 128 tiles (84 KiB with the zero border at the +-1 (mod 32) pitch: one
-// 16-wave workgroup per CU, which already saturates the VALU).  ntx == 0: no tiling needed / possible.
+// Tiling of a slice that does not fit LDS: 64 x 96 tiles, whatever the batch (so a slice's sinogram does not depend
+// on what it is batched with).  NS slices of the batch share a workgroup, interleaved per LDS pixel, so that one
+// address computation (the kernel is VALU-bound on it) serves NS taps: 4 slices fill LDS (149 KiB with the zero
+// border at the +-1 (mod 32) pitch, one 16-wave workgroup per CU), 2 or 1 leave room for 2 workgroups per CU.
+// ntx == 0: no tiling needed / possible.
+static int pick_tile_ns(int S, bool tie_fix)
+{
+    int ns = S >= 3 ? 4 : (S == 2 ? 2 : 1);
+    if (const char *e = getenv("CTPVAE_TUNE_NS")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) ns = v;
+    }
+    return tie_fix ? 1 : ns;   // the negative-tie fix of an unpadded canvas is not in the interleaved (asm) path
+}
 static TileSpec pick_tiles(int H, int W, int interp)
 {
     TileSpec ts{};
@@ -910,14 +1044,19 @@ static TileSpec pick_tiles(int H, int W, int interp)
     const int wb = W + 2;
     const size_t whole = (size_t)(H + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
     if (whole <= (size_t)kMaxLdsBytes) return ts;
-    ts.tw = std::min(W, 128);
-    ts.th = std::min(H, 128);
+    ts.tw = std::min(W, 64);
+    ts.th = std::min(H, 96);
     ts.ntx = ceil_div(W, ts.tw);
     ts.nty = ceil_div(H, ts.th);
     const float diag = sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th));
     ts.radius = 0.5f * diag + 3.0f;
     ts.nb = ((int)ceilf(2.0f * ts.radius) + 2 + 63) / 64 * 64;
     return ts;
+}
+static size_t tile_lds_bytes(const TileSpec &ts, int ns)
+{
+    const int wb = ts.tw + 2;
+    return (size_t)(ts.th + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float) * ns;
 }
 
 }  // namespace ctpvae
@@ -1002,34 +1141,45 @@ int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int P
     CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev, "rotate_fwd_tiled: null pointer");
     if (int rc = check_geom("rotate_fwd_tiled", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
     const RotGeom g{S, H, W, PH, PW, py, px, A};
+    const bool tie_fix = (px == 0 || py == 0);
+    const int ns = pick_tile_ns(S, tie_fix);
     const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
     CTPVAE_REQUIRE(ts.ntx > 0, "rotate_fwd_tiled: a %dx%d slice fits LDS whole; call ctpvae_rotate_fwd_f32", H, W);
-    const int nt = ts.ntx * ts.nty;
-    CTPVAE_REQUIRE((long long)S * nt <= 65535, "rotate_fwd_tiled: at most 65535 tiles per call (got %lld)", (long long)S * nt);
-    const int wb = ts.tw + 2;
-    const size_t lds_bytes = (size_t)(ts.th + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
+    const int nt = ts.ntx * ts.nty, groups = ceil_div(S, ns);
+    CTPVAE_REQUIRE((long long)groups * nt <= 65535, "rotate_fwd_tiled: at most 65535 tiles per call (got %lld)", (long long)groups * nt);
+    CTPVAE_REQUIRE(nt <= kMaxTiles, "rotate_fwd_tiled: at most %d tiles per slice (got %d)", kMaxTiles, nt);
+    const size_t lds_bytes = tile_lds_bytes(ts, ns);
+    // a copy of the transform rows behind the tile, when it fits
+    const size_t t8_need = (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int);   // + class list + task counter
+    const size_t t8_bytes = lds_bytes + t8_need <= (size_t)kMaxLdsBytes ? t8_need : 0;
     // about one 16-wave workgroup per CU: groups per bank class so that tiles x 2 classes x groups covers the chip
     const int tasks = A * (ts.nb / 64);
-    int G = std::max(1, (int)(256.0 / (2.0 * S * nt) + 0.5));
+    int G = std::max(1, (int)(256.0 / (2.0 * groups * nt) + 0.5));
     G = std::min(G, std::max(1, tasks / 2));
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
-    const bool tie_fix = (px == 0 || py == 0);
     auto launch = [&](auto kernel) -> int {
         static bool attr_set = false;  // one flag per instantiation
         if (!attr_set) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kernel, dim3(2 * G, S * nt), dim3(64 * waves), lds_bytes, (hipStream_t)stream, img_dev, g, ts,
-                           T8_dev, 0, (float *)workspace_dev);
+        hipLaunchKernelGGL(kernel, dim3(2 * G, groups * nt), dim3(64 * waves), lds_bytes + t8_bytes, (hipStream_t)stream,
+                           img_dev, g, ts, T8_dev, t8_bytes ? (int)(lds_bytes / sizeof(float)) : 0, (float *)workspace_dev);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel (tiled)");
         return CTPVAE_OK;
     };
-    if (int rc = tie_fix ? launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, true>)
-                         : launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true>))
-        return rc;
-    hipLaunchKernelGGL(rotate_tile_reduce_kernel, dim3(ceil_div(PW, 256), A, S), dim3(256), 0, (hipStream_t)stream,
+    int rc;
+    if (tie_fix)
+        rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, true, 1>);
+    else if (ns == 4)
+        rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 4>);
+    else if (ns == 2)
+        rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 2>);
+    else
+        rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 1>);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rotate_tile_reduce_kernel, dim3(ceil_div(PW, 64), A, S), dim3(64), 0, (hipStream_t)stream,
                        (const float *)workspace_dev, g, ts, T8_dev, sino_dev);
     CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
     return CTPVAE_OK;

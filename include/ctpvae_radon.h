@@ -75,7 +75,7 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
                           ctpvae_stream_t stream);
 
 /* ---- a2 for slices larger than LDS (512 x 512): tiled forward, NEAREST -----------------------
- * The slice is cut into 128 x 128 tiles; every tile is staged once and serves all angles, the tiles' partial sums
+ * The slice is cut into tiles 64 wide x 96 tall; every tile is staged once and serves all angles, the tiles' partial sums
  * (workspace) are then added in ascending tile order (row-major over the slice):
  *     sino[s][a][j] = ((0 + p_0) + p_1) + ...,  p_t = sum over canvas rows i, ascending, of the taps inside tile t.
  * Tap indices are exactly those of ctpvae_rotate_fwd_f32; only the association of the fp32 sum differs.

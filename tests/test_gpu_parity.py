@@ -274,7 +274,7 @@ def test_inputs_in_other_forms(oracle):
 
 
 def test_large_image_is_tiled(oracle):
-    """512x512 (BASELINE config 5) does not fit LDS: the forward cuts the slice into 128x128 tiles, every tile staged
+    """512x512 (BASELINE config 5) does not fit LDS: the forward cuts the slice into 96x64 tiles, every tile staged
     once for all angles.  Same taps as the whole-slice kernels; the sum is associated tile by tile, which the oracle
     restates (rotate_fwd_tiled) -- bit-exact against that, within REL of the row-sequential sum, and bit-exact against
     the row-sequential oracle when tiling is switched off (generic kernel)."""
@@ -287,9 +287,11 @@ def test_large_image_is_tiled(oracle):
     geom = oracle.Geometry(512, 512, True)
     x = torch.from_numpy(img).to(d)
     got = to_np(plan.forward(x))
-    np.testing.assert_array_equal(got[[0, 2]], oracle.rotate_fwd_tiled(img[[0, 2]], geom, to_np(plan.T8), (128, 128)))
+    np.testing.assert_array_equal(got[[0, 2]], oracle.rotate_fwd_tiled(img[[0, 2]], geom, to_np(plan.T8), (96, 64)))
     seq = oracle.rotate_fwd(img[:1], geom, to_np(plan.T8), 0)
     assert rel_err(got[:1], seq) <= REL
+    # a slice's sinogram does not depend on its batch (1, 2 and 3 slices take 1, 2 and 4 slices per workgroup)
+    assert torch.equal(plan.forward(x[1:2])[0], plan.forward(x)[1]) and torch.equal(plan.forward(x[1:3])[0], plan.forward(x)[1])
     untiled = RotatePlan(theta, 512, 512, True, d, use_plan=False)
     assert not untiled.tiled
     np.testing.assert_array_equal(to_np(untiled.forward(x[:1])), seq)
@@ -300,7 +302,7 @@ def test_large_image_is_tiled(oracle):
 
 @pytest.mark.parametrize("shape,pad,A,S", [((300, 200), True, 7, 2), ((129, 385), False, 5, 1), ((256, 256), True, 33, 4)])
 def test_tiled_forward_ragged(oracle, shape, pad, A, S):
-    """Edge tiles smaller than 128, unpadded canvases (negative-tie rounding at the canvas edge), odd angle counts."""
+    """Edge tiles smaller than 96x64, unpadded canvases (negative-tie rounding at the canvas edge), odd angle counts."""
     d = dev()
     rng = np.random.default_rng(A)
     theta = rng.uniform(-1.0, 4.0, A)
@@ -309,7 +311,7 @@ def test_tiled_forward_ragged(oracle, shape, pad, A, S):
     assert plan.tiled
     geom = oracle.Geometry(shape[0], shape[1], pad)
     np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
-                                  oracle.rotate_fwd_tiled(img, geom, to_np(plan.T8), (128, 128)))
+                                  oracle.rotate_fwd_tiled(img, geom, to_np(plan.T8), (96, 64)))
 
 
 def test_siddon_against_oracle_and_golden(oracle, golden_dir):

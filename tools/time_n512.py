@@ -1,6 +1,8 @@
 """Developer timing of the 512x512 x 90-angle projector pair (BASELINE config 5) -- not part of the product."""
 import os, sys, time, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from ct_pvae_amd import _lib
+if os.environ.get('CTPVAE_VARIANT_LIB'): _lib.LIB_PATH = os.environ['CTPVAE_VARIANT_LIB']
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 def timeit(f, n=20):
@@ -18,3 +20,10 @@ if len(sys.argv) > 2:
     for G in (1, 2, 3, 4, 6, 8):
         os.environ["CTPVAE_TUNE_G"] = str(G)
         print(f"  G={G}: fwd %.0f us" % timeit(lambda: plan.forward(x, out=out)))
+if len(sys.argv) > 3:
+    os.environ.pop("CTPVAE_TUNE_G", None)
+    for ns in (1, 2, 4):
+        os.environ["CTPVAE_TUNE_NS"] = str(ns)
+        for G in (1, 2):
+            os.environ["CTPVAE_TUNE_G"] = str(G)
+            print(f"  NS={ns} G={G}: fwd %.0f us" % timeit(lambda: plan.forward(x, out=out)))

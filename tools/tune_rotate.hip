@@ -26,7 +26,7 @@ __global__ void empty_kernel() {}
 
 int main(int argc, char **argv)
 {
-    const int S = argc > 1 ? atoi(argv[1]) : 50, A = argc > 2 ? atoi(argv[2]) : 20, N = 128;
+    const int S = argc > 1 ? atoi(argv[1]) : 50, A = argc > 2 ? atoi(argv[2]) : 20, N = argc > 3 && atoi(argv[3]) > 0 ? atoi(argv[3]) : 128;
     const int P = ctpvae_num_proj_pix(N, N), pad = (P - N) / 2;
     std::vector<float> theta(A), img((size_t)S * N * N), g((size_t)S * A * P);
     for (int a = 0; a < A; ++a) theta[a] = (float)(M_PI * (a * (180 / A)) / 180.0);
@@ -43,7 +43,36 @@ int main(int argc, char **argv)
     CK(hipDeviceSynchronize());
 
     printf("S=%d A=%d N=%d P=%d\n", S, A, N, P);
-    if (argc > 3) {   // counter mode: a few launches of the product kernels only
+    if (N > 256) {   // slices larger than LDS: the tiled forward and the segment backward
+        const long long wsb = ctpvae_rotate_fwd_tiled_workspace_bytes(S, N, N, P, P, A, 0);
+        void *ws; CK(hipMalloc(&ws, wsb));
+        printf("tiled fwd: %.2f us (workspace %.1f MB)\n", time_us([&] { if (ctpvae_rotate_fwd_tiled_f32(d_img, S, N, N, P, P, pad, pad, d_T, A, ws, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); } }, 50), wsb / 1e6);
+        printf("segment bwd: %.2f us\n", time_us([&] { ctpvae_rotate_bwd_f32(d_g, S, A, P, P, d_Ti, 0, 0, N, N, pad, pad, d_gimg, nullptr); }, 50));
+#ifdef CTPVAE_TUNE_STAMPS
+        {
+            CK(hipDeviceSynchronize());
+            ctpvae_rotate_fwd_tiled_f32(d_img, S, N, N, P, P, pad, pad, d_T, A, ws, d_sino, nullptr);
+            CK(hipDeviceSynchronize());
+            const int nw = getenv("CTPVAE_TUNE_NW") ? atoi(getenv("CTPVAE_TUNE_NW")) : 192 * 16;
+            std::vector<long long> st(8 * nw);
+            CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(ctpvae::g_stamps), st.size() * 8));
+            long long t0min = st[0], tend = 0;
+            for (int w = 0; w < nw; ++w) { t0min = std::min(t0min, st[8 * w]); tend = std::max(tend, st[8 * w + 5]); }
+            double seg[3] = {0, 0, 0}, start = 0, km = 0, endsk = 0, lastwalk = 0;
+            for (int w = 0; w < nw; ++w) lastwalk += (double)(st[8 * w + 4] - st[8 * w + 3]);
+            double lastsetup = 0; for (int w = 0; w < nw; ++w) lastsetup += (double)(st[8 * w + 3] - st[8 * w + 7]);
+            printf("last task of each wave: setup %.0f cycles, walk %.0f cycles, end-of-walk -> wave end %.0f\n", lastsetup / nw, lastwalk / nw, [&]{ double e = 0; for (int w = 0; w < nw; ++w) e += (double)(st[8 * w + 5] - st[8 * w + 4]); return e / nw; }());
+            for (int w = 0; w < nw; ++w) {
+                seg[0] += (double)(st[8 * w + 1] - st[8 * w]); seg[1] += (double)(st[8 * w + 2] - st[8 * w + 1]); seg[2] += (double)(st[8 * w + 5] - st[8 * w + 2]);
+                start += (double)(st[8 * w] - t0min); km += (double)st[8 * w + 6]; endsk += (double)(tend - st[8 * w + 5]);
+            }
+            printf("tiled stamps over %d waves (cycles): start-skew %.0f | stage-issue %.0f | barrier %.0f | tasks %.0f | idle-after-end %.0f | last kmax %.1f | first-start->last-end %lld\n",
+                   nw, start / nw, seg[0] / nw, seg[1] / nw, seg[2] / nw, endsk / nw, km / nw, tend - t0min);
+        }
+#endif
+        return 0;
+    }
+    if (argc > 4) {   // counter mode: a few launches of the product kernels only
         void *fp, *bp;
         CK(hipMalloc(&fp, ctpvae_rotate_plan_bytes(N, N, P, P, A, 0))); CK(hipMalloc(&bp, ctpvae_rotate_plan_bytes(N, N, P, P, A, 1)));
         ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, fp, bp, nullptr);
@@ -130,7 +159,7 @@ int main(int argc, char **argv)
         return 0;
     }
 #endif
-    auto kern = ctpvae::rotate_fwd_fast_kernel<0, false>;
+    auto kern = ctpvae::rotate_fwd_fast_kernel<0, false, false, 1>;
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int nrays = A * P;
     for (int rpb : {384, 768, 1024, 1856}) {
@@ -138,7 +167,7 @@ int main(int argc, char **argv)
         for (int block : {384, 768, 1024}) {
             if (block > rpb) continue;
             dim3 grid((nrays + rpb - 1) / rpb, S);
-            float t = time_us([&] { hipLaunchKernelGGL(kern, grid, dim3(block), lds, 0, d_img, geo, d_T, rpb, d_sino); }, 100);
+            float t = time_us([&] { hipLaunchKernelGGL(kern, grid, dim3(block), lds, 0, d_img, geo, ctpvae::TileSpec{}, d_T, rpb, d_sino); }, 100);
             printf("fwd rpb=%4d block=%4d grid=%4u x %d : %.2f us\n", rpb, block, grid.x, S, t);
         }
     }
