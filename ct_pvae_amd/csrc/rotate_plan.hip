@@ -39,7 +39,7 @@ struct PlanGeom {
 
 struct FwdLayout {
     int nJB, PWpad, NG, Galloc, pitch, zero;
-    long long off_cls, off_rng, off_idx, bytes;
+    long long off_cls, off_clist, off_rng, off_idx, bytes;
 };
 constexpr int kBwdPitch = 257;   // dwords per staged cotangent row (== 1 mod 32; bins, then zeros up to cell 256)
 constexpr int kBwdChunk = 64;    // angles staged per pass: row offsets (<= 63 * 1028 B) fit ds_read's 16-bit immediate
@@ -72,7 +72,8 @@ static FwdLayout fwd_layout(const PlanGeom &g)
     L.pitch = pitch_mod32_is_1(g.W);
     L.zero = g.H * L.pitch;
     L.off_cls = 0;
-    L.off_rng = ((long long)g.A * 4 + 255) / 256 * 256;
+    L.off_clist = (long long)g.A * 4;                                     // two lists of (count, angles...)
+    L.off_rng = (L.off_clist + 2ll * (g.A + 1) * 4 + 255) / 256 * 256;
     L.off_idx = (L.off_rng + (long long)g.A * L.nJB * 8 + 255) / 256 * 256;
     L.bytes = L.off_idx + (long long)g.A * L.Galloc * L.PWpad * 16;
     return L;
@@ -93,7 +94,7 @@ static BwdLayout bwd_layout(const PlanGeom &g)
 static bool fwd_plan_fits(const PlanGeom &g)
 {
     const FwdLayout L = fwd_layout(g);
-    return L.zero < 65535 && (size_t)(L.zero + 1) * 4 <= (size_t)kMaxLdsBytes;
+    return L.zero < 65535 && (size_t)(L.zero + 1) * 4 + 16 <= (size_t)kMaxLdsBytes;   // image, zero cell, task counter
 }
 static bool bwd_plan_fits(const PlanGeom &g) { return g.PW <= 255; }
 
@@ -242,6 +243,25 @@ __device__ __forceinline__ void gather8(const float *lds, const uint4 q, float (
     v[7] = lds_at(lds, a7);
 }
 
+// clist[c] = (count, the angles of class c in ascending order): the planned kernels' task lists
+__global__ __launch_bounds__(64) void rotate_class_list_kernel(int A, FwdLayout L, char *__restrict__ plan)
+{
+    const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
+    int *clist = reinterpret_cast<int *>(plan + L.off_clist);
+    const int lane = threadIdx.x;
+    for (int c = 0; c < 2; ++c) {
+        int *list = clist + c * (A + 1);
+        int n = 0;
+        for (int a0 = 0; a0 < A; a0 += 64) {
+            const bool in = a0 + lane < A && cls[a0 + lane] == c;
+            const unsigned long long m = __ballot(in);
+            if (in) list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
+            n += __popcll(m);
+        }
+        if (lane == 0) list[0] = n;
+    }
+}
+
 // Forward.  Workgroup = (slice s, class c, group gi): stages the slice once (LDS-DMA, mirrored for class 0), then each
 // wave takes the (angle, bin block) tasks of its class round-robin.  A task streams its index groups four loads deep,
 // gathers the previous group's eight taps while the next indices are in flight, and adds in row order.
@@ -290,6 +310,54 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     const float *im = img + (size_t)s * g.H * g.W;
     CTPVAE_PSTAMP(0);
 
+    // Tasks of this workgroup: (angle of its class, bin block), m = jb * ncls + ai counted from the central bin blocks
+    // (the longest rays) outwards; group gi of G takes m = gi, gi + G, ...  A wave's FIRST task is fixed (its wave
+    // number), so its range and first four index vectors are requested here, before the slice is even staged; later
+    // tasks come from an LDS counter, each one prepared (scalar loads of the range, index loads) while the previous
+    // one is being gathered.
+    const int *clist = reinterpret_cast<const int *>(plan + L.off_clist) + c * (g.A + 1);
+    const int *rng = reinterpret_cast<const int *>(plan + L.off_rng);
+    const uint4 *idx = reinterpret_cast<const uint4 *>(plan + L.off_idx);
+    const int ncls = clist[0];
+    const int ntask = ncls * L.nJB;
+#ifdef CTPVAE_TUNE_NOIDX
+    const size_t st = 0;   // timing only: every group re-reads the first index vector (no index streaming)
+#else
+    const size_t st = (size_t)L.PWpad;
+#endif
+    struct Task {
+        bool valid;
+        int a, j, ng;
+        const uint4 *p;
+        uint4 q0, q1, q2, q3;
+    };
+    auto prepare = [&](int m) -> Task {
+        Task t;
+        t.valid = m < ntask;
+        t.a = t.j = t.ng = 0;
+        t.p = idx;
+        t.q0 = t.q1 = t.q2 = t.q3 = uint4{0, 0, 0, 0};
+        if (t.valid) {   // wave-uniform
+            const int jb = m / ncls, ai = m - jb * ncls;
+            t.a = clist[1 + ai];
+            const int first = rng[(t.a * L.nJB + jb) * 2], last = kRngBias - rng[(t.a * L.nJB + jb) * 2 + 1];
+            const int g0 = last >= first ? first : 0;
+            t.ng = last >= first ? last - first + 1 : 0;   // row groups any of this block's rays needs
+            t.j = lane_to_bin(g.PW, jb, lane);
+            t.p = idx + ((size_t)t.a * L.Galloc + g0) * L.PWpad + jb * 64 + lane;
+            // index vectors of groups 0..3 (loads run up to four groups past ng: the table keeps 8 dead groups)
+            t.q0 = t.p[0];
+            t.q1 = t.p[st];
+            t.q2 = t.p[2 * st];
+            t.q3 = t.p[3 * st];
+            t.p += 4 * st;
+        }
+        return t;
+    };
+    Task cur = prepare(gi + G * wave);
+    int *next_task = reinterpret_cast<int *>(lds + (L.zero + 1) * NS);
+    if (threadIdx.x == 0) *next_task = nwaves;
+
     // Stage the slice(s): 16-byte loads, conflict-free ds_write_b32 (see stage_rows_v4).
     stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves, NS);
     if (NS == 2) stage_rows(lds + 1, im + (has2 ? (size_t)g.H * g.W : 0), g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves, NS);
@@ -298,40 +366,17 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     __syncthreads();
     CTPVAE_PSTAMP(2);
 
-    const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
-    const int *rng = reinterpret_cast<const int *>(plan + L.off_rng);
-    const uint4 *idx = reinterpret_cast<const uint4 *>(plan + L.off_idx);
-    const int T = g.A * L.nJB;
-    int matched = 0;
-    // tasks t = gi, gi + G, ... with (a, jb) = (t / nJB, t % nJB), advanced without dividing
-    const int da = G / L.nJB, djb = G - da * L.nJB;
-    int a = gi / L.nJB, jb = gi - a * L.nJB;
-    for (int t = gi; t < T; t += G, a += da, jb += djb) {
-        if (jb >= L.nJB) {
-            jb -= L.nJB;
-            ++a;
-        }
-        if (cls[a] != c) continue;
-        const bool mine = (matched % nwaves) == wave;
-        ++matched;
-        if (!mine) continue;
+    while (cur.valid) {
+        int m = 0;
+        if (lane == 0) m = atomicAdd(next_task, 1);
+        const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m) * G + gi);
 
-        const int first = rng[(a * L.nJB + jb) * 2], last = kRngBias - rng[(a * L.nJB + jb) * 2 + 1];
-        const int g0 = last >= first ? first : 0;
-        const int ng = last >= first ? last - first + 1 : 0;   // row groups any of this block's rays needs
-        const int j = lane_to_bin(g.PW, jb, lane);
-        const uint4 *p = idx + ((size_t)a * L.Galloc + g0) * L.PWpad + jb * 64 + lane;
-#ifdef CTPVAE_TUNE_NOIDX
-        const size_t st = 0;   // timing only: every group re-reads the first index vector (no index streaming)
-#else
-        const size_t st = (size_t)L.PWpad;
-#endif
+        const int ng = cur.ng;
+        const uint4 *p = cur.p;
         vec_t acc = 0.0f;
         if (ng > 0) {
             // q0..q3: index vectors of groups n..n+3 (loads in flight); va/vb: gathers of group n / n+1 in flight.
-            // Loads and gathers run up to four groups past `ng`: the table keeps 8 dead groups behind the canvas.
-            uint4 q0 = p[0], q1 = p[st], q2 = p[2 * st], q3 = p[3 * st];
-            p += 4 * st;
+            uint4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2, q3 = cur.q3;
             vec_t va[8], vb[8];
             gather8(lds, q0, va);
             q0 = p[0];
@@ -363,14 +408,15 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
                 if (n + 4 >= ng) break;
             }
         }
-        if ((unsigned)j < (unsigned)g.PW) {
+        if ((unsigned)cur.j < (unsigned)g.PW) {
             if constexpr (NS == 1) {
-                sino[((size_t)s * g.A + a) * g.PW + j] = acc;
+                sino[((size_t)s * g.A + cur.a) * g.PW + cur.j] = acc;
             } else {
-                sino[((size_t)s * g.A + a) * g.PW + j] = acc.x;
-                if (has2) sino[((size_t)(s + 1) * g.A + a) * g.PW + j] = acc.y;
+                sino[((size_t)s * g.A + cur.a) * g.PW + cur.j] = acc.x;
+                if (has2) sino[((size_t)(s + 1) * g.A + cur.a) * g.PW + cur.j] = acc.y;
             }
         }
+        cur = nxt;
     }
     CTPVAE_PSTAMP(3);
 }
@@ -520,6 +566,8 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
         hipLaunchKernelGGL(rotate_fwd_plan_kernel, dim3(L.nJB, A, L.Galloc), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L,
                            (char *)fwd_plan_dev);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_plan_kernel");
+        hipLaunchKernelGGL(rotate_class_list_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, L, (char *)fwd_plan_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_class_list_kernel");
     }
     if (bwd_plan_dev) {
         CTPVAE_REQUIRE(Tinv8_dev, "rotate_plan_build: backward plan needs the inverted transforms");
@@ -545,15 +593,15 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
     const int T = A * L.nJB;   // (angle, bin block) tasks per slice
     // Two slices per workgroup (one index stream serves both) when the interleaved pair fits LDS and the launch has
     // enough tasks that pairing still leaves >= ~8 tasks for every CU; otherwise one slice per workgroup.
-    int ns = ((size_t)(L.zero + 1) * 8 <= (size_t)kMaxLdsBytes && (long long)S * T >= 2ll * 256 * 8) ? 2 : 1;
+    int ns = ((size_t)(L.zero + 1) * 8 + 16 <= (size_t)kMaxLdsBytes && (long long)S * T >= 2ll * 256 * 8) ? 2 : 1;
     if (const char *e = getenv("CTPVAE_TUNE_NS")) ns = atoi(e) == 2 ? 2 : 1;
-    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns;
+    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns + 16;   // + the task counter
     const int units = (S + ns - 1) / ns;
     // the tasks of one unit are dealt to G groups per mirror class; about 1.6 workgroups per CU chip-wide when two fit
     // a CU, one otherwise; at most 16 waves each
     const int wgs_per_cu = shmem * 2 <= (size_t)kMaxLdsBytes ? 2 : 1;
     int G = (int)std::max<long long>(1, (long long)(256 * (wgs_per_cu == 2 ? 1.6 : 1.0) / (2.0 * units) + 0.5));
-    G = std::min(G, std::max(1, T / 2));
+    G = std::min(G, std::min(12, std::max(1, T / 2)));   // every group re-stages the slice: beyond ~12 that costs more than it buys (B=5: 8.1 us at 12, 13.9 us at 30)
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, (T + 2 * G - 1) / (2 * G)));
     const int wgs_per_slice = 2 * G;
