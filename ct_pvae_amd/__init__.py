@@ -7,6 +7,7 @@ from .forward_functions import (RotatePlan, num_proj_pix, pad_amounts, pad_phant
                                 project_tf_low_mem)
 from .helper_functions import (calculate_log_prob_M_given_R, create_sinogram, create_sinograms,  # noqa: F401
                                gaussian_poisson_log_prob)
-from .fbp import iradon  # noqa: F401
+from .create_masks import create_all_masks  # noqa: F401
+from .fbp import iradon, iradon_all  # noqa: F401
 
 __version__ = "0.1.0"

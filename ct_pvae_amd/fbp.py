@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from .forward_functions import _stream_ptr
 
-__all__ = ["iradon"]
+__all__ = ["iradon", "iradon_all", "ramp_filter"]
 
 
 def iradon(sinogram, theta, x_size, y_size, filter_1d):
@@ -43,3 +43,42 @@ def iradon(sinogram, theta, x_size, y_size, filter_1d):
                                                   int(x_size), int(y_size), recon.data_ptr(), _stream_ptr()),
                    "fbp_backproject")
     return recon
+
+
+def ramp_filter(P):
+    """skimage.transform.radon_transform._get_fourier_filter(P, 'ramp') squeezed (scikit-image 0.18), even P --
+    the filter the reference's own iradon call sites pass (ctvae/helper_functions.py:507-510, commented alternative)."""
+    n = np.concatenate((np.arange(1, P / 2 + 1, 2, dtype=int), np.arange(P / 2 - 1, 0, -2, dtype=int)))
+    f = np.zeros(P)
+    f[0] = 0.25
+    f[1::2] = -1 / (np.pi * n) ** 2
+    return 2 * np.real(np.fft.fft(f))
+
+
+def iradon_all(all_proj_samples, all_masks, num_proj_pix, theta, algorithms, sqrt_reg, x_size, y_size, save_path=None,
+               train=False, **kwargs):
+    """Initial reconstructions that feed the encoder (ctvae/helper_functions.py:477-529): one channel per entry of
+    `algorithms` from the dose-normalised sparse sinogram, plus the unfiltered back-projection of the mask.
+
+    The reference calls tomopy.recon (CPU) per algorithm; this build has the GPU filtered back-projection only, so
+    every entry of `algorithms` must be "fbp" (ramp filter, the reference's own iradon alternative at :507-510) --
+    gridrec / SIRT / TV are outside the projector path.  Returns [n][x_size][y_size][len(algorithms) + 1] float32 on
+    the sinograms' device and, like the reference, writes / reads ``all_input_encode.npy`` under `save_path`."""
+    import os
+    if not train:
+        arr = np.load(os.path.join(save_path, "all_input_encode.npy"))
+        dev = all_proj_samples.device if isinstance(all_proj_samples, torch.Tensor) else torch.device("cuda", 0)
+        return torch.from_numpy(np.asarray(arr, np.float32)).to(dev)
+    for alg in algorithms:
+        if alg != "fbp":
+            raise NotImplementedError(f"iradon_all: algorithm {alg!r} is not part of this build (GPU 'fbp' only)")
+    P = int(num_proj_pix)
+    mask_expand = all_masks[..., None].expand(-1, -1, P)
+    expand = torch.where(mask_expand > sqrt_reg, all_proj_samples / mask_expand.clamp_min(1e-30), all_proj_samples)
+    chans = [iradon(expand.contiguous(), theta, x_size, y_size, ramp_filter(P)) for _ in algorithms]
+    chans.append(iradon(mask_expand.contiguous(), theta, x_size, y_size, np.ones(P)))   # filter_name='none'
+    out = torch.stack(chans, dim=-1).to(torch.float32)
+    if save_path is not None:
+        os.makedirs(save_path, exist_ok=True)
+        np.save(os.path.join(save_path, "all_input_encode.npy"), out.cpu().numpy())
+    return out

@@ -34,7 +34,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import phantoms, sharding
-from .fbp import iradon
+from .create_masks import create_all_masks
+from .fbp import iradon, iradon_all, ramp_filter  # noqa: F401  (ramp_filter re-exported)
 from .forward_functions import num_proj_pix
 from .helper_functions import calculate_log_prob_M_given_R, create_sinograms
 
@@ -203,15 +204,6 @@ def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_dec
 # ---------------------------------------------------------------------------------------------------------
 # driver
 # ---------------------------------------------------------------------------------------------------------
-def ramp_filter(P):
-    """skimage.transform.radon_transform._get_fourier_filter(P, 'ramp') squeezed (scikit-image 0.18), even P."""
-    n = np.concatenate((np.arange(1, P / 2 + 1, 2, dtype=int), np.arange(P / 2 - 1, 0, -2, dtype=int)))
-    f = np.zeros(P)
-    f[0] = 0.25
-    f[1::2] = -1 / (np.pi * n) ** 2
-    return 2 * np.real(np.fft.fft(f))
-
-
 class AngleStream:
     """Shuffled, repeating stream of 0..A-1 in chunks of `api` (ctvae/helper_functions.py:104-107)."""
 
@@ -258,23 +250,15 @@ class PVAETrainer:
         self.x_size = self.y_size = int(math.floor(self.P / math.sqrt(2) - 2))      # ctvae/main_ct_vae.py:160-161
         imgs = phantoms.foam_batch(a.td, N, seed=0, supersample=2)
         sino = create_sinograms(torch.from_numpy(imgs).to(dev), self.theta_np, pad=True).clamp_min(0)   # [td][A][P]
-        # dose masks, ctvae/create_masks.py:45-63
-        masks = torch.zeros((a.td, a.num_angles), device=dev)
-        rng = np.random.default_rng(0)
-        for k in range(a.td):
-            idx = rng.permutation(a.num_angles)[:a.nsa] if a.random else phantoms.sparse_angle_indices(a.num_angles, a.nsa)
-            masks[k, torch.as_tensor(idx, device=dev)] = 1.0 / a.nsa
-        # sparse noisy measurements, ctvae/create_masks.py:94-95 (the data is simulated at the FINAL pnm)
-        g = torch.Generator(device=dev).manual_seed(0)
-        proj_masked = sino * masks[..., None]
-        self.proj_samples = torch.poisson(proj_masked * a.pnm, generator=g) / a.pnm
+        # dose masks and sparse noisy measurements, ctvae/create_masks.py:45-95 (simulated at the FINAL pnm)
+        masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=None, poisson_noise_multiplier=a.pnm,
+                                                    num_sparse_angles=a.nsa, random=a.random, train=True,
+                                                    truncate_dataset=a.td, device=dev)
         self.masks, self.truth = masks, torch.from_numpy(imgs).to(dev)
-        # initial reconstructions for the encoder, ctvae/helper_functions.py:490-520 with FBP on the GPU
-        m_exp = masks[..., None].expand(-1, -1, self.P)
-        expand = torch.where(m_exp > self.sqrt_reg, self.proj_samples / m_exp.clamp_min(1e-30), self.proj_samples)
-        rec = iradon(expand, self.theta_np, self.x_size, self.y_size, ramp_filter(self.P))
-        rec_mask = iradon(m_exp.contiguous(), self.theta_np, self.x_size, self.y_size, np.ones(self.P))
-        self.input_encode = torch.stack([rec, rec_mask], dim=1).to(torch.float32)          # [td][2][X][Y]
+        # initial reconstructions for the encoder, ctvae/helper_functions.py:477-529 with FBP on the GPU
+        enc_in = iradon_all(self.proj_samples, masks, self.P, self.theta_np, ["fbp"], self.sqrt_reg, self.x_size,
+                            self.y_size, save_path=None, train=True)                  # [td][X][Y][2]
+        self.input_encode = enc_in.permute(0, 3, 1, 2).contiguous()                   # [td][2][X][Y]
         self.theta = torch.from_numpy(self.theta_np.astype(np.float32)).to(dev)
         self.order = np.random.default_rng(11)
 

@@ -87,3 +87,30 @@ def test_data_parallel_ranks_stay_in_lockstep(tmp_path):
     a, b = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(a["flat"], b["flat"])
     assert a["losses"] == b["losses"] and all(math.isfinite(x) for x in a["losses"])
+
+
+@pytest.mark.gpu
+def test_setup_chain_on_the_device(tmp_path):
+    """The steps either side of the projector in the reference's setup (create_all_masks -> iradon_all), on the GPU:
+    files written like the reference's, reloaded bit for bit, encoder input = [n][X][Y][algorithms + mask]."""
+    import numpy as np
+    from ct_pvae_amd import create_all_masks, iradon_all, phantoms
+    from ct_pvae_amd.helper_functions import create_sinograms
+    d = torch.device("cuda", 0)
+    theta = phantoms.dense_theta(180)
+    imgs = torch.from_numpy(phantoms.foam_batch(4, 128, seed=3, supersample=2)).to(d)
+    sino = create_sinograms(imgs, theta, pad=True)
+    masks, samples = create_all_masks(sino, 180, save_path=str(tmp_path), poisson_noise_multiplier=1e3,
+                                      num_sparse_angles=20, train=True, truncate_dataset=4)
+    assert masks.device.type == "cuda" and samples.shape == (4, 180, 184)
+    enc = iradon_all(samples, masks, 184, theta, ["fbp"], float(np.finfo(np.float32).eps), 128, 128,
+                     save_path=str(tmp_path), train=True)
+    assert enc.shape == (4, 128, 128, 2) and enc.dtype == torch.float32 and torch.isfinite(enc).all()
+    # the FBP channel resembles the phantom (sparse, noisy: loose), the mask channel is the same for uniform masks
+    c = np.corrcoef(enc[0, ..., 0].cpu().numpy().ravel(), imgs[0].cpu().numpy().ravel())[0, 1]
+    assert c > 0.6
+    assert torch.allclose(enc[0, ..., 1], enc[3, ..., 1])
+    again = iradon_all(samples, masks, 184, theta, ["fbp"], 1e-7, 128, 128, save_path=str(tmp_path), train=False)
+    assert torch.equal(again, enc)
+    with pytest.raises(NotImplementedError):
+        iradon_all(samples, masks, 184, theta, ["sirt"], 1e-7, 128, 128, train=True)
