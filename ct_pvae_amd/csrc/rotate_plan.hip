@@ -456,14 +456,25 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
 // each group of sixteen angles it loads the PPT index vectors (16 B = 16 taps), gathers and adds in angle order.
 template <int PPT, int MAXT>
 __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
-                                                                 const uint4 *__restrict__ idx, int tiles_y,
+                                                                 const uint4 *__restrict__ idx, int tiles_y, int g_S,
                                                                  float *__restrict__ gimg)
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int tiles = L.nXB * tiles_y;
-    const int s = blockIdx.x / tiles;
-    const int tile = blockIdx.x - s * tiles;
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only): the tiles of one slice are placed on one
+    // XCD so that its cotangent rows are fetched into one L2 -- block = (s / 8) * 8 * tiles + tile * 8 + s % 8.
+    int s, tile;
+    {
+        const int per8 = 8 * tiles, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
+        if ((octet + 1) * 8 <= g_S) {
+            tile = rem >> 3;
+            s = octet * 8 + (rem & 7);
+        } else {   // the last, partial octet is laid out slice-major
+            s = octet * 8 + rem / tiles;
+            tile = rem - (rem / tiles) * tiles;
+        }
+    }
     const int xb = tile % L.nXB, ty = tile / L.nXB;
     const float *gs = gsino + (size_t)s * g.A * g.PW;
     const int xcol = xb * 64 + lane;
@@ -650,7 +661,7 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
             attr_set = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
-                           (const uint4 *)bwd_plan_dev, tiles_y, gimg_dev);
+                           (const uint4 *)bwd_plan_dev, tiles_y, S, gimg_dev);
         return CTPVAE_OK;
     };
     if (int rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<kPpt, 256>) : launch(rotate_bwd_planned_kernel<kPpt, 1024>)) return rc;

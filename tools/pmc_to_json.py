@@ -1,0 +1,58 @@
+"""Developer tool: turn rocprofv3 outputs (sqlite .db, one per pass) into the summaries kept under profiles/.
+
+    python tools/pmc_to_json.py stats  <kernel-trace.db>  > profiles/rNN_kernel_stats.csv
+    python tools/pmc_to_json.py traffic <fetch.db> <write.db> > profiles/rNN_traffic_pmc.json
+
+traffic: FETCH_SIZE and WRITE_SIZE come from separate --pmc passes (TCC slots: 3 + 2 > 4); counters are KiB per dispatch,
+averaged over dispatches of a kernel; gfx950 correction from MI355X_MICROARCH.md: FETCH_SIZE tallies the 128-B requests
+of 16-B-per-lane reads at 64 B, so bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  Infinity-Cache hits are included."""
+import json
+import re
+import sqlite3
+import sys
+
+
+def _short(name):
+    name = re.sub(r"\(.*", "", name)            # drop the argument list
+    return name.replace("void ", "").strip()
+
+
+def stats(db_path):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    print("Name,Calls,TotalDurationNs,AverageNs,Percentage")
+    for name, calls, total, avg, pct in rows:
+        print(f"\"{_short(name)}\",{calls},{total * 1000:.0f},{avg * 1000:.0f},{pct:.2f}")
+
+
+def _counter_means(db_path, counter):
+    db = sqlite3.connect(db_path)
+    tables = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
+    view = "counters_collection" if "counters_collection" in tables else None
+    if view is None:
+        raise SystemExit(f"{db_path}: no counters_collection view (tables: {tables[:12]}...)")
+    cols = [d[1] for d in db.execute(f"pragma table_info({view})")]
+    kcol = "kernel_name" if "kernel_name" in cols else "name"
+    q = f"select {kcol}, dispatch_id, sum(value) from {view} where counter_name = ? group by {kcol}, dispatch_id"
+    per = {}
+    for k, _, v in db.execute(q, (counter,)):
+        per.setdefault(_short(k), []).append(v)
+    return {k: sum(v) / len(v) for k, v in per.items()}
+
+
+def traffic(fetch_db, write_db):
+    f, w = _counter_means(fetch_db, "FETCH_SIZE"), _counter_means(write_db, "WRITE_SIZE")
+    out = {"_how": __doc__.split("traffic:")[1].strip().replace("\n", " "), "kernels": {}}
+    for k in sorted(set(f) | set(w)):
+        if "ctpvae" not in k:
+            continue
+        fk, wk = f.get(k, 0.0), w.get(k, 0.0)
+        out["kernels"][k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "traffic_bytes_per_launch": (2 * fk + wk) * 1024}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2])
+    else:
+        traffic(sys.argv[2], sys.argv[3])
