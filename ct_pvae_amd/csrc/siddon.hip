@@ -7,9 +7,12 @@
 // the fly with two cursors, evaluating exactly the same fp32 expressions, so no per-ray arrays exist
 // and the slice is read from LDS.  Compiled with -ffp-contract=off; '/' and sqrtf are correctly
 // rounded (hipcc default), so the result equals the CPU restatement bit for bit.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
+#include "lds_stage.h"
 
 namespace ctpvae {
 
@@ -19,7 +22,7 @@ struct SidGeom {
 };
 
 template <bool USE_LDS>
-__global__ __launch_bounds__(256) void siddon_fwd_kernel(const float *__restrict__ obj, SidGeom g,
+__global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restrict__ obj, SidGeom g,
                                                          const float *__restrict__ sin_t,
                                                          const float *__restrict__ cos_t,
                                                          const int *__restrict__ quad_t, int p_per_blk,
@@ -30,12 +33,9 @@ __global__ __launch_bounds__(256) void siddon_fwd_kernel(const float *__restrict
     const int p0 = blockIdx.x * p_per_blk;
     const int np = min(p_per_blk, g.dt - p0);
     const float *model_g = obj + (size_t)s * g.ox * g.oz;
-    const int pitch = g.oz + 1;
+    const int pitch = g.oz + ((1 - (g.oz & 31)) & 31);   // == 1 (mod 32): conflict-free staging, see lds_stage.h
     if (USE_LDS) {
-        for (int q = threadIdx.x; q < g.ox * g.oz; q += blockDim.x) {
-            const int r = q / g.oz, c = q - r * g.oz;
-            lds[r * pitch + c] = model_g[q];
-        }
+        stage_rows(lds, model_g, g.ox, g.oz, g.oz, pitch, false, threadIdx.x & 63, threadIdx.x >> 6, blockDim.x >> 6);
         __syncthreads();
     }
     const int ox = g.ox, oz = g.oz;
@@ -57,52 +57,87 @@ __global__ __launch_bounds__(256) void siddon_fwd_kernel(const float *__restrict
         const float slope = (srcy - dety) / (srcx - detx);
         const float islope = (srcx - detx) / (srcy - dety);
 
-        // list a: crossings with y = gridy[n], x = coordx(n); the kept n form one contiguous run
-        int a_lo = 0, a_cnt = 0;
-        for (int n = 0; n <= oz; ++n) {
-            const float cx = islope * ((gy0 + n) - srcy) + srcx;
-            if (cx >= gx_gt && cx <= gx_le) {
-                if (a_cnt == 0) a_lo = n;
-                ++a_cnt;
+        // list a: crossings with y = gridy[n], x = coordx(n) = islope * (gridy[n] - srcy) + srcx, kept iff
+        // gx_gt <= x <= gx_le; list b: crossings with x = gridx[n], y = coordy(n), kept iff gy_gt <= y <= gy_le.
+        // Every fp32 step of coord(n) is monotone in n, so the kept n form one contiguous run whose ends are found by
+        // bisection on the SAME expression (libtomo scans all n; same set).  A non-finite slope (a ray exactly along
+        // a grid direction) keeps the scan.
+        int a_lo = 0, a_cnt = 0, b_lo = 0, b_cnt = 0;
+        auto kept_run = [](float sl, float g0, float src_u, float src_v, float lo, float hi, int N, int &first, int &cnt) {
+            auto coord = [&](int n) { return sl * ((g0 + n) - src_u) + src_v; };
+            first = 0;
+            cnt = 0;
+            if (!(fabsf(sl) <= 3.0e38f)) {   // inf / NaN
+                for (int n = 0; n <= N; ++n) {
+                    const float c = coord(n);
+                    if (c >= lo && c <= hi) {
+                        if (cnt == 0) first = n;
+                        ++cnt;
+                    }
+                }
+                return;
             }
-        }
-        // list b: crossings with x = gridx[n], y = coordy(n)
-        int b_lo = 0, b_cnt = 0;
-        for (int n = 0; n <= ox; ++n) {
-            const float cy = slope * ((gx0 + n) - srcx) + srcy;
-            if (cy >= gy_gt && cy <= gy_le) {
-                if (b_cnt == 0) b_lo = n;
-                ++b_cnt;
+            const bool inc = coord(0) <= coord(N);
+            // smallest n whose coordinate has entered [lo, hi] from its low side, smallest n that has left it
+            int l = 0, r = N + 1;      // first n with  (inc ? c >= lo : c <= hi)
+            while (l < r) {
+                const int m = (l + r) >> 1;
+                const float c = coord(m);
+                if (inc ? c >= lo : c <= hi) r = m; else l = m + 1;
             }
-        }
+            const int n_in = l;
+            l = n_in, r = N + 1;       // first n >= n_in with (inc ? c > hi : c < lo)
+            while (l < r) {
+                const int m = (l + r) >> 1;
+                const float c = coord(m);
+                if (inc ? c > hi : c < lo) r = m; else l = m + 1;
+            }
+            first = n_in;
+            cnt = l - n_in;
+        };
+        kept_run(islope, gy0, srcy, srcx, gx_gt, gx_le, oz, a_lo, a_cnt);
+        kept_run(slope, gx0, srcx, srcy, gy_gt, gy_le, ox, b_lo, b_cnt);
         const int csize = a_cnt + b_cnt;
         float acc = 0.0f;
-        int i = 0, j = 0;
+        // The merge of libtomo's two sorted lists, with two cursors.  List a runs over its kept n upwards in
+        // quadrant 1 and downwards otherwise; gridy[n] = gy0 + n is exact in fp32, so a running +-1.0f gives the same
+        // values as int -> float.  An exhausted list shows +inf as its key: "a_key < b_key" then reproduces
+        // sort_intersections' choice (a first only if strictly smaller; the other list once one has run out).
+        const float kInf = __builtin_inff();
+        const float da = quadrant ? 1.0f : -1.0f;
+        float a_y = gy0 + (float)(quadrant ? a_lo : a_lo + a_cnt - 1);
+        float a_x = islope * (a_y - srcy) + srcx;
+        float a_key = a_cnt > 0 ? a_x : kInf;
+        int a_rem = a_cnt;
+        float b_x = gx0 + (float)b_lo;
+        float b_y = slope * (b_x - srcx) + srcy;
+        float b_key = b_cnt > 0 ? b_x : kInf;
+        int b_rem = b_cnt;
         float px_prev = 0.0f, py_prev = 0.0f;
         for (int k = 0; k < csize; ++k) {
-            // head of list a (ascending n in quadrant 1, descending otherwise) and of list b
-            const int an = a_lo + (quadrant ? i : (a_cnt - 1 - i));
-            const float a_y = gy0 + an;
-            const float a_x = islope * (a_y - srcy) + srcx;
-            const int bn = b_lo + j;
-            const float b_x = gx0 + bn;
-            const float b_y = slope * (b_x - srcx) + srcy;
-            bool take_a;
-            if (i < a_cnt && j < b_cnt)
-                take_a = a_x < b_x;
-            else
-                take_a = i < a_cnt;
+            const bool take_a = a_key < b_key;
             const float cx = take_a ? a_x : b_x;
             const float cy = take_a ? a_y : b_y;
-            i += take_a ? 1 : 0;
-            j += take_a ? 0 : 1;
+            {   // advance the list that was taken (selects, not a branch: the lanes of a wave disagree all the time)
+                const float na_y = a_y + da, na_x = islope * (na_y - srcy) + srcx;
+                const float nb_x = b_x + 1.0f, nb_y = slope * (nb_x - srcx) + srcy;
+                const int na_rem = a_rem - 1, nb_rem = b_rem - 1;
+                const float na_key = na_rem > 0 ? na_x : kInf, nb_key = nb_rem > 0 ? nb_x : kInf;
+                a_y = take_a ? na_y : a_y;
+                a_x = take_a ? na_x : a_x;
+                a_key = take_a ? na_key : a_key;
+                a_rem = take_a ? na_rem : a_rem;
+                b_x = take_a ? b_x : nb_x;
+                b_y = take_a ? b_y : nb_y;
+                b_key = take_a ? b_key : nb_key;
+                b_rem = take_a ? b_rem : nb_rem;
+            }
             if (k > 0) {
                 const float diffx = cx - px_prev, diffy = cy - py_prev;
                 const float dist = sqrtf(diffx * diffx + diffy * diffy);
                 const float midx = (cx + px_prev) * 0.5f, midy = (cy + py_prev) * 0.5f;
-                const float x1 = midx + hx, x2 = midy + hz;
-                const int i1 = (int)x1, i2 = (int)x2;
-                const int indx = i1 - (i1 > x1), indy = i2 - (i2 > x2);
+                // libtomo: i1 = (int)x1; indx = i1 - (i1 > x1)  ==  floor(x1)
+                const int indx = (int)floorf(midx + hx), indy = (int)floorf(midy + hz);
                 // libtomo reads model[indy + indx*oz] unchecked; midpoints lie strictly inside the grid
                 const int ix = min(max(indx, 0), ox - 1), iy = min(max(indy, 0), oz - 1);
                 const float m = USE_LDS ? lds[ix * pitch + iy] : model_g[(size_t)ix * oz + iy];
@@ -161,11 +196,16 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
     if (mov - std::floor(mov) < 0.01f) mov += 0.01f;
     mov += 0.5f;
     const SidGeom g{oy, ox, oz, dt, dx, mov};
-    const size_t lds_bytes = (size_t)ox * (oz + 1) * sizeof(float);
+    const size_t lds_bytes = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
     const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
     int ppb = dt;
     while (ppb > 1 && (long long)oy * ceil_div(dt, ppb) < 512) ppb = (ppb + 1) / 2;
-    const dim3 grid(ceil_div(dt, ppb), oy), block(256);
+    // the kernel is VALU-bound and every workgroup holds the slice in LDS (two fit a CU): 16 waves per workgroup
+    // keep 8 waves on every SIMD (4 waves per workgroup left 2 per SIMD -- one wave issues a VALU op every ~4.4 cycles)
+    int threads = std::min(1024, ceil_div(ppb * dx, 64) * 64);
+    if (const char *e = getenv("CTPVAE_TUNE_SIDDON_THREADS")) threads = std::max(64, std::min(1024, atoi(e) / 64 * 64));
+    if (const char *e = getenv("CTPVAE_TUNE_SIDDON_PPB")) ppb = std::max(1, std::min(dt, atoi(e)));
+    const dim3 grid(ceil_div(dt, ppb), oy), block(threads);
     auto launch = [&](auto kernel, size_t shmem) -> int {
         if (shmem > 64 * 1024)
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
