@@ -608,11 +608,24 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
     if (const char *e = getenv("CTPVAE_TUNE_NS")) ns = atoi(e) == 2 ? 2 : 1;
     const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns + 16;   // + the task counter
     const int units = (S + ns - 1) / ns;
-    // the tasks of one unit are dealt to G groups per mirror class; about 1.6 workgroups per CU chip-wide when two fit
-    // a CU, one otherwise; at most 16 waves each
-    const int wgs_per_cu = shmem * 2 <= (size_t)kMaxLdsBytes ? 2 : 1;
-    int G = (int)std::max<long long>(1, (long long)(256 * (wgs_per_cu == 2 ? 1.6 : 1.0) / (2.0 * units) + 0.5));
-    G = std::min(G, std::min(12, std::max(1, T / 2)));   // every group re-stages the slice: beyond ~12 that costs more than it buys (B=5: 8.1 us at 12, 13.9 us at 30)
+    // The tasks of one unit are dealt to G groups per mirror class.  What a launch costs is the bytes its busiest CU
+    // pulls through its L2->CU path: per workgroup one staged unit plus ~1 KB of indices per row
+    // group of each of its tasks; the busiest CU holds ceil(workgroups / 256) of them.  Take the G that minimises
+    // that (measured at B=50, A=20: G=2 10.3 us, G=4 10.9 us, G=3 12.2 us, as the model orders them); every group
+    // re-stages the unit, so beyond ~12 groups more workgroups cost more than they buy (B=5: 8.1 us at 12, 13.9 at 30).
+    int G = 1;
+    {
+        const double fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0, task_kb = 0.85 * L.NG;
+        double best = 0.0;
+        for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
+            const long long wgs = 2ll * units * cand;
+            const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand));
+            if (cand == 1 || cost < best * 0.98) {   // a tie goes to fewer, fatter workgroups
+                best = cost;
+                G = cand;
+            }
+        }
+    }
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, (T + 2 * G - 1) / (2 * G)));
     const int wgs_per_slice = 2 * G;
