@@ -300,9 +300,12 @@ def test_large_image_is_tiled(oracle):
                                   oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0))
 
 
-@pytest.mark.parametrize("shape,pad,A,S", [((300, 200), True, 7, 2), ((129, 385), False, 5, 1), ((256, 256), True, 33, 4)])
+@pytest.mark.parametrize("shape,pad,A,S", [((300, 200), True, 7, 2), ((129, 385), False, 5, 1), ((256, 256), True, 33, 4),
+                                          ((200, 200), True, 400, 3), ((200, 200), True, 1, 5)])
 def test_tiled_forward_ragged(oracle, shape, pad, A, S):
-    """Edge tiles smaller than 96x64, unpadded canvases (negative-tie rounding at the canvas edge), odd angle counts."""
+    """Edge tiles smaller than 96x64, unpadded canvases (negative-tie rounding at the canvas edge), odd angle counts, one
+    angle (an empty bank class), and more angles than fit behind a 4-slice tile in LDS (the kernel then scans the
+    transform table instead of reading its LDS copy and class list)."""
     d = dev()
     rng = np.random.default_rng(A)
     theta = rng.uniform(-1.0, 4.0, A)
