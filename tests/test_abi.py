@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_binding_table_matches_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == declared_symbols()
     lib = built_lib.load()
-    assert lib.ctpvae_abi_version() == 1000
+    assert lib.ctpvae_abi_version() == 1001
 
 
 def test_host_only_entry_points(built_lib):
@@ -53,6 +53,16 @@ def test_host_only_entry_points(built_lib):
     assert lib.ctpvae_pad_amounts(128, 184, ctypes.byref(lo), ctypes.byref(hi)) == 0
     assert (lo.value, hi.value) == (28, 28)
     assert lib.ctpvae_siddon_dx(128, 128, 1) == 184 and lib.ctpvae_siddon_dx(128, 128, 0) == 128
+
+
+def test_tiled_workspace_rule(built_lib):
+    """Host-only size rule of the tiled forward: 0 when the slice fits LDS whole or the interpolation is bilinear,
+    else S x tiles x A x slots fp32 (512x512: 8 x 6 tiles of 64 x 96, 128 slots)."""
+    lib = built_lib.load()
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(50, 128, 128, 184, 184, 20, 0) == 0
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 1) == 0
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 0) == 8 * 48 * 90 * 128 * 4
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(0, 512, 512, 728, 728, 90, 0) == built_lib.EINVAL
 
 
 def test_bad_arguments_are_reported_not_thrown(built_lib):
