@@ -29,9 +29,15 @@ def env_world():
 
 
 def init_from_env(backend=None):
-    """One process per GPU: bind the device and join the default group.  Returns (world, rank, local_rank)."""
+    """One process per GPU: bind the device and join the default group.  Returns (world, rank, device index).
+
+    CTPVAE_REHEARSE_ONE_GPU=1 rehearses a multi-rank launch on a box with ONE GPU: every rank binds device 0 and the
+    group runs over gloo (RCCL needs one device per rank).  Same code path otherwise; used by the tests only."""
     world, rank, local = env_world()
     use_cuda = torch.cuda.is_available()
+    rehearse = os.environ.get("CTPVAE_REHEARSE_ONE_GPU", "") == "1"
+    if rehearse:
+        local, backend = 0, "gloo"
     if use_cuda:
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():

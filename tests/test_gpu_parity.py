@@ -403,3 +403,33 @@ def test_bad_shapes_raise():
         cp.project_tf_fast(torch.zeros(8, 8, device=d), np.zeros((2, 2)), dim=2)
     with pytest.raises(ValueError):
         cp.project_tf_fast(torch.zeros(8, 8, device=d), np.zeros(0), dim=2)
+
+
+def test_bench_under_torchrun_two_ranks():
+    """bench.py launched exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed
+    on this box's single GPU: both ranks bind device 0 and the group runs over gloo.  One JSON line from rank 0, whole-job
+    value, the contract's keys."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CTPVAE_REHEARSE_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30",
+           "--warmup", "5"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    # whole-job value: 2 ranks x 50 objects x 20 angles per step
+    assert abs(d["value"] - 2 * 50 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only
