@@ -92,3 +92,10 @@ def test_siddon_tables_match_oracle(built_lib, oracle):
               ((tp < 0) & (((tp + 2 * np.pi) < np.pi / 2) | (((tp + 2 * np.pi) >= np.pi) & ((tp + 2 * np.pi) < 1.5 * np.pi)))))
     away = np.abs(np.mod(tp, np.pi / 2)) > 1e-5
     np.testing.assert_array_equal(q[away], want_q[away].astype(np.int32))
+
+
+def test_driver_build_entry_point():
+    """__graft_entry__.build() is what the driver runs on the GPU-less host every round: it must compile, load the
+    library and agree with it about the ABI version."""
+    import __graft_entry__ as entry
+    entry.build()
