@@ -281,6 +281,17 @@ def main():
     t_fwd = avg_launch_seconds(lambda: plan.forward(x, out=sino))
     t_bwd = avg_launch_seconds(lambda: plan.backward(g, out=gimg))
 
+    # spread of single steps (median and p10/p90): one event pair per fwd+adj step, 200 steps; each figure
+    # carries the ~1.5 us of its own event pair, so read it as a distribution, not as `ms_per_step`
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    torch.cuda.synchronize()
+    for e0, e1 in ev:
+        e0.record()
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    step_us = np.array([e0.elapsed_time(e1) * 1e3 for e0, e1 in ev])
+
     # ---- the same step through the public autograd API (secondary) -----------------------------------------
     x4 = x[..., None].clone().requires_grad_(True)
     g4 = g[..., None]
@@ -331,6 +342,8 @@ def main():
                      "kernel_us": {"rotate_fwd": t_fwd * 1e6, "rotate_bwd_tfcompat": t_bwd * 1e6},
                      "note": "object lives in LDS for all angles: LDS-gather/VALU bound, HBM fraction is small by construction"},
         "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
+        "step_us_event_pairs": {"p10": float(np.percentile(step_us, 10)), "median": float(np.median(step_us)),
+                                "p90": float(np.percentile(step_us, 90)), "n": len(step_us)},
         "api": {"value": B * A * n_api / api_elapsed, "unit": "projections/s",
                 "what": "project_tf_fast(...).backward() through torch.autograd, same workload, 1 GPU"},
     }
