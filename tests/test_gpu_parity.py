@@ -433,3 +433,66 @@ def test_bench_under_torchrun_two_ranks():
     # whole-job value: 2 ranks x 50 objects x 20 angles per step
     assert abs(d["value"] - 2 * 50 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+
+
+def test_random_geometries_against_the_oracle(oracle):
+    """Seeded random small geometries (odd sizes, 1-pixel slices, unpadded canvases, 1..40 angles, any angle values):
+    planned or direct, whichever the geometry takes, forward and tf_compat backward are bit-exact against the oracle; the
+    exact backward stays the transpose."""
+    d = dev()
+    rng = np.random.default_rng(20261004)
+    for case in range(24):
+        H, W = int(rng.integers(1, 150)), int(rng.integers(1, 150))
+        if case < 4:
+            H, W = [(1, 1), (1, 77), (93, 1), (3, 2)][case]
+        pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 41)), int(rng.integers(1, 7))
+        theta = rng.uniform(-2 * np.pi, 2 * np.pi, A)
+        if case % 3 == 0:
+            theta[: min(A, 4)] = [0.0, np.pi / 2, np.pi, -np.pi / 2][: min(A, 4)]      # exact ties in the rounding
+        img = rng.standard_normal((S, H, W)).astype(np.float32)
+        geom = oracle.Geometry(H, W, pad)
+        for use_plan in (True, False):
+            plan = RotatePlan(theta, H, W, pad, d, use_plan=use_plan)
+            got = to_np(plan.forward(torch.from_numpy(img).to(d)))
+            want = oracle.rotate_fwd(img, geom, to_np(plan.T8), 0)
+            np.testing.assert_array_equal(got, want, err_msg=f"fwd case {case}: {H}x{W} pad={pad} A={A} S={S} plan={use_plan}")
+            g = rng.standard_normal(got.shape).astype(np.float32)
+            gb = to_np(plan.backward(torch.from_numpy(g).to(d)))
+            np.testing.assert_array_equal(gb, oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0),
+                                          err_msg=f"bwd case {case}: {H}x{W} pad={pad} A={A} S={S} plan={use_plan}")
+        ex = RotatePlan(theta, H, W, pad, d, backward="exact")
+        lhs = float((to_np(ex.forward(torch.from_numpy(img).to(d))).astype(np.float64) * g).sum())
+        rhs = float((to_np(ex.backward(torch.from_numpy(g).to(d))).astype(np.float64) * img).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (case, lhs, rhs)
+
+
+def test_random_siddon_and_tiled_geometries(oracle):
+    """Seeded random cases for the two other projectors: the TomoPy-style one (odd / rectangular grids, padded and not,
+    angles of every quadrant incl. exactly axis-aligned ones, where the bisection of the crossing lists falls back to
+    libtomo's scan) and the tiled forward (random slice shapes larger than LDS)."""
+    d = dev()
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        ox, oz = int(rng.integers(2, 97)), int(rng.integers(2, 97))
+        pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 13)), int(rng.integers(1, 4))
+        theta = rng.uniform(-7.0, 7.0, A)
+        theta[: min(A, 3)] = [0.0, np.pi / 2, np.pi][: min(A, 3)]
+        img = rng.random((S, ox, oz), dtype=np.float32)
+        got = cp.create_sinograms(img, theta, pad=pad)
+        np.testing.assert_array_equal(got, np.swapaxes(oracle.siddon_project(img, theta, pad=pad), 0, 1),
+                                      err_msg=f"siddon case {case}: {ox}x{oz} pad={pad} A={A} S={S}")
+    for case in range(4):
+        H, W = int(rng.integers(150, 330)), int(rng.integers(210, 330))
+        pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 9)), int(rng.integers(1, 6))
+        theta = rng.uniform(-np.pi, np.pi, A)
+        img = rng.standard_normal((S, H, W)).astype(np.float32)
+        plan = RotatePlan(theta, H, W, pad, d)
+        assert plan.tiled
+        geom = oracle.Geometry(H, W, pad)
+        np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
+                                      oracle.rotate_fwd_tiled(img, geom, to_np(plan.T8), (96, 64)),
+                                      err_msg=f"tiled case {case}: {H}x{W} pad={pad} A={A} S={S}")
+        g = rng.standard_normal((S, A, geom.PW)).astype(np.float32)
+        np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
+                                      oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0),
+                                      err_msg=f"segment bwd case {case}: {H}x{W} pad={pad} A={A} S={S}")
