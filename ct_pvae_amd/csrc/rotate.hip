@@ -12,6 +12,7 @@
 // order -- the same summation order as reduce_sum(axis=1) on the reference, so results are
 // reproducible bit for bit against the CPU restatement.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -1091,7 +1092,7 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
         const dim3 grid((unsigned)((nrays + rpb - 1) / rpb), S);
         const bool tie_fix = (px == 0 || py == 0);
         auto launch = [&](auto kernel) -> int {
-            static bool attr_set = false;  // one flag per instantiation (the lambda is instantiated per kernel)
+            static std::atomic<bool> attr_set{false};  // one flag per instantiation (the lambda is instantiated per kernel)
             if (!attr_set) {
                 CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                kMaxLdsBytes));
@@ -1159,7 +1160,7 @@ int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int P
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
     auto launch = [&](auto kernel) -> int {
-        static bool attr_set = false;  // one flag per instantiation
+        static std::atomic<bool> attr_set{false};  // one flag per instantiation
         if (!attr_set) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
             attr_set = true;

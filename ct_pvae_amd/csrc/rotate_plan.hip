@@ -24,6 +24,7 @@
 // Backward plan  idx[a8][y][x]: uint4 = for angles 8*a8..8*a8+7, the dword index of the cotangent cell
 //                               (a * pitchg + bin) that TensorFlow's gradient op reads for pixel (y, x), or `zero`.
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 #include <type_traits>
@@ -631,7 +632,7 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
     const int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static bool attr_set = false;   // one flag per instantiation
+        static std::atomic<bool> attr_set{false};   // one flag per instantiation
         if (!attr_set) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
             attr_set = true;
@@ -668,7 +669,7 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
     const long long nblk = (long long)S * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static bool attr_set = false;   // one flag per instantiation
+        static std::atomic<bool> attr_set{false};   // one flag per instantiation
         if (!attr_set) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
             attr_set = true;
