@@ -489,6 +489,9 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int y = min(y0 + k * nwaves, g.H - 1);   // rows past the slice re-read the last row, never stored
+#ifdef CTPVAE_TUNE_BWD_NOIDX
+            if (a16 > 0) continue;   // timing only: every group reuses the first index vectors (no index streaming)
+#endif
             q[k] = p[((size_t)a16 * g.H + y) * L.Wpad];
         }
     };
@@ -509,7 +512,12 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
             const int n_live = min(16, na4 - AL);
             float v[PPT][16];
 #pragma unroll
+#ifdef CTPVAE_TUNE_BWD_NOLDS
+            for (int k = 0; k < PPT; ++k)   // timing only: no gathers, the index words stand in for the taps
+                for (int e = 0; e < 16; ++e) v[k][e] = __uint_as_float((&q[k].x)[e & 3] & 0x3fffffu);
+#else
             for (int k = 0; k < PPT; ++k) gather16<AL>(lds, q[k], n_live, v[k]);
+#endif
             const int next = (ac + AL) / 16 + 1;         // all index vectors of this group consumed: prefetch the next
             if (next < L.NA16) load_group(next);
             __builtin_amdgcn_sched_barrier(0);
