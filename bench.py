@@ -203,9 +203,7 @@ def n512_mode(args, world, rank, dev):
     ones = torch.ones_like(sino)
 
     def step():
-        plan.forward(x, out=sino)
-        lib.ctpvae_loglik_fwd_f32(sino.data_ptr(), mask.data_ptr(), meas.data_ptr(), B, A, plan.PW, pnm.data_ptr(),
-                                  ctypes.c_float(eps), lp.data_ptr(), _stream_ptr())
+        plan.forward_loglik(x, mask, meas, pnm, eps, out=sino, out_lp=lp)      # projection + log-likelihood, fused
         lib.ctpvae_loglik_bwd_f32(sino.data_ptr(), mask.data_ptr(), meas.data_ptr(), ones.data_ptr(), B, A, plan.PW,
                                   pnm.data_ptr(), ctypes.c_float(eps), gp.data_ptr(), None, _stream_ptr())
         plan.backward(gp, out=gx)
@@ -219,7 +217,7 @@ def n512_mode(args, world, rank, dev):
                           "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"batch={B}/GPU 512x512, 90 angles, P={plan.PW}, nearest fwd + "
-                                                 "Gaussian-Poisson log-likelihood fwd/bwd + tf_compat adj (tiled fwd, 4 slices per workgroup; segment-staged adj)"},
+                                                 "fused Gaussian-Poisson log-likelihood, its backward + tf_compat adj (tiled fwd, 4 slices per workgroup; segment-staged adj)"},
                           "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS}))
 
 

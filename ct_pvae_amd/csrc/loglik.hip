@@ -1,10 +1,9 @@
 // loglik.hip -- Gaussian-approximated Poisson log-likelihood of a sinogram (a8,
 // ctvae/helper_functions.py:360-368) and its backward.  Elementwise over [B][A][P]; HBM-bound.
 #include "common.h"
+#include "loglik_math.h"
 
 namespace ctpvae {
-
-constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
 __global__ __launch_bounds__(256) void loglik_fwd_kernel(const float *__restrict__ proj,
                                                          const float *__restrict__ mask,
@@ -14,11 +13,7 @@ __global__ __launch_bounds__(256) void loglik_fwd_kernel(const float *__restrict
 {
     const float pnm = *pnm_p;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-        const float m = mask[k / P];
-        const float loc = proj[k] * m;
-        const float scale = eps + sqrtf(loc / pnm + eps);
-        const float z = x[k] / scale - loc / scale;
-        out[k] = -0.5f * (z * z) - (kHalfLog2Pi + logf(scale));
+        out[k] = gaussian_poisson_logp(proj[k], mask[k / P], x[k], pnm, eps);
     }
 }
 

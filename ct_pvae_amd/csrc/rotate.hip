@@ -17,6 +17,7 @@
 
 #include "common.h"
 #include "lds_stage.h"
+#include "loglik_math.h"
 
 namespace ctpvae {
 
@@ -604,8 +605,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 // One wave = 64 consecutive bins of one (slice, angle): it first lists, in ascending order, the tiles whose slot range
 // touches its bins (about a quarter of them), then adds their partial sums.
 constexpr int kMaxTiles = 1024;
+template <bool EPI>   // EPI: also write the log-probability of the measured sample under every ray-sum (loglik_math.h)
 __global__ __launch_bounds__(64) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
-                                                                const float *__restrict__ T8, float *__restrict__ sino)
+                                                                const float *__restrict__ T8, float *__restrict__ sino,
+                                                                LogLikEpilogue epi)
 {
     __shared__ int list_tile[kMaxTiles], list_first[kMaxTiles];
     const int lane = threadIdx.x, j0 = blockIdx.x * 64, j = j0 + lane, a = blockIdx.y, s = blockIdx.z;
@@ -650,7 +653,9 @@ __global__ __launch_bounds__(64) void rotate_tile_reduce_kernel(const float *__r
 #pragma unroll
         for (int u = 0; u < U; ++u) acc += ok[u] ? v[u] : 0.0f;   // + 0.0f leaves the sum unchanged
     }
-    sino[((size_t)s * g.A + a) * g.PW + j] = acc;
+    const size_t o = ((size_t)s * g.A + a) * g.PW + j;
+    sino[o] = acc;
+    if constexpr (EPI) epi.lp[o] = gaussian_poisson_logp(acc, epi.mask[(size_t)s * g.A + a], epi.meas[o], *epi.pnm, epi.eps);
 }
 
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
@@ -1136,8 +1141,8 @@ long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, i
     return (long long)S * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
 }
 
-int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
-                                const float *T8_dev, int A, void *workspace_dev, float *sino_dev, ctpvae_stream_t stream)
+static int launch_fwd_tiled(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
+                           int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev, "rotate_fwd_tiled: null pointer");
     if (int rc = check_geom("rotate_fwd_tiled", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
@@ -1180,10 +1185,30 @@ int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int P
     else
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 1>);
     if (rc) return rc;
-    hipLaunchKernelGGL(rotate_tile_reduce_kernel, dim3(ceil_div(PW, 64), A, S), dim3(64), 0, (hipStream_t)stream,
-                       (const float *)workspace_dev, g, ts, T8_dev, sino_dev);
+    if (epi.lp)
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<true>, dim3(ceil_div(PW, 64), A, S), dim3(64), 0, (hipStream_t)stream,
+                           (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
+    else
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<false>, dim3(ceil_div(PW, 64), A, S), dim3(64), 0, (hipStream_t)stream,
+                           (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
     CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
     return CTPVAE_OK;
+}
+
+int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                const float *T8_dev, int A, void *workspace_dev, float *sino_dev, ctpvae_stream_t stream)
+{
+    return launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev, LogLikEpilogue{}, stream);
+}
+
+int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                       const float *T8_dev, int A, void *workspace_dev, const float *mask_dev,
+                                       const float *meas_dev, const float *pnm_dev, float eps, float *sino_dev,
+                                       float *lp_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_tiled_loglik: null pointer");
+    return launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev,
+                            LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev}, stream);
 }
 
 int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,

@@ -31,6 +31,7 @@
 
 #include "common.h"
 #include "lds_stage.h"
+#include "loglik_math.h"
 
 namespace ctpvae {
 
@@ -283,10 +284,13 @@ __device__ long long g_pstamps[8 * 65536];
 // NS = 2: two slices per workgroup, interleaved as float2 in LDS -- ONE index stream and ONE ds_read_b64 per tap serve
 // both slices (the index stream is what binds the kernel, section 6 of DESIGN.md).  Used when a launch has enough
 // tasks to keep every CU busy with half as many workgroups.
-template <int NS>
+// EPI: the log-likelihood epilogue -- besides the ray-sum, every store also writes the log-probability
+// of the measured sample under it (mask [S][A], measured [S][A][PW]), the expression of loglik.hip, so that
+// calculate_log_prob_M_given_R costs one launch instead of two and the sinogram is not read back.
+template <int NS, bool EPI>
 __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *__restrict__ img, PlanGeom g, FwdLayout L,
                                                                   const char *__restrict__ plan, int wgs_per_slice,
-                                                                  int g_S, float *__restrict__ sino)
+                                                                  int g_S, float *__restrict__ sino, LogLikEpilogue epi)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -410,11 +414,16 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
             }
         }
         if ((unsigned)cur.j < (unsigned)g.PW) {
+            auto store = [&](int sl, float v) {
+                const size_t o = ((size_t)sl * g.A + cur.a) * g.PW + cur.j;
+                sino[o] = v;
+                if constexpr (EPI) epi.lp[o] = gaussian_poisson_logp(v, epi.mask[(size_t)sl * g.A + cur.a], epi.meas[o], *epi.pnm, epi.eps);
+            };
             if constexpr (NS == 1) {
-                sino[((size_t)s * g.A + cur.a) * g.PW + cur.j] = acc;
+                store(s, acc);
             } else {
-                sino[((size_t)s * g.A + cur.a) * g.PW + cur.j] = acc.x;
-                if (has2) sino[((size_t)(s + 1) * g.A + cur.a) * g.PW + cur.j] = acc.y;
+                store(s, acc.x);
+                if (has2) store(s + 1, acc.y);
             }
         }
         cur = nxt;
@@ -601,8 +610,8 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
     return CTPVAE_OK;
 }
 
-int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
-                                  float *sino_dev, ctpvae_stream_t stream)
+static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
+                              float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(img_dev && fwd_plan_dev && sino_dev, "rotate_fwd_planned: null pointer");
     CTPVAE_REQUIRE(S > 0, "rotate_fwd_planned: need at least one slice");
@@ -646,11 +655,28 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
             attr_set = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev);
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
     };
-    return ns == 2 ? launch(rotate_fwd_planned_kernel<2>) : launch(rotate_fwd_planned_kernel<1>);
+    if (epi.lp) return ns == 2 ? launch(rotate_fwd_planned_kernel<2, true>) : launch(rotate_fwd_planned_kernel<1, true>);
+    return ns == 2 ? launch(rotate_fwd_planned_kernel<2, false>) : launch(rotate_fwd_planned_kernel<1, false>);
+}
+
+int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
+                                  float *sino_dev, ctpvae_stream_t stream)
+{
+    return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev, LogLikEpilogue{}, stream);
+}
+
+int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                         const void *fwd_plan_dev, const float *mask_dev, const float *meas_dev,
+                                         const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
+                                         ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_planned_loglik: null pointer");
+    return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev,
+                              LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev}, stream);
 }
 
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A, const void *bwd_plan_dev,

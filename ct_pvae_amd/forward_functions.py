@@ -19,6 +19,8 @@ gets implicitly from TensorFlow:
 """
 import math
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -220,6 +222,31 @@ class RotatePlan:
         if rc:
             _lib.check(rc, "rotate_fwd")
         return out
+
+    def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None):
+        """Planned forward with the log-likelihood epilogue (one launch): returns (sino, lp), both [S][A][PW];
+        lp = Normal(loc = sino * mask, scale = eps + sqrt(loc / pnm + eps)).log_prob(meas).  Planned and tiled geometries."""
+        S = img.shape[0]
+        ws = self._tile_workspace(S)
+        if self._fwd_plan is None and ws is None:
+            raise ValueError("forward_loglik needs a planned or tiled forward (nearest)")
+        if out is None:
+            out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+        if out_lp is None:
+            out_lp = torch.empty_like(out)
+        if self._fwd_plan is not None:
+            rc = self._lib.ctpvae_rotate_fwd_planned_loglik_f32(
+                img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), mask.data_ptr(),
+                meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(), out_lp.data_ptr(),
+                _stream_ptr(self._dev_index))
+        else:
+            rc = self._lib.ctpvae_rotate_fwd_tiled_loglik_f32(
+                img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,
+                ws.data_ptr(), mask.data_ptr(), meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
+                out_lp.data_ptr(), _stream_ptr(self._dev_index))
+        if rc:
+            _lib.check(rc, "rotate_fwd_planned_loglik")
+        return out, out_lp
 
     def backward(self, gsino, out=None):
         S = gsino.shape[0]

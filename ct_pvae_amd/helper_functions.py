@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .forward_functions import _stream_ptr, project_tf_fast
+from .forward_functions import _cached_plan, _stream_ptr, project_tf_fast
 
 __all__ = ["create_sinogram", "create_sinograms", "calculate_log_prob_M_given_R", "gaussian_poisson_log_prob"]
 
@@ -115,15 +115,60 @@ def gaussian_poisson_log_prob(proj, mask, proj_sample, poisson_noise_multiplier,
                                          proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
 
 
+class _ProjectLogLik(torch.autograd.Function):
+    """a2 + a8 in one launch: planned forward with the log-likelihood epilogue; the backward is the
+    elementwise log-likelihood backward followed by the projector's backward, exactly as the two-step path."""
+
+    @staticmethod
+    def forward(ctx, slices, plan, mask, x, pnm, eps):
+        sino, lp = plan.forward_loglik(slices, mask, x, pnm, eps)
+        ctx.save_for_backward(sino, mask, x, pnm)
+        ctx.plan, ctx.eps = plan, eps
+        return lp
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        sino, mask, x, pnm = ctx.saved_tensors
+        B, A, P = sino.shape
+        gout = gout.contiguous()
+        gproj = torch.empty_like(sino)
+        gpnm = torch.empty((), dtype=torch.float32, device=sino.device) if ctx.needs_input_grad[4] else None
+        with torch.cuda.device(sino.device):
+            _lib.check(lib.ctpvae_loglik_bwd_f32(sino.data_ptr(), mask.data_ptr(), x.data_ptr(), gout.data_ptr(),
+                                                 B, A, P, pnm.data_ptr(), ctypes.c_float(ctx.eps),
+                                                 gproj.data_ptr(), gpnm.data_ptr() if gpnm is not None else None,
+                                                 _stream_ptr()), "loglik_bwd")
+            gimg = ctx.plan.backward(gproj) if ctx.needs_input_grad[0] else None
+        return gimg, None, None, None, (gpnm.reshape(pnm.shape) if gpnm is not None else None), None
+
+
 def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise_multiplier, sqrt_reg,
                                  theta=None, angles_i=None, pad=True):
     """ctvae/helper_functions.py:336-368.  output_sample [B][X][Y][1], mask [B][angles], proj_sample
-    [B][angles][P]; returns the log-probabilities [B][angles_used][P][1]."""
+    [B][angles][P]; returns the log-probabilities [B][angles_used][P][1].
+
+    When the geometry takes the planned or the tiled forward (nearest) the projection and the log-probability are
+    one launch (the same numbers, bit for bit, as project_tf_fast followed by gaussian_poisson_log_prob)."""
     if angles_i is not None:
         angles_i = torch.as_tensor(angles_i, device=output_sample.device).long()
         theta = torch.as_tensor(theta, device=output_sample.device)[angles_i].to(torch.float32)
         mask = mask[:, angles_i]
         proj_sample = proj_sample[:, angles_i]
+    x = output_sample
+    if (isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[3] == 1 and x.device.type == "cuda"
+            and x.dtype == torch.float32 and x.shape[0] > 0):
+        slices = x[..., 0].contiguous()
+        plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, "nearest", "tf_compat")
+        if plan.planned[0] or plan.tiled:
+            pnm = poisson_noise_multiplier
+            if not isinstance(pnm, torch.Tensor):
+                pnm = torch.tensor(float(pnm), dtype=torch.float32, device=x.device)
+            pnm = pnm.to(device=x.device, dtype=torch.float32)
+            with torch.cuda.device(x.device):
+                logp = _ProjectLogLik.apply(slices, plan, mask.to(torch.float32).contiguous(),
+                                            proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
+            return logp.unsqueeze(-1)
     proj = project_tf_fast(output_sample, theta, pad=pad, dim=2, integrate_vae=True)
     logp = gaussian_poisson_log_prob(proj[..., 0], mask, proj_sample, poisson_noise_multiplier, sqrt_reg)
     return logp.unsqueeze(-1)

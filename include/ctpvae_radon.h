@@ -20,6 +20,8 @@
  *                                              ctvae/main_ct_vae.py:471-481) and its exact transpose
  *   ctpvae_rotate_plan_* / _planned_f32        the same two operators, batched: index arithmetic hoisted
  *                                              out of the per-object work (no counterpart in the reference)
+ *   ctpvae_rotate_fwd_planned_loglik_f32       project_tf_fast + the Normal log_prob of calculate_log_prob_M_given_R
+ *                                              ctvae/helper_functions.py:359-368, one launch
  *   ctpvae_siddon_tables_f32 / _fwd_f32        create_sinogram -> tomopy.project
  *                                              ctvae/helper_functions.py:33-38
  *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
@@ -86,6 +88,12 @@ int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int P
                                 const float *T8_dev, int A, void *workspace_dev, float *sino_dev,
                                 ctpvae_stream_t stream);
 
+/* ... and with the log-likelihood epilogue of ctpvae_rotate_fwd_planned_loglik_f32 (below) in its reduce pass. */
+int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                       const float *T8_dev, int A, void *workspace_dev, const float *mask_dev,
+                                       const float *meas_dev, const float *pnm_dev, float eps, float *sino_dev,
+                                       float *lp_dev, ctpvae_stream_t stream);
+
 /* ---- a4: backward of the above -------------------------------------------------------------
  * gsino_dev [S][A][PW] cotangent.  gimg_dev [S][H][W] (overwritten).
  * mode CTPVAE_BWD_TF_COMPAT: T8_dev must hold the INVERTED rows (Tinv8 above).
@@ -110,6 +118,13 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
                                  int py, int px, void *fwd_plan_dev, void *bwd_plan_dev, ctpvae_stream_t stream);
 int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
                                   const void *fwd_plan_dev, float *sino_dev, ctpvae_stream_t stream);
+/* a8 fused into a2: the planned forward that also writes, for every ray-sum, the log-probability of the
+ * measured sample under it -- lp[s][a][j] = ctpvae_loglik_fwd_f32's expression on (sino[s][a][j], mask[s][a],
+ * meas[s][a][j]) -- in the same launch.  sino_dev is still written (the backward needs it). */
+int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                         const void *fwd_plan_dev, const float *mask_dev, const float *meas_dev,
+                                         const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
+                                         ctpvae_stream_t stream);
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
                                   const void *bwd_plan_dev, float *gimg_dev, ctpvae_stream_t stream);
 

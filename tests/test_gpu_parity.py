@@ -393,6 +393,40 @@ def test_calculate_log_prob_M_given_R(oracle):
     assert rel_err(to_np(got)[..., 0], want) <= 2e-5
 
 
+@pytest.mark.parametrize("B,N,A", [(5, 128, 20), (50, 128, 20), (3, 40, 7), (60, 64, 90), (3, 256, 6)])
+def test_fused_projector_loglik_equals_two_steps(B, N, A):
+    """calculate_log_prob_M_given_R in one launch (planned forward + log-likelihood epilogue) against the
+    two-step path it replaces (project_tf_fast, then gaussian_poisson_log_prob): same values bit for bit, same
+    gradients w.r.t. the reconstruction and a trainable pnm (also through slice pairs, and through the tiled forward's
+    reduce pass: the last two cases)."""
+    from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
+    d = dev()
+    rng = np.random.default_rng(B + N)
+    theta = torch.from_numpy(np.linspace(0, np.pi, A, endpoint=False).astype(np.float32)).to(d)
+    P = cp.num_proj_pix(N, N)
+    mask = torch.full((B, A), 1.0 / A, device=d)
+    meas = torch.from_numpy(rng.random((B, A, P), dtype=np.float32) * 3).to(d)
+    eps = float(np.finfo(np.float32).eps)
+    up = torch.from_numpy(rng.standard_normal((B, A, P, 1)).astype(np.float32)).to(d)
+    outs = []
+    for fused in (True, False):
+        x = torch.from_numpy(rng_img(B, N)).to(d).requires_grad_(True)
+        pnm = torch.tensor(1e3, device=d, requires_grad=True)
+        if fused:
+            lp = cp.calculate_log_prob_M_given_R(x, mask, meas, pnm, eps, theta=theta, pad=True)
+        else:
+            proj = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+            lp = gaussian_poisson_log_prob(proj[..., 0], mask, meas, pnm, eps).unsqueeze(-1)
+        (lp * up).sum().backward()
+        outs.append((lp.detach(), x.grad.detach(), pnm.grad.detach()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert abs(float(outs[0][2]) - float(outs[1][2])) <= 1e-4 * abs(float(outs[1][2])) + 1e-12   # atomics order
+
+
+def rng_img(B, N):
+    return np.random.default_rng(1234).random((B, N, N, 1), dtype=np.float32)
+
+
 def test_bad_shapes_raise():
     d = dev()
     with pytest.raises(ValueError):
