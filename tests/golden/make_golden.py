@@ -33,8 +33,26 @@ def rotate_case(name, img, theta, pad, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
 
 
+def tiled_case():
+    """rotate_fwd_tiled (the association the build uses for slices larger than LDS) on a 220 x 190 slice -- the
+    smallest kind that the HIP path tiles -- with coarse pixel values so that the file stays small."""
+    rng = np.random.default_rng(6)
+    img = (np.round(rng.random((1, 220, 190)) * 16) / 16).astype(np.float32)
+    theta = np.array([0.0, 0.3, np.pi / 4, 1.9, np.pi / 2, 2.8])
+    geom = orc.Geometry(220, 190, True)
+    T = orc.rotate_transforms(theta, geom.PH, geom.PW)
+    np.savez_compressed(os.path.join(OUT, "rotate_tiled.npz"), img=img, theta=theta, T8=T,
+                        fwd_tiled_96x64=orc.rotate_fwd_tiled(img, geom, T, (96, 64)),
+                        fwd_tiled_50x40=orc.rotate_fwd_tiled(img, geom, T, (50, 40)),
+                        fwd_rowwise=orc.rotate_fwd(img, geom, T, NEAREST))
+
+
 def main():
     orc.build(force=True)
+    if sys.argv[1:] == ["tiled"]:
+        tiled_case()
+        return
+    tiled_case()
     rng = np.random.default_rng(0)
     # the reference's 2x2 toy set (scripts/create_toy_images.py:36-40), no padding
     rotate_case("rotate_toy", phantoms.toy_images(), np.array([0, np.pi / 2]), False, 1)

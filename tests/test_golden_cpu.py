@@ -47,3 +47,18 @@ def test_iradon_and_loglik_golden(oracle, golden_dir):
     z = load(golden_dir, "loglik")
     np.testing.assert_array_equal(oracle.loglik(z["proj"], z["mask"], z["x"], float(z["pnm"]), float(z["eps"])),
                                   z["out"])
+
+
+def test_tiled_summation_golden(oracle, golden_dir):
+    """The tile-blocked association of the row sum (what the HIP path uses for slices larger than LDS): pinned for two
+    tile shapes; whatever the tiles, the taps are those of the row-wise sum, so the three agree to fp32 rounding."""
+    z = load(golden_dir, "rotate_tiled")
+    geom = oracle.Geometry(220, 190, True)
+    np.testing.assert_array_equal(oracle.rotate_transforms(z["theta"], geom.PH, geom.PW), z["T8"])
+    for tile, key in (((96, 64), "fwd_tiled_96x64"), ((50, 40), "fwd_tiled_50x40")):
+        np.testing.assert_array_equal(oracle.rotate_fwd_tiled(z["img"], geom, z["T8"], tile), z[key])
+        assert np.abs(z[key] - z["fwd_rowwise"]).max() <= 2e-6 * np.abs(z["fwd_rowwise"]).max()
+    # one tile that covers the slice IS the row-wise sum
+    np.testing.assert_array_equal(oracle.rotate_fwd_tiled(z["img"], geom, z["T8"], (220, 190)), z["fwd_rowwise"])
+    with pytest.raises(ValueError):
+        oracle.rotate_fwd_tiled(z["img"], geom, z["T8"], (0, 64))

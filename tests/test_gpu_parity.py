@@ -500,6 +500,16 @@ def test_random_geometries_against_the_oracle(oracle):
         assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (case, lhs, rhs)
 
 
+def test_tiled_forward_against_golden(golden_dir):
+    """The committed tiled vector (220 x 190, the smallest kind of slice the HIP path tiles)."""
+    z = np.load(os.path.join(golden_dir, "rotate_tiled.npz"))
+    d = dev()
+    plan = RotatePlan(z["theta"], 220, 190, True, d)
+    assert plan.tiled
+    np.testing.assert_array_equal(to_np(plan.T8), z["T8"])
+    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(z["img"]).to(d))), z["fwd_tiled_96x64"])
+
+
 def test_random_siddon_and_tiled_geometries(oracle):
     """Seeded random cases for the two other projectors: the TomoPy-style one (odd / rectangular grids, padded and not,
     angles of every quadrant incl. exactly axis-aligned ones, where the bisection of the crossing lists falls back to
