@@ -6,11 +6,18 @@
 //   floor + four zero-filled taps.  The zero-padded canvas of pad_phantom is never materialised: a
 //   tap is live only if it lands in the H x W core that sits at (py, px) of the PH x PW canvas.
 //
-// Work decomposition (MI355X): one workgroup = one slice x one group of angles.  The slice is staged
-// once into LDS (row pitch W+1 so that a wave walking a column at theta ~ 90 deg does not hit one
-// bank) and every lane owns one ray (angle a, detector bin j), walking the canvas rows i = 0..PH-1 in
-// order -- the same summation order as reduce_sum(axis=1) on the reference, so results are
-// reproducible bit for bit against the CPU restatement.
+// Kernels in this file (the gather-plan kernels, which serve batched NEAREST projection of slices that fit LDS, are
+// in rotate_plan.hip):
+//   rotate_fwd_fast_kernel        direct forward out of a zero-bordered LDS copy of the slice: bilinear, unpadded
+//                                 canvases, and -- TILED -- slices larger than LDS (512 x 512), cut into 64 x 96 tiles
+//                                 that are each staged once for all angles, 4 slices interleaved per LDS pixel;
+//   rotate_tile_reduce_kernel     adds the tiles' partial sinograms in tile order (+ the log-likelihood epilogue);
+//   rotate_bwd_tfcompat_seg_kernel  direct NEAREST backward: an 80-bin cotangent segment per angle and pixel tile;
+//   rotate_bwd_tfcompat_fast_kernel bilinear backward (whole cotangent rows in LDS);
+//   rotate_fwd_kernel, rotate_bwd_tfcompat_kernel, rotate_bwd_exact_kernel   generic fallbacks, exact transpose.
+// Every lane owns one ray (angle a, detector bin j) and walks canvas rows in ascending order -- the summation order of
+// reduce_sum(axis=1) as the CPU restatement fixes it -- or, tiled, the rows inside each tile and then the tiles in
+// order (oracle_rotate_fwd_tiled); results are reproducible bit for bit against the restatement either way.
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>

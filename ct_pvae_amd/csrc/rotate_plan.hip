@@ -17,12 +17,13 @@
 //                               is outside the H x W core or the row is past the canvas.
 //                rng[a][jb]   : first row-group and group count (multiple of 4) that any of the 64 rays of bin
 //                               block jb needs -- the kernel's wave-uniform loop bounds.
+//                clist[c]     : (count, angles of class c ascending) -- the planned kernel's task lists.
 //                cls[a]       : 1 if lanes walk the slice with column and row moving the same way, else 0; for
 //                               class 0 the slice is staged (and indexed) column-mirrored, so that consecutive
 //                               detector bins always advance by |dx| + |dy| in [1, 1.42] LDS banks: at most two
 //                               lanes of a 32-lane group share a bank at any angle.
-// Backward plan  idx[a8][y][x]: uint4 = for angles 8*a8..8*a8+7, the dword index of the cotangent cell
-//                               (a * pitchg + bin) that TensorFlow's gradient op reads for pixel (y, x), or `zero`.
+// Backward plan  idx[a16][y][x]: uint4 = for angles 16*a16..16*a16+15, one BYTE each: the detector bin that
+//                               TensorFlow's gradient op reads for pixel (y, x), or 255 (a cell holding 0.0f).
 #include <algorithm>
 #include <atomic>
 #include <climits>
