@@ -43,6 +43,8 @@ def parse():
                     help="projector: the headline fwd+adj metric, BASELINE config 2 (default; --angles 180 = config 4's "
                          "per-GPU share); train: config 3, P-VAE steps/s; siddon: config 1, TomoPy-style forward; "
                          "n512: config 5, 512x512 x 90 angles fwd + log-likelihood + adj")
+    ap.add_argument("--n512-batch", type=int, default=32,
+                    help="objects per GPU in --mode n512 (32: 768 tile workgroups = 3 full rounds on 256 CUs; 8: 192)")
     return ap.parse_args()
 
 
@@ -186,7 +188,7 @@ def n512_mode(args, world, rank, dev):
     for all angles with 4 slices interleaved per workgroup; the backward stages an 80-bin cotangent segment per angle
     and pixel tile."""
     from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
-    B, N, A = 8, 512, 90
+    B, N, A = args.n512_batch, 512, 90   # SURVEY 8d c5: B per GPU chosen to fill the chip with whole rounds of workgroups
     theta = np.pi * np.arange(A) / A
     plan = RotatePlan(theta, N, N, True, dev)
     x = torch.rand((B, N, N), device=dev)
