@@ -540,3 +540,36 @@ def test_random_siddon_and_tiled_geometries(oracle):
         np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
                                       oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0),
                                       err_msg=f"segment bwd case {case}: {H}x{W} pad={pad} A={A} S={S}")
+
+
+def test_launches_are_graph_capturable():
+    """The library allocates nothing and never synchronises, so a caller can capture its launches into a HIP graph
+    (torch.cuda.graph) and replay them: same results as eager launches."""
+    d = dev()
+    theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
+    plan = RotatePlan(theta, 128, 128, True, d)
+    x = torch.rand((6, 128, 128), device=d)
+    g = torch.rand((6, 20, 184), device=d)
+    sino, gimg = torch.empty((6, 20, 184), device=d), torch.empty_like(x)
+
+    def step():
+        plan.forward(x, out=sino)
+        plan.backward(g, out=gimg)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                  # warm-up off the default stream (plans, one-time attributes)
+        step()
+    torch.cuda.synchronize()
+    want_s, want_g = sino.clone(), gimg.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    sino.zero_()
+    gimg.zero_()
+    x2 = torch.rand_like(x)
+    x.copy_(x2)                                     # new input in the captured buffers
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gimg, want_g)                # same cotangent -> same gradient image
+    assert torch.equal(sino, plan.forward(x2))      # the replay projected the new input
+    assert not torch.equal(sino, want_s)
