@@ -187,7 +187,6 @@ def n512_mode(args, world, rank, dev):
     log-likelihood + backward.  The slice (1 MiB) does not fit LDS: the forward cuts it into 64x96 tiles, each staged once
     for all angles with 4 slices interleaved per workgroup; the backward stages an 80-bin cotangent segment per angle
     and pixel tile."""
-    from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
     B, N, A = args.n512_batch, 512, 90   # SURVEY 8d c5: B per GPU chosen to fill the chip with whole rounds of workgroups
     theta = np.pi * np.arange(A) / A
     plan = RotatePlan(theta, N, N, True, dev)

@@ -60,7 +60,6 @@ def _dp_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    from ct_pvae_amd import sharding
     torch.cuda.set_device(0)                      # both ranks share the box's one GPU; gloo carries the gradients
     dist.init_process_group("gloo")
     args = tr.get_args("--nsa 20 --td 8 -b 4 --ns 1 --api 10 --pnm 1e4 --normal -i 3 --train".split())
