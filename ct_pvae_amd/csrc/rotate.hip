@@ -831,8 +831,11 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
                                                                       const float *__restrict__ Tinv8, int chunk_a,
                                                                       float *__restrict__ gimg)
 {
-    extern __shared__ float lds[];   // [chunk_a][kSegPitch] segments, then [chunk_a][2] ints (first bin, class)
+    // [chunk_a][kSegPitch] segments, then per angle: (first bin, class) ints and (t0, t1, t2, segment byte base) for
+    // the all-inside fast loop, which reads everything it needs per angle with one broadcast ds_read_b128
+    extern __shared__ float lds[];
     int *meta = reinterpret_cast<int *>(lds + chunk_a * kSegPitch);
+    f32x4 *meta4 = reinterpret_cast<f32x4 *>(lds + ((chunk_a * (kSegPitch + 2) + 3) & ~3));
     const int s = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -854,6 +857,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
     for (int ac = 0; ac < g.A; ac += chunk_a) {
         const int na = min(chunk_a, g.A - ac);
         if (ac > 0) __syncthreads();
+        int any_outside = 0;
         for (int al = threadIdx.x; al < na; al += blockDim.x) {
             const float *t = Tinv8 + 8 * (size_t)(ac + al);
             const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
@@ -872,8 +876,10 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
             }
             meta[2 * al] = first;
             meta[2 * al + 1] = cls;
+            meta4[al] = f32x4{t0, t1, t2, __int_as_float((al * kSegPitch - first) * 4 + lds_base)};
+            any_outside |= cls;
         }
-        __syncthreads();
+        const bool all_inside = __syncthreads_or(any_outside) == 0;   // (also the barrier behind the table)
         const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
         {
             constexpr int U = 8;   // loads in flight per thread; unconditional (clamped), the select comes after
@@ -898,6 +904,50 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
         }
         __syncthreads();
 
+        if (all_inside) {
+            // Every angle of the chunk maps the whole tile inside the canvas (a padded canvas always does): no class
+            // test, no scalar loads -- the angle's three coefficients and segment base arrive with one broadcast
+            // ds_read_b128, fetched one angle ahead, and the gathers of angle al are consumed under those of al + 1.
+            auto taps = [&](const f32x4 m, float (&v)[PPT]) {
+                const float xa = m.x * fx;
+                const int k4 = __float_as_int(m.w);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const float x = (xa + m.y * fy[k]) + m.z;
+                    int addr;   // (round(x) - first) * 4 + segment base: one convert, one shift-add
+                    asm("v_cvt_rpi_i32_f32 %0, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(addr) : "v"(x), "v"(k4));
+                    v[k] = lds_abs(addr);
+                }
+            };
+            float va[PPT], vb[PPT];
+            f32x4 m = meta4[0];
+            f32x4 mn = meta4[min(1, na - 1)];
+            taps(m, va);
+            for (int al = 1; al + 1 < na; al += 2) {      // angles al (-> vb) and al + 1 (-> va)
+                m = mn;
+                mn = meta4[al + 1];
+                taps(m, vb);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+                m = mn;
+                mn = meta4[min(al + 2, na - 1)];
+                taps(m, va);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+            }
+            if ((na & 1) == 0) {                           // even count: one angle (na - 1) is still to be gathered
+                taps(mn, vb);
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+            }
+        } else
         for (int al = 0; al < na; ++al) {
             const float *t = Tinv8 + 8 * (size_t)(ac + al);   // wave-uniform: scalar loads
             const float t0 = t[0], t1 = t[1], t2 = t[2];
@@ -1229,7 +1279,7 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
         // 64-column x 32-row tiles, an 80-bin cotangent segment per angle in LDS (<= 31 KiB per chunk of angles)
         constexpr int kPpt = 8;
         const int chunk_a = std::min(A, 96);
-        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) + 2 * sizeof(int));
+        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) + 2 * sizeof(int) + 4 * sizeof(float)) + 16;
         const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * kPpt), S), block(256);
         hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<kPpt>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g,
                            T8_dev, chunk_a, gimg_dev);
