@@ -1277,12 +1277,18 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
     const RotGeom g{S, H, W, PH, PW, py, px, A};
     if (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
         // 64-column x 32-row tiles, an 80-bin cotangent segment per angle in LDS (<= 31 KiB per chunk of angles)
-        constexpr int kPpt = 8;
         const int chunk_a = std::min(A, 96);
         const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) + 2 * sizeof(int) + 4 * sizeof(float)) + 16;
-        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * kPpt), S), block(256);
-        hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<kPpt>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g,
-                           T8_dev, chunk_a, gimg_dev);
+        // 8 rows per lane (64 x 32 tiles); 4 (64 x 16) when that is what it takes to put ~2 workgroups on every CU
+        int ppt = (long long)S * ceil_div(W, 64) * ceil_div(H, 32) >= 512 ? 8 : 4;
+        if (const char *e = getenv("CTPVAE_TUNE_SEG_PPT")) ppt = atoi(e) == 4 ? 4 : 8;
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), S), block(256);
+        if (ppt == 8)
+            hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<8>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev,
+                               chunk_a, gimg_dev);
+        else
+            hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<4>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev,
+                               chunk_a, gimg_dev);
         CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_seg_kernel");
         return CTPVAE_OK;
     }
