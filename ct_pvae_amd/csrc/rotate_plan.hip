@@ -639,14 +639,19 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
             const long long wgs = 2ll * units * cand;
             const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand));
-            if (cand == 1 || cost < best * 0.98) {   // a tie goes to fewer, fatter workgroups
-                best = cost;
+            if (cand == 1 || cost <= best * 1.03) {   // a near-tie goes to more workgroups: more staging overlaps tasks
+                best = std::min(best == 0.0 ? cost : best, cost);
                 G = cand;
             }
         }
     }
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
-    const int waves = std::min(16, std::max(1, (T + 2 * G - 1) / (2 * G)));
+    // one wave per task of the busiest group, but never fewer than stage the unit in ONE batch of eight 16-byte loads
+    // per lane (64 KiB -> 8 waves): a workgroup of 6 waves spends two load round trips on its fill (B=50, G=5:
+    // 12.1 us with 6 waves, 8.7 us with 8)
+    const int stage_waves = (int)std::min<size_t>(16, ceil_div((int)(shmem / 1024), 8));
+    int waves = std::min(16, std::max(stage_waves, (T + 2 * G - 1) / (2 * G)));
+    if (const char *e = getenv("CTPVAE_TUNE_WAVES")) waves = std::max(1, std::min(16, atoi(e)));
     const int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
