@@ -329,11 +329,13 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
     // LDS pixel (r, c) is NS consecutive floats, one per slice of the group (a short last group repeats its last slice).
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+        if constexpr (NS == 1) {
+            stage_rows(lds + BORDER * pitch + BORDER, im, g.H, g.W, gfull.W, pitch, false, lane, wave, nwaves);
+        } else {
+            const float *srcs[NS];
 #pragma unroll
-        for (int n = 0; n < NS; ++n) {
-            const int sn = min(s + n, gfull.S - 1) - s;
-            stage_rows(lds + (BORDER * pitch + BORDER) * NS + n, im + (size_t)sn * gfull.H * gfull.W, g.H, g.W, gfull.W, pitch,
-                       false, lane, wave, nwaves, NS);
+            for (int n = 0; n < NS; ++n) srcs[n] = im + (size_t)(min(s + n, gfull.S - 1) - s) * gfull.H * gfull.W;
+            stage_rows_interleaved<NS>(lds + (BORDER * pitch + BORDER) * NS, srcs, g.H, g.W, gfull.W, pitch, lane, wave, nwaves);
         }
         for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
             const int r = p / pitch, c = p - r * pitch;
