@@ -74,10 +74,10 @@ __device__ __forceinline__ void stage_rows(float *lds, const float *__restrict__
 // NS slices interleaved per LDS pixel (pixel (r, c) = NS consecutive floats, one per slice): the NS float4 loads of a
 // 4-pixel unit are issued together -- one load round trip for all slices, not one per slice -- and written as four
 // NS-wide vectors (ds_write_b64 / _b128), a quarter of the LDS instructions of per-slice dword writes.
-// src[n] are the slices' first rows (same stride); needs cols % 4 == 0 and 16-byte aligned rows like stage_rows_v4.
+// src[n] are the slices' first rows (same stride), optionally column-mirrored; needs cols % 4 == 0 and 16-byte aligned rows like stage_rows_v4.
 template <int NS>
 __device__ __forceinline__ void stage_rows_interleaved_v4(float *lds, const float *const (&src)[NS], int rows, int cols,
-                                                          int src_stride, int pitch, int lane, int wave, int nwaves)
+                                                          int src_stride, int pitch, bool mirror, int lane, int wave, int nwaves)
 {
     typedef float vec_t __attribute__((ext_vector_type(NS)));
     const int ncb = (cols + 31) >> 5, npc = (ncb + 1) >> 1, nrq = (rows + 3) >> 2;
@@ -96,7 +96,8 @@ __device__ __forceinline__ void stage_rows_interleaved_v4(float *lds, const floa
             const bool ok = rq < nrq && r_[u] < rows && c_[u] < cols;
             const int rl = min(r_[u], rows - 1), cl = min(c_[u], cols - 4);   // unconditional, clamped loads
 #pragma unroll
-            for (int n = 0; n < NS; ++n) v[u][n] = *reinterpret_cast<const float4 *>(src[n] + (size_t)rl * src_stride + cl);
+            for (int n = 0; n < NS; ++n)
+                v[u][n] = *reinterpret_cast<const float4 *>(src[n] + (size_t)rl * src_stride + (mirror ? cols - 4 - cl : cl));
             if (!ok) r_[u] = -1;
             rq += d_rq;
             pc += d_pc;
@@ -112,10 +113,10 @@ __device__ __forceinline__ void stage_rows_interleaved_v4(float *lds, const floa
             vec_t w0, w1, w2, w3;
 #pragma unroll
             for (int n = 0; n < NS; ++n) {
-                w0[n] = v[u][n].x;
-                w1[n] = v[u][n].y;
-                w2[n] = v[u][n].z;
-                w3[n] = v[u][n].w;
+                w0[n] = mirror ? v[u][n].w : v[u][n].x;
+                w1[n] = mirror ? v[u][n].z : v[u][n].y;
+                w2[n] = mirror ? v[u][n].y : v[u][n].z;
+                w3[n] = mirror ? v[u][n].x : v[u][n].w;
             }
             d[0] = w0;
             d[1] = w1;
@@ -126,17 +127,17 @@ __device__ __forceinline__ void stage_rows_interleaved_v4(float *lds, const floa
 }
 template <int NS>
 __device__ __forceinline__ void stage_rows_interleaved(float *lds, const float *const (&src)[NS], int rows, int cols,
-                                                       int src_stride, int pitch, int lane, int wave, int nwaves)
+                                                       int src_stride, int pitch, bool mirror, int lane, int wave, int nwaves)
 {
     bool aligned = (cols & 3) == 0 && (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(lds) & (4 * NS - 1)) == 0;
 #pragma unroll
     for (int n = 0; n < NS; ++n) aligned = aligned && (reinterpret_cast<uintptr_t>(src[n]) & 15) == 0;
     if (aligned) {
-        stage_rows_interleaved_v4<NS>(lds, src, rows, cols, src_stride, pitch, lane, wave, nwaves);
+        stage_rows_interleaved_v4<NS>(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves);
     } else {
 #pragma unroll
         for (int n = 0; n < NS; ++n)
-            stage_rows_scalar(lds + n, src[n], rows, cols, src_stride, pitch, false, wave * 64 + lane, nwaves * 64, NS);
+            stage_rows_scalar(lds + n, src[n], rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64, NS);
     }
 }
 

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
             const float *srcs[NS];
 #pragma unroll
             for (int n = 0; n < NS; ++n) srcs[n] = im + (size_t)(min(s + n, gfull.S - 1) - s) * gfull.H * gfull.W;
-            stage_rows_interleaved<NS>(lds + (BORDER * pitch + BORDER) * NS, srcs, g.H, g.W, gfull.W, pitch, lane, wave, nwaves);
+            stage_rows_interleaved<NS>(lds + (BORDER * pitch + BORDER) * NS, srcs, g.H, g.W, gfull.W, pitch, false, lane, wave, nwaves);
         }
         for (int p = threadIdx.x; p < 2 * BORDER * pitch; p += blockDim.x) {
             const int r = p / pitch, c = p - r * pitch;

@@ -365,8 +365,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     if (threadIdx.x == 0) *next_task = nwaves;
 
     // Stage the slice(s): 16-byte loads, conflict-free ds_write_b32 (see stage_rows_v4).
-    stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves, NS);
-    if (NS == 2) stage_rows(lds + 1, im + (has2 ? (size_t)g.H * g.W : 0), g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves, NS);
+    if constexpr (NS == 1) {
+        stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+    } else {   // both slices of the pair in one load round trip, written as float2
+        const float *srcs[2] = {im, im + (has2 ? (size_t)g.H * g.W : 0)};
+        stage_rows_interleaved<2>(lds, srcs, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+    }
     if (threadIdx.x < NS) lds[L.zero * NS + threadIdx.x] = 0.0f;
     CTPVAE_PSTAMP(1);
     __syncthreads();
