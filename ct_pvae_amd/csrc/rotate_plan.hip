@@ -625,30 +625,55 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     CTPVAE_REQUIRE(fwd_plan_fits(g), "rotate_fwd_planned: a %dx%d slice does not fit the plan's LDS image", H, W);
     const FwdLayout L = fwd_layout(g);
     const int T = A * L.nJB;   // (angle, bin block) tasks per slice
-    // Two slices per workgroup (one index stream serves both) when the interleaved pair fits LDS and the launch has
-    // enough tasks that pairing still leaves >= ~8 tasks for every CU; otherwise one slice per workgroup.
-    int ns = ((size_t)(L.zero + 1) * 8 + 16 <= (size_t)kMaxLdsBytes && (long long)S * T >= 2ll * 256 * 8) ? 2 : 1;
-    if (const char *e = getenv("CTPVAE_TUNE_NS")) ns = atoi(e) == 2 ? 2 : 1;
-    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns + 16;   // + the task counter
-    const int units = (S + ns - 1) / ns;
-    // The tasks of one unit are dealt to G groups per mirror class.  What a launch costs is the bytes its busiest CU
-    // pulls through its L2->CU path: per workgroup one staged unit plus ~1 KB of indices per row
-    // group of each of its tasks; the busiest CU holds ceil(workgroups / 256) of them.  Take the G that minimises
-    // that (measured at B=50, A=20: G=2 10.3 us, G=4 10.9 us, G=3 12.2 us, as the model orders them); every group
-    // re-stages the unit, so beyond ~12 groups more workgroups cost more than they buy (B=5: 8.1 us at 12, 13.9 at 30).
-    int G = 1;
+    // Launch shape.  What a launch costs is the bytes its busiest CU pulls through its L2->CU path (DESIGN.md section
+    // 6): per workgroup one staged unit -- a slice, or a PAIR of slices interleaved as float2, whose index stream, unpack
+    // and ds_read_b64 serve both -- plus ~1 KB of indices per row group of each of its tasks; the busiest CU holds
+    // ceil(workgroups / 256) of them.  The tasks of a unit are dealt to G groups per mirror class; take the (pairing, G)
+    // that minimises the cost (measured at B=50, A=20: pairs G=5 7.9 us, singles G=5 8.9 us, G=2 10.3 us, G=3 12.3 us,
+    // as the model orders them).  Near-ties go to more workgroups (more staging overlaps tasks); every group re-stages
+    // the unit, so beyond ~12 groups more workgroups cost more than they buy (B=5: 8.1 us at 12, 13.9 us at 30).
+    const bool pairs_fit = (size_t)(L.zero + 1) * 8 + 16 <= (size_t)kMaxLdsBytes && S >= 2;
+    int ns = 1, G = 1;
     {
-        const double fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0, task_kb = 0.85 * L.NG;
+        const double task_kb = 0.85 * L.NG;
         double best = 0.0;
-        for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
-            const long long wgs = 2ll * units * cand;
-            const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand));
-            if (cand == 1 || cost <= best * 1.03) {   // a near-tie goes to more workgroups: more staging overlaps tasks
-                best = std::min(best == 0.0 ? cost : best, cost);
-                G = cand;
+        for (int cand_ns = 1; cand_ns <= (pairs_fit ? 2 : 1); ++cand_ns) {
+            const double fill_kb = (double)g.H * g.W * 4.0 * cand_ns / 1024.0;
+            const long long cand_units = (S + cand_ns - 1) / cand_ns;
+            // the index table is streamed into the L2 of every XCD that holds a unit (units are dealt to XCDs by
+            // octets); with few units and many angles that fabric traffic, not the CU's own path, is what pairing
+            // halves (B=8, A=180: 19 us single, 12 us paired).  In the same KB-per-CU currency, fabric at ~2/3 of
+            // the CUs' aggregate rate:
+            const double fabric_kb = 1.5 * ((double)L.bytes / 1024.0) * (double)std::min<long long>(8, cand_units) / 256.0;
+            for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
+                const long long wgs = 2ll * cand_units * cand;
+                const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand)) + fabric_kb;
+                if (best == 0.0 || cost <= best * 1.03) {
+                    best = best == 0.0 ? cost : std::min(best, cost);
+                    ns = cand_ns;
+                    G = cand;
+                }
             }
         }
     }
+    if (const char *e = getenv("CTPVAE_TUNE_NS")) {
+        const int want = atoi(e) == 2 ? 2 : 1;
+        if (want != ns) {   // forced pairing: best G for it
+            ns = want;
+            const double task_kb = 0.85 * L.NG, fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0;
+            const long long cand_units = (S + ns - 1) / ns;
+            double best = 0.0;
+            for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
+                const double cost = (double)((2ll * cand_units * cand + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand));
+                if (best == 0.0 || cost <= best * 1.03) {
+                    best = best == 0.0 ? cost : std::min(best, cost);
+                    G = cand;
+                }
+            }
+        }
+    }
+    const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns + 16;   // + the task counter
+    const int units = (S + ns - 1) / ns;
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     // one wave per task of the busiest group, but never fewer than stage the unit in ONE batch of eight 16-byte loads
     // per lane (64 KiB -> 8 waves): a workgroup of 6 waves spends two load round trips on its fill (B=50, G=5:
