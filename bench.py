@@ -259,9 +259,11 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
 
     # ---- per-kernel durations, HIP events on the launch stream (torch's current stream) -------------------
-    # One event pair brackets n_ev back-to-back launches of ONE kernel: an event per launch costs ~1.5 us of stream
-    # time and would be charged to the kernel; this way the figure is the kernel plus the dispatch gap to its successor,
-    # which is what a stream of them costs (rocprofv3's per-dispatch average, profiles/, excludes that gap).
+    # One event pair brackets n_ev back-to-back launches of ONE kernel: the average duration of a launch in a stream of
+    # them.  (An event pair per launch does not work on this stack: two events with nothing between them read ~5 us
+    # apart, and subtracting that under-reads the kernel.)  rocprofv3's per-dispatch average (profiles/) is the span
+    # first-wave-start -> last-wave-end of one dispatch, which overlaps its neighbours' ramp and drain: it reads ~10 %
+    # higher (8.8 + 8.2 us) than these (7.9 + 7.4 us), whose sum matches the measured 15.6 us per step.
     n_ev = min(max(args.steps, 50), 400)
 
     def avg_launch_seconds(fn):
