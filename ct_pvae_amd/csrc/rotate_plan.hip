@@ -436,65 +436,80 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     CTPVAE_PSTAMP(3);
 }
 
-// four byte taps of one dword -> four LDS byte offsets inside a cotangent row (SDWA: select a byte, shift by 2)
+// four byte taps of one dword -> four LDS byte offsets inside a cotangent row (SDWA: select a byte, shift by
+// log2(bytes per cell): 2, or 3 when two slices are interleaved as float2)
+template <int SHIFT>
 __device__ __forceinline__ void unpack4(unsigned pk, int &b0, int &b1, int &b2, int &b3)
 {
-    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(b0) : "v"(pk));
-    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(b1) : "v"(pk));
-    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(b2) : "v"(pk));
-    asm("v_lshlrev_b32_sdwa %0, 2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(b3) : "v"(pk));
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(b0) : "v"(pk), "i"(SHIFT));
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(b1) : "v"(pk), "i"(SHIFT));
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(b2) : "v"(pk), "i"(SHIFT));
+    asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(b3) : "v"(pk), "i"(SHIFT));
+}
+template <int NS> __device__ __forceinline__ typename SliceVec<NS>::type lds_at_vec(const float *lds, int byte_off)
+{
+    return *reinterpret_cast<const typename SliceVec<NS>::type *>(reinterpret_cast<const char *>(lds) + byte_off);
 }
 // the 16 taps of `q` are staged rows AL0 .. AL0+15: the row offset is a compile-time ds_read immediate, the address
-// VGPR is just the SDWA-extracted bin * 4 -- no address arithmetic per tap
-template <int AL0>
-__device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_live, float (&v)[16])
+// VGPR is just the SDWA-extracted bin * cell size -- no address arithmetic per tap
+template <int AL0, int NS>
+__device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_live, typename SliceVec<NS>::type (&v)[16])
 {
     // n_live (wave-uniform): staged rows AL0 .. AL0+n_live-1 exist; a partial last group skips whole dwords of taps
+    constexpr int ROW = kBwdPitch * 4 * NS;   // bytes per staged row
     const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         if (4 * d < n_live) {
             int b0, b1, b2, b3;
-            unpack4(w[d], b0, b1, b2, b3);
-            v[4 * d + 0] = lds_at(lds, b0 + (AL0 + 4 * d + 0) * kBwdPitch * 4);
-            v[4 * d + 1] = lds_at(lds, b1 + (AL0 + 4 * d + 1) * kBwdPitch * 4);
-            v[4 * d + 2] = lds_at(lds, b2 + (AL0 + 4 * d + 2) * kBwdPitch * 4);
-            v[4 * d + 3] = lds_at(lds, b3 + (AL0 + 4 * d + 3) * kBwdPitch * 4);
+            unpack4<NS == 1 ? 2 : 3>(w[d], b0, b1, b2, b3);
+            v[4 * d + 0] = lds_at_vec<NS>(lds, b0 + (AL0 + 4 * d + 0) * ROW);
+            v[4 * d + 1] = lds_at_vec<NS>(lds, b1 + (AL0 + 4 * d + 1) * ROW);
+            v[4 * d + 2] = lds_at_vec<NS>(lds, b2 + (AL0 + 4 * d + 2) * ROW);
+            v[4 * d + 3] = lds_at_vec<NS>(lds, b3 + (AL0 + 4 * d + 3) * ROW);
         } else {
             v[4 * d + 0] = v[4 * d + 1] = v[4 * d + 2] = v[4 * d + 3] = 0.0f;
         }
     }
 }
 
-// Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x (4 x PPT)-row tile): stages a chunk of the
-// slice's cotangent rows (257-dword rows, zeros behind the bins), then every lane owns one column and PPT rows; for
+// Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x (waves x PPT)-row tile): stages a chunk of the
+// slice's cotangent rows (257-cell rows, zeros behind the bins), then every lane owns one column and PPT rows; for
 // each group of sixteen angles it loads the PPT index vectors (16 B = 16 taps), gathers and adds in angle order.
-template <int PPT, int MAXT>
+// NS = 2: two slices per workgroup, their cotangent rows fetched together and interleaved as float2 -- one index
+// stream, one SDWA unpack and one ds_read_b64 per tap serve both (rows are then 2056 B, so a chunk is 32 angles to keep
+// the row offsets immediates).
+template <int PPT, int MAXT, int NS>
 __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y, int g_S,
                                                                  float *__restrict__ gimg)
 {
+    typedef typename SliceVec<NS>::type vec_t;
+    constexpr int kChunk = kBwdChunk / NS;
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int tiles = L.nXB * tiles_y;
-    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only): the tiles of one slice are placed on one
-    // XCD so that its cotangent rows are fetched into one L2 -- block = (s / 8) * 8 * tiles + tile * 8 + s % 8.
-    int s, tile;
+    const int units = (g_S + NS - 1) / NS;
+    // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only): the tiles of one slice (pair) are placed
+    // on one XCD so that its cotangent rows are fetched into one L2 -- block = (u / 8) * 8 * tiles + tile * 8 + u % 8.
+    int u, tile;
     {
         const int per8 = 8 * tiles, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
-        if ((octet + 1) * 8 <= g_S) {
+        if ((octet + 1) * 8 <= units) {
             tile = rem >> 3;
-            s = octet * 8 + (rem & 7);
-        } else {   // the last, partial octet is laid out slice-major
-            s = octet * 8 + rem / tiles;
+            u = octet * 8 + (rem & 7);
+        } else {   // the last, partial octet is laid out unit-major
+            u = octet * 8 + rem / tiles;
             tile = rem - (rem / tiles) * tiles;
         }
     }
+    const int s = u * NS;
+    const bool has2 = NS == 2 && s + 1 < g_S;   // an odd batch ends with a half-empty pair (slice s staged twice)
     const int xb = tile % L.nXB, ty = tile / L.nXB;
     const float *gs = gsino + (size_t)s * g.A * g.PW;
     const int xcol = xb * 64 + lane;
     const int y0 = ty * (nwaves * PPT) + wave;   // this wave's rows: y0, y0 + nwaves, ...
-    float acc[PPT];
+    vec_t acc[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) acc[k] = 0.0f;
     const uint4 *p = idx + (size_t)xcol;
@@ -511,34 +526,42 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     };
     load_group(0);       // index loads fly while the cotangent rows land
 
-    for (int ac = 0; ac < g.A; ac += L.chunkA) {
-        const int na = min(L.chunkA, g.A - ac);
+    const int chunk = min(L.NA16 * 16, kChunk);
+    for (int ac = 0; ac < g.A; ac += chunk) {
+        const int na = min(chunk, g.A - ac);
         const int na4 = (na + 3) & ~3;              // taps are consumed a dword (4 angles) at a time
         if (ac > 0) __syncthreads();
         // a dead tap is byte 255: only cell 255 of every row (never a bin: PW <= 255) must hold 0.0f
-        for (int t = threadIdx.x; t < na4; t += blockDim.x) lds[t * kBwdPitch + 255] = 0.0f;
-        stage_rows(lds, gs + (size_t)ac * g.PW, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        for (int t = threadIdx.x; t < na4 * NS; t += blockDim.x) lds[((t / NS) * kBwdPitch + 255) * NS + (t % NS)] = 0.0f;
+        if constexpr (NS == 1) {
+            stage_rows(lds, gs + (size_t)ac * g.PW, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        } else {
+            const float *srcs[2] = {gs + (size_t)ac * g.PW, gs + (has2 ? (size_t)g.A * g.PW : 0) + (size_t)ac * g.PW};
+            stage_rows_interleaved<2>(lds, srcs, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        }
         __syncthreads();
         // up to four groups of sixteen staged angles, unrolled so that every row offset is an immediate
         auto group = [&](auto al_tag) {
             constexpr int AL = decltype(al_tag)::value;
-            if (AL >= na4) return;                       // wave-uniform
-            const int n_live = min(16, na4 - AL);
-            float v[PPT][16];
+            if constexpr (AL < kChunk) {
+                if (AL >= na4) return;                       // wave-uniform
+                const int n_live = min(16, na4 - AL);
+                vec_t v[PPT][16];
 #pragma unroll
 #ifdef CTPVAE_TUNE_BWD_NOLDS
-            for (int k = 0; k < PPT; ++k)   // timing only: no gathers, the index words stand in for the taps
-                for (int e = 0; e < 16; ++e) v[k][e] = __uint_as_float((&q[k].x)[e & 3] & 0x3fffffu);
+                for (int k = 0; k < PPT; ++k)   // timing only: no gathers, the index words stand in for the taps
+                    for (int e = 0; e < 16; ++e) v[k][e] = __uint_as_float((&q[k].x)[e & 3] & 0x3fffffu);
 #else
-            for (int k = 0; k < PPT; ++k) gather16<AL>(lds, q[k], n_live, v[k]);
+                for (int k = 0; k < PPT; ++k) gather16<AL, NS>(lds, q[k], n_live, v[k]);
 #endif
-            const int next = (ac + AL) / 16 + 1;         // all index vectors of this group consumed: prefetch the next
-            if (next < L.NA16) load_group(next);
-            __builtin_amdgcn_sched_barrier(0);
+                const int next = (ac + AL) / 16 + 1;         // all index vectors of this group consumed: prefetch the next
+                if (next < L.NA16) load_group(next);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < PPT; ++k)
+                for (int k = 0; k < PPT; ++k)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[k] += v[k][e];   // skipped taps hold +0.0f
+                    for (int e = 0; e < 16; ++e) acc[k] += v[k][e];   // skipped taps hold +0.0f
+            }
         };
         group(std::integral_constant<int, 0>{});
         group(std::integral_constant<int, 16>{});
@@ -549,7 +572,14 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int y = y0 + k * nwaves;
-            if (y < g.H) gimg[((size_t)s * g.H + y) * g.W + xcol] = acc[k];
+            if (y < g.H) {
+                if constexpr (NS == 1) {
+                    gimg[((size_t)s * g.H + y) * g.W + xcol] = acc[k];
+                } else {
+                    gimg[((size_t)s * g.H + y) * g.W + xcol] = acc[k].x;
+                    if (has2) gimg[((size_t)(s + 1) * g.H + y) * g.W + xcol] = acc[k].y;
+                }
+            }
         }
     }
 }
@@ -723,19 +753,29 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd_planned: the backward plan stores bins as bytes (PW=%d > 255)", PW);
     const BwdLayout L = bwd_layout(g);
-    const size_t shmem = (size_t)L.chunkA * L.pitchg * sizeof(float);
-    constexpr int kPpt = 4;
-    // Tile = 64 columns x (waves x 4) rows.  Every workgroup of a slice stages ALL the slice's cotangent rows: with many
+    // Two slices per workgroup (one index stream, one unpack and one ds_read_b64 per tap serve both; each lane then
+    // owns 2 rows instead of 4) once the batch is large enough to still fill the chip: measured B=50: 7.6 -> 6.4 us at
+    // A=20, 16.5 -> 13.8 us at A=90, 28.3 -> 25.4 us at A=180; a wash below ~32 slices.
+    int ns = S >= 32 ? 2 : 1;
+    if (const char *e = getenv("CTPVAE_TUNE_BNS")) ns = (atoi(e) == 2 && S >= 2) ? 2 : 1;
+    const int ppt = ns == 2 ? 2 : 4;
+    const int units = ceil_div(S, ns);
+    // staged chunk: up to 64 rows of one slice, or 32 rows of an interleaved pair
+    const size_t shmem = (size_t)std::min(L.NA16 * 16, kBwdChunk / ns) * L.pitchg * sizeof(float) * ns;
+    // Tile = 64 columns x (waves x ppt) rows.  Every workgroup of a slice stages ALL the slice's cotangent rows: with many
     // angles taller tiles amortise that staging (measured, B=50 A=180: 44 -> 28 us from 4 to 16 waves); with few angles
     // the staging is small and short tiles win, because four small workgroups per CU overlap each other's staging and
     // barrier waits while one 16-wave workgroup (114 VGPRs: one per CU) cannot (B=400 A=20: 34 us vs 45 us).
     int waves = 4;
-    if (A >= 32)
-        while (waves < 16 && (long long)S * L.nXB * ceil_div(H, 2 * waves * kPpt) >= 200 && waves * kPpt < H) waves *= 2;
+    if (ns == 2)
+        waves = A >= 64 ? 16 : 8;   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many (sweeps, tools/tune_rotate.hip)
+    else if (A >= 32)
+        while (waves < 16 && (long long)units * L.nXB * ceil_div(H, 2 * waves * ppt) >= 200 && waves * ppt < H) waves *= 2;
+    while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has
     if (const char *e = getenv("CTPVAE_TUNE_BW")) waves = std::min(16, std::max(1, atoi(e)));
-    const int rows_per_wg = waves * kPpt;
+    const int rows_per_wg = waves * ppt;
     const int tiles_y = ceil_div(H, rows_per_wg);
-    const long long nblk = (long long)S * L.nXB * tiles_y;
+    const long long nblk = (long long)units * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
         static std::atomic<bool> attr_set{false};   // one flag per instantiation
@@ -747,7 +787,12 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
                            (const uint4 *)bwd_plan_dev, tiles_y, S, gimg_dev);
         return CTPVAE_OK;
     };
-    if (int rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<kPpt, 256>) : launch(rotate_bwd_planned_kernel<kPpt, 1024>)) return rc;
+    int rc;
+    if (ns == 2)
+        rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<2, 256, 2>) : launch(rotate_bwd_planned_kernel<2, 1024, 2>);
+    else
+        rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<4, 256, 1>) : launch(rotate_bwd_planned_kernel<4, 1024, 1>);
+    if (rc) return rc;
     CTPVAE_LAUNCH_CHECK("rotate_bwd_planned_kernel");
     return CTPVAE_OK;
 }

@@ -237,6 +237,28 @@ def test_paired_slices_equal_single_slices(oracle, shape, pad, A, S, monkeypatch
     np.testing.assert_array_equal(to_np(two[-1:]), oracle.rotate_fwd(to_np(x[-1:]), geom, to_np(plan.T8), 0))
 
 
+@pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 5), ((128, 128), True, 180, 7), ((40, 100), True, 33, 3),
+                                          ((65, 31), False, 9, 1), ((2, 2), False, 2, 2), ((128, 128), True, 70, 40)])
+def test_paired_backward_equals_single(oracle, shape, pad, A, S, monkeypatch):
+    """The planned backward runs one or two slices per workgroup (two: cotangent rows fetched together and interleaved
+    as float2 behind one index stream, 32-angle chunks); both forms are the same operator bit for bit."""
+    d = dev()
+    rng = np.random.default_rng(A * 7 + S)
+    theta = rng.uniform(-1.0, 4.0, A)
+    plan = RotatePlan(theta, shape[0], shape[1], pad, d)
+    assert plan.planned[1]
+    g = torch.from_numpy(rng.standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
+    monkeypatch.setenv("CTPVAE_TUNE_BNS", "1")
+    one = plan.backward(g)
+    monkeypatch.setenv("CTPVAE_TUNE_BNS", "2")
+    two = plan.backward(g)
+    monkeypatch.delenv("CTPVAE_TUNE_BNS")
+    auto = plan.backward(g)
+    assert torch.equal(one, two) and torch.equal(one, auto)
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    np.testing.assert_array_equal(to_np(two[-1:]), oracle.rotate_bwd_tfcompat(to_np(g[-1:]), geom, to_np(plan.Tinv8), 0))
+
+
 def test_mixed_planned_forward_direct_backward(oracle):
     """192x192: the slice still fits the forward plan's LDS image (148 KiB), but P = 274 bins do not fit the backward
     plan's byte taps -- forward planned, backward direct, both bit-exact."""
