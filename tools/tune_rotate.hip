@@ -115,14 +115,17 @@ int main(int argc, char **argv)
     const ctpvae::RotGeom geo{S, N, N, P, P, pad, pad, A};
     const size_t lds = (size_t)(N + 2) * 161 * 4;
 #ifdef CTPVAE_TUNE_STAMPS
-    for (int Gs : {2, 3, 4, 5}) {
+    for (int cfg : {15, 25, 24}) {   // (slices per workgroup, groups)
+        const int Gs = cfg % 10, nsl = cfg / 10;
         char gb[16]; snprintf(gb, 16, "%d", Gs); setenv("CTPVAE_TUNE_G", gb, 1);
+        snprintf(gb, 16, "%d", nsl); setenv("CTPVAE_TUNE_NS", gb, 1);
         void *fp; CK(hipMalloc(&fp, ctpvae_rotate_plan_bytes(N, N, P, P, A, 0)));
         ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, fp, nullptr, nullptr);
         for (int rep = 0; rep < 2; ++rep) { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); CK(hipDeviceSynchronize()); }
         const int G = Gs;
-        const int T = A * 3, wv = std::min(16, (T + 2 * G - 1) / (2 * G)), nw = S * 2 * G * wv;
-        printf("G=%d: %d workgroups x %d waves\n", G, S * 2 * G, wv);
+        const int units = (S + nsl - 1) / nsl;
+        const int T = A * 3, wv = std::min(16, std::max(nsl == 2 ? 16 : 8, (T + 2 * G - 1) / (2 * G))), nw = units * 2 * G * wv;
+        printf("NS=%d G=%d: %d workgroups x %d waves\n", nsl, G, units * 2 * G, wv);
         std::vector<long long> st(8 * nw);
         CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(ctpvae::g_pstamps), st.size() * 8));
         double seg[3] = {0, 0, 0};
