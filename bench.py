@@ -262,8 +262,8 @@ def main():
     # One event pair brackets n_ev back-to-back launches of ONE kernel: the average duration of a launch in a stream of
     # them.  (An event pair per launch does not work on this stack: two events with nothing between them read ~5 us
     # apart, and subtracting that under-reads the kernel.)  rocprofv3's per-dispatch average (profiles/) is the span
-    # first-wave-start -> last-wave-end of one dispatch, which overlaps its neighbours' ramp and drain: it reads ~10 %
-    # higher (8.8 + 8.2 us) than these (7.9 + 7.4 us), whose sum matches the measured 15.6 us per step.
+    # first-wave-start -> last-wave-end of one dispatch, which can overlap its neighbours' ramp and drain: it reads a few
+    # per cent off these (8.4 / 6.7 us against 8.1 / 6.8 us here), whose sum matches the measured step.
     n_ev = min(max(args.steps, 50), 400)
 
     def avg_launch_seconds(fn):
