@@ -611,19 +611,23 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 }
 
 // sino[s][a][j] = sum over tiles, ascending, of the partial sums of the tiles whose slot range holds bin j.
-// One wave = 64 consecutive bins of one (slice, angle): it first lists, in ascending order, the tiles whose slot range
-// touches its bins (about a quarter of them), then adds their partial sums.
-constexpr int kMaxTiles = 1024;
+// Workgroup = up to 1024 bins of one (slice, angle); every wave owns 64 consecutive bins: it lists, 64 tiles at a time
+// and in ascending order, the tiles whose slot range touches its bins (about a quarter of them: ballot + popcount into
+// a per-wave LDS list), then adds their partial sums, eight loads in flight.
 template <bool EPI>   // EPI: also write the log-probability of the measured sample under every ray-sum (loglik_math.h)
-__global__ __launch_bounds__(64) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
-                                                                const float *__restrict__ T8, float *__restrict__ sino,
-                                                                LogLikEpilogue epi)
+__global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
+                                                                  const float *__restrict__ T8, float *__restrict__ sino,
+                                                                  LogLikEpilogue epi)
 {
-    __shared__ int list_tile[kMaxTiles], list_first[kMaxTiles];
-    const int lane = threadIdx.x, j0 = blockIdx.x * 64, j = j0 + lane, a = blockIdx.y, s = blockIdx.z;
+    __shared__ int list_tile[16][64], list_first[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64, j = j0 + lane, a = blockIdx.y, s = blockIdx.z;
+    if (j0 >= g.PW) return;                         // (whole waves only: no barrier below)
     const float *t = T8 + 8 * a;
     const int nt = ts.ntx * ts.nty;
-    int n = 0;
+    const float *pa = partial + ((size_t)s * nt * g.A + a) * ts.nb;   // tile stride: A * nb
+    const size_t tstride = (size_t)g.A * ts.nb;
+    float acc = 0.0f;
     for (int base = 0; base < nt; base += 64) {
         const int tile = base + lane;
         bool rel = false;
@@ -636,32 +640,30 @@ __global__ __launch_bounds__(64) void rotate_tile_reduce_kernel(const float *__r
             rel = fb <= j0 + 63 && fb + ts.nb > j0;
         }
         const unsigned long long m = __ballot(rel);
+        const int n = __popcll(m);
         if (rel) {
-            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            list_tile[pos] = tile;
-            list_first[pos] = fb;
+            const int pos = __popcll(m & ((1ull << lane) - 1ull));
+            list_tile[wave][pos] = tile;
+            list_first[wave][pos] = fb;
         }
-        n += __popcll(m);
+        __builtin_amdgcn_wave_barrier();              // the list is this wave's own: LDS writes are in order
+        constexpr int U = 8;   // loads in flight; unconditional (slot clamped to a valid cell), the select comes after
+        for (int i0 = 0; i0 < n; i0 += U) {
+            float v[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(i0 + u, n - 1);
+                const int slot = j - list_first[wave][i];
+                ok[u] = i0 + u < n && j < g.PW && (unsigned)slot < (unsigned)ts.nb;
+                v[u] = pa[list_tile[wave][i] * tstride + (ok[u] ? slot : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += ok[u] ? v[u] : 0.0f;   // + 0.0f leaves the sum unchanged
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
     if (j >= g.PW) return;
-    const float *pa = partial + ((size_t)s * nt * g.A + a) * ts.nb;   // tile stride: A * nb
-    const size_t tstride = (size_t)g.A * ts.nb;
-    float acc = 0.0f;
-    constexpr int U = 8;   // loads in flight; unconditional (slot clamped to a valid cell), the select comes after
-    for (int i0 = 0; i0 < n; i0 += U) {
-        float v[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u, n - 1);
-            const int slot = j - list_first[i];
-            ok[u] = i0 + u < n && (unsigned)slot < (unsigned)ts.nb;
-            v[u] = pa[list_tile[i] * tstride + (ok[u] ? slot : 0)];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) acc += ok[u] ? v[u] : 0.0f;   // + 0.0f leaves the sum unchanged
-    }
     const size_t o = ((size_t)s * g.A + a) * g.PW + j;
     sino[o] = acc;
     if constexpr (EPI) epi.lp[o] = gaussian_poisson_logp(acc, epi.mask[(size_t)s * g.A + a], epi.meas[o], *epi.pnm, epi.eps);
@@ -1212,7 +1214,6 @@ static int launch_fwd_tiled(const float *img_dev, int S, int H, int W, int PH, i
     CTPVAE_REQUIRE(ts.ntx > 0, "rotate_fwd_tiled: a %dx%d slice fits LDS whole; call ctpvae_rotate_fwd_f32", H, W);
     const int nt = ts.ntx * ts.nty, groups = ceil_div(S, ns);
     CTPVAE_REQUIRE((long long)groups * nt <= 65535, "rotate_fwd_tiled: at most 65535 tiles per call (got %lld)", (long long)groups * nt);
-    CTPVAE_REQUIRE(nt <= kMaxTiles, "rotate_fwd_tiled: at most %d tiles per slice (got %d)", kMaxTiles, nt);
     const size_t lds_bytes = tile_lds_bytes(ts, ns);
     // a copy of the transform rows behind the tile, when it fits
     const size_t t8_need = (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int);   // + class list + task counter
@@ -1244,11 +1245,13 @@ static int launch_fwd_tiled(const float *img_dev, int S, int H, int W, int PH, i
     else
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 1>);
     if (rc) return rc;
+    const int rwaves = std::min(16, ceil_div(PW, 64));   // waves per workgroup: 64 bins each
+    const dim3 rgrid(ceil_div(PW, 64 * rwaves), A, S), rblock(64 * rwaves);
     if (epi.lp)
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<true>, dim3(ceil_div(PW, 64), A, S), dim3(64), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream,
                            (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
     else
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<false>, dim3(ceil_div(PW, 64), A, S), dim3(64), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream,
                            (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
     CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
     return CTPVAE_OK;
