@@ -830,17 +830,21 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_fast_kernel(const flo
 //   2  the segment would not hold the span (the table row is not a rotation): bounds-tested reads from global memory.
 // Every pixel adds its angles in ascending order (bit-identical to the oracle), whatever the class.
 constexpr int kSegBins = 80, kSegPitch = kSegBins + 1;   // cell kSegBins of every segment is 0.0f
-template <int PPT>
+template <int PPT, int NS>   // NS = 2: two slices per workgroup, segments interleaved as float2 -- one coordinate, one
+                             // convert, one address and one ds_read_b64 per tap serve both slices
 __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const float *__restrict__ gsino, RotGeom g,
                                                                       const float *__restrict__ Tinv8, int chunk_a,
                                                                       float *__restrict__ gimg)
 {
-    // [chunk_a][kSegPitch] segments, then per angle: (first bin, class) ints and (t0, t1, t2, segment byte base) for
-    // the all-inside fast loop, which reads everything it needs per angle with one broadcast ds_read_b128
+    typedef typename PixVec<NS>::type vec_t;
+    constexpr int SHIFT = NS == 1 ? 2 : 3;
+    // [chunk_a][kSegPitch] segment cells (NS floats each), then per angle: (first bin, class) ints and (t0, t1, t2,
+    // segment byte base) for the all-inside fast loop, which reads all it needs per angle with one broadcast ds_read_b128
     extern __shared__ float lds[];
-    int *meta = reinterpret_cast<int *>(lds + chunk_a * kSegPitch);
-    f32x4 *meta4 = reinterpret_cast<f32x4 *>(lds + ((chunk_a * (kSegPitch + 2) + 3) & ~3));
-    const int s = blockIdx.z;
+    int *meta = reinterpret_cast<int *>(lds + chunk_a * kSegPitch * NS);
+    f32x4 *meta4 = reinterpret_cast<f32x4 *>(lds + ((chunk_a * (kSegPitch * NS + 2) + 3) & ~3));
+    const int s = blockIdx.z * NS;
+    const bool has2 = NS == 2 && s + 1 < g.S;     // an odd batch ends with a half-empty pair (slice s read twice)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
@@ -851,7 +855,8 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
     const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
     const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
 
-    float acc[PPT], fy[PPT];
+    vec_t acc[PPT];
+    float fy[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         acc[k] = 0.0f;
@@ -880,16 +885,17 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
             }
             meta[2 * al] = first;
             meta[2 * al + 1] = cls;
-            meta4[al] = f32x4{t0, t1, t2, __int_as_float((al * kSegPitch - first) * 4 + lds_base)};
+            meta4[al] = f32x4{t0, t1, t2, __int_as_float((al * kSegPitch - first) * 4 * NS + lds_base)};
             any_outside |= cls;
         }
         const bool all_inside = __syncthreads_or(any_outside) == 0;   // (also the barrier behind the table)
         const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
+        const size_t src2 = has2 ? (size_t)g.A * g.PW : 0;      // offset of the pair's second slice
         {
-            constexpr int U = 8;   // loads in flight per thread; unconditional (clamped), the select comes after
+            constexpr int U = 8 / NS;   // cells in flight per thread; loads unconditional (clamped), the select comes after
             const int ncell = na * kSegPitch;
             for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
-                float v[U];
+                vec_t v[U];
                 bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -897,12 +903,18 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
                     const int al = p / kSegPitch, q = p - al * kSegPitch;
                     const int j = meta[2 * al] + q;
                     ok[u] = q < kSegBins && (unsigned)j < (unsigned)g.PW;
-                    v[u] = src[al * g.PW + min(max(j, 0), g.PW - 1)];
+                    const float *cell = src + al * g.PW + min(max(j, 0), g.PW - 1);
+                    if constexpr (NS == 1) {
+                        v[u] = cell[0];
+                    } else {
+                        v[u].x = cell[0];
+                        v[u].y = cell[src2];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int p = p0 + u * (int)blockDim.x;
-                    if (p < ncell) lds[p] = ok[u] ? v[u] : 0.0f;
+                    if (p < ncell) reinterpret_cast<vec_t *>(lds)[p] = ok[u] ? v[u] : vec_t(0.0f);
                 }
             }
         }
@@ -912,18 +924,18 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
             // Every angle of the chunk maps the whole tile inside the canvas (a padded canvas always does): no class
             // test, no scalar loads -- the angle's three coefficients and segment base arrive with one broadcast
             // ds_read_b128, fetched one angle ahead, and the gathers of angle al are consumed under those of al + 1.
-            auto taps = [&](const f32x4 m, float (&v)[PPT]) {
+            auto taps = [&](const f32x4 m, vec_t (&v)[PPT]) {
                 const float xa = m.x * fx;
                 const int k4 = __float_as_int(m.w);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k) {
                     const float x = (xa + m.y * fy[k]) + m.z;
-                    int addr;   // (round(x) - first) * 4 + segment base: one convert, one shift-add
-                    asm("v_cvt_rpi_i32_f32 %0, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(addr) : "v"(x), "v"(k4));
-                    v[k] = lds_abs(addr);
+                    int addr;   // (round(x) - first) * cell bytes + segment base: one convert, one shift-add
+                    asm("v_cvt_rpi_i32_f32 %0, %1\n\tv_lshl_add_u32 %0, %0, %3, %2" : "=&v"(addr) : "v"(x), "v"(k4), "i"(SHIFT));
+                    v[k] = lds_abs_vec<NS>(addr);
                 }
             };
-            float va[PPT], vb[PPT];
+            vec_t va[PPT], vb[PPT];
             f32x4 m = meta4[0];
             f32x4 mn = meta4[min(1, na - 1)];
             taps(m, va);
@@ -954,37 +966,28 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
         } else
         for (int al = 0; al < na; ++al) {
             const float *t = Tinv8 + 8 * (size_t)(ac + al);   // wave-uniform: scalar loads
-            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
             const int first = __builtin_amdgcn_readfirstlane(meta[2 * al]);
             const int cls = __builtin_amdgcn_readfirstlane(meta[2 * al + 1]);
-            const float xa = t0 * fx;
-            if (cls == 0) {
-                const int k4 = __builtin_amdgcn_readfirstlane((al * kSegPitch - first) * 4 + lds_base);
-                float v[PPT];
+            const float xa = t0 * fx, ya = t3 * fx;
+            const vec_t *seg = reinterpret_cast<const vec_t *>(lds) + al * kSegPitch;
+            const float *grow = src + (size_t)al * g.PW;
 #pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    const float x = (xa + t1 * fy[k]) + t2;
-                    int addr;   // (round(x) - first) * 4 + segment base: one convert, one shift-add
-                    asm("v_cvt_rpi_i32_f32 %0, %1\n\tv_lshl_add_u32 %0, %0, 2, %2" : "=&v"(addr) : "v"(x), "s"(k4));
-                    v[k] = lds_abs(addr);
-                }
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) acc[k] += v[k];
-            } else {
-                const float t3 = t[3], t4 = t[4], t5 = t[5];
-                const float ya = t3 * fx;
-                const float *seg = lds + al * kSegPitch;
-                const float *grow = src + (size_t)al * g.PW;
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) {
-                    const float x = (xa + t1 * fy[k]) + t2;
-                    const float y = (ya + t4 * fy[k]) + t5;
-                    const bool ok = (x > -0.5f) & (x < x_hi) & (y > -0.5f) & (y < y_hi);
-                    const int ix = ok ? cvt_rpi(x) : 0;
-                    if (cls == 1)
-                        acc[k] += seg[ok ? ix - first : kSegBins];
-                    else
-                        acc[k] += ok ? grow[ix] : 0.0f;
+            for (int k = 0; k < PPT; ++k) {
+                const float x = (xa + t1 * fy[k]) + t2;
+                const float y = (ya + t4 * fy[k]) + t5;
+                // class 0 needs no test; classes 1 and 2 apply the reference's zero fill
+                const bool ok = cls == 0 || ((x > -0.5f) & (x < x_hi) & (y > -0.5f) & (y < y_hi));
+                const int ix = ok ? cvt_rpi(x) : 0;
+                if (cls != 2) {
+                    acc[k] += seg[ok ? ix - first : kSegBins];
+                } else if constexpr (NS == 1) {
+                    acc[k] += ok ? grow[ix] : 0.0f;
+                } else {
+                    vec_t gv;
+                    gv.x = ok ? grow[ix] : 0.0f;
+                    gv.y = ok ? grow[src2 + ix] : 0.0f;
+                    acc[k] += gv;
                 }
             }
         }
@@ -993,7 +996,14 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int r = r0 + k * nwaves;
-            if (r < g.H) gimg[((size_t)s * g.H + r) * g.W + c] = acc[k];
+            if (r < g.H) {
+                if constexpr (NS == 1) {
+                    gimg[((size_t)s * g.H + r) * g.W + c] = acc[k];
+                } else {
+                    gimg[((size_t)s * g.H + r) * g.W + c] = acc[k].x;
+                    if (has2) gimg[((size_t)(s + 1) * g.H + r) * g.W + c] = acc[k].y;
+                }
+            }
         }
     }
 }
@@ -1282,18 +1292,25 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
     const RotGeom g{S, H, W, PH, PW, py, px, A};
     if (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
         // 64-column x 32-row tiles, an 80-bin cotangent segment per angle in LDS (<= 31 KiB per chunk of angles)
-        const int chunk_a = std::min(A, 96);
-        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) + 2 * sizeof(int) + 4 * sizeof(float)) + 16;
+        // two slices per workgroup (shared coordinates and addresses, ds_read_b64) once the batch can spare the workgroups
+        int ns = S >= 16 ? 2 : 1;
+        if (const char *e = getenv("CTPVAE_TUNE_SEG_NS")) ns = (atoi(e) == 2 && S >= 2) ? 2 : 1;
+        const int units = ceil_div(S, ns);
+        int chunk_a = std::min(A, ns == 2 ? 48 : 96);   // ~32 KiB of LDS either way: five 4-wave workgroups per CU
+        if (const char *e = getenv("CTPVAE_TUNE_SEG_CHUNK")) chunk_a = std::max(1, std::min(A, std::min(atoi(e), ns == 2 ? 90 : 180)));
+        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * ns + 2 * sizeof(int) + 4 * sizeof(float)) + 16;
         // 8 rows per lane (64 x 32 tiles); 4 (64 x 16) when that is what it takes to put ~2 workgroups on every CU
-        int ppt = (long long)S * ceil_div(W, 64) * ceil_div(H, 32) >= 512 ? 8 : 4;
+        int ppt = (long long)units * ceil_div(W, 64) * ceil_div(H, 32) >= 512 ? 8 : 4;
         if (const char *e = getenv("CTPVAE_TUNE_SEG_PPT")) ppt = atoi(e) == 4 ? 4 : 8;
-        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), S), block(256);
-        if (ppt == 8)
-            hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<8>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev,
-                               chunk_a, gimg_dev);
-        else
-            hipLaunchKernelGGL(rotate_bwd_tfcompat_seg_kernel<4>, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev,
-                               chunk_a, gimg_dev);
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), units), block(256);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev, chunk_a, gimg_dev);
+        };
+        if (ns == 2) {
+            if (ppt == 8) launch(rotate_bwd_tfcompat_seg_kernel<8, 2>); else launch(rotate_bwd_tfcompat_seg_kernel<4, 2>);
+        } else {
+            if (ppt == 8) launch(rotate_bwd_tfcompat_seg_kernel<8, 1>); else launch(rotate_bwd_tfcompat_seg_kernel<4, 1>);
+        }
         CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_seg_kernel");
         return CTPVAE_OK;
     }

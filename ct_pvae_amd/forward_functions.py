@@ -250,9 +250,9 @@ class RotatePlan:
 
     def backward_uses_plan(self, S):
         """Large batches at few angles: the direct segment kernel (no index stream) is the faster of the two
-        bit-identical backward paths -- measured 27 vs 32 us at B=400 A=20, 30 vs 35 us at B=200 A=45; the plan wins
+        bit-identical backward paths -- measured 21 vs 28 us at B=400 A=20, 24 vs 26 us at B=200 A=45, 7.7 vs 8.8 us at B=80 A=20; the plan wins
         everywhere else."""
-        return self._want_bwd_plan and not (S >= 100 and self.A <= 64)
+        return self._want_bwd_plan and not (S >= 80 and self.A <= 64)
 
     def backward(self, gsino, out=None):
         S = gsino.shape[0]

@@ -125,8 +125,8 @@ int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int
                                          const void *fwd_plan_dev, const float *mask_dev, const float *meas_dev,
                                          const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
                                          ctpvae_stream_t stream);
-/* (Which backward: both give the same bits.  The planned one wins except for large batches at few angles -- S >= 100
- * and A <= 64 -- where ctpvae_rotate_bwd_f32's segment kernel, which streams no indices, is 15 % faster.) */
+/* (Which backward: both give the same bits.  The planned one wins except for large batches at few angles -- S >= 80
+ * and A <= 64 -- where ctpvae_rotate_bwd_f32's segment kernel, which streams no indices, is up to 25 % faster.) */
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
                                   const void *bwd_plan_dev, float *gimg_dev, ctpvae_stream_t stream);
 

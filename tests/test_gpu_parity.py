@@ -259,6 +259,28 @@ def test_paired_backward_equals_single(oracle, shape, pad, A, S, monkeypatch):
     np.testing.assert_array_equal(to_np(two[-1:]), oracle.rotate_bwd_tfcompat(to_np(g[-1:]), geom, to_np(plan.Tinv8), 0))
 
 
+@pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 5), ((192, 192), True, 100, 3), ((40, 100), False, 33, 4),
+                                          ((300, 200), True, 7, 2), ((128, 128), True, 20, 33)])
+def test_paired_segment_backward_equals_single(oracle, shape, pad, A, S, monkeypatch):
+    """The direct (segment) backward runs one or two slices per workgroup (two: segments interleaved as float2, one
+    coordinate / address / ds_read_b64 per tap for both); same operator bit for bit -- padded (all-inside fast loop),
+    unpadded (zero-fill classes), more angles than one chunk, odd batches."""
+    d = dev()
+    rng = np.random.default_rng(A * 3 + S)
+    theta = rng.uniform(-1.0, 4.0, A)
+    plan = RotatePlan(theta, shape[0], shape[1], pad, d, use_plan=False)
+    g = torch.from_numpy(rng.standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
+    monkeypatch.setenv("CTPVAE_TUNE_SEG_NS", "1")
+    one = plan.backward(g)
+    monkeypatch.setenv("CTPVAE_TUNE_SEG_NS", "2")
+    two = plan.backward(g)
+    monkeypatch.delenv("CTPVAE_TUNE_SEG_NS")
+    auto = plan.backward(g)
+    assert torch.equal(one, two) and torch.equal(one, auto)
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    np.testing.assert_array_equal(to_np(two[-1:]), oracle.rotate_bwd_tfcompat(to_np(g[-1:]), geom, to_np(plan.Tinv8), 0))
+
+
 def test_mixed_planned_forward_direct_backward(oracle):
     """192x192: the slice still fits the forward plan's LDS image (148 KiB), but P = 274 bins do not fit the backward
     plan's byte taps -- forward planned, backward direct, both bit-exact."""
