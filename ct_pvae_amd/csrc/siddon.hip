@@ -21,21 +21,35 @@ struct SidGeom {
     float mov;
 };
 
-template <bool USE_LDS>
+// NS = 2: two slices per workgroup, interleaved as float2 in LDS -- the crossings, segment lengths and pixel indices of
+// a ray depend on the geometry only, so one walk serves both slices (the loop is VALU-bound on exactly that arithmetic).
+typedef float sid_f32x2 __attribute__((ext_vector_type(2)));
+template <int NS> struct SidVec { typedef float type; };
+template <> struct SidVec<2> { typedef sid_f32x2 type; };
+template <bool USE_LDS, int NS>
 __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restrict__ obj, SidGeom g,
                                                          const float *__restrict__ sin_t,
                                                          const float *__restrict__ cos_t,
                                                          const int *__restrict__ quad_t, int p_per_blk,
                                                          float *__restrict__ data)
 {
+    typedef typename SidVec<NS>::type vec_t;
+    static_assert(NS == 1 || USE_LDS, "paired slices live in LDS");
     extern __shared__ float lds[];
-    const int s = blockIdx.y;
+    const int s = blockIdx.y * NS;
+    const bool has2 = NS == 2 && s + 1 < g.oy;     // an odd batch ends with a half-empty pair
     const int p0 = blockIdx.x * p_per_blk;
     const int np = min(p_per_blk, g.dt - p0);
     const float *model_g = obj + (size_t)s * g.ox * g.oz;
     const int pitch = g.oz + ((1 - (g.oz & 31)) & 31);   // == 1 (mod 32): conflict-free staging, see lds_stage.h
     if (USE_LDS) {
-        stage_rows(lds, model_g, g.ox, g.oz, g.oz, pitch, false, threadIdx.x & 63, threadIdx.x >> 6, blockDim.x >> 6);
+        if constexpr (NS == 1) {
+            stage_rows(lds, model_g, g.ox, g.oz, g.oz, pitch, false, threadIdx.x & 63, threadIdx.x >> 6, blockDim.x >> 6);
+        } else {
+            const float *srcs[2] = {model_g, model_g + (has2 ? (size_t)g.ox * g.oz : 0)};
+            stage_rows_interleaved<2>(lds, srcs, g.ox, g.oz, g.oz, pitch, false, threadIdx.x & 63, threadIdx.x >> 6,
+                                      blockDim.x >> 6);
+        }
         __syncthreads();
     }
     const int ox = g.ox, oz = g.oz;
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
         kept_run(islope, gy0, srcy, srcx, gx_gt, gx_le, oz, a_lo, a_cnt);
         kept_run(slope, gx0, srcx, srcy, gy_gt, gy_le, ox, b_lo, b_cnt);
         const int csize = a_cnt + b_cnt;
-        float acc = 0.0f;
+        vec_t acc = 0.0f;
         // The merge of libtomo's two sorted lists, with two cursors.  List a runs over its kept n upwards in
         // quadrant 1 and downwards otherwise; gridy[n] = gy0 + n is exact in fp32, so a running +-1.0f gives the same
         // values as int -> float.  An exhausted list shows +inf as its key: "a_key < b_key" then reproduces
@@ -140,13 +154,22 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
                 const int indx = (int)floorf(midx + hx), indy = (int)floorf(midy + hz);
                 // libtomo reads model[indy + indx*oz] unchecked; midpoints lie strictly inside the grid
                 const int ix = min(max(indx, 0), ox - 1), iy = min(max(indy, 0), oz - 1);
-                const float m = USE_LDS ? lds[ix * pitch + iy] : model_g[(size_t)ix * oz + iy];
+                vec_t m;
+                if constexpr (NS == 1)
+                    m = USE_LDS ? lds[ix * pitch + iy] : model_g[(size_t)ix * oz + iy];
+                else
+                    m = reinterpret_cast<const vec_t *>(lds)[ix * pitch + iy];
                 acc += m * dist;
             }
             px_prev = cx;
             py_prev = cy;
         }
-        data[((size_t)s * g.dt + p) * g.dx + d] = acc;
+        if constexpr (NS == 1) {
+            data[((size_t)s * g.dt + p) * g.dx + d] = acc;
+        } else {
+            data[((size_t)s * g.dt + p) * g.dx + d] = acc.x;
+            if (has2) data[((size_t)(s + 1) * g.dt + p) * g.dx + d] = acc.y;
+        }
     }
 }
 
@@ -196,16 +219,21 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
     if (mov - std::floor(mov) < 0.01f) mov += 0.01f;
     mov += 0.5f;
     const SidGeom g{oy, ox, oz, dt, dx, mov};
-    const size_t lds_bytes = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
-    const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
+    const size_t lds_one = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
+    const bool use_lds = lds_one <= (size_t)kMaxLdsBytes;
+    // two slices per workgroup when the pair fits LDS and the call has slices to pair
+    int ns = (oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
+    if (const char *e = getenv("CTPVAE_TUNE_SIDDON_NS")) ns = (atoi(e) == 2 && oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
+    const int units = ceil_div(oy, ns);
+    const size_t lds_bytes = lds_one * ns;
     int ppb = dt;
-    while (ppb > 1 && (long long)oy * ceil_div(dt, ppb) < 512) ppb = (ppb + 1) / 2;
-    // the kernel is VALU-bound and every workgroup holds the slice in LDS (two fit a CU): 16 waves per workgroup
-    // keep 8 waves on every SIMD (4 waves per workgroup left 2 per SIMD -- one wave issues a VALU op every ~4.4 cycles)
+    while (ppb > 1 && (long long)units * ceil_div(dt, ppb) < 512) ppb = (ppb + 1) / 2;
+    // the kernel is VALU-bound and every workgroup holds its slice(s) in LDS: 16 waves per workgroup keep 8 (4 with a
+    // pair) waves on every SIMD (4 waves per workgroup left 2 per SIMD -- one wave issues a VALU op every ~4.4 cycles)
     int threads = std::min(1024, ceil_div(ppb * dx, 64) * 64);
     if (const char *e = getenv("CTPVAE_TUNE_SIDDON_THREADS")) threads = std::max(64, std::min(1024, atoi(e) / 64 * 64));
     if (const char *e = getenv("CTPVAE_TUNE_SIDDON_PPB")) ppb = std::max(1, std::min(dt, atoi(e)));
-    const dim3 grid(ceil_div(dt, ppb), oy), block(threads);
+    const dim3 grid(ceil_div(dt, ppb), units), block(threads);
     auto launch = [&](auto kernel, size_t shmem) -> int {
         if (shmem > 64 * 1024)
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -215,7 +243,8 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
         CTPVAE_LAUNCH_CHECK("siddon_fwd_kernel");
         return CTPVAE_OK;
     };
-    return use_lds ? launch(siddon_fwd_kernel<true>, lds_bytes) : launch(siddon_fwd_kernel<false>, 0);
+    if (!use_lds) return launch(siddon_fwd_kernel<false, 1>, 0);
+    return ns == 2 ? launch(siddon_fwd_kernel<true, 2>, lds_bytes) : launch(siddon_fwd_kernel<true, 1>, lds_bytes);
 }
 
 }  // extern "C"

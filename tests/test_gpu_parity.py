@@ -377,6 +377,22 @@ def test_siddon_against_oracle_and_golden(oracle, golden_dir):
     np.testing.assert_array_equal(got, np.swapaxes(oracle.siddon_project(foam, theta, pad=True), 0, 1))
 
 
+def test_paired_siddon_equals_single(monkeypatch):
+    """create_sinograms walks every ray once for two slices (interleaved in LDS) when the call has slices to pair; same
+    numbers as one slice per workgroup, bit for bit, odd batches included."""
+    foam = phantoms.foam_batch(5, 128, seed=2, supersample=2)
+    theta = phantoms.dense_theta(180)[::7]
+    monkeypatch.setenv("CTPVAE_TUNE_SIDDON_NS", "1")
+    one = cp.create_sinograms(foam, theta, pad=True)
+    monkeypatch.setenv("CTPVAE_TUNE_SIDDON_NS", "2")
+    two = cp.create_sinograms(foam, theta, pad=True)
+    monkeypatch.delenv("CTPVAE_TUNE_SIDDON_NS")
+    auto = cp.create_sinograms(foam, theta, pad=True)
+    np.testing.assert_array_equal(one, two)
+    np.testing.assert_array_equal(one, auto)
+    np.testing.assert_array_equal(one[4], cp.create_sinogram(foam[4], theta, pad=True))
+
+
 def test_iradon_against_oracle_and_golden(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "iradon.npz"))
     d = dev()
