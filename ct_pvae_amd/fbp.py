@@ -13,6 +13,22 @@ from .forward_functions import _stream_ptr
 __all__ = ["iradon", "iradon_all", "ramp_filter"]
 
 
+_CACHE = {}
+_CACHE_MAX = 32
+
+
+def _cached(key, make):
+    """Small keyed store for the per-filter / per-angle-set device tables (the filter kernel Re(ifft(filter_1d)) and
+    cos/sin of theta): the reference recomputes them inside every call; here a repeated call costs two launches."""
+    val = _CACHE.get(key)
+    if val is None:
+        val = make()
+        if len(_CACHE) >= _CACHE_MAX:
+            _CACHE.pop(next(iter(_CACHE)))
+        _CACHE[key] = val
+    return val
+
+
 def iradon(sinogram, theta, x_size, y_size, filter_1d):
     """sinogram [batch][angles][num_proj_pix] -> reconstruction [batch][x_size][y_size] (float64)."""
     lib = _lib.load()
@@ -30,9 +46,20 @@ def iradon(sinogram, theta, x_size, y_size, filter_1d):
     filt = filt.reshape(-1)
     if filt.shape[0] != P:
         raise ValueError(f"filter_1d must hold num_proj_pix={P} values (got {filt.shape[0]})")
-    hker = torch.from_numpy(np.ascontiguousarray(np.fft.ifft(filt.astype(np.complex128)).real)).to(dev)
-    th = torch.as_tensor(theta).detach().to(device=dev, dtype=torch.float64)
-    cos_t, sin_t = torch.cos(th).contiguous(), torch.sin(th).contiguous()
+    hker = _cached(("hker", filt.tobytes(), str(filt.dtype), str(dev)), lambda: torch.from_numpy(
+        np.ascontiguousarray(np.fft.ifft(filt.astype(np.complex128)).real)).to(dev))
+    if isinstance(theta, torch.Tensor) and theta.device.type == "cuda":
+        th = theta.detach().to(device=dev, dtype=torch.float64)
+        cos_t, sin_t = torch.cos(th).contiguous(), torch.sin(th).contiguous()
+    else:   # host-resident angle set: the tables are made once
+        th_np = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
+                                                dtype=np.float64))
+
+        def make():
+            th = torch.from_numpy(th_np).to(dev)
+            return torch.cos(th).contiguous(), torch.sin(th).contiguous()
+
+        cos_t, sin_t = _cached(("trig", th_np.tobytes(), str(dev)), make)
     sino = sinogram.to(torch.float64).contiguous()
     filtered = torch.empty_like(sino)
     recon = torch.empty((B, int(x_size), int(y_size)), dtype=torch.float64, device=dev)
