@@ -633,3 +633,26 @@ def test_launches_are_graph_capturable():
     assert torch.equal(gimg, want_g)                # same cotangent -> same gradient image
     assert torch.equal(sino, plan.forward(x2))      # the replay projected the new input
     assert not torch.equal(sino, want_s)
+
+
+def test_bench_single_process_contract():
+    """`python bench.py` as the driver runs it at N = 1 (few steps here): one JSON line with the contract's keys, the
+    roofline and cpu_baseline objects, traffic from the committed PMC passes for the default workload."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "10"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 60 and d["warmup"] == 10 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] is not None and r["traffic"] > 4.0e6
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] > 1e7                      # tens of millions of projections per second on an MI355X
