@@ -341,7 +341,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
                      "traffic": traffic, "algorithmic_bytes_per_launch": bytes_dir,
                      "kernel_us": {"rotate_fwd": t_fwd * 1e6, "rotate_bwd_tfcompat": t_bwd * 1e6},
-                     "note": "object lives in LDS for all angles: LDS-gather/VALU bound, HBM fraction is small by construction"},
+                     "note": "object lives in LDS for all angles; the launch is bound by dispatch + L2->CU bytes (indices, fills) + per-task LDS latency chains, so the HBM fraction is small by construction (DESIGN.md section 6)"},
         "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
         "step_us_event_pairs": {"p10": float(np.percentile(step_us, 10)), "median": float(np.median(step_us)),
                                 "p90": float(np.percentile(step_us, 90)), "n": len(step_us)},
