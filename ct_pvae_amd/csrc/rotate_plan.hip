@@ -42,7 +42,7 @@ struct PlanGeom {
 
 struct FwdLayout {
     int nJB, PWpad, NG, Galloc, pitch, zero;
-    long long off_cls, off_clist, off_rng, off_idx, bytes;
+    long long off_cls, off_clist, off_first, off_rng, off_idx, bytes;
 };
 constexpr int kBwdPitch = 257;   // dwords per staged cotangent row (== 1 mod 32; bins, then zeros up to cell 256)
 constexpr int kBwdChunk = 64;    // angles staged per pass: row offsets (<= 63 * 1028 B) fit ds_read's 16-bit immediate
@@ -76,7 +76,8 @@ static FwdLayout fwd_layout(const PlanGeom &g)
     L.zero = g.H * L.pitch;
     L.off_cls = 0;
     L.off_clist = (long long)g.A * 4;                                     // two lists of (count, angles...)
-    L.off_rng = (L.off_clist + 2ll * (g.A + 1) * 4 + 255) / 256 * 256;
+    L.off_first = (L.off_clist + 2ll * (g.A + 1) * 4 + 255) / 256 * 256;   // first live canvas row of every ray
+    L.off_rng = (L.off_first + (long long)g.A * L.PWpad * 4 + 255) / 256 * 256;
     L.off_idx = (L.off_rng + (long long)g.A * L.nJB * 8 + 255) / 256 * 256;
     L.bytes = L.off_idx + (long long)g.A * L.Galloc * L.PWpad * 16;
     return L;
@@ -119,7 +120,45 @@ __device__ __forceinline__ int wave_max_i(int v)
 }
 
 // ---- plan builders: the reference arithmetic, evaluated exactly, once per geometry ---------------------------
-// One wave per (bin block, angle, row group).  rng[a][jb] = {first live group, kRngBias - last live group}, both
+// The taps of a ray are stored from ITS OWN first live row on: group g of ray (a, j) holds canvas rows
+// first[a][j] + 8g .. + 8g + 7.  The 64 rays of a bin block enter the slice at different rows (by up to 64 |tan| rows),
+// and walking them from a common first row visited 134 rows per task for 85 useful ones; aligned at their own entry
+// they need max-chord / 8 groups.  The order of every ray's sum is unchanged (rows ascending; skipped rows were +0.0f).
+// ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round, zero fill -- LDS index of the tap or -1
+__device__ __forceinline__ int fwd_tap(const PlanGeom &g, const FwdLayout &L, bool plus, float xj, float yj, float t1,
+                                       float t2, float t4, float t5, int i)
+{
+    const float fi = (float)i;
+    const float x = (xj + t1 * fi) + t2;
+    const float y = (yj + t4 * fi) + t5;
+    const int ix = (int)__builtin_roundf(x) - g.px;
+    const int iy = (int)__builtin_roundf(y) - g.py;
+    if ((unsigned)ix < (unsigned)g.W && (unsigned)iy < (unsigned)g.H) return iy * L.pitch + (plus ? ix : g.W - 1 - ix);
+    return -1;
+}
+// pass 1, one wave per (bin block, angle): first live row of every ray (PH if the ray misses the slice)
+__global__ __launch_bounds__(64) void rotate_fwd_first_kernel(PlanGeom g, const float *__restrict__ T8, FwdLayout L,
+                                                              char *__restrict__ plan)
+{
+    const int a = blockIdx.y, jb = blockIdx.x, lane = threadIdx.x;
+    const int j = lane_to_bin(g.PW, jb, lane);
+    const float *t = T8 + 8 * a;
+    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
+    int *cls = reinterpret_cast<int *>(plan + L.off_cls);
+    int *first = reinterpret_cast<int *>(plan + L.off_first);
+    if (jb == 0 && lane == 0) cls[a] = plus ? 1 : 0;
+    const float xj = t0 * (float)j, yj = t3 * (float)j;
+    int f = g.PH;
+    if ((unsigned)j < (unsigned)g.PW)
+        for (int i = 0; i < g.PH; ++i)
+            if (fwd_tap(g, L, plus, xj, yj, t1, t2, t4, t5, i) >= 0) {
+                f = i;
+                break;
+            }
+    first[(size_t)a * L.PWpad + jb * 64 + lane] = f;
+}
+// pass 2, one wave per (bin block, angle, row group): rng[a][jb] = {first live group, kRngBias - last live group}, both
 // reduced with atomicMin over the groups (the buffer is preset to 0x7f7f7f7f by the host-side memset).
 constexpr int kRngBias = 0x7f7f7f7f;
 __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const float *__restrict__ T8, FwdLayout L,
@@ -130,26 +169,21 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
     const float *t = T8 + 8 * a;
     const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
     const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
-    int *cls = reinterpret_cast<int *>(plan + L.off_cls);
+    const int *first = reinterpret_cast<const int *>(plan + L.off_first);
     int *rng = reinterpret_cast<int *>(plan + L.off_rng);
     uint4 *idx = reinterpret_cast<uint4 *>(plan + L.off_idx);
-    if (jb == 0 && gq == 0 && lane == 0) cls[a] = plus ? 1 : 0;
     const float xj = t0 * (float)j, yj = t3 * (float)j;
+    const int i0 = first[(size_t)a * L.PWpad + jb * 64 + lane] + 8 * gq;
     unsigned e16[8];
     bool any = false;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int i = 8 * gq + e;
+        const int i = i0 + e;
         unsigned v = (unsigned)L.zero;
         if (i < g.PH && (unsigned)j < (unsigned)g.PW) {
-            // ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round, zero fill
-            const float fi = (float)i;
-            const float x = (xj + t1 * fi) + t2;
-            const float y = (yj + t4 * fi) + t5;
-            const int ix = (int)__builtin_roundf(x) - g.px;
-            const int iy = (int)__builtin_roundf(y) - g.py;
-            if ((unsigned)ix < (unsigned)g.W && (unsigned)iy < (unsigned)g.H) {
-                v = (unsigned)(iy * L.pitch + (plus ? ix : g.W - 1 - ix));
+            const int tap = fwd_tap(g, L, plus, xj, yj, t1, t2, t4, t5, i);
+            if (tap >= 0) {
+                v = (unsigned)tap;
                 any = true;
             }
         }
@@ -627,6 +661,9 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
         const FwdLayout L = fwd_layout(g);
         CTPVAE_REQUIRE(L.Galloc <= 65535, "rotate_plan_build: canvas too tall");
         CTPVAE_HIP(hipMemsetAsync((char *)fwd_plan_dev + L.off_rng, 0x7f, (size_t)A * L.nJB * 8, (hipStream_t)stream));
+        hipLaunchKernelGGL(rotate_fwd_first_kernel, dim3(L.nJB, A), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L,
+                           (char *)fwd_plan_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_first_kernel");
         hipLaunchKernelGGL(rotate_fwd_plan_kernel, dim3(L.nJB, A, L.Galloc), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L,
                            (char *)fwd_plan_dev);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_plan_kernel");
@@ -665,7 +702,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     const bool pairs_fit = (size_t)(L.zero + 1) * 8 + 16 <= (size_t)kMaxLdsBytes && S >= 2;
     int ns = 1, G = 1;
     {
-        const double task_kb = 0.85 * L.NG;
+        const double task_kb = 0.6 * L.NG;   // ~1 KB per row group, ~0.6 NG groups per task (rays aligned at their own first row)
         double best = 0.0;
         for (int cand_ns = 1; cand_ns <= (pairs_fit ? 2 : 1); ++cand_ns) {
             const double fill_kb = (double)g.H * g.W * 4.0 * cand_ns / 1024.0;
@@ -690,7 +727,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         const int want = atoi(e) == 2 ? 2 : 1;
         if (want != ns) {   // forced pairing: best G for it
             ns = want;
-            const double task_kb = 0.85 * L.NG, fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0;
+            const double task_kb = 0.6 * L.NG, fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0;
             const long long cand_units = (S + ns - 1) / ns;
             double best = 0.0;
             for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
