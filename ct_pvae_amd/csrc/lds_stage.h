@@ -125,6 +125,61 @@ __device__ __forceinline__ void stage_rows_interleaved_v4(float *lds, const floa
         }
     }
 }
+// The same staging in two phases, for software pipelining: issue() requests up to NB units per lane into registers,
+// commit() writes them to LDS later (after the consumers of the buffer's previous contents have passed a barrier).
+// fits(): the whole block must be covered by NB units per lane, and meet stage_rows_interleaved_v4's alignment rules.
+template <int NS, int NB>
+struct StagedRows {
+    float4 v[NB][NS];
+    int r_[NB], c_[NB];
+    __device__ __forceinline__ static bool fits(const float *const (&src)[NS], int rows, int cols, int src_stride, int nwaves)
+    {
+        const int ncb = (cols + 31) >> 5, npc = (ncb + 1) >> 1, nrq = (rows + 3) >> 2;
+        bool ok = nrq * npc <= NB * nwaves && (cols & 3) == 0 && (src_stride & 3) == 0;
+#pragma unroll
+        for (int n = 0; n < NS; ++n) ok = ok && (reinterpret_cast<uintptr_t>(src[n]) & 15) == 0;
+        return ok;
+    }
+    __device__ __forceinline__ void issue(const float *const (&src)[NS], int rows, int cols, int src_stride, int lane, int wave,
+                                          int nwaves)
+    {
+        const int ncb = (cols + 31) >> 5, npc = (ncb + 1) >> 1, nrq = (rows + 3) >> 2;
+        const int h = lane >> 5, k = (lane & 31) >> 3, m = lane & 7;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int pp = wave + u * nwaves, rq = pp / npc, pc = pp - rq * npc;
+            r_[u] = 4 * rq + k;
+            c_[u] = 32 * (2 * pc + h) + 4 * m;
+            const bool ok = rq < nrq && r_[u] < rows && c_[u] < cols;
+            const int rl = min(r_[u], rows - 1), cl = min(c_[u], cols - 4);   // unconditional, clamped loads
+#pragma unroll
+            for (int n = 0; n < NS; ++n) v[u][n] = *reinterpret_cast<const float4 *>(src[n] + (size_t)rl * src_stride + cl);
+            if (!ok) r_[u] = -1;
+        }
+    }
+    __device__ __forceinline__ void commit(float *lds, int pitch) const
+    {
+        typedef float vec_t __attribute__((ext_vector_type(NS)));
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (r_[u] < 0) continue;
+            vec_t *d = reinterpret_cast<vec_t *>(lds) + (r_[u] * pitch + c_[u]);
+            vec_t w0, w1, w2, w3;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                w0[n] = v[u][n].x;
+                w1[n] = v[u][n].y;
+                w2[n] = v[u][n].z;
+                w3[n] = v[u][n].w;
+            }
+            d[0] = w0;
+            d[1] = w1;
+            d[2] = w2;
+            d[3] = w3;
+        }
+    }
+};
+
 template <int NS>
 __device__ __forceinline__ void stage_rows_interleaved(float *lds, const float *const (&src)[NS], int rows, int cols,
                                                        int src_stride, int pitch, bool mirror, int lane, int wave, int nwaves)

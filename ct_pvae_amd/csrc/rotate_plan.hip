@@ -561,17 +561,41 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     load_group(0);       // index loads fly while the cotangent rows land
 
     const int chunk = min(L.NA16 * 16, kChunk);
+    // Pairs in 16-wave workgroups (many angles, several chunks): the cotangent rows of chunk c + 1 are requested into
+    // registers (two units per lane) before the gathers of chunk c and written to LDS after them -- each chunk's load
+    // round trip hides behind the previous chunk's gather phase instead of standing between two barriers.
+    constexpr bool kPipe = NS == 2;                 // (the single-slice form has no registers to spare: 143 VGPRs with it)
+    constexpr int kAheadUnits = 2;                  // 32 rows of a pair over 16 waves
+    StagedRows<NS, kPipe ? kAheadUnits : 1> ahead;
+    bool ahead_valid = false;
+    auto chunk_srcs = [&](int ac, const float *(&srcs)[NS]) {
+        srcs[0] = gs + (size_t)ac * g.PW;
+        if constexpr (NS == 2) srcs[1] = gs + (has2 ? (size_t)g.A * g.PW : 0) + (size_t)ac * g.PW;
+    };
     for (int ac = 0; ac < g.A; ac += chunk) {
         const int na = min(chunk, g.A - ac);
         const int na4 = (na + 3) & ~3;              // taps are consumed a dword (4 angles) at a time
         if (ac > 0) __syncthreads();
         // a dead tap is byte 255: only cell 255 of every row (never a bin: PW <= 255) must hold 0.0f
         for (int t = threadIdx.x; t < na4 * NS; t += blockDim.x) lds[((t / NS) * kBwdPitch + 255) * NS + (t % NS)] = 0.0f;
-        if constexpr (NS == 1) {
+        if (ahead_valid) {
+            ahead.commit(lds, kBwdPitch);           // requested during the previous chunk's gathers
+        } else if constexpr (NS == 1) {
             stage_rows(lds, gs + (size_t)ac * g.PW, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
         } else {
-            const float *srcs[2] = {gs + (size_t)ac * g.PW, gs + (has2 ? (size_t)g.A * g.PW : 0) + (size_t)ac * g.PW};
+            const float *srcs[NS];
+            chunk_srcs(ac, srcs);
             stage_rows_interleaved<2>(lds, srcs, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        }
+        ahead_valid = false;
+        if (kPipe && ac + chunk < g.A) {            // wave-uniform
+            const float *srcs[NS];
+            chunk_srcs(ac + chunk, srcs);
+            const int nna = min(chunk, g.A - (ac + chunk));
+            if (StagedRows<NS, kPipe ? kAheadUnits : 1>::fits(srcs, nna, g.PW, g.PW, nwaves)) {
+                ahead.issue(srcs, nna, g.PW, g.PW, lane, wave, nwaves);
+                ahead_valid = true;
+            }
         }
         __syncthreads();
         // up to four groups of sixteen staged angles, unrolled so that every row offset is an immediate
