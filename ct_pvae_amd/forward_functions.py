@@ -185,6 +185,13 @@ class RotatePlan:
         """(forward uses a plan, backward uses / will use a plan)"""
         return self._fwd_plan is not None, self._want_bwd_plan
 
+    def _check(self, t, shape_tail, what):
+        """Operand checks before a launch: the kernels index by these shapes and would read out of bounds otherwise."""
+        if (t.dim() != 1 + len(shape_tail) or tuple(t.shape[1:]) != shape_tail or t.dtype != torch.float32
+                or not t.is_contiguous() or t.device != self.T8.device or t.shape[0] < 1):
+            raise ValueError(f"{what} must be a contiguous float32 tensor [S]{list(shape_tail)} on {self.T8.device} "
+                             f"(got {tuple(t.shape)}, {t.dtype}, {t.device}, contiguous={t.is_contiguous()})")
+
     def _tile_workspace(self, S):
         """Device workspace of the tiled forward for S slices, or None when this geometry is not tiled."""
         if not self._use_tiles or self._fwd_plan is not None:
@@ -204,9 +211,14 @@ class RotatePlan:
         return self._tile_workspace(1) is not None
 
     def forward(self, img, out=None):
+        self._check(img, (self.H, self.W), "img")
         S = img.shape[0]
         if out is None:
             out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+        else:
+            self._check(out, (self.A, self.PW), "out")
+            if out.shape[0] != S:
+                raise ValueError(f"out holds {out.shape[0]} sinograms for {S} slices")
         ws = self._tile_workspace(S)
         if self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
@@ -226,14 +238,25 @@ class RotatePlan:
     def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None):
         """Planned forward with the log-likelihood epilogue (one launch): returns (sino, lp), both [S][A][PW];
         lp = Normal(loc = sino * mask, scale = eps + sqrt(loc / pnm + eps)).log_prob(meas).  Planned and tiled geometries."""
+        self._check(img, (self.H, self.W), "img")
         S = img.shape[0]
         ws = self._tile_workspace(S)
         if self._fwd_plan is None and ws is None:
             raise ValueError("forward_loglik needs a planned or tiled forward (nearest)")
+        self._check(meas, (self.A, self.PW), "meas")
+        self._check(mask, (self.A,), "mask")
+        if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
+            raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
         if out is None:
             out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+        else:
+            self._check(out, (self.A, self.PW), "out")
         if out_lp is None:
             out_lp = torch.empty_like(out)
+        else:
+            self._check(out_lp, (self.A, self.PW), "out_lp")
+        if out.shape[0] != S or out_lp.shape[0] != S:
+            raise ValueError("out / out_lp must hold one sinogram per slice")
         if self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_loglik_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), mask.data_ptr(),
@@ -255,9 +278,14 @@ class RotatePlan:
         return self._want_bwd_plan and not (S >= 80 and self.A <= 64)
 
     def backward(self, gsino, out=None):
+        self._check(gsino, (self.A, self.PW), "gsino")
         S = gsino.shape[0]
         if out is None:
             out = torch.empty((S, self.H, self.W), dtype=torch.float32, device=gsino.device)
+        else:
+            self._check(out, (self.H, self.W), "out")
+            if out.shape[0] != S:
+                raise ValueError(f"out holds {out.shape[0]} slices for {S} sinograms")
         if self.backward_uses_plan(S):
             if self._bwd_plan is None:
                 self._bwd_plan = self._build_plan(1)

@@ -656,3 +656,26 @@ def test_bench_single_process_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 1e7                      # tens of millions of projections per second on an MI355X
+
+
+def test_raw_operator_checks_its_operands():
+    """RotatePlan.forward / backward / forward_loglik launch kernels that index by the plan's shapes: a tensor of another
+    shape, dtype, device or layout is refused on the host (ValueError), never handed to a kernel."""
+    d = dev()
+    plan = RotatePlan(np.linspace(0, 3, 5), 40, 60, True, d)
+    x = torch.rand((2, 40, 60), device=d)
+    g = torch.rand((2, 5, plan.PW), device=d)
+    plan.forward(x), plan.backward(g)
+    for bad in (torch.rand((2, 60, 40), device=d), torch.rand((2, 40, 60), device=d, dtype=torch.float64),
+                torch.rand((2, 40, 60)), torch.rand((2, 40, 120), device=d)[:, :, ::2], torch.rand((40, 60), device=d),
+                torch.rand((0, 40, 60), device=d)):
+        with pytest.raises(ValueError):
+            plan.forward(bad)
+    with pytest.raises(ValueError):
+        plan.forward(x, out=torch.empty((3, 5, plan.PW), device=d))
+    with pytest.raises(ValueError):
+        plan.backward(torch.rand((2, 5, plan.PW + 1), device=d))
+    with pytest.raises(ValueError):
+        plan.backward(g, out=torch.empty((2, 60, 40), device=d))
+    with pytest.raises(ValueError):
+        plan.forward_loglik(x, torch.rand((2, 4), device=d), g, torch.tensor(1e3, device=d), 1e-7)
