@@ -107,9 +107,18 @@ def gaussian_poisson_log_prob(proj, mask, proj_sample, poisson_noise_multiplier,
     proj, proj_sample [B][A][P]; mask [B][A]; poisson_noise_multiplier a python number or a 0-d/1-element tensor
     (it may require grad: --train_pnm)."""
     dev = proj.device
+    if dev.type != "cuda":
+        raise _lib.RadonLibraryError(f"proj lives on {dev}: the log-likelihood runs on a HIP device only; there is no CPU path")
+    if proj.dim() != 3 or tuple(proj_sample.shape) != tuple(proj.shape) or tuple(mask.shape) != tuple(proj.shape[:2]):
+        raise ValueError(f"need proj [B][A][P], mask [B][A], proj_sample [B][A][P] (got {tuple(proj.shape)}, "
+                         f"{tuple(mask.shape)}, {tuple(proj_sample.shape)})")
+    if mask.device != dev or proj_sample.device != dev:
+        raise ValueError("proj, mask and proj_sample must live on the same device")
     pnm = poisson_noise_multiplier
     if not isinstance(pnm, torch.Tensor):
         pnm = torch.tensor(float(pnm), dtype=torch.float32, device=dev)
+    if pnm.numel() != 1:
+        raise ValueError("poisson_noise_multiplier must be a number or a one-element tensor")
     pnm = pnm.to(device=dev, dtype=torch.float32)
     return _GaussianPoissonLogProb.apply(proj.contiguous(), mask.to(torch.float32).contiguous(),
                                          proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
@@ -165,6 +174,10 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
             if not isinstance(pnm, torch.Tensor):
                 pnm = torch.tensor(float(pnm), dtype=torch.float32, device=x.device)
             pnm = pnm.to(device=x.device, dtype=torch.float32)
+            if (tuple(mask.shape) != (slices.shape[0], plan.A) or tuple(proj_sample.shape) != (slices.shape[0], plan.A, plan.PW)
+                    or mask.device != x.device or proj_sample.device != x.device or pnm.numel() != 1):
+                raise ValueError(f"need mask [B][A] and proj_sample [B][A][P] = [{slices.shape[0]}][{plan.A}][{plan.PW}] on "
+                                 f"{x.device} (got {tuple(mask.shape)}, {tuple(proj_sample.shape)})")
             with torch.cuda.device(x.device):
                 logp = _ProjectLogLik.apply(slices, plan, mask.to(torch.float32).contiguous(),
                                             proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))

@@ -679,3 +679,19 @@ def test_raw_operator_checks_its_operands():
         plan.backward(g, out=torch.empty((2, 60, 40), device=d))
     with pytest.raises(ValueError):
         plan.forward_loglik(x, torch.rand((2, 4), device=d), g, torch.tensor(1e3, device=d), 1e-7)
+
+
+def test_likelihood_entry_points_check_their_operands():
+    d = dev()
+    theta = torch.linspace(0, 3, 6, device=d)
+    x = torch.rand((2, 32, 32, 1), device=d)
+    P = cp.num_proj_pix(32, 32)
+    with pytest.raises(ValueError):
+        cp.calculate_log_prob_M_given_R(x, torch.rand((2, 5), device=d), torch.rand((2, 6, P), device=d), 1e3, 1e-7, theta=theta)
+    with pytest.raises(ValueError):
+        cp.calculate_log_prob_M_given_R(x, torch.rand((2, 6), device=d), torch.rand((2, 6, P + 1), device=d), 1e3, 1e-7, theta=theta)
+    with pytest.raises(ValueError):
+        cp.gaussian_poisson_log_prob(torch.rand((2, 6, P), device=d), torch.rand((2, 6), device=d),
+                                     torch.rand((2, 5, P), device=d), 1e3, 1e-7)
+    ok = cp.calculate_log_prob_M_given_R(x, torch.rand((2, 6), device=d), torch.rand((2, 6, P), device=d), 1e3, 1e-7, theta=theta)
+    assert ok.shape == (2, 6, P, 1)
