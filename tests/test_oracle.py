@@ -226,3 +226,30 @@ def test_loglik_matches_scipy(oracle):
     loc = proj.astype(np.float64) * mask[..., None]
     want = norm.logpdf(x, loc=loc, scale=eps + np.sqrt(loc / 1e4 + eps))
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
+
+
+def test_nearest_projector_is_discontinuous_in_the_trig_bits(oracle):
+    """Why parity with TensorFlow cannot be promised bin by bin without TensorFlow's own cos/sin bits (DESIGN.md section
+    2): a +-1 ulp change of every cos/sin leaves all but a handful of ray-sums bit-identical, and moves those few by a
+    whole pixel value."""
+    from ct_pvae_amd import phantoms
+    img = phantoms.foam_batch(1, 128, seed=0, supersample=2)
+    theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
+    g = oracle.Geometry(128, 128, True)
+    T = oracle.rotate_transforms(theta, g.PH, g.PW)
+    ref = oracle.rotate_fwd(img, g, T, 0)
+    rng = np.random.default_rng(0)
+    T2 = T.copy()
+    for a in range(T.shape[0]):
+        up = np.float32(np.inf) if rng.random() < 0.5 else np.float32(-np.inf)
+        c = np.nextafter(T[a, 0], up).astype(np.float32)
+        s = np.nextafter(T[a, 3], -up).astype(np.float32)
+        W = np.float32(g.PW)
+        xo = np.float32(((W - 1) - (c * (W - 1) - s * (W - 1))) / np.float32(2))
+        yo = np.float32(((W - 1) - (s * (W - 1) + c * (W - 1))) / np.float32(2))
+        T2[a] = [c, -s, xo, s, c, yo, 0, 0]
+    out = oracle.rotate_fwd(img, g, T2, 0)
+    changed = np.abs(out - ref) > 0
+    assert changed.mean() < 2e-3                                  # all but a handful of bins: bit-identical
+    if changed.any():
+        assert np.abs(out - ref).max() <= 2.0                      # a flipped tap moves a ray-sum by at most ~a pixel
