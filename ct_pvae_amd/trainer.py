@@ -286,11 +286,16 @@ class PVAETrainer:
         loss.backward()
         grads = [p.grad for p in self.opt.param_groups[0]["params"] if p.grad is not None]
         sharding.allreduce_flat_(grads, average=False)                     # ONE bucket, one all-reduce
-        for gr in grads:
-            torch.nan_to_num_(gr, nan=0.0)                                 # tf.where(is_nan, 0, grad)
-            n = gr.norm()
-            if n > a.norm:                                                 # tf.clip_by_norm(g, norm), per tensor
-                gr.mul_(a.norm / n)
+        # tf.where(is_nan, 0, grad), then tf.clip_by_norm(g, norm) per tensor (ctvae/main_ct_vae.py:482-484) -- in one
+        # flat buffer and a handful of multi-tensor launches, with no host round trip (a Python `if norm > clip` per
+        # tensor would synchronise 76 times a step)
+        flat = torch.cat([gr.reshape(-1) for gr in grads])
+        torch.nan_to_num_(flat, nan=0.0)
+        views = list(flat.split([gr.numel() for gr in grads]))
+        norms = torch.stack(torch._foreach_norm(views))
+        scales = (a.norm / norms).clamp_(max=1.0)                          # norm / max(l2, norm); l2 = 0 -> 1
+        torch._foreach_mul_(views, list(scales.unbind()))
+        torch._foreach_copy_(grads, [v.view_as(gr) for v, gr in zip(views, grads)])
         self.opt.step()
         self.iter += 1
         return float(loss.item()) if self.world == 1 else self._global_loss(loss)
