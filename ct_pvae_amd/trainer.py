@@ -59,16 +59,19 @@ class ConvBlock(nn.Module):
     def __init__(self, cin, cout, k, stride, transpose):
         super().__init__()
         self.k, self.stride, self.transpose = k, stride, transpose
+        # the two convolutions of the maxout are ONE convolution with 2 * cout output channels (half the launches);
+        # each half is initialised as its own GlorotUniform layer
         if transpose:
             pad = (k - stride + 1) // 2
             opad = stride + 2 * pad - k
-            mk = lambda: nn.ConvTranspose2d(cin, cout, k, stride=stride, padding=pad, output_padding=opad)
+            self.ab = nn.ConvTranspose2d(cin, 2 * cout, k, stride=stride, padding=pad, output_padding=opad)
+            halves = self.ab.weight.data.chunk(2, dim=1)        # ConvTranspose2d weight: [cin][cout][k][k]
         else:
-            mk = lambda: nn.Conv2d(cin, cout, k, stride=stride, padding=0)
-        self.a, self.b = mk(), mk()
-        for m in (self.a, self.b):
-            nn.init.xavier_uniform_(m.weight)      # GlorotUniform
-            nn.init.zeros_(m.bias)
+            self.ab = nn.Conv2d(cin, 2 * cout, k, stride=stride, padding=0)
+            halves = self.ab.weight.data.chunk(2, dim=0)        # Conv2d weight: [cout][cin][k][k]
+        for h in halves:
+            nn.init.xavier_uniform_(h)             # GlorotUniform (fan-in / fan-out of ONE of the two convolutions)
+        nn.init.zeros_(self.ab.bias)
 
     def forward(self, x):
         if not self.transpose:
@@ -77,7 +80,8 @@ class ConvBlock(nn.Module):
                 p = self.k - (n % self.stride if n % self.stride else self.stride)
                 pads += [p // 2 + p % 2, p // 2]
             x = F.pad(x, pads, mode="circular")
-        return torch.maximum(self.a(x), self.b(x))
+        a, b = self.ab(x).chunk(2, dim=1)
+        return torch.maximum(a, b)
 
 
 class EncodeNet(nn.Module):
