@@ -105,7 +105,7 @@ def train_mode(args, world, rank, dev):
     """BASELINE config 3: main_ct_vae.py --nsa 20 --td 50 -b 5 --ns 2 --api 20 (README.md:80), HIP projector decoder."""
     from ct_pvae_amd import trainer as tr
     targs = tr.get_args(f"--nsa 20 --td 50 -b {5 * world} --ns 2 --api 20 --pnm 1e4 --pnm_start 1e3 --random --normal "
-                        f"-i {args.steps + args.warmup} --train".split())
+                        f"-i {args.steps + args.warmup} --train --miopen_find".split())
     t = tr.PVAETrainer(targs, dev)
     for _ in range(args.warmup):
         t.train_step()

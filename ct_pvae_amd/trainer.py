@@ -226,6 +226,11 @@ class PVAETrainer:
         self.args, self.dev = args, device
         self.world, self.rank, _ = sharding.env_world()
         self.sqrt_reg = EPS32
+        # the nets' shapes are static: --miopen_find lets MIOpen search its convolution algorithms once (14.9 -> 11.5 ms
+        # per step at batch 5 on the MI355X, after a search that costs tens of seconds; channels-last was measured too
+        # and loses)
+        if getattr(args, "miopen_find", False):
+            torch.backends.cudnn.benchmark = True
         torch.manual_seed(1234 + self.rank)
         a = args
         self.pnm_anneal = math.exp(math.log(a.pnm / a.pnm_start) / max(a.num_iter, 1)) if a.pnm_start else 1.0
@@ -376,6 +381,8 @@ def get_args(argv=None):
     p.add_argument("--save_path", default=None)
     p.add_argument("--se", type=int, dest="stride_encode", default=2)
     p.add_argument("--si", type=int, dest="si", default=100000)
+    p.add_argument("--miopen_find", action="store_true",
+                   help="search MIOpen's convolution algorithms once (torch.backends.cudnn.benchmark); not in the reference")
     p.add_argument("--td", type=int, dest="td", default=100)
     p.add_argument("--train", action="store_true")
     # synthetic-data knobs (the reference reads these from its dataset folder)
