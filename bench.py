@@ -134,7 +134,7 @@ def train_mode(args, world, rank, dev):
                           "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "P-VAE step: encoder + 2 x (decoder, TruncatedNormal sample, HIP "
+                          "config": {"workload": "P-VAE step: encoder + 2 samples x (decoder, TruncatedNormal sample, HIP "
                                                  "projector fwd, log-likelihood) + backward + Adam; 5 objects/GPU, 20 of 180 angles"},
                           "projector_ms_per_step": proj_s * 1e3, "projector_share": proj_s / (elapsed / args.steps)}))
 

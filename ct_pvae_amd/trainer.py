@@ -183,25 +183,30 @@ def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_dec
         for sk in skips:
             loc, log_scale = sk.chunk(2, dim=1)
             q.append((loc, positive_range(log_scale) + sqrt_reg))
-    log_prob_M, recon = [], None
-    for _ in range(num_samples):
-        if deterministic:
-            q_sample = skips
-        else:
-            q_sample = [loc + scale * torch.randn_like(loc) for loc, scale in q]
-        alpha, beta = model_decode(q_sample)
-        dist = TruncatedNormal(positive_range(alpha), positive_range(beta), low=0.0, high=1e10)
-        output_sample = dist.rsample()                                   # [B][1][X][Y]
-        log_prob_R_given_z = dist.log_prob(output_sample)
-        lp = calculate_log_prob_M_given_R(output_sample.permute(0, 2, 3, 1), mask, proj_sample,
-                                          poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad)
-        log_prob_M.append(lp.sum(dim=(1, 2, 3)) + log_prob_R_given_z.sum(dim=(1, 2, 3)))
-        recon = output_sample
+    # The reference draws its `num_samples` latent samples in a Python loop (:263-312); they are independent, so here
+    # they ride the batch axis: ONE decoder pass and ONE projector + likelihood pass over num_samples * B objects
+    # (sample-major), the same estimator with half the launches at ns = 2.
+    ns = 1 if deterministic else int(num_samples)
+    B = input_encode.shape[0]
+    if deterministic:
+        q_sample = skips
+    else:
+        q_sample = [loc.repeat(ns, 1, 1, 1) + scale.repeat(ns, 1, 1, 1) * torch.randn((ns * B,) + tuple(loc.shape[1:]),
+                                                                                      device=loc.device, dtype=loc.dtype)
+                    for loc, scale in q]
+    alpha, beta = model_decode(q_sample)
+    dist = TruncatedNormal(positive_range(alpha), positive_range(beta), low=0.0, high=1e10)
+    output_sample = dist.rsample()                                       # [ns * B][1][X][Y]
+    log_prob_R_given_z = dist.log_prob(output_sample)
+    lp = calculate_log_prob_M_given_R(output_sample.permute(0, 2, 3, 1), mask.repeat(ns, 1), proj_sample.repeat(ns, 1, 1),
+                                      poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad)
+    log_prob_M = (lp.sum(dim=(1, 2, 3)) + log_prob_R_given_z.sum(dim=(1, 2, 3))).view(ns, B)
+    recon = output_sample[(ns - 1) * B:]
     if deterministic:
         kl = torch.zeros_like(log_prob_M[0])
     else:
         kl = sum(kl_normal_std(loc, scale).sum(dim=(1, 2, 3)) for loc, scale in q[1:])   # the input level is unused
-    loglik = torch.stack(log_prob_M).mean(dim=0)
+    loglik = log_prob_M.mean(dim=0)
     return kl_anneal * kl_multiplier * kl - loglik, kl, loglik, recon
 
 
