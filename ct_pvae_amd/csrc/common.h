@@ -34,6 +34,15 @@ int fail(int code, const char *fmt, ...);
 
 constexpr int kMaxLdsBytes = 160 * 1024;  // LDS per CU on gfx950; one workgroup may take all of it
 
+// Optional per-slice factor applied by a backward kernel in its final store: gimg[s] = scale[s * stride] * (sum over
+// angles).  ptr == nullptr: no factor (x 1.0f, exact).  The backward is linear, so this is the upstream gradient of a
+// per-slice sum (an expanded tensor: stride 0 over angles and bins) applied without materialising it.
+struct SliceScale {
+    const float *ptr;
+    long long stride;
+    __device__ __forceinline__ float at(int s) const { return ptr ? ptr[(long long)s * stride] : 1.0f; }
+};
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace ctpvae

@@ -86,7 +86,7 @@ using namespace ctpvae;
 
 extern "C" {
 
-int ctpvae_abi_version(void) { return 1002; }
+int ctpvae_abi_version(void) { return 1003; }
 
 const char *ctpvae_last_error(void) { return err_buf(); }
 

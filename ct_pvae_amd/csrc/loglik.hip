@@ -28,17 +28,10 @@ __global__ __launch_bounds__(256) void loglik_bwd_kernel(const float *__restrict
     const float pnm = *pnm_p;
     float gp_local = 0.0f;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-        const float m = mask[k / P];
-        const float loc = proj[k] * m;
-        const float root = sqrtf(loc / pnm + eps);
-        const float scale = eps + root;
-        const float z = (x[k] - loc) / scale;
+        float dpnm;
         const float g = gout[k];
-        const float dscale = (z * z - 1.0f) / scale;      // d logp / d scale
-        const float dscale_du = 0.5f / root;               // d scale / d (loc/pnm + eps)
-        const float dloc = z / scale + dscale * dscale_du / pnm;
-        gproj[k] = g * dloc * m;
-        gp_local += g * dscale * dscale_du * (-loc / (pnm * pnm));
+        gproj[k] = g * gaussian_poisson_dlogp(proj[k], mask[k / P], x[k], pnm, eps, dpnm);
+        gp_local += g * dpnm;
     }
     if (gpnm) {
         for (int off = 32; off > 0; off >>= 1) gp_local += __shfl_down(gp_local, off, 64);

@@ -18,11 +18,36 @@ __device__ __forceinline__ float gaussian_poisson_logp(float proj, float m, floa
     return -0.5f * (z * z) - (kHalfLog2Pi + logf(scale));
 }
 
+// d logp / d proj (the mask factor included) and d logp / d pnm of the same sample: what the backward multiplies the
+// upstream gradient by.  One expression for loglik_bwd_kernel and for the projector epilogue that stores dlp.
+__device__ __forceinline__ float gaussian_poisson_dlogp(float proj, float m, float x, float pnm, float eps, float &dpnm)
+{
+    const float loc = proj * m;
+    const float root = sqrtf(loc / pnm + eps);
+    const float scale = eps + root;
+    const float z = (x - loc) / scale;
+    const float dscale = (z * z - 1.0f) / scale;       // d logp / d scale
+    const float dscale_du = 0.5f / root;                // d scale / d (loc/pnm + eps)
+    dpnm = dscale * dscale_du * (-loc / (pnm * pnm));
+    return (z / scale + dscale * dscale_du / pnm) * m;
+}
+
 // what a projector kernel needs to write log-probabilities next to its ray-sums (lp == nullptr: no epilogue)
 struct LogLikEpilogue {
     const float *mask, *meas, *pnm;   // [S][A], [S][A][PW], one value
     float eps;
     float *lp;                        // [S][A][PW]
+    float *dlp;                       // [S][A][PW] d lp / d ray-sum for the backward, or nullptr
+
+    __device__ __forceinline__ void write(size_t o, size_t sa, float raysum) const
+    {
+        const float m = mask[sa], x = meas[o], pnm_v = *pnm;
+        lp[o] = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
+        if (dlp) {
+            float unused;
+            dlp[o] = gaussian_poisson_dlogp(raysum, m, x, pnm_v, eps, unused);
+        }
+    }
 };
 
 }  // namespace ctpvae

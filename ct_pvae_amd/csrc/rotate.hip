@@ -666,7 +666,7 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
     if (j >= g.PW) return;
     const size_t o = ((size_t)s * g.A + a) * g.PW + j;
     sino[o] = acc;
-    if constexpr (EPI) epi.lp[o] = gaussian_poisson_logp(acc, epi.mask[(size_t)s * g.A + a], epi.meas[o], *epi.pnm, epi.eps);
+    if constexpr (EPI) epi.write(o, (size_t)s * g.A + a, acc);
 }
 
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
@@ -834,7 +834,7 @@ template <int PPT, int NS>   // NS = 2: two slices per workgroup, segments inter
                              // convert, one address and one ds_read_b64 per tap serve both slices
 __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const float *__restrict__ gsino, RotGeom g,
                                                                       const float *__restrict__ Tinv8, int chunk_a,
-                                                                      float *__restrict__ gimg)
+                                                                      SliceScale scale, float *__restrict__ gimg)
 {
     typedef typename PixVec<NS>::type vec_t;
     constexpr int SHIFT = NS == 1 ? 2 : 3;
@@ -845,6 +845,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
     f32x4 *meta4 = reinterpret_cast<f32x4 *>(lds + ((chunk_a * (kSegPitch * NS + 2) + 3) & ~3));
     const int s = blockIdx.z * NS;
     const bool has2 = NS == 2 && s + 1 < g.S;     // an odd batch ends with a half-empty pair (slice s read twice)
+    const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
@@ -998,10 +999,10 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
             const int r = r0 + k * nwaves;
             if (r < g.H) {
                 if constexpr (NS == 1) {
-                    gimg[((size_t)s * g.H + r) * g.W + c] = acc[k];
+                    gimg[((size_t)s * g.H + r) * g.W + c] = k0 * acc[k];
                 } else {
-                    gimg[((size_t)s * g.H + r) * g.W + c] = acc[k].x;
-                    if (has2) gimg[((size_t)(s + 1) * g.H + r) * g.W + c] = acc[k].y;
+                    gimg[((size_t)s * g.H + r) * g.W + c] = k0 * acc[k].x;
+                    if (has2) gimg[((size_t)(s + 1) * g.H + r) * g.W + c] = k1 * acc[k].y;
                 }
             }
         }
@@ -1276,17 +1277,28 @@ int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int P
 int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                                        const float *T8_dev, int A, void *workspace_dev, const float *mask_dev,
                                        const float *meas_dev, const float *pnm_dev, float eps, float *sino_dev,
-                                       float *lp_dev, ctpvae_stream_t stream)
+                                       float *lp_dev, float *dlp_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_tiled_loglik: null pointer");
     return launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev,
-                            LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev}, stream);
+                            LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev}, stream);
 }
 
 int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
                           int mode, int H, int W, int py, int px, float *gimg_dev, ctpvae_stream_t stream)
 {
+    return ctpvae_rotate_bwd_scaled_f32(gsino_dev, S, A, PH, PW, T8_dev, interp, mode, H, W, py, px, nullptr, 0, gimg_dev, stream);
+}
+
+int ctpvae_rotate_bwd_scaled_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
+                                 int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
+                                 float *gimg_dev, ctpvae_stream_t stream)
+{
     CTPVAE_REQUIRE(gsino_dev && T8_dev && gimg_dev, "rotate_bwd: null pointer");
+    // only the NEAREST / TF_COMPAT segment kernel applies the per-slice factor in its store
+    CTPVAE_REQUIRE(scale_dev == nullptr || (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && S <= 65535 &&
+                                            getenv("CTPVAE_FORCE_GENERIC") == nullptr),
+                   "rotate_bwd_scaled: a per-slice scale needs interp=NEAREST, mode=TF_COMPAT and S <= 65535");
     if (int rc = check_geom("rotate_bwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     CTPVAE_REQUIRE(mode == CTPVAE_BWD_TF_COMPAT || mode == CTPVAE_BWD_EXACT, "rotate_bwd: unknown mode %d", mode);
     const RotGeom g{S, H, W, PH, PW, py, px, A};
@@ -1304,7 +1316,8 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
         if (const char *e = getenv("CTPVAE_TUNE_SEG_PPT")) ppt = atoi(e) == 4 ? 4 : 8;
         const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), units), block(256);
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev, chunk_a, gimg_dev);
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev, chunk_a,
+                               SliceScale{scale_dev, scale_stride}, gimg_dev);
         };
         if (ns == 2) {
             if (ppt == 8) launch(rotate_bwd_tfcompat_seg_kernel<8, 2>); else launch(rotate_bwd_tfcompat_seg_kernel<4, 2>);

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
             auto store = [&](int sl, float v) {
                 const size_t o = ((size_t)sl * g.A + cur.a) * g.PW + cur.j;
                 sino[o] = v;
-                if constexpr (EPI) epi.lp[o] = gaussian_poisson_logp(v, epi.mask[(size_t)sl * g.A + cur.a], epi.meas[o], *epi.pnm, epi.eps);
+                if constexpr (EPI) epi.write(o, (size_t)sl * g.A + cur.a, v);
             };
             if constexpr (NS == 1) {
                 store(s, acc);
@@ -516,7 +516,7 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
 template <int PPT, int MAXT, int NS>
 __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y, int g_S,
-                                                                 float *__restrict__ gimg)
+                                                                 SliceScale scale, float *__restrict__ gimg)
 {
     typedef typename SliceVec<NS>::type vec_t;
     constexpr int kChunk = kBwdChunk / NS;
@@ -539,6 +539,7 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     }
     const int s = u * NS;
     const bool has2 = NS == 2 && s + 1 < g_S;   // an odd batch ends with a half-empty pair (slice s staged twice)
+    const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
     const int xb = tile % L.nXB, ty = tile / L.nXB;
     const float *gs = gsino + (size_t)s * g.A * g.PW;
     const int xcol = xb * 64 + lane;
@@ -632,10 +633,10 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
             const int y = y0 + k * nwaves;
             if (y < g.H) {
                 if constexpr (NS == 1) {
-                    gimg[((size_t)s * g.H + y) * g.W + xcol] = acc[k];
+                    gimg[((size_t)s * g.H + y) * g.W + xcol] = k0 * acc[k];
                 } else {
-                    gimg[((size_t)s * g.H + y) * g.W + xcol] = acc[k].x;
-                    if (has2) gimg[((size_t)(s + 1) * g.H + y) * g.W + xcol] = acc[k].y;
+                    gimg[((size_t)s * g.H + y) * g.W + xcol] = k0 * acc[k].x;
+                    if (has2) gimg[((size_t)(s + 1) * g.H + y) * g.W + xcol] = k1 * acc[k].y;
                 }
             }
         }
@@ -798,15 +799,22 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
 int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
                                          const void *fwd_plan_dev, const float *mask_dev, const float *meas_dev,
                                          const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
-                                         ctpvae_stream_t stream)
+                                         float *dlp_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_planned_loglik: null pointer");
     return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev,
-                              LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev}, stream);
+                              LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev}, stream);
 }
 
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A, const void *bwd_plan_dev,
                                   float *gimg_dev, ctpvae_stream_t stream)
+{
+    return ctpvae_rotate_bwd_planned_scaled_f32(gsino_dev, S, H, W, PH, PW, A, bwd_plan_dev, nullptr, 0, gimg_dev, stream);
+}
+
+int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                         const void *bwd_plan_dev, const float *scale_dev, long long scale_stride,
+                                         float *gimg_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(gsino_dev && bwd_plan_dev && gimg_dev, "rotate_bwd_planned: null pointer");
     CTPVAE_REQUIRE(S > 0, "rotate_bwd_planned: need at least one slice");
@@ -845,7 +853,7 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
             attr_set = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
-                           (const uint4 *)bwd_plan_dev, tiles_y, S, gimg_dev);
+                           (const uint4 *)bwd_plan_dev, tiles_y, S, SliceScale{scale_dev, scale_stride}, gimg_dev);
         return CTPVAE_OK;
     };
     int rc;

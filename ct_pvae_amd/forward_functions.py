@@ -198,20 +198,28 @@ class RotatePlan:
         with torch.cuda.device(self._dev_index):
             return self._forward(img, out)
 
-    def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None):
+    def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False):
         """Forward with the log-likelihood epilogue (one launch): returns (sino, lp), both [S][A][PW];
-        lp = Normal(loc = sino * mask, scale = eps + sqrt(loc / pnm + eps)).log_prob(meas).  Planned and tiled geometries."""
+        lp = Normal(loc = sino * mask, scale = eps + sqrt(loc / pnm + eps)).log_prob(meas).  Planned and tiled geometries.
+        with_dlp: also returns d lp / d sino (third value), which `backward(dlp, scale=...)` turns into the image
+        gradient without an elementwise pass."""
         if _current_device() == self._dev_index:
-            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp)
+            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp)
         with torch.cuda.device(self._dev_index):
-            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp)
+            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp)
 
-    def backward(self, gsino, out=None):
-        """cotangents [S][A][PW] -> gradient images [S][H][W] (the mode chosen at construction)."""
+    def backward(self, gsino, out=None, scale=None):
+        """cotangents [S][A][PW] -> gradient images [S][H][W] (the mode chosen at construction).
+        scale: optional float32 device tensor of S per-slice factors (any stride, 0 included: an expanded scalar)
+        applied in the kernel's store -- nearest / tf_compat only (`supports_scale`)."""
         if _current_device() == self._dev_index:
-            return self._backward(gsino, out)
+            return self._backward(gsino, out, scale)
         with torch.cuda.device(self._dev_index):
-            return self._backward(gsino, out)
+            return self._backward(gsino, out, scale)
+
+    @property
+    def supports_scale(self):
+        return self.interp == _lib.NEAREST and self.mode == _lib.BWD_TF_COMPAT
 
     def _check(self, t, shape_tail, what):
         """Operand checks before a launch: the kernels index by these shapes and would read out of bounds otherwise.
@@ -270,7 +278,7 @@ class RotatePlan:
             _lib.check(rc, "rotate_fwd")
         return out
 
-    def _forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None):
+    def _forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False):
         self._check(img, (self.H, self.W), "img")
         S = img.shape[0]
         ws = self._tile_workspace(S)
@@ -290,19 +298,27 @@ class RotatePlan:
             self._check(out_lp, (self.A, self.PW), "out_lp")
         if out.shape[0] != S or out_lp.shape[0] != S:
             raise ValueError("out / out_lp must hold one sinogram per slice")
+        if with_dlp or out_dlp is not None:
+            if out_dlp is None:
+                out_dlp = torch.empty_like(out)
+            else:
+                self._check(out_dlp, (self.A, self.PW), "out_dlp")
+                if out_dlp.shape[0] != S:
+                    raise ValueError("out_dlp must hold one sinogram per slice")
+        dlp_ptr = out_dlp.data_ptr() if out_dlp is not None else None
         if self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_loglik_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), mask.data_ptr(),
-                meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(), out_lp.data_ptr(),
+                meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(), out_lp.data_ptr(), dlp_ptr,
                 _stream_ptr(self._dev_index))
         else:
             rc = self._lib.ctpvae_rotate_fwd_tiled_loglik_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,
                 ws.data_ptr(), mask.data_ptr(), meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
-                out_lp.data_ptr(), _stream_ptr(self._dev_index))
+                out_lp.data_ptr(), dlp_ptr, _stream_ptr(self._dev_index))
         if rc:
             _lib.check(rc, "rotate_fwd_planned_loglik")
-        return out, out_lp
+        return (out, out_lp, out_dlp) if out_dlp is not None else (out, out_lp)
 
     def backward_uses_plan(self, S):
         """Large batches at few angles: the direct segment kernel (no index stream) is the faster of the two
@@ -310,9 +326,17 @@ class RotatePlan:
         everywhere else."""
         return self._want_bwd_plan and not (S >= 80 and self.A <= 64)
 
-    def _backward(self, gsino, out=None):
+    def _backward(self, gsino, out=None, scale=None):
         self._check(gsino, (self.A, self.PW), "gsino")
         S = gsino.shape[0]
+        sc_ptr, sc_stride = None, 0
+        if scale is not None:
+            if not self.supports_scale:
+                raise ValueError("a per-slice scale needs interp='nearest' and backward='tf_compat'")
+            if (scale.dim() != 1 or scale.shape[0] != S or scale.dtype is not torch.float32 or scale.device != self._tdev):
+                raise ValueError(f"scale must be a float32 tensor of {S} per-slice factors on {self._tdev} "
+                                 f"(got {tuple(scale.shape)}, {scale.dtype}, {scale.device})")
+            sc_ptr, sc_stride = scale.data_ptr(), scale.stride(0)
         if out is None:
             out = torch.empty((S, self.H, self.W), dtype=torch.float32, device=gsino.device)
         else:
@@ -322,13 +346,14 @@ class RotatePlan:
         if self.backward_uses_plan(S):
             if self._bwd_plan is None:
                 self._bwd_plan = self._build_plan(1)
-            rc = self._lib.ctpvae_rotate_bwd_planned_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
-                                                         self._bwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+            rc = self._lib.ctpvae_rotate_bwd_planned_scaled_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                                self._bwd_plan.data_ptr(), sc_ptr, sc_stride, out.data_ptr(),
+                                                                _stream_ptr(self._dev_index))
         else:
             tab = self.Tinv8 if self.mode == _lib.BWD_TF_COMPAT else self.T8
-            rc = self._lib.ctpvae_rotate_bwd_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, tab.data_ptr(),
-                                                 self.interp, self.mode, self.H, self.W, self.py, self.px,
-                                                 out.data_ptr(), _stream_ptr(self._dev_index))
+            rc = self._lib.ctpvae_rotate_bwd_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, tab.data_ptr(),
+                                                        self.interp, self.mode, self.H, self.W, self.py, self.px,
+                                                        sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
         if rc:
             _lib.check(rc, "rotate_bwd")
         return out

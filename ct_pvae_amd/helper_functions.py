@@ -125,18 +125,33 @@ def gaussian_poisson_log_prob(proj, mask, proj_sample, poisson_noise_multiplier,
 
 
 class _ProjectLogLik(torch.autograd.Function):
-    """a2 + a8 in one launch: planned forward with the log-likelihood epilogue; the backward is the
-    elementwise log-likelihood backward followed by the projector's backward, exactly as the two-step path."""
+    """a2 + a8 in one launch: planned / tiled forward with the log-likelihood epilogue.
+
+    Backward, when only the reconstruction needs a gradient: the epilogue also stored d lp / d sino, and the upstream
+    gradient of a per-object sum (what find_loss_vae_unsup takes, ctvae/helper_functions.py:305-312: autograd hands it
+    over as an expanded tensor, stride 0 over angles and bins) rides the projector's backward as a per-slice factor
+    -- ONE launch, no [B][A][P] cotangent in HBM.  Any other upstream gradient multiplies dlp elementwise first; a
+    trainable pnm (--train_pnm) takes the two-step backward (ctpvae_loglik_bwd_f32, which also reduces d/d pnm)."""
 
     @staticmethod
     def forward(ctx, slices, plan, mask, x, pnm, eps):
-        sino, lp = plan.forward_loglik(slices, mask, x, pnm, eps)
-        ctx.save_for_backward(sino, mask, x, pnm)
         ctx.plan, ctx.eps = plan, eps
+        ctx.fused_bwd = ctx.needs_input_grad[0] and not ctx.needs_input_grad[4] and plan.supports_scale
+        if ctx.fused_bwd:
+            _, lp, dlp = plan.forward_loglik(slices, mask, x, pnm, eps, with_dlp=True)
+            ctx.save_for_backward(dlp)
+        else:
+            sino, lp = plan.forward_loglik(slices, mask, x, pnm, eps)
+            ctx.save_for_backward(sino, mask, x, pnm)
         return lp
 
     @staticmethod
     def backward(ctx, gout):
+        if ctx.fused_bwd:
+            dlp, = ctx.saved_tensors
+            if gout.stride(1) == 0 and gout.stride(2) == 0:
+                return ctx.plan.backward(dlp, scale=gout[:, 0, 0]), None, None, None, None, None
+            return ctx.plan.backward(gout * dlp), None, None, None, None, None
         lib = _lib.load()
         sino, mask, x, pnm = ctx.saved_tensors
         B, A, P = sino.shape

@@ -92,7 +92,7 @@ int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int P
 int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                                        const float *T8_dev, int A, void *workspace_dev, const float *mask_dev,
                                        const float *meas_dev, const float *pnm_dev, float eps, float *sino_dev,
-                                       float *lp_dev, ctpvae_stream_t stream);
+                                       float *lp_dev, float *dlp_dev, ctpvae_stream_t stream);
 
 /* ---- a4: backward of the above -------------------------------------------------------------
  * gsino_dev [S][A][PW] cotangent.  gimg_dev [S][H][W] (overwritten).
@@ -101,6 +101,14 @@ int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W
 int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev,
                           int interp, int mode, int H, int W, int py, int px, float *gimg_dev,
                           ctpvae_stream_t stream);
+/* ... with a per-slice factor applied in the kernel's own store: gimg[s] = scale_dev[s * scale_stride] * (the sum).
+ * This is the backward half of SURVEY 8 f1: with gsino_dev = the dlp the fused forward wrote and scale = the upstream
+ * gradient of sum(lp[s]) (TF's gradient of reduce_sum is a broadcast: stride 0 over angles and bins), the whole
+ * backward of calculate_log_prob_M_given_R (ctvae/helper_functions.py:336-368) is this one launch.
+ * scale_dev NULL = ctpvae_rotate_bwd_f32; otherwise interp NEAREST and mode TF_COMPAT only. */
+int ctpvae_rotate_bwd_scaled_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev,
+                                 int interp, int mode, int H, int W, int py, int px, const float *scale_dev,
+                                 long long scale_stride, float *gimg_dev, ctpvae_stream_t stream);
 
 /* ---- gather plans (NEAREST): the tap indices of a geometry, computed once, reused for every slice ----------
  * The tap a sample reads depends on (angle, canvas row, detector bin) only, so for batched projection the index
@@ -120,15 +128,21 @@ int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int
                                   const void *fwd_plan_dev, float *sino_dev, ctpvae_stream_t stream);
 /* a8 fused into a2: the planned forward that also writes, for every ray-sum, the log-probability of the
  * measured sample under it -- lp[s][a][j] = ctpvae_loglik_fwd_f32's expression on (sino[s][a][j], mask[s][a],
- * meas[s][a][j]) -- in the same launch.  sino_dev is still written (the backward needs it). */
+ * meas[s][a][j]) -- in the same launch.  sino_dev is still written.  dlp_dev (may be NULL) receives
+ * d lp / d sino [S][A][PW], i.e. what ctpvae_loglik_bwd_f32 multiplies the upstream gradient by, so that the backward
+ * needs no elementwise pass: see ctpvae_rotate_bwd_planned_scaled_f32. */
 int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
                                          const void *fwd_plan_dev, const float *mask_dev, const float *meas_dev,
                                          const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
-                                         ctpvae_stream_t stream);
+                                         float *dlp_dev, ctpvae_stream_t stream);
 /* (Which backward: both give the same bits.  The planned one wins except for large batches at few angles -- S >= 80
  * and A <= 64 -- where ctpvae_rotate_bwd_f32's segment kernel, which streams no indices, is up to 25 % faster.) */
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
                                   const void *bwd_plan_dev, float *gimg_dev, ctpvae_stream_t stream);
+/* ... with the per-slice factor of ctpvae_rotate_bwd_scaled_f32 (scale_dev NULL = no factor). */
+int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                         const void *bwd_plan_dev, const float *scale_dev, long long scale_stride,
+                                         float *gimg_dev, ctpvae_stream_t stream);
 
 /* ---- a7: TomoPy-style ray-driven projector --------------------------------------------------
  * Tables (host side, fp32): theta [dt] -> sin, cos of fmodf(theta, 2*pi) and libtomo's quadrant flag. */

@@ -483,6 +483,65 @@ def test_fused_projector_loglik_equals_two_steps(B, N, A):
     assert abs(float(outs[0][2]) - float(outs[1][2])) <= 1e-4 * abs(float(outs[1][2])) + 1e-12   # atomics order
 
 
+@pytest.mark.parametrize("B,N,A", [(5, 128, 20), (51, 128, 20), (81, 48, 12), (3, 256, 6), (17, 256, 6)])
+@pytest.mark.parametrize("upstream", ["per_object", "scalar", "elementwise"])
+def test_fused_loglik_backward_is_one_launch_and_matches_two_steps(B, N, A, upstream):
+    """Backward half of SURVEY 8 f1: with only the reconstruction differentiated, the fused forward stores d lp / d sino
+    and the projector's backward applies the upstream gradient of a per-object sum as a per-slice factor in its store
+    (planned pairs / singles, segment kernel pairs / singles with odd batches).  Against the two-step path (projector,
+    elementwise log-likelihood, their two backward kernels): <= 1e-5 of the largest gradient (the factor multiplies
+    after the sum over angles instead of before it)."""
+    from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
+    d = dev()
+    rng = np.random.default_rng(7 * B + N)
+    theta = torch.from_numpy(np.linspace(0, np.pi, A, endpoint=False).astype(np.float32)).to(d)
+    P = cp.num_proj_pix(N, N)
+    mask = torch.from_numpy((rng.random((B, A), dtype=np.float32) + 0.5) / A).to(d)
+    meas = torch.from_numpy(rng.random((B, A, P), dtype=np.float32) * 3).to(d)
+    eps = float(np.finfo(np.float32).eps)
+    w = torch.from_numpy(rng.standard_normal(B).astype(np.float32)).to(d)
+    up = torch.from_numpy(rng.standard_normal((B, A, P, 1)).astype(np.float32)).to(d)
+
+    def loss(lp):
+        if upstream == "per_object":
+            return (lp.sum(dim=(1, 2, 3)) * w).sum()
+        if upstream == "scalar":
+            return lp.sum() * 0.37
+        return (lp * up).sum()
+
+    grads = []
+    for fused in (True, False):
+        x = torch.from_numpy(rng_img(B, N)).to(d).requires_grad_(True)
+        if fused:
+            lp = cp.calculate_log_prob_M_given_R(x, mask, meas, 1e3, eps, theta=theta, pad=True)
+            assert type(lp.grad_fn.next_functions[0][0]).__name__.startswith("_ProjectLogLik")
+        else:
+            proj = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+            lp = gaussian_poisson_log_prob(proj[..., 0], mask, meas, 1e3, eps).unsqueeze(-1)
+        loss(lp).backward()
+        grads.append(x.grad.detach())
+    assert torch.isfinite(grads[0]).all()
+    assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[1].abs().max())
+
+
+def test_backward_scale_operand_checks():
+    d = dev()
+    theta = np.linspace(0, np.pi, 6, endpoint=False)
+    plan = cp.RotatePlan(theta, 32, 32, True, d)
+    g = torch.randn(4, 6, plan.PW, device=d)
+    base = plan.backward(g)
+    sc = torch.tensor([2.0, -1.0, 0.5, 0.0], device=d)
+    assert torch.equal(plan.backward(g, scale=sc), base * sc.view(4, 1, 1))
+    assert torch.equal(plan.backward(g, scale=torch.tensor(3.0, device=d).expand(4)), base * 3.0)
+    with pytest.raises(ValueError):
+        plan.backward(g, scale=sc[:3])
+    with pytest.raises(ValueError):
+        plan.backward(g, scale=sc.double())
+    bil = cp.RotatePlan(theta, 32, 32, True, d, interp="bilinear")
+    with pytest.raises(ValueError):
+        bil.backward(g, scale=sc)
+
+
 def rng_img(B, N):
     return np.random.default_rng(1234).random((B, N, N, 1), dtype=np.float32)
 
