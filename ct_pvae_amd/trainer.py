@@ -52,6 +52,60 @@ def positive_range(x, offset=EPS32):
     return (torch.exp(torch.clamp(x, -1e10, 10)) + offset) * neg + (x + 1) * (1 - neg)
 
 
+class _Maxout(torch.autograd.Function):
+    """max of the two halves of the channel axis (ctvae/models.py:330-341, tf.maximum of two convolutions).  One
+    comparison mask kept for the backward, which writes both halves of the gradient directly: 2 + 3 launches instead of
+    the 14 of chunk + torch.maximum under autograd (two slice-backward fills and copies, mask, tie handling, add).
+    Ties send the gradient to the first convolution, as TensorFlow's MaximumGrad does (x >= y)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        c = y.shape[1] // 2
+        a, b = y[:, :c], y[:, c:]
+        first = a >= b
+        ctx.save_for_backward(first)
+        return torch.where(first, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        first, = ctx.saved_tensors
+        c = g.shape[1]
+        gy = g.new_empty((g.shape[0], 2 * c) + tuple(g.shape[2:]))
+        torch.mul(g, first, out=gy[:, :c])
+        torch.sub(g, gy[:, :c], out=gy[:, c:])        # g where the second convolution won, 0 elsewhere (exact)
+        return gy
+
+
+class _PeriodicPad(torch.autograd.Function):
+    """'periodic' padding of the two spatial axes (ctvae/models.py:219-263) as two gathers; the backward is the two
+    matching scatter-adds (every source pixel receives at most two terms per axis, so the sum does not depend on the
+    order).  4 + 6 launches instead of the ~20 of F.pad(mode='circular') under autograd (slice assignments forward,
+    slice-backward fills, copies and adds backward)."""
+    _index = {}
+
+    @classmethod
+    def index(cls, n, lo, hi, device):
+        key = (n, lo, hi, str(device))
+        idx = cls._index.get(key)
+        if idx is None:
+            idx = cls._index[key] = (torch.arange(-lo, n + hi, device=device) % n)
+        return idx
+
+    @staticmethod
+    def forward(ctx, x, pads):
+        wl, wr, hl, hr = pads
+        ctx.ih = _PeriodicPad.index(x.shape[2], hl, hr, x.device)
+        ctx.iw = _PeriodicPad.index(x.shape[3], wl, wr, x.device)
+        ctx.hw = x.shape[2:]
+        return x.index_select(2, ctx.ih).index_select(3, ctx.iw)
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.hw
+        gw = g.new_zeros(g.shape[:3] + (W,)).index_add_(3, ctx.iw, g)
+        return gw.new_zeros(gw.shape[:2] + (H, W)).index_add_(2, ctx.ih, gw), None
+
+
 class ConvBlock(nn.Module):
     """Conv2D => maxout of two convolutions (ctvae/models.py:267-342); 'periodic' padding for the strided/plain
     convolutions (:219-263), Conv2DTranspose(padding='same') for up-sampling."""
@@ -79,9 +133,8 @@ class ConvBlock(nn.Module):
             for n in (x.shape[-1], x.shape[-2]):   # F.pad wants the last axis first
                 p = self.k - (n % self.stride if n % self.stride else self.stride)
                 pads += [p // 2 + p % 2, p // 2]
-            x = F.pad(x, pads, mode="circular")
-        a, b = self.ab(x).chunk(2, dim=1)
-        return torch.maximum(a, b)
+            x = _PeriodicPad.apply(x, tuple(pads))
+        return _Maxout.apply(self.ab(x))
 
 
 class EncodeNet(nn.Module):

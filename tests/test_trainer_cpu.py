@@ -68,3 +68,26 @@ def test_ramp_filter_and_args():
     a = tr.get_args("--nsa 20 --td 50 -b 5 --ns 2 --api 20 --pnm 1e4 --pnm_start 1e3 --random --normal -i 1000 --train".split())
     assert (a.nsa, a.td, a.batch_size, a.ns, a.api, a.pnm, a.pnm_start, a.random, a.num_iter) == (20, 50, 5, 2, 20, 1e4, 1e3, True, 1000)
     assert math.isclose(math.exp(math.log(a.pnm / a.pnm_start) / a.num_iter) ** 1000, 10.0, rel_tol=1e-9)
+
+
+def test_periodic_pad_and_maxout_match_their_torch_definitions():
+    """The trainer's two launch-saving autograd functions against F.pad(mode='circular') and chunk + torch.maximum:
+    same values, same gradients (ctvae/models.py:219-263 periodic padding, :330-341 maxout)."""
+    import torch.nn.functional as F
+    from ct_pvae_amd.trainer import _Maxout, _PeriodicPad
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 7, 9, dtype=torch.float64, requires_grad=True)
+    for pads in [(1, 1, 1, 1), (2, 1, 1, 2), (3, 2, 0, 1)]:
+        a, b = _PeriodicPad.apply(x, pads), F.pad(x, list(pads), mode="circular")
+        assert torch.equal(a, b)
+        w = torch.randn_like(a)
+        ga, = torch.autograd.grad((a * w).sum(), x)
+        gb, = torch.autograd.grad((b * w).sum(), x)
+        assert torch.allclose(ga, gb, atol=1e-13)
+    y = torch.randn(2, 8, 5, 5, dtype=torch.float64, requires_grad=True)
+    m1, m2 = _Maxout.apply(y), torch.maximum(*y.chunk(2, 1))
+    assert torch.equal(m1, m2)
+    w = torch.randn_like(m1)
+    g1, = torch.autograd.grad((m1 * w).sum(), y)
+    g2, = torch.autograd.grad((m2 * w).sum(), y)
+    assert torch.equal(g1, g2)
