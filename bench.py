@@ -108,11 +108,11 @@ def train_mode(args, world, rank, dev):
                         f"-i {args.steps + args.warmup} --train --miopen_find".split())
     t = tr.PVAETrainer(targs, dev)
     for _ in range(args.warmup):
-        t.train_step()
+        t.train_step(sync=False)
     barrier_sync(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        t.train_step()
+        t.train_step(sync=False)
     barrier_sync(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
     # projector share: the same 2 x (fwd + bwd) on 5 objects x 20 angles per step, timed alone

@@ -337,7 +337,10 @@ class PVAETrainer:
         return self.proj_samples[idx], self.masks[idx], self.input_encode[idx]
 
     # -- one step (CT_VAE.train_step, ctvae/main_ct_vae.py:463-486) -------------------------------------------
-    def train_step(self):
+    def train_step(self, sync=True):
+        """One optimisation step.  sync=True returns the loss as a python float (a host round trip, as the reference's
+        per-iteration `.numpy()`); sync=False returns it as a 0-d device tensor so that the host keeps queueing the
+        next step's ~800 launches while the GPU finishes this one (`train` reads the losses back in blocks)."""
         a = self.args
         proj_sample, mask, input_encode = self._batch()
         angles_i = torch.as_tensor(self.angles.next(), device=self.dev)
@@ -365,24 +368,30 @@ class PVAETrainer:
         torch._foreach_copy_(grads, [v.view_as(gr) for v, gr in zip(views, grads)])
         self.opt.step()
         self.iter += 1
-        return float(loss.item()) if self.world == 1 else self._global_loss(loss)
-
-    def _global_loss(self, loss):
-        t = loss.detach().clone()
-        torch.distributed.all_reduce(t)
-        return float(t.item())
+        loss = loss.detach()
+        if self.world > 1:
+            loss = loss.clone()
+            torch.distributed.all_reduce(loss)
+        return float(loss.item()) if sync else loss
 
     def train(self):
         a = self.args
-        losses, t0 = [], time.time()
+        losses, pending, t0 = [], [], time.time()
+        every = max(a.num_iter // 10, 1)
         for it in range(a.num_iter):
-            loss = self.train_step()
-            losses.append(loss)
-            if self.rank == 0 and (it % max(a.num_iter // 10, 1) == 0 or it == a.num_iter - 1):
-                print(f"Iteration number: {it}  Training loss_M_VAE: {loss:.6f}", flush=True)
-            if math.isnan(loss):
-                raise SystemExit("loss is NaN")                            # ctvae/main_ct_vae.py:401-402
-            if a.save_path and self.rank == 0 and (it % a.si == 0 or it == a.num_iter - 1):
+            pending.append(self.train_step(sync=False))
+            report = it % every == 0 or it == a.num_iter - 1
+            saving = bool(a.save_path) and (it % a.si == 0 or it == a.num_iter - 1)
+            if report or saving or len(pending) >= 32:
+                # losses come back in blocks: one host round trip per block instead of one per iteration; the
+                # reference's NaN stop (ctvae/main_ct_vae.py:401-402) therefore acts within 32 iterations
+                losses += torch.stack(pending).tolist()
+                pending = []
+                if any(math.isnan(v) for v in losses[-32:]):
+                    raise SystemExit("loss is NaN")
+            if report and self.rank == 0:
+                print(f"Iteration number: {it}  Training loss_M_VAE: {losses[-1]:.6f}", flush=True)
+            if saving and self.rank == 0:
                 self.save(os.path.join(a.save_path, "training_checkpoints", f"ckpt-{it}.pt"), losses)
         return losses, time.time() - t0
 
