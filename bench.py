@@ -62,6 +62,17 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
+def close_timed_region(t0, world):
+    """Closing bracket of a timed region: this rank's K steps are complete (synchronize) -> read the clock -> barrier +
+    synchronize -> MAX over ranks.  The clock is read before the closing barrier so that the collective's own latency
+    (tens of microseconds over 8 ranks, against 14 us steps) is not billed to the steps; the maximum over ranks still
+    spans from the common start to the slowest rank's last kernel."""
+    torch.cuda.synchronize()
+    local = time.perf_counter() - t0
+    barrier_sync(world)
+    return max_over_ranks(local, world)
+
+
 def max_over_ranks(seconds, world):
     return sharding.max_over_ranks(seconds)
 
@@ -113,8 +124,7 @@ def train_mode(args, world, rank, dev):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         t.train_step(sync=False)
-    barrier_sync(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    elapsed = close_timed_region(t0, world)
     # projector share: the same 2 x (fwd + bwd) on 5 objects x 20 angles per step, timed alone
     from ct_pvae_amd.forward_functions import RotatePlan as RP
     theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
@@ -146,8 +156,7 @@ def _time_loop(fn, steps, warmup, world):
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
-    barrier_sync(world)
-    return max_over_ranks(time.perf_counter() - t0, world)
+    return close_timed_region(t0, world)
 
 
 def siddon_mode(args, world, rank, dev):
@@ -251,8 +260,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier_sync(world)
-    elapsed = max_over_ranks(time.perf_counter() - t0, world)
+    elapsed = close_timed_region(t0, world)
 
     # ---- per-kernel durations, HIP events on the launch stream (torch's current stream) -------------------
     # One event pair brackets n_ev back-to-back launches of ONE kernel: the average duration of a launch in a stream of

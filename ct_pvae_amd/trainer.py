@@ -333,21 +333,33 @@ class PVAETrainer:
         """Global batch of `-b` examples, the same on every rank; each rank keeps its shard."""
         idx = self.order.choice(self.args.td, size=self.args.batch_size, replace=False)
         lo, hi = sharding.shard_range(len(idx), self.rank, self.world)
-        idx = torch.as_tensor(idx[lo:hi], device=self.dev)
+        idx = self._to_device(idx[lo:hi])
         return self.proj_samples[idx], self.masks[idx], self.input_encode[idx]
 
+    def _to_device(self, host_array):
+        """Small per-step index arrays go up through pinned memory without waiting: a plain torch.as_tensor(...,
+        device=) is a blocking copy that first drains the stream, i.e. idles the GPU while the host prepares a step."""
+        t = torch.from_numpy(np.ascontiguousarray(host_array))
+        if self.dev.type != "cuda":
+            return t
+        return t.pin_memory().to(self.dev, non_blocking=True)
+
     # -- one step (CT_VAE.train_step, ctvae/main_ct_vae.py:463-486) -------------------------------------------
-    def train_step(self, sync=True):
-        """One optimisation step.  sync=True returns the loss as a python float (a host round trip, as the reference's
-        per-iteration `.numpy()`); sync=False returns it as a 0-d device tensor so that the host keeps queueing the
-        next step's ~800 launches while the GPU finishes this one (`train` reads the losses back in blocks)."""
+    def _next_inputs(self):
+        """Host side of a step: the batch, the angle subset and the two annealed scalars."""
         a = self.args
         proj_sample, mask, input_encode = self._batch()
-        angles_i = torch.as_tensor(self.angles.next(), device=self.dev)
-        pnm_i = self.pnm * (self.pnm_anneal ** self.iter)
+        angles_i = self._to_device(self.angles.next())
+        pnm_factor = self.pnm_anneal ** self.iter
         self.kl_anneal = min(max(self.kl_anneal * a.klaf, 0.0), 100.0)
+        return proj_sample, mask, input_encode, angles_i, pnm_factor, self.kl_anneal
+
+    def _loss_and_update(self, proj_sample, mask, input_encode, angles_i, pnm_factor, kl_anneal):
+        """Device side of a step: ELBO, backward, NaN filter + clip, Adam."""
+        a = self.args
+        pnm_i = self.pnm * pnm_factor
         loss_vec, kl, loglik, _ = find_loss_vae_unsup(proj_sample, mask, input_encode, self.enc, self.dec, pnm_i,
-                                                      self.sqrt_reg, self.kl_anneal, a.klm, num_samples=a.ns,
+                                                      self.sqrt_reg, kl_anneal, a.klm, num_samples=a.ns,
                                                       theta=self.theta, angles_i=angles_i, pad=True,
                                                       deterministic=a.deterministic)
         # mean over the GLOBAL batch: each rank contributes sum/global_B, gradients are then summed over ranks
@@ -367,8 +379,14 @@ class PVAETrainer:
         torch._foreach_mul_(views, list(scales.unbind()))
         torch._foreach_copy_(grads, [v.view_as(gr) for v, gr in zip(views, grads)])
         self.opt.step()
+        return loss.detach()
+
+    def train_step(self, sync=True):
+        """One optimisation step.  sync=True returns the loss as a python float (a host round trip, as the reference's
+        per-iteration `.numpy()`); sync=False returns it as a 0-d device tensor so that the host keeps queueing the
+        next step's ~800 launches while the GPU finishes this one (`train` reads the losses back in blocks)."""
+        loss = self._loss_and_update(*self._next_inputs())
         self.iter += 1
-        loss = loss.detach()
         if self.world > 1:
             loss = loss.clone()
             torch.distributed.all_reduce(loss)
