@@ -43,6 +43,9 @@ def parse():
                     help="projector: the headline fwd+adj metric, BASELINE config 2 (default; --angles 180 = config 4's "
                          "per-GPU share); train: config 3, P-VAE steps/s; siddon: config 1, TomoPy-style forward; "
                          "n512: config 5, 512x512 x 90 angles fwd + log-likelihood + adj")
+    ap.add_argument("--grad-allreduce", action="store_true",
+                    help="config 4 (batch=400 over 8 GPUs, 180 angles): every step also sums one flat fp32 bucket of the "
+                         "P-VAE's 711,164 gradients (2.8 MB) over the ranks -- the data-parallel trainer's only collective")
     ap.add_argument("--n512-batch", type=int, default=32,
                     help="objects per GPU in --mode n512 (32: 768 tile workgroups = 3 full rounds on 256 CUs; 8: 192)")
     return ap.parse_args()
@@ -250,9 +253,13 @@ def main():
     sino = torch.empty((B, A, P), dtype=torch.float32, device=dev)
     gimg = torch.empty((B, N, N), dtype=torch.float32, device=dev)
 
+    bucket = torch.zeros(711164, dtype=torch.float32, device=dev) if args.grad_allreduce else None
+
     def step():
         plan.forward(x, out=sino)
         plan.backward(g, out=gimg)
+        if bucket is not None and world > 1:
+            torch.distributed.all_reduce(bucket)                 # RCCL over xGMI: the bucket is already flat
 
     for _ in range(args.warmup):
         step()
@@ -338,7 +345,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"batch={B}/GPU {N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
-                   "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}"},
+                   "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}",
+                   "grad_allreduce_bytes_per_step": 4 * 711164 if args.grad_allreduce else 0},
         "ray_sums_per_s_per_gpu": proj_per_s * P / world,
         "hbm_fraction_whole_step": (2 * bytes_dir / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
