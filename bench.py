@@ -43,6 +43,8 @@ def parse():
                     help="projector: the headline fwd+adj metric, BASELINE config 2 (default; --angles 180 = config 4's "
                          "per-GPU share); train: config 3, P-VAE steps/s; siddon: config 1, TomoPy-style forward; "
                          "n512: config 5, 512x512 x 90 angles fwd + log-likelihood + adj")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every step from Python instead of replaying HIP graphs of 10 steps (projector mode)")
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="config 4 (batch=400 over 8 GPUs, 180 angles): every step also sums one flat fp32 bucket of the "
                          "P-VAE's 711,164 gradients (2.8 MB) over the ranks -- the data-parallel trainer's only collective")
@@ -263,9 +265,24 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # The two launches of a step take 6-8 us each -- about what one Python call of them costs the host -- so the timed
+    # loop replays HIP graphs of 10 steps (20 kernel nodes, the same launches in the same order) and launches only the
+    # K mod 10 remaining steps from Python: the GPU runs back to back whatever the host's speed (measured: 13.97 us per
+    # step replayed against 14.45 us launched on a fast host, and host-bound on a slow one).  Not with the RCCL bucket.
+    chunk, graph = 10, None
+    if not args.no_graph and bucket is None and args.steps >= chunk:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(chunk):
+                step()
+        graph.replay()                                    # one untimed replay (graph upload)
+    n_replay, n_eager = divmod(args.steps, chunk) if graph is not None else (0, args.steps)
     barrier_sync(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(n_replay):
+        graph.replay()
+    for _ in range(n_eager):
         step()
     elapsed = close_timed_region(t0, world)
 
@@ -278,13 +295,21 @@ def main():
     n_ev = min(max(args.steps, 50), 400)
 
     def avg_launch_seconds(fn):
+        """The n_ev launches are captured once into a HIP graph and replayed between the two events, so the figure is
+        the GPU's back-to-back launch duration whatever the host's speed (a Python call of a 6-7 us kernel costs about
+        as much on the host: timed from a Python loop the shorter kernel reads as host time on a slow box)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(n_ev):
+                fn()
         runs = []
         for _ in range(5):
             torch.cuda.synchronize()
             e0.record()
-            for _ in range(n_ev):
-                fn()
+            graph.replay()
             e1.record()
             torch.cuda.synchronize()
             runs.append(e0.elapsed_time(e1) * 1e-3 / n_ev)
@@ -346,7 +371,9 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"batch={B}/GPU {N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
                    "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}",
-                   "grad_allreduce_bytes_per_step": 4 * 711164 if args.grad_allreduce else 0},
+                   "grad_allreduce_bytes_per_step": 4 * 711164 if args.grad_allreduce else 0,
+                   "launch": (f"{n_replay} replays of a HIP graph of {chunk} steps + {n_eager} steps launched from Python"
+                              if graph is not None else "every step launched from Python")},
         "ray_sums_per_s_per_gpu": proj_per_s * P / world,
         "hbm_fraction_whole_step": (2 * bytes_dir / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
