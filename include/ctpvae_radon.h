@@ -22,6 +22,9 @@
  *                                              out of the per-object work (no counterpart in the reference)
  *   ctpvae_rotate_fwd_planned_loglik_f32       project_tf_fast + the Normal log_prob of calculate_log_prob_M_given_R
  *                                              ctvae/helper_functions.py:359-368, one launch
+ *   ctpvae_rotate_bwd{,_planned}_scaled_f32    the gradient of the same caller w.r.t. the reconstruction (autodiff of
+ *                                              ctvae/helper_functions.py:359-368 under the per-object sum of
+ *                                              :305-312), one launch
  *   ctpvae_siddon_tables_f32 / _fwd_f32        create_sinogram -> tomopy.project
  *                                              ctvae/helper_functions.py:33-38
  *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
