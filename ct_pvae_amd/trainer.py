@@ -31,11 +31,10 @@ import time
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import phantoms, sharding
 from .create_masks import create_all_masks
-from .fbp import iradon, iradon_all, ramp_filter  # noqa: F401  (ramp_filter re-exported)
+from .fbp import iradon_all
 from .forward_functions import num_proj_pix
 from .helper_functions import calculate_log_prob_M_given_R, create_sinograms
 
@@ -130,7 +129,7 @@ class ConvBlock(nn.Module):
     def forward(self, x):
         if not self.transpose:
             pads = []
-            for n in (x.shape[-1], x.shape[-2]):   # F.pad wants the last axis first
+            for n in (x.shape[-1], x.shape[-2]):   # last axis first, as torch.nn.functional.pad orders them
                 p = self.k - (n % self.stride if n % self.stride else self.stride)
                 pads += [p // 2 + p % 2, p // 2]
             x = _PeriodicPad.apply(x, tuple(pads))

@@ -63,7 +63,8 @@ def test_kl_and_angle_stream():
 
 
 def test_ramp_filter_and_args():
-    f = tr.ramp_filter(184)
+    from ct_pvae_amd.fbp import ramp_filter
+    f = ramp_filter(184)
     assert f.shape == (184,) and abs(f[0]) < 1e-2 and np.argmax(f) in (92, 91, 93)
     a = tr.get_args("--nsa 20 --td 50 -b 5 --ns 2 --api 20 --pnm 1e4 --pnm_start 1e3 --random --normal -i 1000 --train".split())
     assert (a.nsa, a.td, a.batch_size, a.ns, a.api, a.pnm, a.pnm_start, a.random, a.num_iter) == (20, 50, 5, 2, 20, 1e4, 1e3, True, 1000)

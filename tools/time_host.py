@@ -1,5 +1,5 @@
 """Developer check: is the fwd+adj loop GPU-bound or host-bound?  (enqueue time vs completion time)"""
-import os, sys, time, torch, numpy as np
+import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ct_pvae_amd import phantoms
 from ct_pvae_amd.forward_functions import RotatePlan

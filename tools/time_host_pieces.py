@@ -1,5 +1,5 @@
 """Developer check: where does the host time of one RotatePlan.forward call go?"""
-import os, sys, timeit, torch, numpy as np
+import os, sys, timeit, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ct_pvae_amd import phantoms, forward_functions as ff
 from ct_pvae_amd.forward_functions import RotatePlan

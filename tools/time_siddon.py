@@ -1,5 +1,5 @@
 """Developer timing of the TomoPy-style projector (create_sinograms) -- not part of the product."""
-import os, sys, time, torch, numpy as np
+import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ct_pvae_amd import helper_functions as hf, phantoms
 dev = torch.device('cuda', 0)
