@@ -294,7 +294,7 @@ class PVAETrainer:
         self._make_data()
         fm = [int(a.nfm * a.nfmm ** i) for i in range(a.num_blocks)]
         fmm = 1 if a.deterministic else 2
-        self.enc = EncodeNet(2, fm, fmm, a.kernel_size, a.stride_encode, a.il, a.ik).to(device)
+        self.enc = EncodeNet(len(a.algorithms) + 1, fm, fmm, a.kernel_size, a.stride_encode, a.il, a.ik).to(device)
         self.dec = DecodeNet(self.enc.channels, fmm, 1, a.kernel_size, a.stride_encode, a.il, a.ik).to(device)
         if self.world > 1:   # identical initial weights on every rank
             for p in list(self.enc.parameters()) + list(self.dec.parameters()):
@@ -322,7 +322,7 @@ class PVAETrainer:
                                                     truncate_dataset=a.td, device=dev)
         self.masks, self.truth = masks, torch.from_numpy(imgs).to(dev)
         # initial reconstructions for the encoder, ctvae/helper_functions.py:477-529 with FBP on the GPU
-        enc_in = iradon_all(self.proj_samples, masks, self.P, self.theta_np, ["fbp"], self.sqrt_reg, self.x_size,
+        enc_in = iradon_all(self.proj_samples, masks, self.P, self.theta_np, list(a.algorithms), self.sqrt_reg, self.x_size,
                             self.y_size, save_path=None, train=True)                  # [td][X][Y][2]
         self.input_encode = enc_in.permute(0, 3, 1, 2).contiguous()                   # [td][2][X][Y]
         self.theta = torch.from_numpy(self.theta_np.astype(np.float32)).to(dev)
@@ -468,6 +468,9 @@ def get_args(argv=None):
     p.add_argument("--miopen_find", action="store_true",
                    help="search MIOpen's convolution algorithms once (torch.backends.cudnn.benchmark); not in the reference")
     p.add_argument("--td", type=int, dest="td", default=100)
+    p.add_argument("--algorithms", nargs="+", default=["fbp"],
+                   help="initial reconstructions fed to the encoder, one channel each (ctvae/main_ct_vae.py:111-112; the "
+                        "reference's default is TomoPy's gridrec -- this build has the GPU 'fbp' only)")
     p.add_argument("--train", action="store_true")
     # synthetic-data knobs (the reference reads these from its dataset folder)
     p.add_argument("--n_pixel", type=int, default=128)

@@ -113,3 +113,16 @@ def test_setup_chain_on_the_device(tmp_path):
     assert torch.equal(again, enc)
     with pytest.raises(NotImplementedError):
         iradon_all(samples, masks, 184, theta, ["sirt"], 1e-7, 128, 128, train=True)
+
+
+def test_algorithms_flag_sets_the_encoder_channels():
+    """--algorithms (ctvae/main_ct_vae.py:111-112): one encoder input channel per initial reconstruction, plus the mask's
+    back-projection; anything but the GPU 'fbp' is refused by name."""
+    args = tr.get_args("--nsa 20 --td 6 -b 3 --ns 2 --api 10 --pnm 1e4 --random --normal -i 2 --train "
+                       "--algorithms fbp fbp".split())
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    assert tuple(t.input_encode.shape) == (6, 3, 128, 128)
+    assert math.isfinite(t.train_step())
+    bad = tr.get_args("--nsa 20 --td 6 -b 3 --train --algorithms gridrec".split())
+    with pytest.raises(NotImplementedError):
+        tr.PVAETrainer(bad, torch.device("cuda", 0))
