@@ -32,7 +32,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import phantoms, sharding
+from . import dataset_io, phantoms, sharding
 from .create_masks import create_all_masks
 from .fbp import iradon_all
 from .forward_functions import num_proj_pix
@@ -306,21 +306,31 @@ class PVAETrainer:
         self.angles = AngleStream(self.num_angles, a.api, seed=7)     # same stream on every rank
         self.iter = 0
 
-    # -- synthetic dataset (stands in for dataset_foam/*.npy) ------------------------------------------------
+    # -- dataset: --input_path (the reference's dataset_<name>/ folder) or a synthetic foam set -----------------
     def _make_data(self):
         a, dev = self.args, self.dev
-        N = a.n_pixel
-        self.theta_np = phantoms.dense_theta(a.num_angles)
-        self.num_angles = a.num_angles
-        self.P = num_proj_pix(N, N)
+        if a.input_path:
+            # x_train_sinograms.npy + dataset_parameters.npy as scripts/images_to_sinograms.py writes them
+            # (ctvae/main_ct_vae.py:152-161); the phantoms themselves are not part of that folder
+            sino_np, self.theta_np, self.P = dataset_io.get_sinograms(a.input_path)
+            a.td = min(a.td, sino_np.shape[0])
+            sino = torch.from_numpy(np.ascontiguousarray(sino_np[:a.td], dtype=np.float32)).to(dev)
+            self.theta_np = np.asarray(self.theta_np, dtype=np.float64)
+            self.num_angles = a.num_angles = len(self.theta_np)
+            imgs = None
+        else:
+            N = a.n_pixel
+            self.theta_np = phantoms.dense_theta(a.num_angles)
+            self.num_angles = a.num_angles
+            self.P = num_proj_pix(N, N)
+            imgs = phantoms.foam_batch(a.td, N, seed=0, supersample=2)
+            sino = create_sinograms(torch.from_numpy(imgs).to(dev), self.theta_np, pad=True).clamp_min(0)   # [td][A][P]
         self.x_size = self.y_size = int(math.floor(self.P / math.sqrt(2) - 2))      # ctvae/main_ct_vae.py:160-161
-        imgs = phantoms.foam_batch(a.td, N, seed=0, supersample=2)
-        sino = create_sinograms(torch.from_numpy(imgs).to(dev), self.theta_np, pad=True).clamp_min(0)   # [td][A][P]
         # dose masks and sparse noisy measurements, ctvae/create_masks.py:45-95 (simulated at the FINAL pnm)
         masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=None, poisson_noise_multiplier=a.pnm,
                                                     num_sparse_angles=a.nsa, random=a.random, train=True,
                                                     truncate_dataset=a.td, device=dev)
-        self.masks, self.truth = masks, torch.from_numpy(imgs).to(dev)
+        self.masks, self.truth = masks, (torch.from_numpy(imgs).to(dev) if imgs is not None else None)
         # initial reconstructions for the encoder, ctvae/helper_functions.py:477-529 with FBP on the GPU
         enc_in = iradon_all(self.proj_samples, masks, self.P, self.theta_np, list(a.algorithms), self.sqrt_reg, self.x_size,
                             self.y_size, save_path=None, train=True)                  # [td][X][Y][2]
@@ -434,7 +444,34 @@ class PVAETrainer:
         lat = [s.chunk(2, dim=1)[0] for s in skips] if not self.args.deterministic else skips
         alpha, _ = self.dec(lat)
         rec = positive_range(alpha)[:, 0]
+        if self.truth is None:                    # a dataset folder holds sinograms only
+            return float("nan"), float("nan")
         return float(((rec - self.truth[:n]) ** 2).mean()), float(((self.input_encode[:n, 0] - self.truth[:n]) ** 2).mean())
+
+    @torch.no_grad()
+    def final_evaluation(self, save_path=None):
+        """CT_VAE.final_evaluation (ctvae/main_ct_vae.py:427-460): the unshuffled dataset in batches of `-b`, ALL angles,
+        no update; keeps every batch's loss and one sample of the output distribution per object, and writes
+        loss_final.npy / reconstruction_final.npy ([n][X][Y][1]) -- the file bin/final_merit.py scores."""
+        a = self.args
+        lo, hi = sharding.shard_range(a.batch_size, self.rank, self.world)
+        nb = hi - lo
+        losses, recons = [], []
+        for k in range(0, (a.td // nb) * nb, nb):
+            sl = slice(k, k + nb)
+            loss_vec, _, _, recon = find_loss_vae_unsup(self.proj_samples[sl], self.masks[sl], self.input_encode[sl], self.enc,
+                                                        self.dec, self.pnm, self.sqrt_reg, self.kl_anneal, a.klm,
+                                                        num_samples=a.ns, theta=self.theta, angles_i=None, pad=True,
+                                                        deterministic=a.deterministic)
+            losses.append(loss_vec.sum() / nb / 1e5)
+            recons.append(recon.permute(0, 2, 3, 1))
+        loss_final = torch.stack(losses).cpu().numpy()
+        reconstruction_final = torch.cat(recons).cpu().numpy()
+        if save_path is not None and self.rank == 0:
+            os.makedirs(save_path, exist_ok=True)
+            np.save(os.path.join(save_path, "loss_final.npy"), loss_final)
+            np.save(os.path.join(save_path, "reconstruction_final.npy"), reconstruction_final)
+        return loss_final, reconstruction_final
 
 
 def get_args(argv=None):
@@ -463,6 +500,10 @@ def get_args(argv=None):
     p.add_argument("--train_pnm", action="store_true")
     p.add_argument("--random", action="store_true")
     p.add_argument("--save_path", default=None)
+    p.add_argument("--input_path", default=None,
+                   help="dataset folder written by scripts/images_to_sinograms.py (x_train_sinograms.npy, "
+                        "dataset_parameters.npy); without it a seeded synthetic foam set of --td phantoms is made")
+    p.add_argument("--no_final_eval", action="store_true", help="skip the final evaluation (ctvae/main_ct_vae.py:113)")
     p.add_argument("--se", type=int, dest="stride_encode", default=2)
     p.add_argument("--si", type=int, dest="si", default=100000)
     p.add_argument("--miopen_find", action="store_true",
@@ -484,6 +525,10 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     tr = PVAETrainer(args, dev)
     losses, secs = tr.train()
+    if not args.no_final_eval:
+        loss_final, _ = tr.final_evaluation(args.save_path)
+        if rank == 0:
+            print(f"Average loss final : {float(loss_final.mean()):.6f}")
     if rank == 0:
         mse, mse_fbp = tr.evaluate()
         print(f"{len(losses)} iterations in {secs:.1f} s ({len(losses) / secs:.2f} it/s); loss {losses[0]:.5f} -> {losses[-1]:.5f}; "

@@ -1,5 +1,6 @@
 """The P-VAE training step with the HIP projector as physics decoder (README quick-check recipe, scaled down)."""
 import math
+import os
 
 import pytest
 import torch
@@ -126,3 +127,31 @@ def test_algorithms_flag_sets_the_encoder_channels():
     bad = tr.get_args("--nsa 20 --td 6 -b 3 --train --algorithms gridrec".split())
     with pytest.raises(NotImplementedError):
         tr.PVAETrainer(bad, torch.device("cuda", 0))
+
+
+def test_reference_dataset_folder_in_and_reconstruction_file_out(tmp_path):
+    """SURVEY 8 f4 end to end: a dataset folder in the layout scripts/images_to_sinograms.py writes (made here with the
+    GPU TomoPy-style projector) is what --input_path trains from, and final_evaluation leaves loss_final.npy and
+    reconstruction_final.npy in the layout bin/final_merit.py reads and compare() scores."""
+    import numpy as np
+    from ct_pvae_amd import dataset_io, phantoms
+    imgs = phantoms.foam_batch(6, 64, seed=3, supersample=2)
+    ds = str(tmp_path / "dataset_foam")
+    theta = np.linspace(0, np.pi, 60, endpoint=False)
+    sino = dataset_io.images_to_sinograms(imgs, ds, theta=theta)
+    assert sino.shape == (6, 60, 94) and sorted(os.listdir(ds)) == ["dataset_parameters.npy", "x_size.npy",
+                                                                    "x_train_sinograms.npy", "y_size.npy"]
+    out = str(tmp_path / "run")
+    args = tr.get_args(f"--input_path {ds} --save_path {out} --nsa 10 --td 6 -b 3 --ns 2 --api 10 --pnm 1e4 --random "
+                       "--normal -i 3 --train".split())
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    assert t.P == 94 and t.x_size == 64 and t.num_angles == 60 and t.truth is None
+    assert tuple(t.proj_samples.shape) == (6, 60, 94) and tuple(t.input_encode.shape) == (6, 2, 64, 64)
+    losses, _ = t.train()
+    assert len(losses) == 3 and all(math.isfinite(v) for v in losses)
+    loss_final, recon = t.final_evaluation(out)
+    assert loss_final.shape == (2,) and recon.shape == (6, 64, 64, 1) and np.isfinite(recon).all() and (recon >= 0).all()
+    saved = np.load(os.path.join(out, "reconstruction_final.npy"))
+    assert np.array_equal(saved, recon) and os.path.exists(os.path.join(out, "loss_final.npy"))
+    mse, ssim, psnr = dataset_io.compare(imgs[0], saved[0, ..., 0], verbose=False)
+    assert np.isfinite([mse, ssim, psnr]).all()
