@@ -117,6 +117,9 @@ class ConvBlock(nn.Module):
         if transpose:
             pad = (k - stride + 1) // 2
             opad = stride + 2 * pad - k
+            if not 0 <= opad < stride:             # e.g. the toy recipe's --ks 2 --se 1: one pixel too many, cropped by the decoder
+                pad = max((k - stride) // 2, 0)
+                opad = min(max(stride + 2 * pad - k, 0), stride - 1)
             self.ab = nn.ConvTranspose2d(cin, 2 * cout, k, stride=stride, padding=pad, output_padding=opad)
             halves = self.ab.weight.data.chunk(2, dim=1)        # ConvTranspose2d weight: [cin][cout][k][k]
         else:
@@ -309,6 +312,7 @@ class PVAETrainer:
     # -- dataset: --input_path (the reference's dataset_<name>/ folder) or a synthetic foam set -----------------
     def _make_data(self):
         a, dev = self.args, self.dev
+        self.pad = not a.no_pad
         if a.input_path:
             # x_train_sinograms.npy + dataset_parameters.npy as scripts/images_to_sinograms.py writes them
             # (ctvae/main_ct_vae.py:152-161); the phantoms themselves are not part of that folder
@@ -322,13 +326,15 @@ class PVAETrainer:
             N = a.n_pixel
             self.theta_np = phantoms.dense_theta(a.num_angles)
             self.num_angles = a.num_angles
-            self.P = num_proj_pix(N, N)
+            self.P = num_proj_pix(N, N) if self.pad else N
             imgs = phantoms.foam_batch(a.td, N, seed=0, supersample=2)
-            sino = create_sinograms(torch.from_numpy(imgs).to(dev), self.theta_np, pad=True).clamp_min(0)   # [td][A][P]
-        self.x_size = self.y_size = int(math.floor(self.P / math.sqrt(2) - 2))      # ctvae/main_ct_vae.py:160-161
+            sino = create_sinograms(torch.from_numpy(imgs).to(dev), self.theta_np, pad=self.pad).clamp_min(0)   # [td][A][P]
+        # ctvae/main_ct_vae.py:156-161: --no_pad sinograms are as wide as the object
+        self.x_size = self.y_size = int(math.floor(self.P / math.sqrt(2) - 2)) if self.pad else self.P
         # dose masks and sparse noisy measurements, ctvae/create_masks.py:45-95 (simulated at the FINAL pnm)
         masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=None, poisson_noise_multiplier=a.pnm,
-                                                    num_sparse_angles=a.nsa, random=a.random, train=True,
+                                                    num_sparse_angles=a.nsa, random=a.random, train=True, real_data=a.real_data,
+                                                    toy_masks=a.toy_masks,
                                                     truncate_dataset=a.td, device=dev)
         self.masks, self.truth = masks, (torch.from_numpy(imgs).to(dev) if imgs is not None else None)
         # initial reconstructions for the encoder, ctvae/helper_functions.py:477-529 with FBP on the GPU
@@ -369,7 +375,7 @@ class PVAETrainer:
         pnm_i = self.pnm * pnm_factor
         loss_vec, kl, loglik, _ = find_loss_vae_unsup(proj_sample, mask, input_encode, self.enc, self.dec, pnm_i,
                                                       self.sqrt_reg, kl_anneal, a.klm, num_samples=a.ns,
-                                                      theta=self.theta, angles_i=angles_i, pad=True,
+                                                      theta=self.theta, angles_i=angles_i, pad=self.pad,
                                                       deterministic=a.deterministic)
         # mean over the GLOBAL batch: each rank contributes sum/global_B, gradients are then summed over ranks
         loss = loss_vec.sum() / a.batch_size / 1e5
@@ -461,7 +467,7 @@ class PVAETrainer:
             sl = slice(k, k + nb)
             loss_vec, _, _, recon = find_loss_vae_unsup(self.proj_samples[sl], self.masks[sl], self.input_encode[sl], self.enc,
                                                         self.dec, self.pnm, self.sqrt_reg, self.kl_anneal, a.klm,
-                                                        num_samples=a.ns, theta=self.theta, angles_i=None, pad=True,
+                                                        num_samples=a.ns, theta=self.theta, angles_i=None, pad=self.pad,
                                                         deterministic=a.deterministic)
             losses.append(loss_vec.sum() / nb / 1e5)
             recons.append(recon.permute(0, 2, 3, 1))
@@ -503,6 +509,9 @@ def get_args(argv=None):
     p.add_argument("--input_path", default=None,
                    help="dataset folder written by scripts/images_to_sinograms.py (x_train_sinograms.npy, "
                         "dataset_parameters.npy); without it a seeded synthetic foam set of --td phantoms is made")
+    p.add_argument("--real", action="store_true", dest="real_data", help="real data: no simulated noise (ctvae/main_ct_vae.py:105)")
+    p.add_argument("--no_pad", action="store_true", help="sinograms have no zero-padding (ctvae/main_ct_vae.py:107)")
+    p.add_argument("--toy_masks", action="store_true", help="the toy problem's two-angle masks (ctvae/main_ct_vae.py:109)")
     p.add_argument("--no_final_eval", action="store_true", help="skip the final evaluation (ctvae/main_ct_vae.py:113)")
     p.add_argument("--se", type=int, dest="stride_encode", default=2)
     p.add_argument("--si", type=int, dest="si", default=100000)

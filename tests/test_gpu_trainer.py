@@ -155,3 +155,23 @@ def test_reference_dataset_folder_in_and_reconstruction_file_out(tmp_path):
     assert np.array_equal(saved, recon) and os.path.exists(os.path.join(out, "loss_final.npy"))
     mse, ssim, psnr = dataset_io.compare(imgs[0], saved[0, ..., 0], verbose=False)
     assert np.isfinite([mse, ssim, psnr]).all()
+
+
+def test_toy_recipe(tmp_path):
+    """README.md:199 (the toy problem): 2x2 objects, two angles, no padding, the two-angle toy masks, one angle per
+    example -- from a dataset folder made as scripts/create_toy_images.py + images_to_sinograms.py --toy make it."""
+    import numpy as np
+    from ct_pvae_amd import dataset_io, phantoms
+    imgs = np.tile(np.repeat(phantoms.toy_images(), 2, axis=0), (4, 1, 1))          # [16][2][2]
+    ds = str(tmp_path / "dataset_toy_discrete2")
+    sino = dataset_io.images_to_sinograms(imgs, ds, theta=np.array([0.0, np.pi / 2]), pad=False)
+    assert sino.shape == (16, 2, 2) and np.allclose(sino[0], [[0.4, 0.6], [0.7, 0.3]], atol=1e-6)
+    args = tr.get_args(f"--input_path {ds} -b 4 --pnm 10000 -i 5 --td 16 --train --nsa 1 --ik 2 --il 5 --ks 2 --nb 3 "
+                       "--api 2 --se 1 --no_pad --ns 10 --pnm_start 1000 --normal --toy_masks".split())
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    assert t.P == 2 and t.x_size == 2 and not t.pad
+    assert torch.equal(t.masks[:4].cpu(), torch.tensor([[1.0, 0.0], [0.0, 1.0], [1.0, 0.0], [0.0, 1.0]]))
+    losses, _ = t.train()
+    assert len(losses) == 5 and all(math.isfinite(v) for v in losses)
+    _, recon = t.final_evaluation()
+    assert recon.shape == (16, 2, 2, 1)
