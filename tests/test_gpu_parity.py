@@ -594,12 +594,17 @@ def test_random_geometries_against_the_oracle(oracle):
     planned or direct, whichever the geometry takes, forward and tf_compat backward are bit-exact against the oracle; the
     exact backward stays the transpose."""
     d = dev()
-    rng = np.random.default_rng(20261004)
-    for case in range(24):
+    # CTPVAE_FUZZ_SEED / CTPVAE_FUZZ_CASES: a longer run over other seeds (then with batches large enough for the
+    # slice-pair kernels, S >= 16 / 32), e.g. CTPVAE_FUZZ_SEED=5 CTPVAE_FUZZ_CASES=200 pytest -m gpu -k random
+    fuzz = "CTPVAE_FUZZ_SEED" in os.environ
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 20261004)))
+    for case in range(int(os.environ.get("CTPVAE_FUZZ_CASES", 24))):
         H, W = int(rng.integers(1, 150)), int(rng.integers(1, 150))
         if case < 4:
             H, W = [(1, 1), (1, 77), (93, 1), (3, 2)][case]
         pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 41)), int(rng.integers(1, 7))
+        if fuzz and case % 2:
+            S = int(rng.integers(16, 90))
         theta = rng.uniform(-2 * np.pi, 2 * np.pi, A)
         if case % 3 == 0:
             theta[: min(A, 4)] = [0.0, np.pi / 2, np.pi, -np.pi / 2][: min(A, 4)]      # exact ties in the rounding
@@ -635,8 +640,9 @@ def test_random_siddon_and_tiled_geometries(oracle):
     angles of every quadrant incl. exactly axis-aligned ones, where the bisection of the crossing lists falls back to
     libtomo's scan) and the tiled forward (random slice shapes larger than LDS)."""
     d = dev()
-    rng = np.random.default_rng(77)
-    for case in range(10):
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 77)))
+    n_cases = int(os.environ.get("CTPVAE_FUZZ_CASES", 10))
+    for case in range(n_cases):
         ox, oz = int(rng.integers(2, 97)), int(rng.integers(2, 97))
         pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 13)), int(rng.integers(1, 4))
         theta = rng.uniform(-7.0, 7.0, A)
@@ -645,17 +651,20 @@ def test_random_siddon_and_tiled_geometries(oracle):
         got = cp.create_sinograms(img, theta, pad=pad)
         np.testing.assert_array_equal(got, np.swapaxes(oracle.siddon_project(img, theta, pad=pad), 0, 1),
                                       err_msg=f"siddon case {case}: {ox}x{oz} pad={pad} A={A} S={S}")
-    for case in range(4):
+    for case in range(max(4, n_cases // 4)):
         H, W = int(rng.integers(150, 330)), int(rng.integers(210, 330))
         pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 9)), int(rng.integers(1, 6))
+        if "CTPVAE_FUZZ_SEED" in os.environ and case % 2:
+            S = int(rng.integers(16, 24))          # the segment backward's slice pairs
         theta = rng.uniform(-np.pi, np.pi, A)
         img = rng.standard_normal((S, H, W)).astype(np.float32)
         plan = RotatePlan(theta, H, W, pad, d)
-        assert plan.tiled
+        assert plan.tiled or "CTPVAE_FUZZ_SEED" in os.environ      # (the default seed's four shapes are all tiled)
         geom = oracle.Geometry(H, W, pad)
-        np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
-                                      oracle.rotate_fwd_tiled(img, geom, to_np(plan.T8), (96, 64)),
-                                      err_msg=f"tiled case {case}: {H}x{W} pad={pad} A={A} S={S}")
+        want = (oracle.rotate_fwd_tiled(img, geom, to_np(plan.T8), (96, 64)) if plan.tiled
+                else oracle.rotate_fwd(img, geom, to_np(plan.T8), 0))
+        np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))), want,
+                                      err_msg=f"tiled case {case}: {H}x{W} pad={pad} A={A} S={S} tiled={plan.tiled}")
         g = rng.standard_normal((S, A, geom.PW)).astype(np.float32)
         np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
                                       oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0),
