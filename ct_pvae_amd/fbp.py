@@ -73,13 +73,17 @@ def iradon(sinogram, theta, x_size, y_size, filter_1d):
 
 
 def ramp_filter(P):
-    """skimage.transform.radon_transform._get_fourier_filter(P, 'ramp') squeezed (scikit-image 0.18), even P --
-    the filter the reference's own iradon call sites pass (ctvae/helper_functions.py:507-510, commented alternative)."""
-    n = np.concatenate((np.arange(1, P / 2 + 1, 2, dtype=int), np.arange(P / 2 - 1, 0, -2, dtype=int)))
-    f = np.zeros(P)
-    f[0] = 0.25
-    f[1::2] = -1 / (np.pi * n) ** 2
-    return 2 * np.real(np.fft.fft(f))
+    """The ramp filter of skimage.transform.radon_transform._get_fourier_filter(P, 'ramp') (scikit-image 0.18, squeezed)
+    -- the filter the reference's own iradon call sites pass (ctvae/main_ct_vae.py:181-190, commented) -- for any even P:
+    2 Re(fft(h)) of the band-limited ramp's kernel h[0] = 1/4, h[k] = -1 / (pi n)^2 at odd circular distance
+    n = min(k, P - k), 0 elsewhere.  skimage builds the same array when P / 2 is even (its sizes are powers of two:
+    P = 184 for 128 x 128 objects); for odd P / 2 (P = 94 for 64 x 64) its index arithmetic mis-places half the taps
+    and the reconstruction comes out ~8x too large, so the distances are written out here."""
+    k = np.arange(P)
+    n = np.minimum(k, P - k)
+    h = np.where(n % 2 == 1, -1.0 / (np.pi * np.maximum(n, 1)) ** 2, 0.0)
+    h[0] = 0.25
+    return 2 * np.real(np.fft.fft(h))
 
 
 def iradon_all(all_proj_samples, all_masks, num_proj_pix, theta, algorithms, sqrt_reg, x_size, y_size, save_path=None,

@@ -281,3 +281,23 @@ def test_the_two_projectors_agree_on_a_smooth_phantom(oracle):
     assert max(rel(bil[a], sid[a]) for a in range(12)) < 5e-3
     assert rel(bil[:, ::-1], sid) > 0.3                                                        # detector direction matters
     assert rel(oracle.project_tf_fast(img, -theta, pad=True, dim=2, interp=oracle.BILINEAR)[..., 0], sid) > 0.3
+
+
+def test_ramp_filter_for_any_even_detector(oracle):
+    """ct_pvae_amd.fbp.ramp_filter equals scikit-image 0.18's _get_fourier_filter(P, 'ramp') wherever that function is
+    right (P / 2 even: 184, 728, powers of two) and stays a ramp where skimage's index arithmetic is not (P / 2 odd,
+    e.g. P = 94 for 64 x 64 objects: with skimage's array the FBP of a disc comes out ~8x too large)."""
+    from ct_pvae_amd.fbp import ramp_filter
+    for P in (48, 64, 184, 728):
+        np.testing.assert_array_equal(ramp_filter(P), _ramp(P))
+    n = 64
+    P = oracle.num_proj_pix(n, n)
+    assert P == 94
+    yy, xx = np.mgrid[:n, :n]
+    img = (((xx - n / 2 + .5) ** 2 + (yy - n / 2 + .5) ** 2) < (n / 4) ** 2).astype(np.float32)
+    theta = np.linspace(0, np.pi, 60, endpoint=False)
+    sino = oracle.project_tf_fast(img, theta, pad=True, dim=2, interp=BILINEAR)[..., 0][None]
+    rec = oracle.iradon(sino, theta, n, n, ramp_filter(P))[0]
+    assert 0.85 < rec[img > 0.5].mean() < 1.1 and abs(rec[img < 0.5].mean()) < 0.05
+    bad = oracle.iradon(sino, theta, n, n, _ramp(P))[0]
+    assert bad[img > 0.5].mean() > 5
