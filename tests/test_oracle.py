@@ -301,3 +301,36 @@ def test_ramp_filter_for_any_even_detector(oracle):
     assert 0.85 < rec[img > 0.5].mean() < 1.1 and abs(rec[img < 0.5].mean()) < 0.05
     bad = oracle.iradon(sino, theta, n, n, _ramp(P))[0]
     assert bad[img > 0.5].mean() > 5
+
+
+def test_tf_compat_gradient_approximates_the_true_transpose(oracle):
+    """TensorFlow's registered gradient of the projective transform (the same op with the inverted transform, row a4) is
+    not the exact transpose of the forward, but for a smooth cotangent it must be close to it -- and far from any
+    flipped or transposed version: this pins the sense of the inverted transform in the restatement.  One angle at a
+    time (a single back-projected angle is a smear along the ray direction, maximally sensitive to orientation)."""
+    N = 64
+    yy, xx = np.mgrid[0:N, 0:N].astype(np.float64)
+
+    def blob(cx, cy, s, a):
+        return a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+
+    img = (blob(20, 25, 5, 1.0) + blob(44, 30, 7, 0.6) + blob(30, 48, 4, 0.8)).astype(np.float32)
+    theta = np.linspace(0, np.pi, 12, endpoint=False)
+    geom = oracle.Geometry(N, N, True)
+    T = oracle.rotate_transforms(theta, geom.PH, geom.PW)
+    Ti = oracle.invert_transforms(T)
+    g = oracle.rotate_fwd(img[None], geom, T, BILINEAR)
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    for a in (1, 4, 7, 10):
+        g1 = np.zeros_like(g)
+        g1[0, a] = g[0, a]
+        tf_grad = oracle.rotate_bwd_tfcompat(g1, geom, Ti, NEAREST)[0]
+        transpose = oracle.rotate_bwd_exact(g1, geom, T, BILINEAR)[0]
+        assert rel(tf_grad, transpose) < 0.1
+        assert min(rel(tf_grad[:, ::-1], transpose), rel(tf_grad[::-1], transpose), rel(tf_grad.T, transpose)) > 0.4
+    full_n = oracle.rotate_bwd_tfcompat(g, geom, Ti, NEAREST)[0]
+    full_b = oracle.rotate_bwd_tfcompat(g, geom, Ti, BILINEAR)[0]
+    assert rel(full_n, full_b) < 0.02 and rel(full_b, oracle.rotate_bwd_exact(g, geom, T, BILINEAR)[0]) < 0.05
