@@ -255,13 +255,16 @@ def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_dec
     log_prob_R_given_z = dist.log_prob(output_sample)
     lp = calculate_log_prob_M_given_R(output_sample.permute(0, 2, 3, 1), mask.repeat(ns, 1), proj_sample.repeat(ns, 1, 1),
                                       poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad)
-    log_prob_M = (lp.sum(dim=(1, 2, 3)) + log_prob_R_given_z.sum(dim=(1, 2, 3))).view(ns, B)
+    # :305-306 reduce_sum(..., axis=[0, 1, 2]) of the squeezed [B][A][P] and [B][X][Y] tensors: the log-likelihood of a
+    # sample is ONE number for the whole batch (the batch axis is summed too), the KL below is per object; :329-330 then
+    # broadcast-subtract, and train_step takes the mean over the batch -- i.e. mean_b(KL_b) - sum_b(loglik_b).
+    log_prob_M = (lp.sum(dim=(1, 2, 3)) + log_prob_R_given_z.sum(dim=(1, 2, 3))).view(ns, B).sum(dim=1)    # [ns]
     recon = output_sample[(ns - 1) * B:]
     if deterministic:
-        kl = torch.zeros_like(log_prob_M[0])
+        kl = lp.new_zeros(B)
     else:
         kl = sum(kl_normal_std(loc, scale).sum(dim=(1, 2, 3)) for loc, scale in q[1:])   # the input level is unused
-    loglik = log_prob_M.mean(dim=0)
+    loglik = log_prob_M.mean(dim=0)                                                       # scalar
     return kl_anneal * kl_multiplier * kl - loglik, kl, loglik, recon
 
 
@@ -377,8 +380,11 @@ class PVAETrainer:
                                                       self.sqrt_reg, kl_anneal, a.klm, num_samples=a.ns,
                                                       theta=self.theta, angles_i=angles_i, pad=self.pad,
                                                       deterministic=a.deterministic)
-        # mean over the GLOBAL batch: each rank contributes sum/global_B, gradients are then summed over ranks
-        loss = loss_vec.sum() / a.batch_size / 1e5
+        # ctvae/main_ct_vae.py:478 reduce_mean(loss_M_VAE) / 1e5 = mean_b(KL term) - loglik, where loglik already sums
+        # over the batch.  Written so that the ranks' losses ADD UP to the global one (gradients are summed over ranks):
+        # each rank contributes its objects' KL / global_B and its own objects' log-likelihood.
+        del loss_vec
+        loss = ((kl_anneal * a.klm * kl).sum() / a.batch_size - loglik) / 1e5
         self.opt.zero_grad(set_to_none=True)
         loss.backward()
         grads = [p.grad for p in self.opt.param_groups[0]["params"] if p.grad is not None]
@@ -469,7 +475,7 @@ class PVAETrainer:
                                                         self.dec, self.pnm, self.sqrt_reg, self.kl_anneal, a.klm,
                                                         num_samples=a.ns, theta=self.theta, angles_i=None, pad=self.pad,
                                                         deterministic=a.deterministic)
-            losses.append(loss_vec.sum() / nb / 1e5)
+            losses.append(loss_vec.mean() / 1e5)
             recons.append(recon.permute(0, 2, 3, 1))
         loss_final = torch.stack(losses).cpu().numpy()
         reconstruction_final = torch.cat(recons).cpu().numpy()
