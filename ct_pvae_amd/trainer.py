@@ -432,6 +432,9 @@ class PVAETrainer:
                 print(f"Iteration number: {it}  Training loss_M_VAE: {losses[-1]:.6f}", flush=True)
             if saving and self.rank == 0:
                 self.save(os.path.join(a.save_path, "training_checkpoints", f"ckpt-{it}.pt"), losses)
+                np.save(os.path.join(a.save_path, "train_loss_vec.npy"), np.asarray(losses))      # ctvae/main_ct_vae.py:413
+        if a.save_path and self.rank == 0 and a.num_iter > 0:
+            np.save(os.path.join(a.save_path, "training_time.npy"), (time.time() - t0) / 60)       # minutes, :421-422
         return losses, time.time() - t0
 
     def save(self, path, losses):
