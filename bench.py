@@ -67,6 +67,24 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
+def capture_graph(body):
+    """Capture `body`'s launches into a HIP graph and replay it once (untimed upload); None if capture is not possible
+    here, in which case the caller launches from Python.  thread_local capture mode: with RCCL initialised, its watchdog
+    thread may query events while this thread captures, which the default global mode treats as an error."""
+    torch.cuda.synchronize()
+    try:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            body()
+        graph.replay()
+        torch.cuda.synchronize()
+        return graph
+    except Exception as exc:        # noqa: BLE001 -- any capture failure only costs the graph, never the measurement
+        print(f"[bench] HIP graph capture unavailable ({type(exc).__name__}: {exc}); launching from Python", file=sys.stderr)
+        torch.cuda.synchronize()
+        return None
+
+
 def close_timed_region(t0, world):
     """Closing bracket of a timed region: this rank's K steps are complete (synchronize) -> read the clock -> barrier +
     synchronize -> MAX over ranks.  The clock is read before the closing barrier so that the collective's own latency
@@ -269,14 +287,10 @@ def main():
     # loop replays HIP graphs of 10 steps (20 kernel nodes, the same launches in the same order) and launches only the
     # K mod 10 remaining steps from Python: the GPU runs back to back whatever the host's speed (measured: 13.97 us per
     # step replayed against 14.45 us launched on a fast host, and host-bound on a slow one).  Not with the RCCL bucket.
-    chunk, graph = 10, None
+    chunk = 10
+    graph = None
     if not args.no_graph and bucket is None and args.steps >= chunk:
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for _ in range(chunk):
-                step()
-        graph.replay()                                    # one untimed replay (graph upload)
+        graph = capture_graph(lambda: [step() for _ in range(chunk)])
     n_replay, n_eager = divmod(args.steps, chunk) if graph is not None else (0, args.steps)
     barrier_sync(world)
     t0 = time.perf_counter()
@@ -300,16 +314,17 @@ def main():
         as much on the host: timed from a Python loop the shorter kernel reads as host time on a slow box)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fn()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+
+        def batch():
             for _ in range(n_ev):
                 fn()
+
+        replay = None if args.no_graph else capture_graph(batch)
         runs = []
         for _ in range(5):
             torch.cuda.synchronize()
             e0.record()
-            graph.replay()
+            (replay.replay if replay is not None else batch)()
             e1.record()
             torch.cuda.synchronize()
             runs.append(e0.elapsed_time(e1) * 1e-3 / n_ev)
