@@ -335,14 +335,17 @@ class PVAETrainer:
         # ctvae/main_ct_vae.py:156-161: --no_pad sinograms are as wide as the object
         self.x_size = self.y_size = int(math.floor(self.P / math.sqrt(2) - 2)) if self.pad else self.P
         # dose masks and sparse noisy measurements, ctvae/create_masks.py:45-95 (simulated at the FINAL pnm)
-        masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=None, poisson_noise_multiplier=a.pnm,
-                                                    num_sparse_angles=a.nsa, random=a.random, train=True, real_data=a.real_data,
+        # with --save_path the three setup arrays are written there when training and read back when not (the
+        # reference's train / restore split, ctvae/create_masks.py:70,101-103, ctvae/helper_functions.py:523-526)
+        drawing = bool(a.train) or not a.save_path
+        masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=a.save_path, poisson_noise_multiplier=a.pnm,
+                                                    num_sparse_angles=a.nsa, random=a.random, train=drawing, real_data=a.real_data,
                                                     toy_masks=a.toy_masks,
                                                     truncate_dataset=a.td, device=dev)
         self.masks, self.truth = masks, (torch.from_numpy(imgs).to(dev) if imgs is not None else None)
         # initial reconstructions for the encoder, ctvae/helper_functions.py:477-529 with FBP on the GPU
         enc_in = iradon_all(self.proj_samples, masks, self.P, self.theta_np, list(a.algorithms), self.sqrt_reg, self.x_size,
-                            self.y_size, save_path=None, train=True)                  # [td][X][Y][2]
+                            self.y_size, save_path=a.save_path, train=drawing)        # [td][X][Y][2]
         self.input_encode = enc_in.permute(0, 3, 1, 2).contiguous()                   # [td][2][X][Y]
         self.theta = torch.from_numpy(self.theta_np.astype(np.float32)).to(dev)
         self.order = np.random.default_rng(11)
@@ -442,6 +445,14 @@ class PVAETrainer:
         torch.save({"enc": self.enc.state_dict(), "dec": self.dec.state_dict(), "opt": self.opt.state_dict(),
                     "kl_anneal": self.kl_anneal, "pnm": self.pnm.detach().cpu(), "iter": self.iter, "losses": losses}, path)
 
+    def latest_checkpoint(self):
+        """Path of the newest ckpt-<iteration>.pt under --save_path/training_checkpoints."""
+        folder = os.path.join(self.args.save_path or ".", "training_checkpoints")
+        names = [n for n in (os.listdir(folder) if os.path.isdir(folder) else []) if n.startswith("ckpt-") and n.endswith(".pt")]
+        if not names:
+            raise FileNotFoundError(f"no checkpoint under {folder}")
+        return os.path.join(folder, max(names, key=lambda n: int(n[5:-3])))
+
     def restore(self, path):
         ck = torch.load(path, map_location=self.dev)
         self.enc.load_state_dict(ck["enc"])
@@ -515,6 +526,8 @@ def get_args(argv=None):
     p.add_argument("--train_pnm", action="store_true")
     p.add_argument("--random", action="store_true")
     p.add_argument("--save_path", default=None)
+    p.add_argument("--restore", action="store_true", help="restore the latest checkpoint under --save_path before training / evaluating")
+    p.add_argument("--ulc", action="store_true", dest="use_latest_ckpt", help="accepted: --restore always takes the latest checkpoint")
     p.add_argument("--input_path", default=None,
                    help="dataset folder written by scripts/images_to_sinograms.py (x_train_sinograms.npy, "
                         "dataset_parameters.npy); without it a seeded synthetic foam set of --td phantoms is made")
@@ -542,15 +555,18 @@ def main(argv=None):
     world, rank, local = sharding.init_from_env()
     dev = torch.device("cuda", local)
     tr = PVAETrainer(args, dev)
-    losses, secs = tr.train()
+    if args.restore:                                   # ctvae/main_ct_vae.py:363-368 (--ulc: the latest checkpoint)
+        tr.restore(tr.latest_checkpoint())
+    losses, secs = tr.train() if args.train else ([], 0.0)
     if not args.no_final_eval:
         loss_final, _ = tr.final_evaluation(args.save_path)
         if rank == 0:
             print(f"Average loss final : {float(loss_final.mean()):.6f}")
     if rank == 0:
         mse, mse_fbp = tr.evaluate()
-        print(f"{len(losses)} iterations in {secs:.1f} s ({len(losses) / secs:.2f} it/s); loss {losses[0]:.5f} -> {losses[-1]:.5f}; "
-              f"MSE reconstruction {mse:.5f} (FBP input {mse_fbp:.5f})")
+        if losses:
+            print(f"{len(losses)} iterations in {secs:.1f} s ({len(losses) / secs:.2f} it/s); loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+        print(f"MSE reconstruction {mse:.5f} (FBP input {mse_fbp:.5f})")
     return losses
 
 

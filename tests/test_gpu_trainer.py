@@ -175,3 +175,23 @@ def test_toy_recipe(tmp_path):
     assert len(losses) == 5 and all(math.isfinite(v) for v in losses)
     _, recon = t.final_evaluation()
     assert recon.shape == (16, 2, 2, 1)
+
+
+def test_train_then_restore_and_evaluate_from_the_saved_files(tmp_path):
+    """The reference's two-phase use (README.md:80 with --train, then --restore --ulc without it): training leaves the
+    setup arrays and a checkpoint under --save_path; a second process-equivalent reads all of them back instead of
+    drawing new masks and noise, restores the nets and evaluates."""
+    import numpy as np
+    out = str(tmp_path / "run")
+    base = f"--save_path {out} --nsa 10 --td 6 -b 3 --ns 2 --api 10 --pnm 1e4 --random --normal -i 4 --n_pixel 64 --num_angles 60"
+    tr.main((base + " --train").split())
+    for name in ("all_masks.npy", "all_proj_samples.npy", "all_input_encode.npy", "train_loss_vec.npy",
+                 "reconstruction_final.npy", "loss_final.npy"):
+        assert os.path.exists(os.path.join(out, name)), name
+    again = tr.PVAETrainer(tr.get_args((base + " --restore").split()), torch.device("cuda", 0))  # reloads, does not redraw
+    saved = torch.from_numpy(np.load(os.path.join(out, "all_proj_samples.npy"))).cuda()
+    assert torch.equal(again.proj_samples, saved)
+    again.restore(again.latest_checkpoint())
+    assert again.iter == 4 and again.latest_checkpoint().endswith("ckpt-3.pt")
+    loss_final, recon = again.final_evaluation()
+    assert recon.shape == (6, 64, 64, 1) and np.isfinite(loss_final).all()
