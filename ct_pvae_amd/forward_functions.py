@@ -193,6 +193,8 @@ class RotatePlan:
     # it already is -- costs one cheap query).
     def forward(self, img, out=None):
         """slices [S][H][W] -> sinograms [S][A][PW] (raw operator, no autograd bookkeeping)."""
+        if img.dim() == 3 and img.shape[0] == 0 and tuple(img.shape[1:]) == (self.H, self.W):   # empty batch -> empty batch
+            return out if out is not None else img.new_empty((0, self.A, self.PW))
         if _current_device() == self._dev_index:
             return self._forward(img, out)
         with torch.cuda.device(self._dev_index):
@@ -212,6 +214,8 @@ class RotatePlan:
         """cotangents [S][A][PW] -> gradient images [S][H][W] (the mode chosen at construction).
         scale: optional float32 device tensor of S per-slice factors (any stride, 0 included: an expanded scalar)
         applied in the kernel's store -- nearest / tf_compat only (`supports_scale`)."""
+        if gsino.dim() == 3 and gsino.shape[0] == 0 and tuple(gsino.shape[1:]) == (self.A, self.PW):
+            return out if out is not None else gsino.new_empty((0, self.H, self.W))
         if _current_device() == self._dev_index:
             return self._backward(gsino, out, scale)
         with torch.cuda.device(self._dev_index):
@@ -426,8 +430,6 @@ def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
         slices, dt = _as_slices(phantom[None])
     else:
         raise ValueError(f"dim must be 2 or 3 (got {dim})")
-    if slices.shape[0] == 0:
-        raise ValueError("phantom holds no slices")
     plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, interp, backward)
     if slices.device.index == torch.cuda.current_device():
         sino = plan.apply(slices)  # [S][A][PW]

@@ -114,6 +114,8 @@ def gaussian_poisson_log_prob(proj, mask, proj_sample, poisson_noise_multiplier,
                          f"{tuple(mask.shape)}, {tuple(proj_sample.shape)})")
     if mask.device != dev or proj_sample.device != dev:
         raise ValueError("proj, mask and proj_sample must live on the same device")
+    if proj.numel() == 0:                         # an empty batch has an empty log-likelihood
+        return proj * 0.0
     pnm = poisson_noise_multiplier
     if not isinstance(pnm, torch.Tensor):
         pnm = torch.tensor(float(pnm), dtype=torch.float32, device=dev)

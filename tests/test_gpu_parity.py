@@ -546,6 +546,24 @@ def rng_img(B, N):
     return np.random.default_rng(1234).random((B, N, N, 1), dtype=np.float32)
 
 
+def test_empty_batch_is_an_empty_result():
+    """A batch of zero objects projects to zero sinograms (what the TensorFlow op chain gives), forward and backward,
+    through the raw operator, the public function and the likelihood caller -- no launch, no error."""
+    d = dev()
+    theta = np.linspace(0, np.pi, 6, endpoint=False)
+    plan = RotatePlan(theta, 32, 32, True, d)
+    assert tuple(plan.forward(torch.empty((0, 32, 32), device=d)).shape) == (0, 6, plan.PW)
+    assert tuple(plan.backward(torch.empty((0, 6, plan.PW), device=d)).shape) == (0, 32, 32)
+    x = torch.empty((0, 32, 32, 1), device=d, requires_grad=True)
+    out = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+    assert tuple(out.shape) == (0, 6, plan.PW, 1)
+    out.sum().backward()
+    assert tuple(x.grad.shape) == (0, 32, 32, 1)
+    lp = cp.calculate_log_prob_M_given_R(x, torch.empty((0, 6), device=d), torch.empty((0, 6, plan.PW), device=d), 1e3, 1e-7,
+                                         theta=theta, pad=True)
+    assert tuple(lp.shape) == (0, 6, plan.PW, 1)
+
+
 def test_bad_shapes_raise():
     d = dev()
     with pytest.raises(ValueError):
@@ -737,7 +755,7 @@ def test_raw_operator_checks_its_operands():
     plan.forward(x), plan.backward(g)
     for bad in (torch.rand((2, 60, 40), device=d), torch.rand((2, 40, 60), device=d, dtype=torch.float64),
                 torch.rand((2, 40, 60)), torch.rand((2, 40, 120), device=d)[:, :, ::2], torch.rand((40, 60), device=d),
-                torch.rand((0, 40, 60), device=d)):
+                torch.rand((0, 41, 60), device=d)):
         with pytest.raises(ValueError):
             plan.forward(bad)
     with pytest.raises(ValueError):
