@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/ctpvae_radon.h"
 
@@ -42,6 +43,17 @@ struct SliceScale {
     long long stride;
     __device__ __forceinline__ float at(int s) const { return ptr ? ptr[(long long)s * stride] : 1.0f; }
 };
+
+// Kernels that index slices with a grid y / z dimension take at most this many per launch; their entry points split
+// longer batches (CTPVAE_TUNE_MAX_SLICES: a smaller limit, for the tests of that splitting).
+inline int max_slices_per_launch()
+{
+    if (const char *e = getenv("CTPVAE_TUNE_MAX_SLICES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 65535) return v;
+    }
+    return 65535;
+}
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -98,10 +98,13 @@ int ctpvae_fbp_backproject_f64(const double *filt_dev, int B, int A, int P, cons
     CTPVAE_REQUIRE(filt_dev && cos_dev && sin_dev && recon_dev, "fbp_backproject: null pointer");
     CTPVAE_REQUIRE(B > 0 && A > 0 && P > 1 && X > 0 && Y > 0,
                    "fbp_backproject: bad sizes (B=%d A=%d P=%d X=%d Y=%d)", B, A, P, X, Y);
-    CTPVAE_REQUIRE(B <= 65535, "fbp_backproject: at most 65535 sinograms per call (got %d)", B);
-    hipLaunchKernelGGL(fbp_backproject_kernel, dim3(ceil_div(X * Y, 256), B), dim3(256), 0, (hipStream_t)stream,
-                       filt_dev, B, A, P, cos_dev, sin_dev, X, Y, recon_dev);
-    CTPVAE_LAUNCH_CHECK("fbp_backproject_kernel");
+    const int chunk = max_slices_per_launch();
+    for (int b0 = 0; b0 < B; b0 += chunk) {   // sinograms are indexed with a grid dimension: longer batches go in chunks
+        const int n = B - b0 < chunk ? B - b0 : chunk;
+        hipLaunchKernelGGL(fbp_backproject_kernel, dim3(ceil_div(X * Y, 256), n), dim3(256), 0, (hipStream_t)stream,
+                           filt_dev + (size_t)b0 * A * P, n, A, P, cos_dev, sin_dev, X, Y, recon_dev + (size_t)b0 * X * Y);
+        CTPVAE_LAUNCH_CHECK("fbp_backproject_kernel");
+    }
     return CTPVAE_OK;
 }
 

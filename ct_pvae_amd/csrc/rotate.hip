@@ -1141,9 +1141,19 @@ static size_t tile_lds_bytes(const TileSpec &ts, int ns)
 
 using namespace ctpvae;
 
+// The direct kernels index slices with a grid dimension (<= 65535): the entry points below hand them a longer batch in
+// chunks, back to back on the caller's stream (slices are independent: same results as one launch).
+template <class F>
+static int for_slice_chunks(int S, int chunk, F launch_chunk)
+{
+    for (int s0 = 0; s0 < S; s0 += chunk)
+        if (int rc = launch_chunk(s0, std::min(chunk, S - s0))) return rc;
+    return CTPVAE_OK;
+}
+
 extern "C" {
 
-int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+static int rotate_fwd_one(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                           const float *T8_dev, int A, int interp, float *sino_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(img_dev && T8_dev && sino_dev, "rotate_fwd: null pointer");
@@ -1205,6 +1215,16 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
                    : launch(rotate_fwd_kernel<CTPVAE_BILINEAR, false>, 0);
 }
 
+int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                          const float *T8_dev, int A, int interp, float *sino_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(img_dev && T8_dev && sino_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0, "rotate_fwd: null pointer or empty sizes");
+    return for_slice_chunks(S, max_slices_per_launch(), [&](int s0, int n) {
+        return rotate_fwd_one(img_dev + (size_t)s0 * H * W, n, H, W, PH, PW, py, px, T8_dev, A, interp,
+                              sino_dev + (size_t)s0 * A * PW, stream);
+    });
+}
+
 long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, int PW, int A, int interp)
 {
     if (S <= 0 || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_fwd_tiled_workspace_bytes: bad sizes");
@@ -1213,8 +1233,34 @@ long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, i
     return (long long)S * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
 }
 
+static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
+                               int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream);
+
+// tile workgroups are indexed with a grid dimension too: at most 65535 / tiles slices per launch, the workspace reused by
+// the chunks (they run one after the other on the stream)
 static int launch_fwd_tiled(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
                            int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0,
+                   "rotate_fwd_tiled: null pointer or empty sizes");
+    const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
+    const int nt = std::max(1, ts.ntx * ts.nty);
+    const int chunk = std::max(4, std::min(max_slices_per_launch(), 65535 / nt) / 4 * 4);
+    return for_slice_chunks(S, chunk, [&](int s0, int n) {
+        LogLikEpilogue e = epi;
+        if (e.lp) {
+            e.mask += (size_t)s0 * A;
+            e.meas += (size_t)s0 * A * PW;
+            e.lp += (size_t)s0 * A * PW;
+            if (e.dlp) e.dlp += (size_t)s0 * A * PW;
+        }
+        return launch_fwd_tiled_one(img_dev + (size_t)s0 * H * W, n, H, W, PH, PW, py, px, T8_dev, A, workspace_dev,
+                                    sino_dev + (size_t)s0 * A * PW, e, stream);
+    });
+}
+
+static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
+                               int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev, "rotate_fwd_tiled: null pointer");
     if (int rc = check_geom("rotate_fwd_tiled", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
@@ -1290,9 +1336,25 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
     return ctpvae_rotate_bwd_scaled_f32(gsino_dev, S, A, PH, PW, T8_dev, interp, mode, H, W, py, px, nullptr, 0, gimg_dev, stream);
 }
 
+static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
+                          int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
+                          float *gimg_dev, ctpvae_stream_t stream);
+
 int ctpvae_rotate_bwd_scaled_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
                                  int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
                                  float *gimg_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(gsino_dev && T8_dev && gimg_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0, "rotate_bwd: null pointer or empty sizes");
+    return for_slice_chunks(S, max_slices_per_launch(), [&](int s0, int n) {
+        return rotate_bwd_one(gsino_dev + (size_t)s0 * A * PW, n, A, PH, PW, T8_dev, interp, mode, H, W, py, px,
+                              scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr, scale_stride,
+                              gimg_dev + (size_t)s0 * H * W, stream);
+    });
+}
+
+static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
+                          int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
+                          float *gimg_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(gsino_dev && T8_dev && gimg_dev, "rotate_bwd: null pointer");
     // only the NEAREST / TF_COMPAT segment kernel applies the per-slice factor in its store

@@ -206,7 +206,27 @@ int ctpvae_siddon_tables_f32(const float *theta, int dt, float *sin_out, float *
     return CTPVAE_OK;
 }
 
+static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
+                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
+                          float *data_dev, ctpvae_stream_t stream);
+
+// slices are indexed with a grid dimension (<= 65535): a longer stack goes in chunks, back to back on the stream
 int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
+                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
+                          float *data_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(obj_dev && data_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_fwd: null pointer or empty sizes");
+    const int chunk = std::max(2, max_slices_per_launch() / 2 * 2);   // even: whole slice pairs per chunk
+    for (int s0 = 0; s0 < oy; s0 += chunk) {
+        const int n = std::min(chunk, oy - s0);
+        if (int rc = siddon_fwd_one(obj_dev + (size_t)s0 * ox * oz, n, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center,
+                                    data_dev + (size_t)s0 * dt * dx, stream))
+            return rc;
+    }
+    return CTPVAE_OK;
+}
+
+static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
                           const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
                           float *data_dev, ctpvae_stream_t stream)
 {

@@ -151,7 +151,7 @@ class _ProjectLogLik(torch.autograd.Function):
     def backward(ctx, gout):
         if ctx.fused_bwd:
             dlp, = ctx.saved_tensors
-            if gout.stride(1) == 0 and gout.stride(2) == 0 and dlp.shape[0] <= 65535:   # (the scaled kernels' slice limit)
+            if gout.stride(1) == 0 and gout.stride(2) == 0:
                 return ctx.plan.backward(dlp, scale=gout[:, 0, 0]), None, None, None, None, None
             return ctx.plan.backward(gout * dlp), None, None, None, None, None
         lib = _lib.load()

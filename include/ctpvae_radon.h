@@ -5,6 +5,9 @@
  * no global state except a thread-local last-error string.  `stream` is a hipStream_t passed as
  * void* (NULL = the default stream).
  *
+ * Batches may be of any length: entry points whose kernels index slices with a grid dimension (<= 65535) launch longer
+ * batches in chunks, back to back on `stream`.
+ *
  * All functions return 0 on success and a negative CTPVAE_E* code otherwise; the message is
  * available from ctpvae_last_error().  Nothing is thrown across this boundary.
  *

@@ -546,6 +546,81 @@ def rng_img(B, N):
     return np.random.default_rng(1234).random((B, N, N, 1), dtype=np.float32)
 
 
+@pytest.mark.parametrize("use_plan", [True, False])
+def test_more_slices_than_a_grid_dimension(oracle, use_plan):
+    """70,000 tiny slices: past the 65,535 limit of a grid's y / z dimension, which the direct kernels index slices
+    with (they fall back to their generic forms), and a big 1024 x 1024 slice (P = 1452: tiled forward, segment
+    backward, no byte-sized backward plan) -- the two ends of the size range, bit-exact against the oracle."""
+    d = dev()
+    rng = np.random.default_rng(3)
+    S, N, A = 70000, 8, 3
+    theta = np.array([0.3, 1.1, 2.5])
+    img = rng.standard_normal((S, N, N)).astype(np.float32)
+    plan = RotatePlan(theta, N, N, True, d, use_plan=use_plan)
+    geom = oracle.Geometry(N, N, True)
+    got = to_np(plan.forward(torch.from_numpy(img).to(d)))
+    np.testing.assert_array_equal(got, oracle.rotate_fwd(img, geom, to_np(plan.T8), 0))
+    g = rng.standard_normal(got.shape).astype(np.float32)
+    np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
+                                  oracle.rotate_bwd_tfcompat(g, geom, to_np(plan.Tinv8), 0))
+    if use_plan:
+        big = rng.standard_normal((1, 1024, 1024)).astype(np.float32)
+        plan = RotatePlan(theta, 1024, 1024, True, d)
+        geom = oracle.Geometry(1024, 1024, True)
+        assert plan.tiled and geom.PW == 1452
+        np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(big).to(d))),
+                                      oracle.rotate_fwd_tiled(big, geom, to_np(plan.T8), (96, 64)))
+        gb = rng.standard_normal((1, 3, 1452)).astype(np.float32)
+        np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(gb).to(d))),
+                                      oracle.rotate_bwd_tfcompat(gb, geom, to_np(plan.Tinv8), 0))
+
+
+def test_long_batches_are_launched_in_chunks(monkeypatch):
+    """Entry points whose kernels index slices with a grid dimension split a long batch into launches of at most
+    65,535 slices.  With the limit lowered to 5 (CTPVAE_TUNE_MAX_SLICES) every such path -- direct and tiled forward
+    (with the likelihood epilogue's per-slice operands), segment / bilinear / exact backward (with the per-slice
+    factor), the TomoPy-style projector and the FBP -- must give, bit for bit, what one launch gives."""
+    from ct_pvae_amd import fbp
+    d = dev()
+    rng = np.random.default_rng(11)
+    S, A = 13, 4
+    theta = rng.uniform(0, np.pi, A)
+
+    def run_all():
+        out = []
+        for (H, W), kw in (((40, 60), dict(use_plan=False)), ((220, 190), {}), ((40, 60), dict(interp="bilinear")),
+                           ((24, 24), dict(backward="exact"))):
+            plan = RotatePlan(theta, H, W, True, d, **kw)
+            x = torch.from_numpy(np.random.default_rng(H).standard_normal((S, H, W)).astype(np.float32)).to(d)
+            g = torch.from_numpy(np.random.default_rng(W).standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
+            out += [plan.forward(x), plan.backward(g)]
+            if plan.supports_scale:
+                sc = torch.linspace(-1, 2, S, device=d)
+                out.append(plan.backward(g, scale=sc))
+            if plan.tiled:
+                mask = torch.rand((S, A), device=d) + 0.5
+                meas = torch.rand((S, A, plan.PW), device=d) * 3
+                out += list(plan.forward_loglik(x.abs(), mask, meas, torch.tensor(1e3, device=d), 1e-7, with_dlp=True))
+        imgs = torch.rand((S, 20, 28), device=d)
+        out.append(cp.create_sinograms(imgs, theta))
+        sino = torch.rand((S, A, 30), device=d, dtype=torch.float64)
+        out.append(fbp.iradon(sino, theta, 20, 20, fbp.ramp_filter(30)))
+        torch.cuda.synchronize()
+        return out
+
+    torch.manual_seed(0)
+    whole = run_all()
+    monkeypatch.setenv("CTPVAE_TUNE_MAX_SLICES", "5")
+    torch.manual_seed(0)
+    chunked = run_all()
+    assert len(whole) == len(chunked) >= 14
+    for k, (a, b) in enumerate(zip(whole, chunked)):
+        if k == 12:      # the exact-transpose backward adds with float atomics: equal up to the order of the adds
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(a, b), k
+
+
 def test_empty_batch_is_an_empty_result():
     """A batch of zero objects projects to zero sinograms (what the TensorFlow op chain gives), forward and backward,
     through the raw operator, the public function and the likelihood caller -- no launch, no error."""
