@@ -1,6 +1,7 @@
 // common.h -- shared host-side plumbing of the C ABI (include/ctpvae_radon.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,18 @@ struct SliceScale {
     long long stride;
     __device__ __forceinline__ float at(int s) const { return ptr ? ptr[(long long)s * stride] : 1.0f; }
 };
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: it is set once per (kernel
+// instantiation, device) -- `seen` is that instantiation's bit mask of devices already done.
+inline bool first_use_on_this_device(std::atomic<unsigned long long> &seen)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (seen.load(std::memory_order_relaxed) & bit) return false;
+    seen.fetch_or(bit);
+    return true;
+}
 
 // Kernels that index slices with a grid y / z dimension take at most this many per launch; their entry points split
 // longer batches (CTPVAE_TUNE_MAX_SLICES: a smaller limit, for the tests of that splitting).

@@ -1179,11 +1179,10 @@ static int rotate_fwd_one(const float *img_dev, int S, int H, int W, int PH, int
         const dim3 grid((unsigned)((nrays + rpb - 1) / rpb), S);
         const bool tie_fix = (px == 0 || py == 0);
         auto launch = [&](auto kernel) -> int {
-            static std::atomic<bool> attr_set{false};  // one flag per instantiation (the lambda is instantiated per kernel)
-            if (!attr_set) {
+            static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+            if (first_use_on_this_device(attr_set)) {
                 CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                kMaxLdsBytes));
-                attr_set = true;
             }
             hipLaunchKernelGGL(kernel, grid, dim3(block), fast_lds, (hipStream_t)stream, img_dev, g, TileSpec{}, T8_dev,
                                (int)rpb, sino_dev);
@@ -1282,10 +1281,9 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<bool> attr_set{false};  // one flag per instantiation
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        if (first_use_on_this_device(attr_set)) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-            attr_set = true;
         }
         hipLaunchKernelGGL(kernel, dim3(2 * G, groups * nt), dim3(64 * waves), lds_bytes + t8_bytes, (hipStream_t)stream,
                            img_dev, g, ts, T8_dev, t8_bytes ? (int)(lds_bytes / sizeof(float)) : 0, (float *)workspace_dev);

@@ -776,10 +776,9 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     const int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<bool> attr_set{false};   // one flag per instantiation
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        if (first_use_on_this_device(attr_set)) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-            attr_set = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
                            img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi);
@@ -847,10 +846,9 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
     const long long nblk = (long long)units * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<bool> attr_set{false};   // one flag per instantiation
-        if (!attr_set) {
+        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        if (first_use_on_this_device(attr_set)) {
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-            attr_set = true;
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
                            (const uint4 *)bwd_plan_dev, tiles_y, S, SliceScale{scale_dev, scale_stride}, gimg_dev);
