@@ -1,0 +1,32 @@
+"""Developer sweep: planned forward at the headline size over the launch knobs (CTPVAE_TUNE_NS / _G / _WAVES), timed from
+HIP-graph replays of 200 launches; prints the library's own choice (no knobs) first."""
+import itertools, os, sys, torch, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from ct_pvae_amd import phantoms
+from ct_pvae_amd.forward_functions import RotatePlan
+dev = torch.device('cuda', 0)
+B, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 50), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, A)] if A < 180 else phantoms.dense_theta(180)
+plan = RotatePlan(theta, 128, 128, True, dev)
+x = torch.rand((B, 128, 128), device=dev); out = torch.empty((B, A, plan.PW), device=dev)
+def t_us():
+    plan.forward(x, out=out); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(200): plan.forward(x, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    r = []
+    for _ in range(5):
+        torch.cuda.synchronize(); e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        r.append(e0.elapsed_time(e1) * 1e3 / 200)
+    return float(np.median(r))
+print("library choice: %.2f us" % t_us())
+res = []
+for ns, G, w in itertools.product((1, 2), (1, 2, 3, 4, 5, 6, 8, 10), (8, 12, 16)):
+    os.environ.update(CTPVAE_TUNE_NS=str(ns), CTPVAE_TUNE_G=str(G), CTPVAE_TUNE_WAVES=str(w))
+    try:
+        res.append((t_us(), ns, G, w))
+    except Exception as e:
+        print("skip", ns, G, w, type(e).__name__)
+for t, ns, G, w in sorted(res)[:12]:
+    print("NS=%d G=%2d waves=%2d: %.2f us" % (ns, G, w, t))
