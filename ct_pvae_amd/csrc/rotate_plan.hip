@@ -823,8 +823,9 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
     const BwdLayout L = bwd_layout(g);
     // Two slices per workgroup (one index stream, one unpack and one ds_read_b64 per tap serve both; each lane then
     // owns 2 rows instead of 4) once the batch is large enough to still fill the chip: measured B=50: 7.6 -> 6.4 us at
-    // A=20, 16.5 -> 13.8 us at A=90, 28.3 -> 25.4 us at A=180; a wash below ~32 slices.
-    int ns = S >= 32 ? 2 : 1;
+    // A=20, 16.5 -> 13.8 us at A=90, 28.3 -> 25.4 us at A=180.  Small batches pair up too, in short 4-wave tiles
+    // (tools/sweep_bwd.py: 4.7 -> 4.1 us at S=2..16, 5.3 -> 4.8 us at S=24, A=20; even at A=90).
+    int ns = S >= 2 ? 2 : 1;
     if (const char *e = getenv("CTPVAE_TUNE_BNS")) ns = (atoi(e) == 2 && S >= 2) ? 2 : 1;
     const int ppt = ns == 2 ? 2 : 4;
     const int units = ceil_div(S, ns);
@@ -835,8 +836,8 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
     // the staging is small and short tiles win, because four small workgroups per CU overlap each other's staging and
     // barrier waits while one 16-wave workgroup (114 VGPRs: one per CU) cannot (B=400 A=20: 34 us vs 45 us).
     int waves = 4;
-    if (ns == 2)
-        waves = A >= 64 ? 16 : 8;   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many (sweeps, tools/tune_rotate.hip)
+    if (ns == 2)   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many; half as tall below 32 slices (sweeps)
+        waves = A >= 64 ? (S >= 32 ? 16 : 8) : (S > 16 ? 8 : 4);
     else if (A >= 32)
         while (waves < 16 && (long long)units * L.nXB * ceil_div(H, 2 * waves * ppt) >= 200 && waves * ppt < H) waves *= 2;
     while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has

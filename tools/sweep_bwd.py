@@ -1,0 +1,37 @@
+"""Developer sweep: the two bit-identical nearest backward paths at one size over their launch knobs (planned:
+CTPVAE_TUNE_BNS / _BW; segment: CTPVAE_TUNE_SEG_NS / _SEG_PPT / _SEG_CHUNK), from HIP-graph replays of 200 launches;
+the library's own choices are printed first."""
+import itertools, os, sys, torch, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from ct_pvae_amd import phantoms
+from ct_pvae_amd.forward_functions import RotatePlan
+dev = torch.device('cuda', 0)
+B, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 50), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
+theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, A)] if A < 180 else phantoms.dense_theta(180)
+g = torch.rand((B, A, 184), device=dev); out = torch.empty((B, 128, 128), device=dev)
+def t_us(plan):
+    plan.backward(g, out=out); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(200): plan.backward(g, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    r = []
+    for _ in range(5):
+        torch.cuda.synchronize(); e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
+        r.append(e0.elapsed_time(e1) * 1e3 / 200)
+    return float(np.median(r))
+planned = RotatePlan(theta, 128, 128, True, dev); planned.backward_uses_plan = lambda S: True
+seg = RotatePlan(theta, 128, 128, True, dev); seg.backward_uses_plan = lambda S: False
+auto = RotatePlan(theta, 128, 128, True, dev)
+print("library: %.2f us (%s);  planned default %.2f us, segment default %.2f us" % (
+    t_us(auto), "planned" if auto.backward_uses_plan(B) else "segment", t_us(planned), t_us(seg)))
+res = []
+for ns, w in itertools.product((1, 2), (2, 4, 8, 16)):
+    os.environ.update(CTPVAE_TUNE_BNS=str(ns), CTPVAE_TUNE_BW=str(w))
+    res.append((t_us(planned), "planned NS=%d waves=%2d" % (ns, w)))
+for k in ("CTPVAE_TUNE_BNS", "CTPVAE_TUNE_BW"): os.environ.pop(k)
+for ns, ppt, ch in itertools.product((1, 2), (4, 8), (24, 48, 96)):
+    os.environ.update(CTPVAE_TUNE_SEG_NS=str(ns), CTPVAE_TUNE_SEG_PPT=str(ppt), CTPVAE_TUNE_SEG_CHUNK=str(ch))
+    res.append((t_us(seg), "segment NS=%d ppt=%d chunk=%2d" % (ns, ppt, ch)))
+for t, name in sorted(res)[:8]:
+    print("%-32s %.2f us" % (name, t))
