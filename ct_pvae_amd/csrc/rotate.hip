@@ -1364,8 +1364,10 @@ static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, 
     const RotGeom g{S, H, W, PH, PW, py, px, A};
     if (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
         // 64-column x 32-row tiles, an 80-bin cotangent segment per angle in LDS (<= 31 KiB per chunk of angles)
-        // two slices per workgroup (shared coordinates and addresses, ds_read_b64) once the batch can spare the workgroups
-        int ns = S >= 16 ? 2 : 1;
+        // two slices per workgroup (shared coordinates and addresses, ds_read_b64) once the launch can spare the
+        // workgroups: 16 slices, or pairs that still make 256 tiles of 64 x 16 (tools/sweep_bwd.py: 512 x 512 x 90 angles,
+        // 8 slices 33 -> 25 us, 12 slices 46 -> 32 us; 256 x 256, 4 slices x 20 angles stays single)
+        int ns = (S >= 16 || (S >= 2 && (long long)ceil_div(S, 2) * ceil_div(W, 64) * ceil_div(H, 16) >= 256)) ? 2 : 1;
         if (const char *e = getenv("CTPVAE_TUNE_SEG_NS")) ns = (atoi(e) == 2 && S >= 2) ? 2 : 1;
         const int units = ceil_div(S, ns);
         int chunk_a = std::min(A, ns == 2 ? 48 : 96);   // ~32 KiB of LDS either way: five 4-wave workgroups per CU

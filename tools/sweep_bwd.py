@@ -7,8 +7,10 @@ from ct_pvae_amd import phantoms
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 B, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 50), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
-theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, A)] if A < 180 else phantoms.dense_theta(180)
-g = torch.rand((B, A, 184), device=dev); out = torch.empty((B, 128, 128), device=dev)
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+theta = np.pi * np.arange(A) / A
+auto = RotatePlan(theta, N, N, True, dev)
+g = torch.rand((B, A, auto.PW), device=dev); out = torch.empty((B, N, N), device=dev)
 def t_us(plan):
     plan.backward(g, out=out); torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
@@ -20,16 +22,16 @@ def t_us(plan):
         torch.cuda.synchronize(); e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
         r.append(e0.elapsed_time(e1) * 1e3 / 200)
     return float(np.median(r))
-planned = RotatePlan(theta, 128, 128, True, dev); planned.backward_uses_plan = lambda S: True
-seg = RotatePlan(theta, 128, 128, True, dev); seg.backward_uses_plan = lambda S: False
-auto = RotatePlan(theta, 128, 128, True, dev)
-print("library: %.2f us (%s);  planned default %.2f us, segment default %.2f us" % (
-    t_us(auto), "planned" if auto.backward_uses_plan(B) else "segment", t_us(planned), t_us(seg)))
+has_plan = auto.planned[1]
+planned = RotatePlan(theta, N, N, True, dev); planned.backward_uses_plan = lambda S: True
+seg = RotatePlan(theta, N, N, True, dev); seg.backward_uses_plan = lambda S: False
+print("library: %.2f us (%s);  planned default %s us, segment default %.2f us" % (
+    t_us(auto), "planned" if auto.backward_uses_plan(B) else "segment", ("%.2f" % t_us(planned)) if has_plan else "n/a", t_us(seg)))
 res = []
-for ns, w in itertools.product((1, 2), (2, 4, 8, 16)):
+for ns, w in (itertools.product((1, 2), (2, 4, 8, 16)) if has_plan else ()):
     os.environ.update(CTPVAE_TUNE_BNS=str(ns), CTPVAE_TUNE_BW=str(w))
     res.append((t_us(planned), "planned NS=%d waves=%2d" % (ns, w)))
-for k in ("CTPVAE_TUNE_BNS", "CTPVAE_TUNE_BW"): os.environ.pop(k)
+for k in ("CTPVAE_TUNE_BNS", "CTPVAE_TUNE_BW"): os.environ.pop(k, None)
 for ns, ppt, ch in itertools.product((1, 2), (4, 8), (24, 48, 96)):
     os.environ.update(CTPVAE_TUNE_SEG_NS=str(ns), CTPVAE_TUNE_SEG_PPT=str(ppt), CTPVAE_TUNE_SEG_CHUNK=str(ch))
     res.append((t_us(seg), "segment NS=%d ppt=%d chunk=%2d" % (ns, ppt, ch)))
