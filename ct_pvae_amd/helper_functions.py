@@ -19,19 +19,33 @@ __all__ = ["create_sinogram", "create_sinograms", "calculate_log_prob_M_given_R"
 # a7: create_sinogram -> tomopy.project(phantom[None], theta, center=None, emission=True, pad=pad,
 #                                       sinogram_order=False), squeezed to [angles][dx]
 # ---------------------------------------------------------------------------------------------------------
+_SIDDON_TABLES = {}
+_SIDDON_TABLES_MAX = 16
+
+
 def _siddon_tables(theta, device):
+    """(sin, cos, quadrant) device tables of an angle set.  Keyed by value and kept (a script projects image after image
+    with one theta, scripts/images_to_sinograms.py:62-66): a repeated call uploads nothing, which is also what makes
+    create_sinogram(s) capturable into a HIP graph after its first call."""
     lib = _lib.load()
     th = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
                                          dtype=np.float32))  # tomopy: dtype.as_float32(theta)
     if th.ndim != 1 or th.size == 0:
         raise ValueError(f"theta must be a non-empty 1-D array (got shape {th.shape})")
+    key = (th.tobytes(), str(device))
+    hit = _SIDDON_TABLES.get(key)
+    if hit is not None:
+        return hit
     dt = th.size
     sin_t, cos_t = np.empty(dt, np.float32), np.empty(dt, np.float32)
     quad = np.empty(dt, np.int32)
     _lib.check(lib.ctpvae_siddon_tables_f32(th.ctypes.data, dt, sin_t.ctypes.data, cos_t.ctypes.data,
                                             quad.ctypes.data), "siddon_tables")
-    return (torch.from_numpy(sin_t).to(device), torch.from_numpy(cos_t).to(device),
-            torch.from_numpy(quad).to(device))
+    tables = (torch.from_numpy(sin_t).to(device), torch.from_numpy(cos_t).to(device), torch.from_numpy(quad).to(device))
+    if len(_SIDDON_TABLES) >= _SIDDON_TABLES_MAX:
+        _SIDDON_TABLES.pop(next(iter(_SIDDON_TABLES)))
+    _SIDDON_TABLES[key] = tables
+    return tables
 
 
 def create_sinograms(imgs, theta, pad=True, device=None):
