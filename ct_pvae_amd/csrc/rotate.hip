@@ -1274,10 +1274,13 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     // a copy of the transform rows behind the tile, when it fits
     const size_t t8_need = (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int);   // + class list + task counter
     const size_t t8_bytes = lds_bytes + t8_need <= (size_t)kMaxLdsBytes ? t8_need : 0;
-    // about one 16-wave workgroup per CU: groups per bank class so that tiles x 2 classes x groups covers the chip
+    // Task groups per bank class: as many as keep tiles x 2 classes x groups within ONE round of the 256 CUs (rounding
+    // up instead put 264 workgroups on the chip, a second round for 8 of them: 20.9 vs 16.6 us at 4 x 256 x 256, 90
+    // angles) and leave every workgroup at least 4 waves of tasks (2-wave workgroups stage their tile too slowly:
+    // 20.6 vs 13.3 us at 20 angles) -- tools/sweep_tiled.py.
     const int tasks = A * (ts.nb / 64);
-    int G = std::max(1, (int)(256.0 / (2.0 * groups * nt) + 0.5));
-    G = std::min(G, std::max(1, tasks / 2));
+    int G = std::max(1, 256 / (2 * groups * nt));
+    G = std::min(G, std::max(1, tasks / 8));
     if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
     const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
     auto launch = [&](auto kernel) -> int {
