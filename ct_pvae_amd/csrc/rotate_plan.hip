@@ -12,11 +12,12 @@
 // result is bit-identical to the direct kernels and to the oracle, because the same indices are used and every
 // ray still adds its rows in ascending order (skipped rows and dead taps contribute exactly +0.0f).
 //
-// Forward plan   idx[a][g][j] : uint4 = the 8 taps of rows 8g..8g+7 of ray (a, j), each a dword index into the
-//                               staged slice (row pitch == 1 mod 32), or `zero` (a cell holding 0.0f) if the tap
-//                               is outside the H x W core or the row is past the canvas.
-//                rng[a][jb]   : first row-group and group count (multiple of 4) that any of the 64 rays of bin
-//                               block jb needs -- the kernel's wave-uniform loop bounds.
+// Forward plan   first[a][j]  : the first canvas row at which ray (a, j) is inside the H x W core (its own entry row).
+//                idx[a][g][j] : uint4 = the 8 taps of rows first + 8g .. first + 8g + 7 of ray (a, j), each a dword
+//                               index into the staged slice (row pitch == 1 mod 32), or `zero` (a cell holding 0.0f)
+//                               if the tap is outside the core or the row is past the canvas.
+//                rng[a][jb]   : first and last row group that any of the 64 rays of bin block jb needs -- the
+//                               kernel's wave-uniform loop bounds.
 //                clist[c]     : (count, angles of class c ascending) -- the planned kernel's task lists.
 //                cls[a]       : 1 if lanes walk the slice with column and row moving the same way, else 0; for
 //                               class 0 the slice is staged (and indexed) column-mirrored, so that consecutive
