@@ -524,6 +524,42 @@ def test_fused_loglik_backward_is_one_launch_and_matches_two_steps(B, N, A, upst
     assert float((grads[0] - grads[1]).abs().max()) <= 1e-5 * float(grads[1].abs().max())
 
 
+def test_random_fused_likelihood_cases():
+    """Seeded random (batch, size, angles, upstream gradient kind) cases of calculate_log_prob_M_given_R's one-launch
+    paths against the two-step path: log-probabilities bit for bit, gradients to 1e-5 (CTPVAE_FUZZ_SEED / _CASES: more)."""
+    from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
+    d = dev()
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 404)))
+    for case in range(int(os.environ.get("CTPVAE_FUZZ_CASES", 8))):
+        B, N, A = int(rng.integers(1, 91)), int(rng.integers(8, 141)), int(rng.integers(1, 31))
+        if case % 4 == 3:
+            B, N = int(rng.integers(1, 7)), int(rng.integers(200, 260))              # tiled forward, segment backward
+        kind = ("per_object", "scalar", "elementwise")[case % 3]
+        theta = torch.from_numpy(rng.uniform(0, np.pi, A).astype(np.float32)).to(d)
+        P = cp.num_proj_pix(N, N)
+        mask = torch.from_numpy(((rng.random((B, A)) > 0.3) * (rng.random((B, A)) + 0.2) / A).astype(np.float32)).to(d)
+        meas = torch.from_numpy((rng.random((B, A, P)) * 3).astype(np.float32)).to(d)
+        w = torch.from_numpy(rng.standard_normal(B).astype(np.float32)).to(d)
+        up = torch.from_numpy(rng.standard_normal((B, A, P, 1)).astype(np.float32)).to(d)
+        img = rng.random((B, N, N, 1), dtype=np.float32)
+        res = []
+        for fused in (True, False):
+            x = torch.from_numpy(img).to(d).requires_grad_(True)
+            if fused:
+                lp = cp.calculate_log_prob_M_given_R(x, mask, meas, 1e3, 1e-7, theta=theta, pad=True)
+            else:
+                proj = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+                lp = gaussian_poisson_log_prob(proj[..., 0], mask, meas, 1e3, 1e-7).unsqueeze(-1)
+            loss = {"per_object": lambda: (lp.sum(dim=(1, 2, 3)) * w).sum(), "scalar": lambda: lp.sum() * -0.2,
+                    "elementwise": lambda: (lp * up).sum()}[kind]()
+            loss.backward()
+            res.append((lp.detach(), x.grad.detach()))
+        tag = f"case {case}: B={B} N={N} A={A} {kind}"
+        assert torch.equal(res[0][0], res[1][0]), tag
+        assert torch.isfinite(res[0][1]).all(), tag
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-5 * float(res[1][1].abs().max()) + 1e-30, tag
+
+
 def test_backward_scale_operand_checks():
     d = dev()
     theta = np.linspace(0, np.pi, 6, endpoint=False)
