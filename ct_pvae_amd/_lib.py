@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
+ABI_VERSION = 2000   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -22,9 +23,17 @@ SIGNATURES = {
     "ctpvae_abi_version": (_c_int, []),
     "ctpvae_last_error": (ctypes.c_char_p, []),
     "ctpvae_device_count": (_c_int, []),
+    "ctpvae_tune_set": (_c_int, [ctypes.c_char_p, _c_int]),
+    "ctpvae_tune_active": (_c_int, []),
     "ctpvae_num_proj_pix": (_c_int, [_c_int, _c_int]),
     "ctpvae_pad_amounts": (_c_int, [_c_int, _c_int, _ip, _ip]),
     "ctpvae_rotate_transforms_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
+    "ctpvae_rotate_transforms_host_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_rotate_fwd_planned_sel_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp]),
+    "ctpvae_rotate_fwd_planned_loglik_sel_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
+                                                          _vp, _vp, _c_int, _vp, _c_float, _vp, _vp, _vp, _vp]),
+    "ctpvae_rotate_bwd_sel_scaled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int,
+                                                  _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
     "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                        _c_int, _vp, _vp]),
     "ctpvae_rotate_fwd_tiled_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
@@ -76,8 +85,15 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the library is stale
             fn.restype = res
             fn.argtypes = args
+        if lib.ctpvae_abi_version() != ABI_VERSION:
+            raise RadonLibraryError(f"{LIB_PATH} has ABI {lib.ctpvae_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         _lib = lib
     return _lib
+
+
+def tune(name, value=-1):
+    """Developer knob of the library (see ctpvae_tune_set in include/ctpvae_radon.h); value < 0 unsets, name "*" unsets all."""
+    check(load().ctpvae_tune_set(name.encode(), int(value)), "tune_set")
 
 
 def last_error():

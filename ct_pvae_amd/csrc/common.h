@@ -46,26 +46,38 @@ struct SliceScale {
 };
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of a kernel ON A DEVICE: it is set once per (kernel
-// instantiation, device) -- `seen` is that instantiation's bit mask of devices already done.
-inline bool first_use_on_this_device(std::atomic<unsigned long long> &seen)
-{
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (seen.load(std::memory_order_relaxed) & bit) return false;
-    seen.fetch_or(bit);
-    return true;
-}
+// instantiation, device) -- `seen` is that instantiation's bit mask of devices already done.  The bit is published only
+// AFTER the attribute call succeeded: a second thread that races the first simply sets the attribute again (harmless),
+// it can never launch ahead of it; a failed call leaves the bit clear, so the next launch retries.
+#define CTPVAE_SET_MAX_LDS_ONCE(kernel, seen)                                                                     \
+    do {                                                                                                          \
+        int dev_ = 0;                                                                                             \
+        CTPVAE_HIP(hipGetDevice(&dev_));                                                                          \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                      \
+        if (dev_ >= 64 || !((seen).load(std::memory_order_acquire) & bit_)) {                                     \
+            CTPVAE_HIP(hipFuncSetAttribute((const void *)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                           ::ctpvae::kMaxLdsBytes));                                              \
+            if (dev_ < 64) (seen).fetch_or(bit_, std::memory_order_release);                                      \
+        }                                                                                                         \
+    } while (0)
+
+// Developer knobs (tools/ sweeps and the tests that force one code path against another).  None changes results.
+// They are NOT read from the environment in the launch path: the registry is filled once, when the library is loaded,
+// from CTPVAE_TUNE_<NAME> / CTPVAE_NO_PLAN / CTPVAE_FORCE_GENERIC, and changed afterwards only through
+// ctpvae_tune_set() (include/ctpvae_radon.h).  A knob reads -1 when unset.
+enum Knob {
+    kKnobNoPlan, kKnobForceGeneric, kKnobNs, kKnobG, kKnobWaves, kKnobBns, kKnobBw, kKnobSegNs, kKnobSegChunk,
+    kKnobSegPpt, kKnobTiledNs, kKnobTiledG, kKnobSiddonNs, kKnobSiddonThreads, kKnobSiddonPpb, kKnobMaxSlices,
+    kKnobSiddonBwdThreads, kKnobCount
+};
+int knob(Knob k);
 
 // Kernels that index slices with a grid y / z dimension take at most this many per launch; their entry points split
-// longer batches (CTPVAE_TUNE_MAX_SLICES: a smaller limit, for the tests of that splitting).
+// longer batches (knob MAX_SLICES: a smaller limit, for the tests of that splitting).
 inline int max_slices_per_launch()
 {
-    if (const char *e = getenv("CTPVAE_TUNE_MAX_SLICES")) {
-        const int v = atoi(e);
-        if (v >= 1 && v <= 65535) return v;
-    }
-    return 65535;
+    const int v = knob(kKnobMaxSlices);
+    return (v >= 1 && v <= 65535) ? v : 65535;
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

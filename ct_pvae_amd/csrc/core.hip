@@ -21,9 +21,38 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// ---- developer knobs ---------------------------------------------------------------------------------------------
+static const char *const kKnobNames[kKnobCount] = {
+    "NO_PLAN", "FORCE_GENERIC", "NS", "G", "WAVES", "BNS", "BW", "SEG_NS", "SEG_CHUNK", "SEG_PPT", "TILED_NS", "TILED_G",
+    "SIDDON_NS", "SIDDON_THREADS", "SIDDON_PPB", "MAX_SLICES", "SIDDON_BWD_THREADS"};
+static std::atomic<int> g_knobs[kKnobCount];
+static int find_knob(const char *name)
+{
+    for (int k = 0; k < kKnobCount; ++k)
+        if (strcmp(name, kKnobNames[k]) == 0) return k;
+    return -1;
+}
+// Filled once at load time from the environment (CTPVAE_NO_PLAN / CTPVAE_FORCE_GENERIC: set = 1; CTPVAE_TUNE_<NAME>=n).
+static const bool g_knobs_loaded = [] {
+    for (int k = 0; k < kKnobCount; ++k) {
+        int v = -1;
+        char env[64];
+        if (k == kKnobNoPlan || k == kKnobForceGeneric) {
+            snprintf(env, sizeof env, "CTPVAE_%s", kKnobNames[k]);
+            if (getenv(env) != nullptr) v = 1;
+        } else {
+            snprintf(env, sizeof env, "CTPVAE_TUNE_%s", kKnobNames[k]);
+            if (const char *e = getenv(env)) v = atoi(e);
+        }
+        g_knobs[k].store(v, std::memory_order_relaxed);
+    }
+    return true;
+}();
+int knob(Knob k) { return g_knobs[k].load(std::memory_order_relaxed); }
+
 // 3x3 fp32 inverse by LU with partial pivoting -- the arithmetic TensorFlow's matrix_inverse
 // performs on the flat transform inside the gradient of ImageProjectiveTransformV3.
-__device__ static void inv3x3(const float m[9], float out[9])
+__host__ __device__ static void inv3x3(const float m[9], float out[9])
 {
     float a[3][6];
 #pragma unroll
@@ -59,25 +88,35 @@ __device__ static void inv3x3(const float m[9], float out[9])
         for (int c = 0; c < 3; ++c) out[3 * r + c] = a[r][3 + c];
 }
 
-// One thread per angle.  cos/sin are the correctly rounded fp32 values (fp64 evaluation, rounded once).
-__global__ void rotate_transforms_kernel(const float *__restrict__ theta, int A, float hm1, float wm1,
-                                         float *__restrict__ T8, float *__restrict__ Tinv8)
+// One table row pair.  cos/sin are the correctly rounded fp32 values (fp64 evaluation, rounded once): on the host by
+// the C library, in the kernel by the device library -- the two agree except for rare double roundings, which is why
+// host-resident angle sets take the HOST path (ctpvae_rotate_transforms_host_f32): the rows are then the very bits any
+// other host code (the CPU oracle, a NumPy restatement) computes from the same expressions.
+__host__ __device__ static void transform_rows(float theta, float hm1, float wm1, float *t8, float *tinv8)
 {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= A) return;
-    const float ang = -theta[a];
+    const float ang = -theta;
     const float c = (float)cos((double)ang);
     const float s = (float)sin((double)ang);
     const float cw = c * wm1, sh = s * hm1, sw = s * wm1, ch = c * hm1;
     const float xo = (wm1 - (cw - sh)) / 2.0f;
     const float yo = (hm1 - (sw + ch)) / 2.0f;
-    float t[8] = {c, -s, xo, s, c, yo, 0.0f, 0.0f};
-    for (int k = 0; k < 8; ++k) T8[8 * a + k] = t[k];
-    if (Tinv8) {
-        float m[9] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], 1.0f}, inv[9];
+    const float t[8] = {c, -s, xo, s, c, yo, 0.0f, 0.0f};
+    for (int k = 0; k < 8; ++k) t8[k] = t[k];
+    if (tinv8) {
+        const float m[9] = {t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], 1.0f};
+        float inv[9];
         inv3x3(m, inv);
-        for (int k = 0; k < 8; ++k) Tinv8[8 * a + k] = inv[k] / inv[8];
+        for (int k = 0; k < 8; ++k) tinv8[k] = inv[k] / inv[8];
     }
+}
+
+// One thread per angle.
+__global__ void rotate_transforms_kernel(const float *__restrict__ theta, int A, float hm1, float wm1,
+                                         float *__restrict__ T8, float *__restrict__ Tinv8)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    transform_rows(theta[a], hm1, wm1, T8 + 8 * a, Tinv8 ? Tinv8 + 8 * a : nullptr);
 }
 
 }  // namespace ctpvae
@@ -86,7 +125,27 @@ using namespace ctpvae;
 
 extern "C" {
 
-int ctpvae_abi_version(void) { return 1003; }
+int ctpvae_abi_version(void) { return 2000; }
+
+int ctpvae_tune_set(const char *name, int value)
+{
+    CTPVAE_REQUIRE(name != nullptr, "tune_set: null name");
+    if (strcmp(name, "*") == 0) {   // reset every knob
+        for (int k = 0; k < kKnobCount; ++k) g_knobs[k].store(-1, std::memory_order_relaxed);
+        return CTPVAE_OK;
+    }
+    const int k = find_knob(name);
+    CTPVAE_REQUIRE(k >= 0, "tune_set: unknown knob '%s'", name);
+    g_knobs[k].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return CTPVAE_OK;
+}
+
+int ctpvae_tune_active(void)
+{
+    int n = 0;
+    for (int k = 0; k < kKnobCount; ++k) n += g_knobs[k].load(std::memory_order_relaxed) >= 0;
+    return n;
+}
 
 const char *ctpvae_last_error(void) { return err_buf(); }
 
@@ -111,6 +170,15 @@ int ctpvae_pad_amounts(int n, int P, int *lo, int *hi)
     CTPVAE_REQUIRE(n > 0 && P >= n, "pad_amounts: need 0 < n <= P (got n=%d, P=%d)", n, P);
     *lo = (P - n) / 2;
     *hi = *lo + ((P - n) % 2);
+    return CTPVAE_OK;
+}
+
+int ctpvae_rotate_transforms_host_f32(const float *theta, int A, int H, int W, float *T8, float *Tinv8)
+{
+    CTPVAE_REQUIRE(theta && T8, "rotate_transforms_host: null pointer");
+    CTPVAE_REQUIRE(A > 0 && H > 0 && W > 0, "rotate_transforms_host: bad sizes A=%d H=%d W=%d", A, H, W);
+    for (int a = 0; a < A; ++a)
+        transform_rows(theta[a], (float)H - 1.0f, (float)W - 1.0f, T8 + 8 * a, Tinv8 ? Tinv8 + 8 * a : nullptr);
     return CTPVAE_OK;
 }
 

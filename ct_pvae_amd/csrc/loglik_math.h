@@ -38,10 +38,15 @@ struct LogLikEpilogue {
     float eps;
     float *lp;                        // [S][A][PW]
     float *dlp;                       // [S][A][PW] d lp / d ray-sum for the backward, or nullptr
+    // angle-subset launches only: mask / meas are the DENSE [S][A_plan] / [S][A_plan][PW] arrays, indexed by the plan
+    // angle (the caller's gather mask[:, angles_i], proj_sample[:, angles_i] -- ctvae/helper_functions.py:356-357 --
+    // folded into the load); 0: they are compact like the outputs
+    int dense = 0;
 
-    __device__ __forceinline__ void write(size_t o, size_t sa, float raysum) const
+    // o: offset of the ray-sum in the outputs; om / sa: offsets of its measured sample and its mask entry
+    __device__ __forceinline__ void write(size_t o, size_t om, size_t sa, float raysum) const
     {
-        const float m = mask[sa], x = meas[o], pnm_v = *pnm;
+        const float m = mask[sa], x = meas[om], pnm_v = *pnm;
         lp[o] = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
         if (dlp) {
             float unused;

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
     if (j >= g.PW) return;
     const size_t o = ((size_t)s * g.A + a) * g.PW + j;
     sino[o] = acc;
-    if constexpr (EPI) epi.write(o, (size_t)s * g.A + a, acc);
+    if constexpr (EPI) epi.write(o, o, (size_t)s * g.A + a, acc);
 }
 
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
@@ -834,8 +834,12 @@ template <int PPT, int NS>   // NS = 2: two slices per workgroup, segments inter
                              // convert, one address and one ds_read_b64 per tap serve both slices
 __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const float *__restrict__ gsino, RotGeom g,
                                                                       const float *__restrict__ Tinv8, int chunk_a,
-                                                                      SliceScale scale, float *__restrict__ gimg)
+                                                                      SliceScale scale, float *__restrict__ gimg,
+                                                                      const int *__restrict__ sel, int a_plan)
 {
+    // sel != nullptr: cotangent row k of the g.A rows belongs to row sel[k] of a DENSE table of a_plan angles (the
+    // training loop's per-step angle subset, ctvae/helper_functions.py:350-357); a bad index cannot leave the table
+    auto table_row = [&](int k) { return sel ? min(max(sel[k], 0), a_plan - 1) : k; };
     typedef typename PixVec<NS>::type vec_t;
     constexpr int SHIFT = NS == 1 ? 2 : 3;
     // [chunk_a][kSegPitch] segment cells (NS floats each), then per angle: (first bin, class) ints and (t0, t1, t2,
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
         if (ac > 0) __syncthreads();
         int any_outside = 0;
         for (int al = threadIdx.x; al < na; al += blockDim.x) {
-            const float *t = Tinv8 + 8 * (size_t)(ac + al);
+            const float *t = Tinv8 + 8 * (size_t)table_row(ac + al);
             const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
             const float xa = (t0 * X0 + t1 * Y0) + t2, xb = (t0 * X1 + t1 * Y0) + t2;
             const float xc = (t0 * X0 + t1 * Y1) + t2, xd = (t0 * X1 + t1 * Y1) + t2;
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
             }
         } else
         for (int al = 0; al < na; ++al) {
-            const float *t = Tinv8 + 8 * (size_t)(ac + al);   // wave-uniform: scalar loads
+            const float *t = Tinv8 + 8 * (size_t)table_row(ac + al);   // wave-uniform: scalar loads
             const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
             const int first = __builtin_amdgcn_readfirstlane(meta[2 * al]);
             const int cls = __builtin_amdgcn_readfirstlane(meta[2 * al + 1]);
@@ -1109,8 +1113,8 @@ static int pick_angles_per_block(int S, int A, int PW)
 static int pick_tile_ns(int S, bool tie_fix)
 {
     int ns = S >= 3 ? 4 : (S == 2 ? 2 : 1);
-    if (const char *e = getenv("CTPVAE_TUNE_NS")) {
-        const int v = atoi(e);
+    {
+        const int v = knob(kKnobTiledNs);
         if (v == 1 || v == 2 || v == 4) ns = v;
     }
     return tie_fix ? 1 : ns;   // the negative-tie fix of an unpadded canvas is not in the interleaved (asm) path
@@ -1164,7 +1168,7 @@ static int rotate_fwd_one(const float *img_dev, int S, int H, int W, int PH, int
     const int border = interp == CTPVAE_NEAREST ? 1 : 2;
     const int wb = W + 2 * border;
     const size_t fast_lds = (size_t)(H + 2 * border) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
-    if (fast_lds <= (size_t)kMaxLdsBytes && getenv("CTPVAE_FORCE_GENERIC") == nullptr) {
+    if (fast_lds <= (size_t)kMaxLdsBytes && knob(kKnobForceGeneric) < 0) {
         // rays per workgroup: whole waves, <= 1024, about one workgroup per CU when the launch is small (every
         // workgroup re-stages its slice, and a wave needs its CU's LDS bandwidth more than it needs neighbours)
         const long long nrays = (long long)A * PW;
@@ -1180,10 +1184,7 @@ static int rotate_fwd_one(const float *img_dev, int S, int H, int W, int PH, int
         const bool tie_fix = (px == 0 || py == 0);
         auto launch = [&](auto kernel) -> int {
             static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
-            if (first_use_on_this_device(attr_set)) {
-                CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               kMaxLdsBytes));
-            }
+            CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
             hipLaunchKernelGGL(kernel, grid, dim3(block), fast_lds, (hipStream_t)stream, img_dev, g, TileSpec{}, T8_dev,
                                (int)rpb, sino_dev);
             CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel");
@@ -1228,7 +1229,7 @@ long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, i
 {
     if (S <= 0 || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_fwd_tiled_workspace_bytes: bad sizes");
     const TileSpec ts = pick_tiles(H, W, interp);
-    if (ts.ntx == 0 || getenv("CTPVAE_FORCE_GENERIC") != nullptr) return 0;
+    if (ts.ntx == 0 || knob(kKnobForceGeneric) >= 0) return 0;
     return (long long)S * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
 }
 
@@ -1281,13 +1282,11 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     const int tasks = A * (ts.nb / 64);
     int G = std::max(1, 256 / (2 * groups * nt));
     G = std::min(G, std::max(1, tasks / 8));
-    if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
+    if (knob(kKnobTiledG) > 0) G = knob(kKnobTiledG);
     const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
-        if (first_use_on_this_device(attr_set)) {
-            CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-        }
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3(2 * G, groups * nt), dim3(64 * waves), lds_bytes + t8_bytes, (hipStream_t)stream,
                            img_dev, g, ts, T8_dev, t8_bytes ? (int)(lds_bytes / sizeof(float)) : 0, (float *)workspace_dev);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel (tiled)");
@@ -1339,7 +1338,7 @@ int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, 
 
 static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
                           int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
-                          float *gimg_dev, ctpvae_stream_t stream);
+                          float *gimg_dev, ctpvae_stream_t stream, const int *sel_dev = nullptr, int A_plan = 0);
 
 int ctpvae_rotate_bwd_scaled_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
                                  int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
@@ -1353,36 +1352,52 @@ int ctpvae_rotate_bwd_scaled_f32(const float *gsino_dev, int S, int A, int PH, i
     });
 }
 
+int ctpvae_rotate_bwd_sel_scaled_f32(const float *gsino_dev, int S, int A_plan, int PH, int PW, const float *Tinv8_dev,
+                                     const int *angle_idx_dev, int n_idx, int H, int W, int py, int px,
+                                     const float *scale_dev, long long scale_stride, float *gimg_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(gsino_dev && Tinv8_dev && angle_idx_dev && gimg_dev && S > 0 && H > 0 && W > 0 && PW > 0,
+                   "rotate_bwd_sel: null pointer or empty sizes");
+    CTPVAE_REQUIRE(A_plan > 0 && n_idx > 0, "rotate_bwd_sel: need angles (plan %d, subset %d)", A_plan, n_idx);
+    CTPVAE_REQUIRE(knob(kKnobForceGeneric) < 0, "rotate_bwd_sel: not available with FORCE_GENERIC");
+    return for_slice_chunks(S, max_slices_per_launch(), [&](int s0, int n) {
+        return rotate_bwd_one(gsino_dev + (size_t)s0 * n_idx * PW, n, n_idx, PH, PW, Tinv8_dev, CTPVAE_NEAREST,
+                              CTPVAE_BWD_TF_COMPAT, H, W, py, px,
+                              scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr, scale_stride,
+                              gimg_dev + (size_t)s0 * H * W, stream, angle_idx_dev, A_plan);
+    });
+}
+
 static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,
                           int mode, int H, int W, int py, int px, const float *scale_dev, long long scale_stride,
-                          float *gimg_dev, ctpvae_stream_t stream)
+                          float *gimg_dev, ctpvae_stream_t stream, const int *sel_dev, int A_plan)
 {
     CTPVAE_REQUIRE(gsino_dev && T8_dev && gimg_dev, "rotate_bwd: null pointer");
     // only the NEAREST / TF_COMPAT segment kernel applies the per-slice factor in its store
     CTPVAE_REQUIRE(scale_dev == nullptr || (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && S <= 65535 &&
-                                            getenv("CTPVAE_FORCE_GENERIC") == nullptr),
+                                            knob(kKnobForceGeneric) < 0),
                    "rotate_bwd_scaled: a per-slice scale needs interp=NEAREST, mode=TF_COMPAT and S <= 65535");
     if (int rc = check_geom("rotate_bwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     CTPVAE_REQUIRE(mode == CTPVAE_BWD_TF_COMPAT || mode == CTPVAE_BWD_EXACT, "rotate_bwd: unknown mode %d", mode);
     const RotGeom g{S, H, W, PH, PW, py, px, A};
-    if (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
+    if (mode == CTPVAE_BWD_TF_COMPAT && interp == CTPVAE_NEAREST && knob(kKnobForceGeneric) < 0 && S <= 65535) {
         // 64-column x 32-row tiles, an 80-bin cotangent segment per angle in LDS (<= 31 KiB per chunk of angles)
         // two slices per workgroup (shared coordinates and addresses, ds_read_b64) once the launch can spare the
         // workgroups: 16 slices, or pairs that still make 256 tiles of 64 x 16 (tools/sweep_bwd.py: 512 x 512 x 90 angles,
         // 8 slices 33 -> 25 us, 12 slices 46 -> 32 us; 256 x 256, 4 slices x 20 angles stays single)
         int ns = (S >= 16 || (S >= 2 && (long long)ceil_div(S, 2) * ceil_div(W, 64) * ceil_div(H, 16) >= 256)) ? 2 : 1;
-        if (const char *e = getenv("CTPVAE_TUNE_SEG_NS")) ns = (atoi(e) == 2 && S >= 2) ? 2 : 1;
+        if (knob(kKnobSegNs) >= 0) ns = (knob(kKnobSegNs) == 2 && S >= 2) ? 2 : 1;
         const int units = ceil_div(S, ns);
         int chunk_a = std::min(A, ns == 2 ? 48 : 96);   // ~32 KiB of LDS either way: five 4-wave workgroups per CU
-        if (const char *e = getenv("CTPVAE_TUNE_SEG_CHUNK")) chunk_a = std::max(1, std::min(A, std::min(atoi(e), ns == 2 ? 90 : 180)));
+        if (knob(kKnobSegChunk) >= 0) chunk_a = std::max(1, std::min(A, std::min(knob(kKnobSegChunk), ns == 2 ? 90 : 180)));
         const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * ns + 2 * sizeof(int) + 4 * sizeof(float)) + 16;
         // 8 rows per lane (64 x 32 tiles); 4 (64 x 16) when that is what it takes to put ~2 workgroups on every CU
         int ppt = (long long)units * ceil_div(W, 64) * ceil_div(H, 32) >= 512 ? 8 : 4;
-        if (const char *e = getenv("CTPVAE_TUNE_SEG_PPT")) ppt = atoi(e) == 4 ? 4 : 8;
+        if (knob(kKnobSegPpt) >= 0) ppt = knob(kKnobSegPpt) == 4 ? 4 : 8;
         const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), units), block(256);
         auto launch = [&](auto kernel) {
             hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gsino_dev, g, T8_dev, chunk_a,
-                               SliceScale{scale_dev, scale_stride}, gimg_dev);
+                               SliceScale{scale_dev, scale_stride}, gimg_dev, sel_dev, A_plan);
         };
         if (ns == 2) {
             if (ppt == 8) launch(rotate_bwd_tfcompat_seg_kernel<8, 2>); else launch(rotate_bwd_tfcompat_seg_kernel<4, 2>);
@@ -1392,7 +1407,8 @@ static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, 
         CTPVAE_LAUNCH_CHECK("rotate_bwd_tfcompat_seg_kernel");
         return CTPVAE_OK;
     }
-    if (mode == CTPVAE_BWD_TF_COMPAT && getenv("CTPVAE_FORCE_GENERIC") == nullptr && S <= 65535) {
+    CTPVAE_REQUIRE(sel_dev == nullptr, "rotate_bwd_sel: only the NEAREST / TF_COMPAT segment kernel takes an angle subset (S <= 65535)");
+    if (mode == CTPVAE_BWD_TF_COMPAT && knob(kKnobForceGeneric) < 0 && S <= 65535) {
         // BILINEAR: 64-column x (4 waves x PPT rows) tiles; whole cotangent rows in LDS, <= 48 KiB per chunk
         constexpr int kPpt = 8;
         const int pitchg = PW + 4;

@@ -323,10 +323,18 @@ __device__ long long g_pstamps[8 * 65536];
 // EPI: the log-likelihood epilogue -- besides the ray-sum, every store also writes the log-probability
 // of the measured sample under it (mask [S][A], measured [S][A][PW]), the expression of loglik.hip, so that
 // calculate_log_prob_M_given_R costs one launch instead of two and the sinogram is not read back.
-template <int NS, bool EPI>
+// SEL: the launch projects a SUBSET of the plan's angles -- sel[k], k < n_sel <= 64 * kSelRounds, are plan angle numbers
+// (the training loop's per-step `api` random angles, ctvae/helper_functions.py:350-357, on ONE dense plan built from
+// the host's theta); output row k of every sinogram is plan angle sel[k].  Each wave derives its class's task list
+// from sel and the plan's cls[] with ballots (no list in memory, no extra launch): lane l of round r holds entry
+// 64 r + l, its plan angle and its rank among the entries of class c; the ai-th angle of the class is then one ballot
+// + readlane away.
+constexpr int kSelRounds = 4;
+template <int NS, bool EPI, bool SEL>
 __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *__restrict__ img, PlanGeom g, FwdLayout L,
                                                                   const char *__restrict__ plan, int wgs_per_slice,
-                                                                  int g_S, float *__restrict__ sino, LogLikEpilogue epi)
+                                                                  int g_S, float *__restrict__ sino, LogLikEpilogue epi,
+                                                                  const int *__restrict__ sel, int n_sel)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -359,7 +367,29 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     const int *clist = reinterpret_cast<const int *>(plan + L.off_clist) + c * (g.A + 1);
     const int *rng = reinterpret_cast<const int *>(plan + L.off_rng);
     const uint4 *idx = reinterpret_cast<const uint4 *>(plan + L.off_idx);
-    const int ncls = clist[0];
+    const int A_out = SEL ? n_sel : g.A;   // rows of an output sinogram
+    int sel_a[kSelRounds], sel_rank[kSelRounds], sel_cum[kSelRounds + 1];
+    int ncls;
+    if constexpr (SEL) {
+        const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
+        sel_cum[0] = 0;
+#pragma unroll
+        for (int r = 0; r < kSelRounds; ++r) {
+            const int k = 64 * r + lane;
+            int a = 0, cl = -1;
+            if (k < n_sel) {
+                a = min(max(sel[k], 0), g.A - 1);   // a bad index cannot leave the plan
+                cl = cls[a];
+            }
+            const unsigned long long m = __ballot(cl == c);
+            sel_a[r] = a;
+            sel_rank[r] = cl == c ? (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+            sel_cum[r + 1] = sel_cum[r] + (int)__popcll(m);
+        }
+        ncls = sel_cum[kSelRounds];
+    } else {
+        ncls = clist[0];
+    }
     const int ntask = ncls * L.nJB;
 #ifdef CTPVAE_TUNE_NOIDX
     const size_t st = 0;   // timing only: every group re-reads the first index vector (no index streaming)
@@ -368,19 +398,30 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 #endif
     struct Task {
         bool valid;
-        int a, j, ng;
+        int a, k, j, ng;   // plan angle, output row
         const uint4 *p;
         uint4 q0, q1, q2, q3;
     };
     auto prepare = [&](int m) -> Task {
         Task t;
         t.valid = m < ntask;
-        t.a = t.j = t.ng = 0;
+        t.a = t.k = t.j = t.ng = 0;
         t.p = idx;
         t.q0 = t.q1 = t.q2 = t.q3 = uint4{0, 0, 0, 0};
         if (t.valid) {   // wave-uniform
             const int jb = m / ncls, ai = m - jb * ncls;
-            t.a = clist[1 + ai];
+            if constexpr (SEL) {
+#pragma unroll
+                for (int r = 0; r < kSelRounds; ++r)
+                    if (ai >= sel_cum[r] && ai < sel_cum[r + 1]) {   // wave-uniform
+                        const unsigned long long hit = __ballot(sel_rank[r] == ai - sel_cum[r]);
+                        const int l = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
+                        t.a = __builtin_amdgcn_readlane(sel_a[r], l);
+                        t.k = 64 * r + l;
+                    }
+            } else {
+                t.k = t.a = clist[1 + ai];
+            }
             const int first = rng[(t.a * L.nJB + jb) * 2], last = kRngBias - rng[(t.a * L.nJB + jb) * 2 + 1];
             const int g0 = last >= first ? first : 0;
             t.ng = last >= first ? last - first + 1 : 0;   // row groups any of this block's rays needs
@@ -455,9 +496,13 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
         }
         if ((unsigned)cur.j < (unsigned)g.PW) {
             auto store = [&](int sl, float v) {
-                const size_t o = ((size_t)sl * g.A + cur.a) * g.PW + cur.j;
+                const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
                 sino[o] = v;
-                if constexpr (EPI) epi.write(o, (size_t)sl * g.A + cur.a, v);
+                if constexpr (EPI) {
+                    // measured samples and masks: compact like the outputs, or the dense arrays read at the plan angle
+                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + cur.a : (size_t)sl * A_out + cur.k;
+                    epi.write(o, sa * g.PW + cur.j, sa, v);
+                }
             };
             if constexpr (NS == 1) {
                 store(s, acc);
@@ -662,7 +707,7 @@ extern "C" {
 int ctpvae_rotate_plan_supported(int H, int W, int PH, int PW, int A, int interp, int which)
 {
     if (interp != CTPVAE_NEAREST || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return 0;
-    if (getenv("CTPVAE_NO_PLAN") != nullptr) return 0;
+    if (knob(kKnobNoPlan) >= 0) return 0;
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     return which == 0 ? (fwd_plan_fits(g) ? 1 : 0) : (bwd_plan_fits(g) ? 1 : 0);
 }
@@ -708,16 +753,23 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
     return CTPVAE_OK;
 }
 
+// sel_dev == nullptr: all A angles of the plan; otherwise the n_sel plan angles sel_dev[0..n_sel) (device int32), in
+// that order, are projected -- the launch shape is then sized for n_sel angles.
 static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
-                              float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
+                              float *sino_dev, const LogLikEpilogue &epi, const int *sel_dev, int n_sel,
+                              ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(img_dev && fwd_plan_dev && sino_dev, "rotate_fwd_planned: null pointer");
     CTPVAE_REQUIRE(S > 0, "rotate_fwd_planned: need at least one slice");
     if (int rc = check_plan_geom("rotate_fwd_planned", H, W, PH, PW, 0, 0, A)) return rc;
+    CTPVAE_REQUIRE(sel_dev == nullptr || (n_sel >= 1 && n_sel <= 64 * kSelRounds),
+                   "rotate_fwd_planned: an angle subset holds 1..%d angles (got %d); build a plan for larger ones",
+                   64 * kSelRounds, n_sel);
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     CTPVAE_REQUIRE(fwd_plan_fits(g), "rotate_fwd_planned: a %dx%d slice does not fit the plan's LDS image", H, W);
     const FwdLayout L = fwd_layout(g);
-    const int T = A * L.nJB;   // (angle, bin block) tasks per slice
+    const int A_run = sel_dev ? n_sel : A;      // angles this launch projects
+    const int T = A_run * L.nJB;   // (angle, bin block) tasks per slice
     // Launch shape.  What a launch costs is the bytes its busiest CU pulls through its L2->CU path (DESIGN.md section
     // 6): per workgroup one staged unit -- a slice, or a PAIR of slices interleaved as float2, whose index stream, unpack
     // and ds_read_b64 serve both -- plus ~1 KB of indices per row group of each of its tasks; the busiest CU holds
@@ -737,7 +789,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
             // octets); with few units and many angles that fabric traffic, not the CU's own path, is what pairing
             // halves (B=8, A=180: 19 us single, 12 us paired).  In the same KB-per-CU currency, fabric at ~2/3 of
             // the CUs' aggregate rate:
-            const double fabric_kb = 1.5 * ((double)L.bytes / 1024.0) * (double)std::min<long long>(8, cand_units) / 256.0;
+            const double fabric_kb = 1.5 * ((double)L.bytes * A_run / A / 1024.0) * (double)std::min<long long>(8, cand_units) / 256.0;
             for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
                 const long long wgs = 2ll * cand_units * cand;
                 const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand)) + fabric_kb;
@@ -749,8 +801,8 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
             }
         }
     }
-    if (const char *e = getenv("CTPVAE_TUNE_NS")) {
-        const int want = atoi(e) == 2 ? 2 : 1;
+    if (knob(kKnobNs) >= 0) {
+        const int want = knob(kKnobNs) == 2 ? 2 : 1;
         if (want != ns) {   // forced pairing: best G for it
             ns = want;
             const double task_kb = 0.6 * L.NG, fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0;
@@ -767,33 +819,44 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     }
     const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns + 16;   // + the task counter
     const int units = (S + ns - 1) / ns;
-    if (const char *e = getenv("CTPVAE_TUNE_G")) G = std::max(1, atoi(e));
+    if (knob(kKnobG) > 0) G = knob(kKnobG);
     // one wave per task of the busiest group, but never fewer than stage the unit in ONE batch of eight 16-byte loads
     // per lane (64 KiB -> 8 waves): a workgroup of 6 waves spends two load round trips on its fill (B=50, G=5:
     // 12.1 us with 6 waves, 8.7 us with 8)
     const int stage_waves = (int)std::min<size_t>(16, ceil_div((int)(shmem / 1024), 8));
     int waves = std::min(16, std::max(stage_waves, (T + 2 * G - 1) / (2 * G)));
-    if (const char *e = getenv("CTPVAE_TUNE_WAVES")) waves = std::max(1, std::min(16, atoi(e)));
+    if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
     const int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
-        if (first_use_on_this_device(attr_set)) {
-            CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-        }
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi);
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
     };
-    if (epi.lp) return ns == 2 ? launch(rotate_fwd_planned_kernel<2, true>) : launch(rotate_fwd_planned_kernel<1, true>);
-    return ns == 2 ? launch(rotate_fwd_planned_kernel<2, false>) : launch(rotate_fwd_planned_kernel<1, false>);
+    if (sel_dev) {
+        if (epi.lp) return ns == 2 ? launch(rotate_fwd_planned_kernel<2, true, true>) : launch(rotate_fwd_planned_kernel<1, true, true>);
+        return ns == 2 ? launch(rotate_fwd_planned_kernel<2, false, true>) : launch(rotate_fwd_planned_kernel<1, false, true>);
+    }
+    if (epi.lp) return ns == 2 ? launch(rotate_fwd_planned_kernel<2, true, false>) : launch(rotate_fwd_planned_kernel<1, true, false>);
+    return ns == 2 ? launch(rotate_fwd_planned_kernel<2, false, false>) : launch(rotate_fwd_planned_kernel<1, false, false>);
 }
 
 int ctpvae_rotate_fwd_planned_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
                                   float *sino_dev, ctpvae_stream_t stream)
 {
-    return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev, LogLikEpilogue{}, stream);
+    return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev, LogLikEpilogue{}, nullptr, 0, stream);
+}
+
+int ctpvae_rotate_fwd_planned_sel_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                      const void *fwd_plan_dev, const int *angle_idx_dev, int n_idx, float *sino_dev,
+                                      ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(angle_idx_dev, "rotate_fwd_planned_sel: null angle index");
+    return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev, LogLikEpilogue{}, angle_idx_dev, n_idx,
+                              stream);
 }
 
 int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
@@ -803,7 +866,19 @@ int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int
 {
     CTPVAE_REQUIRE(mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_planned_loglik: null pointer");
     return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev,
-                              LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev}, stream);
+                              LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, 0}, nullptr, 0, stream);
+}
+
+int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                             const void *fwd_plan_dev, const int *angle_idx_dev, int n_idx,
+                                             const float *mask_dev, const float *meas_dev, int dense_inputs,
+                                             const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
+                                             float *dlp_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(angle_idx_dev && mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_planned_loglik_sel: null pointer");
+    return launch_fwd_planned(img_dev, S, H, W, PH, PW, A, fwd_plan_dev, sino_dev,
+                              LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0},
+                              angle_idx_dev, n_idx, stream);
 }
 
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A, const void *bwd_plan_dev,
@@ -827,7 +902,7 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
     // A=20, 16.5 -> 13.8 us at A=90, 28.3 -> 25.4 us at A=180.  Small batches pair up too, in short 4-wave tiles
     // (tools/sweep_bwd.py: 4.7 -> 4.1 us at S=2..16, 5.3 -> 4.8 us at S=24, A=20; even at A=90).
     int ns = S >= 2 ? 2 : 1;
-    if (const char *e = getenv("CTPVAE_TUNE_BNS")) ns = (atoi(e) == 2 && S >= 2) ? 2 : 1;
+    if (knob(kKnobBns) >= 0) ns = (knob(kKnobBns) == 2 && S >= 2) ? 2 : 1;
     const int ppt = ns == 2 ? 2 : 4;
     const int units = ceil_div(S, ns);
     // staged chunk: up to 64 rows of one slice, or 32 rows of an interleaved pair
@@ -842,16 +917,14 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
     else if (A >= 32)
         while (waves < 16 && (long long)units * L.nXB * ceil_div(H, 2 * waves * ppt) >= 200 && waves * ppt < H) waves *= 2;
     while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has
-    if (const char *e = getenv("CTPVAE_TUNE_BW")) waves = std::min(16, std::max(1, atoi(e)));
+    if (knob(kKnobBw) > 0) waves = std::min(16, knob(kKnobBw));
     const int rows_per_wg = waves * ppt;
     const int tiles_y = ceil_div(H, rows_per_wg);
     const long long nblk = (long long)units * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
-        if (first_use_on_this_device(attr_set)) {
-            CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-        }
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
                            (const uint4 *)bwd_plan_dev, tiles_y, S, SliceScale{scale_dev, scale_stride}, gimg_dev);
         return CTPVAE_OK;

@@ -243,7 +243,7 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
     const bool use_lds = lds_one <= (size_t)kMaxLdsBytes;
     // two slices per workgroup when the pair fits LDS and the call has slices to pair
     int ns = (oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
-    if (const char *e = getenv("CTPVAE_TUNE_SIDDON_NS")) ns = (atoi(e) == 2 && oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
+    if (knob(kKnobSiddonNs) >= 0) ns = (knob(kKnobSiddonNs) == 2 && oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
     const int units = ceil_div(oy, ns);
     const size_t lds_bytes = lds_one * ns;
     int ppb = dt;
@@ -251,8 +251,8 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
     // the kernel is VALU-bound and every workgroup holds its slice(s) in LDS: 16 waves per workgroup keep 8 (4 with a
     // pair) waves on every SIMD (4 waves per workgroup left 2 per SIMD -- one wave issues a VALU op every ~4.4 cycles)
     int threads = std::min(1024, ceil_div(ppb * dx, 64) * 64);
-    if (const char *e = getenv("CTPVAE_TUNE_SIDDON_THREADS")) threads = std::max(64, std::min(1024, atoi(e) / 64 * 64));
-    if (const char *e = getenv("CTPVAE_TUNE_SIDDON_PPB")) ppb = std::max(1, std::min(dt, atoi(e)));
+    if (knob(kKnobSiddonThreads) > 0) threads = std::max(64, std::min(1024, knob(kKnobSiddonThreads) / 64 * 64));
+    if (knob(kKnobSiddonPpb) > 0) ppb = std::min(dt, knob(kKnobSiddonPpb));
     const dim3 grid(ceil_div(dt, ppb), units), block(threads);
     auto launch = [&](auto kernel, size_t shmem) -> int {
         if (shmem > 64 * 1024)

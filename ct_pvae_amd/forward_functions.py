@@ -27,7 +27,8 @@ import torch
 
 from . import _lib
 
-__all__ = ["pad_phantom", "project_tf_fast", "project_tf_low_mem", "num_proj_pix", "pad_amounts", "RotatePlan"]
+__all__ = ["pad_phantom", "project_tf_fast", "project_tf_low_mem", "num_proj_pix", "pad_amounts", "RotatePlan",
+           "rotate_tables", "as_angle_index"]
 
 _current_device = getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
 _INTERP = {"nearest": _lib.NEAREST, "bilinear": _lib.BILINEAR}
@@ -108,7 +109,10 @@ def _theta_to_device(theta, device):
 def rotate_tables(theta, H, W, device):
     """Device tables (T8, Tinv8), each [A][8] fp32, for rotating an H x W canvas by -theta (a3/a4).
 
-    Host-resident angle sets are cached by value; device-resident ones cost one tiny kernel launch."""
+    A host-resident angle set (list / numpy / CPU tensor -- the dataset's theta, ctvae/main_ct_vae.py:152) is evaluated
+    ON THE HOST (ctpvae_rotate_transforms_host_f32) and uploaded: the kernels then see the very bits any other host code
+    computes from the same expressions, cached by value.  A device-resident theta costs one tiny kernel launch
+    (device libm: may differ from the host table in rare 1-ulp cases)."""
     lib = _lib.load()
     th, key = _theta_to_device(theta, device)
     if key is not None:
@@ -116,7 +120,18 @@ def rotate_tables(theta, H, W, device):
         hit = _TABLE_CACHE.get(key)
         if hit is not None:
             return hit
-        th = torch.from_numpy(th).to(device)
+        A = th.size
+        if A == 0:
+            raise ValueError("theta is empty")
+        host = np.empty((2, A, 8), dtype=np.float32)
+        _lib.check(lib.ctpvae_rotate_transforms_host_f32(th.ctypes.data, A, H, W, host[0].ctypes.data, host[1].ctypes.data),
+                   "rotate_transforms_host")
+        tables = torch.from_numpy(host).to(device)
+        out = (tables[0], tables[1])
+        if len(_TABLE_CACHE) >= _TABLE_CACHE_MAX:
+            _TABLE_CACHE.pop(next(iter(_TABLE_CACHE)))
+        _TABLE_CACHE[key] = out
+        return out
     A = th.numel()
     if A == 0:
         raise ValueError("theta is empty")
@@ -124,12 +139,19 @@ def rotate_tables(theta, H, W, device):
     with torch.cuda.device(device):
         _lib.check(lib.ctpvae_rotate_transforms_f32(th.data_ptr(), A, H, W, tables[0].data_ptr(),
                                                     tables[1].data_ptr(), _stream_ptr()), "rotate_transforms")
-    out = (tables[0], tables[1])
-    if key is not None:
-        if len(_TABLE_CACHE) >= _TABLE_CACHE_MAX:
-            _TABLE_CACHE.pop(next(iter(_TABLE_CACHE)))
-        _TABLE_CACHE[key] = out
-    return out
+    return tables[0], tables[1]
+
+
+def as_angle_index(angles_i, device):
+    """The per-step angle subset (ctvae/helper_functions.py:350-357) as the int32 device vector the kernels take."""
+    t = torch.as_tensor(angles_i) if not isinstance(angles_i, torch.Tensor) else angles_i
+    if t.dim() != 1 or t.numel() == 0:
+        raise ValueError(f"angles_i must be a non-empty 1-D index vector (got shape {tuple(t.shape)})")
+    if t.dtype.is_floating_point or t.dtype is torch.bool:
+        raise TypeError(f"angles_i must hold integers (got {t.dtype})")
+    if t.device != device or t.dtype is not torch.int32 or not t.is_contiguous():
+        t = t.to(device=device, dtype=torch.int32).contiguous()
+    return t
 
 
 class RotatePlan:
@@ -137,7 +159,9 @@ class RotatePlan:
 
     `forward` / `backward` are the raw operator pair (no autograd bookkeeping); `apply` is differentiable."""
 
-    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True):
+    MAX_SEL = 256   # angles per subset launch of a dense plan (kSelRounds * 64 in rotate_plan.hip)
+
+    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True, _tables=None):
         if interp not in _INTERP:
             raise ValueError(f"interp must be one of {sorted(_INTERP)} (got {interp!r})")
         if backward not in _BACKWARD:
@@ -155,7 +179,8 @@ class RotatePlan:
                 f"the projector runs on a HIP device only (got a tensor on {self.device}); there is no CPU path")
         self.interp, self.mode = _INTERP[interp], _BACKWARD[backward]
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.T8, self.Tinv8 = rotate_tables(theta, self.PH, self.PW, self.device)
+        self._interp_name, self._backward_name, self._pad = interp, backward, bool(pad)
+        self.T8, self.Tinv8 = _tables if _tables is not None else rotate_tables(theta, self.PH, self.PW, self.device)
         self._tdev = self.T8.device
         self._seen = {}
         self.A = self.T8.shape[0]
@@ -191,35 +216,66 @@ class RotatePlan:
 
     # The library launches on the calling thread's current HIP device: make that this plan's device (the common case --
     # it already is -- costs one cheap query).
-    def forward(self, img, out=None):
-        """slices [S][H][W] -> sinograms [S][A][PW] (raw operator, no autograd bookkeeping)."""
-        if img.dim() == 3 and img.shape[0] == 0 and tuple(img.shape[1:]) == (self.H, self.W):   # empty batch -> empty batch
-            return out if out is not None else img.new_empty((0, self.A, self.PW))
-        if _current_device() == self._dev_index:
-            return self._forward(img, out)
-        with torch.cuda.device(self._dev_index):
-            return self._forward(img, out)
+    def subset(self, angles_i):
+        """A plan over rows `angles_i` of this one's tables (two small gathers, no plan kernels): the fallback for angle
+        subsets on paths whose kernels take no angle-index operand (tiled / bilinear forward, exact backward)."""
+        idx = as_angle_index(angles_i, self._tdev).long()
+        return RotatePlan(None, self.H, self.W, self._pad, self.device, interp=self._interp_name,
+                          backward=self._backward_name, use_plan=False if self._fwd_plan is not None else self._use_tiles,
+                          _tables=(self.T8.index_select(0, idx), self.Tinv8.index_select(0, idx)))
 
-    def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False):
+    def sel_supported(self, n, forward=True):
+        """True if a launch over `n` selected angles runs on THIS (dense) plan with an angle-index operand."""
+        if forward:
+            return self._fwd_plan is not None and 1 <= n <= self.MAX_SEL
+        return self.supports_scale and n >= 1
+
+    def forward(self, img, out=None, angles_i=None):
+        """slices [S][H][W] -> sinograms [S][A][PW] (raw operator, no autograd bookkeeping).
+        angles_i: int32 device vector of plan angles -> sinograms [S][len(angles_i)][PW] of those angles, in that order."""
+        n = self.A if angles_i is None else angles_i.numel()
+        if img.dim() == 3 and img.shape[0] == 0 and tuple(img.shape[1:]) == (self.H, self.W):   # empty batch -> empty batch
+            return out if out is not None else img.new_empty((0, n, self.PW))
+        if angles_i is not None and not self.sel_supported(n):
+            return self.subset(angles_i).forward(img, out)
+        if _current_device() == self._dev_index:
+            return self._forward(img, out, angles_i)
+        with torch.cuda.device(self._dev_index):
+            return self._forward(img, out, angles_i)
+
+    def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False,
+                       angles_i=None, dense_inputs=False):
         """Forward with the log-likelihood epilogue (one launch): returns (sino, lp), both [S][A][PW];
         lp = Normal(loc = sino * mask, scale = eps + sqrt(loc / pnm + eps)).log_prob(meas).  Planned and tiled geometries.
         with_dlp: also returns d lp / d sino (third value), which `backward(dlp, scale=...)` turns into the image
-        gradient without an elementwise pass."""
+        gradient without an elementwise pass.
+        angles_i (planned geometries): int32 device vector of plan angles; outputs are [S][len(angles_i)][PW].  With
+        dense_inputs, mask [S][A] and meas [S][A][PW] are the DENSE arrays and the kernel reads them at the selected
+        angles (the reference's tf.gather of both, ctvae/helper_functions.py:356-357, costs no launch)."""
+        if angles_i is not None and not self.sel_supported(angles_i.numel()):
+            if dense_inputs:
+                idx = angles_i.long()
+                mask, meas = mask.index_select(1, idx).contiguous(), meas.index_select(1, idx).contiguous()
+            return self.subset(angles_i).forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp)
         if _current_device() == self._dev_index:
-            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp)
+            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp, angles_i, dense_inputs)
         with torch.cuda.device(self._dev_index):
-            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp)
+            return self._forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp, angles_i, dense_inputs)
 
-    def backward(self, gsino, out=None, scale=None):
+    def backward(self, gsino, out=None, scale=None, angles_i=None):
         """cotangents [S][A][PW] -> gradient images [S][H][W] (the mode chosen at construction).
         scale: optional float32 device tensor of S per-slice factors (any stride, 0 included: an expanded scalar)
-        applied in the kernel's store -- nearest / tf_compat only (`supports_scale`)."""
-        if gsino.dim() == 3 and gsino.shape[0] == 0 and tuple(gsino.shape[1:]) == (self.A, self.PW):
+        applied in the kernel's store -- nearest / tf_compat only (`supports_scale`).
+        angles_i: the cotangents are [S][len(angles_i)][PW], row k belonging to plan angle angles_i[k]."""
+        n = self.A if angles_i is None else angles_i.numel()
+        if gsino.dim() == 3 and gsino.shape[0] == 0 and tuple(gsino.shape[1:]) == (n, self.PW):
             return out if out is not None else gsino.new_empty((0, self.H, self.W))
+        if angles_i is not None and not self.sel_supported(n, forward=False):
+            return self.subset(angles_i).backward(gsino, out, scale)
         if _current_device() == self._dev_index:
-            return self._backward(gsino, out, scale)
+            return self._backward(gsino, out, scale, angles_i)
         with torch.cuda.device(self._dev_index):
-            return self._backward(gsino, out, scale)
+            return self._backward(gsino, out, scale, angles_i)
 
     @property
     def supports_scale(self):
@@ -257,15 +313,30 @@ class RotatePlan:
         """True if the forward cuts slices into LDS-sized tiles (slices larger than LDS, nearest)."""
         return self._tile_workspace(1) is not None
 
-    def _forward(self, img, out=None):
+    def _check_sel(self, angles_i):
+        if (angles_i.dtype is not torch.int32 or angles_i.dim() != 1 or not angles_i.is_contiguous()
+                or angles_i.device != self._tdev):
+            raise ValueError(f"angles_i must be a contiguous int32 vector on {self._tdev} (see as_angle_index; got "
+                             f"{tuple(angles_i.shape)}, {angles_i.dtype}, {angles_i.device})")
+        return angles_i.numel()
+
+    def _forward(self, img, out=None, angles_i=None):
         self._check(img, (self.H, self.W), "img")
         S = img.shape[0]
+        n = self.A if angles_i is None else self._check_sel(angles_i)
         if out is None:
-            out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+            out = torch.empty((S, n, self.PW), dtype=torch.float32, device=img.device)
         else:
-            self._check(out, (self.A, self.PW), "out")
+            self._check(out, (n, self.PW), "out")
             if out.shape[0] != S:
                 raise ValueError(f"out holds {out.shape[0]} sinograms for {S} slices")
+        if angles_i is not None:
+            rc = self._lib.ctpvae_rotate_fwd_planned_sel_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                             self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
+                                                             out.data_ptr(), _stream_ptr(self._dev_index))
+            if rc:
+                _lib.check(rc, "rotate_fwd_planned_sel")
+            return out
         ws = self._tile_workspace(S)
         if self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
@@ -282,35 +353,43 @@ class RotatePlan:
             _lib.check(rc, "rotate_fwd")
         return out
 
-    def _forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False):
+    def _forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False,
+                        angles_i=None, dense_inputs=False):
         self._check(img, (self.H, self.W), "img")
         S = img.shape[0]
         ws = self._tile_workspace(S)
         if self._fwd_plan is None and ws is None:
             raise ValueError("forward_loglik needs a planned or tiled forward (nearest)")
-        self._check(meas, (self.A, self.PW), "meas")
-        self._check(mask, (self.A,), "mask")
+        n = self.A if angles_i is None else self._check_sel(angles_i)
+        n_in = self.A if (angles_i is None or dense_inputs) else n     # angle rows of mask / meas
+        self._check(meas, (n_in, self.PW), "meas")
+        self._check(mask, (n_in,), "mask")
         if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
             raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
         if out is None:
-            out = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=img.device)
+            out = torch.empty((S, n, self.PW), dtype=torch.float32, device=img.device)
         else:
-            self._check(out, (self.A, self.PW), "out")
+            self._check(out, (n, self.PW), "out")
         if out_lp is None:
             out_lp = torch.empty_like(out)
         else:
-            self._check(out_lp, (self.A, self.PW), "out_lp")
+            self._check(out_lp, (n, self.PW), "out_lp")
         if out.shape[0] != S or out_lp.shape[0] != S:
             raise ValueError("out / out_lp must hold one sinogram per slice")
         if with_dlp or out_dlp is not None:
             if out_dlp is None:
                 out_dlp = torch.empty_like(out)
             else:
-                self._check(out_dlp, (self.A, self.PW), "out_dlp")
+                self._check(out_dlp, (n, self.PW), "out_dlp")
                 if out_dlp.shape[0] != S:
                     raise ValueError("out_dlp must hold one sinogram per slice")
         dlp_ptr = out_dlp.data_ptr() if out_dlp is not None else None
-        if self._fwd_plan is not None:
+        if angles_i is not None:
+            rc = self._lib.ctpvae_rotate_fwd_planned_loglik_sel_f32(
+                img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
+                mask.data_ptr(), meas.data_ptr(), 1 if dense_inputs else 0, pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
+                out_lp.data_ptr(), dlp_ptr, _stream_ptr(self._dev_index))
+        elif self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_loglik_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), mask.data_ptr(),
                 meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(), out_lp.data_ptr(), dlp_ptr,
@@ -330,8 +409,9 @@ class RotatePlan:
         everywhere else."""
         return self._want_bwd_plan and not (S >= 80 and self.A <= 64)
 
-    def _backward(self, gsino, out=None, scale=None):
-        self._check(gsino, (self.A, self.PW), "gsino")
+    def _backward(self, gsino, out=None, scale=None, angles_i=None):
+        n = self.A if angles_i is None else self._check_sel(angles_i)
+        self._check(gsino, (n, self.PW), "gsino")
         S = gsino.shape[0]
         sc_ptr, sc_stride = None, 0
         if scale is not None:
@@ -347,7 +427,12 @@ class RotatePlan:
             self._check(out, (self.H, self.W), "out")
             if out.shape[0] != S:
                 raise ValueError(f"out holds {out.shape[0]} slices for {S} sinograms")
-        if self.backward_uses_plan(S):
+        if angles_i is not None:
+            # the segment kernel reads its table rows through the index vector: nothing is gathered, no plan is built
+            rc = self._lib.ctpvae_rotate_bwd_sel_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, self.Tinv8.data_ptr(),
+                                                            angles_i.data_ptr(), n, self.H, self.W, self.py, self.px,
+                                                            sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
+        elif self.backward_uses_plan(S):
             if self._bwd_plan is None:
                 self._bwd_plan = self._build_plan(1)
             rc = self._lib.ctpvae_rotate_bwd_planned_scaled_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
@@ -381,12 +466,32 @@ _PLAN_CACHE = {}
 _PLAN_CACHE_MAX = 16
 
 
+_DEV_THETA_PLANS = {}   # id(theta tensor) -> (weakref, version, {geometry key: plan})
+
+
 def _cached_plan(theta, H, W, pad, device, interp, backward):
     """RotatePlan for this call.  A host-resident angle set (list / numpy / CPU tensor) is keyed by value, so the
-    scripts that project with a fixed theta build their tables and gather plans once; a device-resident theta (the
-    training loop's per-step subset) is rebuilt -- three small launches -- because reading it back would synchronise."""
+    scripts that project with a fixed theta build their tables and gather plans once.  A device-resident theta cannot
+    be read without synchronising; it is keyed by the tensor OBJECT (and its in-place version counter), so a caller that
+    keeps projecting with the same theta tensor -- the dataset's angle list held on the device -- also builds once; a
+    fresh tensor per call (the reference's per-step tf.gather of theta) rebuilds: pass `angles_i` to
+    calculate_log_prob_M_given_R instead, which selects rows of ONE dense plan."""
     if isinstance(theta, torch.Tensor) and theta.device.type == "cuda":
-        return RotatePlan(theta, H, W, pad, device, interp=interp, backward=backward)
+        geo = (H, W, bool(pad), str(device), interp, backward)
+        ent = _DEV_THETA_PLANS.get(id(theta))
+        if ent is not None and ent[0]() is theta and ent[1] == theta._version:
+            plan = ent[2].get(geo)
+            if plan is not None:
+                return plan
+        else:
+            if len(_DEV_THETA_PLANS) >= _PLAN_CACHE_MAX:      # drop dead entries, then the oldest
+                for k in [k for k, e in _DEV_THETA_PLANS.items() if e[0]() is None]:
+                    del _DEV_THETA_PLANS[k]
+                while len(_DEV_THETA_PLANS) >= _PLAN_CACHE_MAX:
+                    _DEV_THETA_PLANS.pop(next(iter(_DEV_THETA_PLANS)))
+            ent = _DEV_THETA_PLANS[id(theta)] = (weakref.ref(theta), theta._version, {})
+        plan = ent[2][geo] = RotatePlan(theta, H, W, pad, device, interp=interp, backward=backward)
+        return plan
     host = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
                                            dtype=np.float32))
     key = (host.tobytes(), H, W, bool(pad), str(device), interp, backward)

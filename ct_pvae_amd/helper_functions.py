@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .forward_functions import _cached_plan, _stream_ptr, project_tf_fast
+from .forward_functions import _cached_plan, _stream_ptr, as_angle_index, project_tf_fast
 
 __all__ = ["create_sinogram", "create_sinograms", "calculate_log_prob_M_given_R", "gaussian_poisson_log_prob"]
 
@@ -89,6 +89,9 @@ class _GaussianPoissonLogProb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, proj, mask, x, pnm, eps):
         lib = _lib.load()
+        for name, t in (("proj", proj), ("mask", mask), ("proj_sample", x), ("pnm", pnm)):
+            if t.dtype is not torch.float32 or not t.is_contiguous():
+                raise TypeError(f"{name} must be contiguous float32 (got {t.dtype}, contiguous={t.is_contiguous()})")
         B, A, P = proj.shape
         out = torch.empty_like(proj)
         with torch.cuda.device(proj.device):
@@ -136,8 +139,14 @@ def gaussian_poisson_log_prob(proj, mask, proj_sample, poisson_noise_multiplier,
     if pnm.numel() != 1:
         raise ValueError("poisson_noise_multiplier must be a number or a one-element tensor")
     pnm = pnm.to(device=dev, dtype=torch.float32)
-    return _GaussianPoissonLogProb.apply(proj.contiguous(), mask.to(torch.float32).contiguous(),
-                                         proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
+    if not proj.dtype.is_floating_point:
+        raise TypeError(f"proj must be floating point (got {proj.dtype})")
+    # the kernels read and write 4-byte floats: every operand is made float32 here (a float64 / half projection from
+    # project_tf_fast's dtype-preserving return would otherwise be read with the wrong element size); the result goes
+    # back in the caller's dtype
+    out = _GaussianPoissonLogProb.apply(proj.to(torch.float32).contiguous(), mask.to(torch.float32).contiguous(),
+                                        proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
+    return out if proj.dtype == torch.float32 else out.to(proj.dtype)
 
 
 class _ProjectLogLik(torch.autograd.Function):
@@ -147,27 +156,35 @@ class _ProjectLogLik(torch.autograd.Function):
     gradient of a per-object sum (what find_loss_vae_unsup takes, ctvae/helper_functions.py:305-312: autograd hands it
     over as an expanded tensor, stride 0 over angles and bins) rides the projector's backward as a per-slice factor
     -- ONE launch, no [B][A][P] cotangent in HBM.  Any other upstream gradient multiplies dlp elementwise first; a
-    trainable pnm (--train_pnm) takes the two-step backward (ctpvae_loglik_bwd_f32, which also reduces d/d pnm)."""
+    trainable pnm (--train_pnm) takes the two-step backward (ctpvae_loglik_bwd_f32, which also reduces d/d pnm).
+
+    angles_i (int32 device vector or None): the step's angle subset of the DENSE plan; mask / x are then the dense
+    [B][A] / [B][A][P] arrays (dense_inputs) and nothing is gathered, rebuilt or re-planned per step."""
 
     @staticmethod
-    def forward(ctx, slices, plan, mask, x, pnm, eps):
-        ctx.plan, ctx.eps = plan, eps
+    def forward(ctx, slices, plan, mask, x, pnm, eps, angles_i=None):
+        ctx.plan, ctx.eps, ctx.angles_i = plan, eps, angles_i
+        dense = angles_i is not None
         ctx.fused_bwd = ctx.needs_input_grad[0] and not ctx.needs_input_grad[4] and plan.supports_scale
         if ctx.fused_bwd:
-            _, lp, dlp = plan.forward_loglik(slices, mask, x, pnm, eps, with_dlp=True)
+            _, lp, dlp = plan.forward_loglik(slices, mask, x, pnm, eps, with_dlp=True, angles_i=angles_i, dense_inputs=dense)
             ctx.save_for_backward(dlp)
         else:
-            sino, lp = plan.forward_loglik(slices, mask, x, pnm, eps)
+            sino, lp = plan.forward_loglik(slices, mask, x, pnm, eps, angles_i=angles_i, dense_inputs=dense)
+            if dense:      # the two-step backward reads compact operands
+                idx = angles_i.long()
+                mask, x = mask.index_select(1, idx).contiguous(), x.index_select(1, idx).contiguous()
             ctx.save_for_backward(sino, mask, x, pnm)
         return lp
 
     @staticmethod
     def backward(ctx, gout):
+        ai = ctx.angles_i
         if ctx.fused_bwd:
             dlp, = ctx.saved_tensors
             if gout.stride(1) == 0 and gout.stride(2) == 0:
-                return ctx.plan.backward(dlp, scale=gout[:, 0, 0]), None, None, None, None, None
-            return ctx.plan.backward(gout * dlp), None, None, None, None, None
+                return ctx.plan.backward(dlp, scale=gout[:, 0, 0], angles_i=ai), None, None, None, None, None, None
+            return ctx.plan.backward(gout * dlp, angles_i=ai), None, None, None, None, None, None
         lib = _lib.load()
         sino, mask, x, pnm = ctx.saved_tensors
         B, A, P = sino.shape
@@ -179,8 +196,8 @@ class _ProjectLogLik(torch.autograd.Function):
                                                  B, A, P, pnm.data_ptr(), ctypes.c_float(ctx.eps),
                                                  gproj.data_ptr(), gpnm.data_ptr() if gpnm is not None else None,
                                                  _stream_ptr()), "loglik_bwd")
-            gimg = ctx.plan.backward(gproj) if ctx.needs_input_grad[0] else None
-        return gimg, None, None, None, (gpnm.reshape(pnm.shape) if gpnm is not None else None), None
+            gimg = ctx.plan.backward(gproj, angles_i=ai) if ctx.needs_input_grad[0] else None
+        return gimg, None, None, None, (gpnm.reshape(pnm.shape) if gpnm is not None else None), None, None
 
 
 def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise_multiplier, sqrt_reg,
@@ -189,30 +206,50 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
     [B][angles][P]; returns the log-probabilities [B][angles_used][P][1].
 
     When the geometry takes the planned or the tiled forward (nearest) the projection and the log-probability are
-    one launch (the same numbers, bit for bit, as project_tf_fast followed by gaussian_poisson_log_prob)."""
+    one launch (the same numbers, bit for bit, as project_tf_fast followed by gaussian_poisson_log_prob).
+
+    angles_i (the step's random angle subset, :350-357): the plan, the transform tables and the gather plan are built
+    ONCE for the whole `theta` (host-resident: on the host, so they are the bits the CPU oracle computes) and the kernels
+    take `angles_i` as an index operand -- nothing is gathered or rebuilt per step, and mask / proj_sample are read at
+    the selected angles by the kernel itself."""
+    x = output_sample
+    fast = (isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[3] == 1 and x.device.type == "cuda"
+            and x.dtype == torch.float32 and x.shape[0] > 0)
+    if fast:
+        slices = x[..., 0]
+        if not slices.is_contiguous():
+            slices = slices.contiguous()
+        plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, "nearest", "tf_compat")
+        if plan.planned[0] or plan.tiled:
+            sel = None
+            if angles_i is not None:
+                sel = as_angle_index(angles_i, x.device)
+                if not plan.planned[0] or sel.numel() > plan.MAX_SEL:     # tiled geometry: gather here, tables in subset()
+                    idx = sel.long()
+                    mask, proj_sample = mask.index_select(1, idx), proj_sample.index_select(1, idx)
+                    plan, sel = plan.subset(sel), None
+            n_in = plan.A
+            pnm = poisson_noise_multiplier
+            if not isinstance(pnm, torch.Tensor):
+                pnm = torch.tensor(float(pnm), dtype=torch.float32, device=x.device)
+            elif pnm.device != x.device or pnm.dtype is not torch.float32:
+                pnm = pnm.to(device=x.device, dtype=torch.float32)
+            if (tuple(mask.shape) != (slices.shape[0], n_in) or tuple(proj_sample.shape) != (slices.shape[0], n_in, plan.PW)
+                    or mask.device != x.device or proj_sample.device != x.device or pnm.numel() != 1):
+                raise ValueError(f"need mask [B][A] and proj_sample [B][A][P] = [{slices.shape[0]}][{n_in}][{plan.PW}] on "
+                                 f"{x.device} (got {tuple(mask.shape)}, {tuple(proj_sample.shape)})")
+            if mask.dtype is not torch.float32 or not mask.is_contiguous():
+                mask = mask.to(torch.float32).contiguous()
+            if proj_sample.dtype is not torch.float32 or not proj_sample.is_contiguous():
+                proj_sample = proj_sample.to(torch.float32).contiguous()
+            with torch.cuda.device(x.device):
+                logp = _ProjectLogLik.apply(slices, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
+            return logp.unsqueeze(-1)
     if angles_i is not None:
         angles_i = torch.as_tensor(angles_i, device=output_sample.device).long()
         theta = torch.as_tensor(theta, device=output_sample.device)[angles_i].to(torch.float32)
         mask = mask[:, angles_i]
         proj_sample = proj_sample[:, angles_i]
-    x = output_sample
-    if (isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[3] == 1 and x.device.type == "cuda"
-            and x.dtype == torch.float32 and x.shape[0] > 0):
-        slices = x[..., 0].contiguous()
-        plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, "nearest", "tf_compat")
-        if plan.planned[0] or plan.tiled:
-            pnm = poisson_noise_multiplier
-            if not isinstance(pnm, torch.Tensor):
-                pnm = torch.tensor(float(pnm), dtype=torch.float32, device=x.device)
-            pnm = pnm.to(device=x.device, dtype=torch.float32)
-            if (tuple(mask.shape) != (slices.shape[0], plan.A) or tuple(proj_sample.shape) != (slices.shape[0], plan.A, plan.PW)
-                    or mask.device != x.device or proj_sample.device != x.device or pnm.numel() != 1):
-                raise ValueError(f"need mask [B][A] and proj_sample [B][A][P] = [{slices.shape[0]}][{plan.A}][{plan.PW}] on "
-                                 f"{x.device} (got {tuple(mask.shape)}, {tuple(proj_sample.shape)})")
-            with torch.cuda.device(x.device):
-                logp = _ProjectLogLik.apply(slices, plan, mask.to(torch.float32).contiguous(),
-                                            proj_sample.to(torch.float32).contiguous(), pnm, float(sqrt_reg))
-            return logp.unsqueeze(-1)
     proj = project_tf_fast(output_sample, theta, pad=pad, dim=2, integrate_vae=True)
     logp = gaussian_poisson_log_prob(proj[..., 0], mask, proj_sample, poisson_noise_multiplier, sqrt_reg)
     return logp.unsqueeze(-1)

@@ -350,6 +350,9 @@ class PVAETrainer:
                             self.y_size, save_path=a.save_path, train=drawing)        # [td][X][Y][2]
         self.input_encode = enc_in.permute(0, 3, 1, 2).contiguous()                   # [td][2][X][Y]
         self.theta = torch.from_numpy(self.theta_np.astype(np.float32)).to(dev)
+        # the projector gets the HOST angle list: its tables and gather plan are then built once, on the host's bits, and
+        # every step only passes its angle subset as an index operand
+        self.theta_host = np.ascontiguousarray(self.theta_np, dtype=np.float32)
         self.order = np.random.default_rng(11)
 
     def _batch(self):
@@ -372,7 +375,7 @@ class PVAETrainer:
         """Host side of a step: the batch, the angle subset and the two annealed scalars."""
         a = self.args
         proj_sample, mask, input_encode = self._batch()
-        angles_i = self._to_device(self.angles.next())
+        angles_i = self._to_device(self.angles.next().astype(np.int32))   # the kernels' index operand is int32
         pnm_factor = self.pnm_anneal ** self.iter
         self.kl_anneal = min(max(self.kl_anneal * a.klaf, 0.0), 100.0)
         return proj_sample, mask, input_encode, angles_i, pnm_factor, self.kl_anneal
@@ -383,7 +386,7 @@ class PVAETrainer:
         pnm_i = self.pnm * pnm_factor
         loss_vec, kl, loglik, _ = find_loss_vae_unsup(proj_sample, mask, input_encode, self.enc, self.dec, pnm_i,
                                                       self.sqrt_reg, kl_anneal, a.klm, num_samples=a.ns,
-                                                      theta=self.theta, angles_i=angles_i, pad=self.pad,
+                                                      theta=self.theta_host, angles_i=angles_i, pad=self.pad,
                                                       deterministic=a.deterministic)
         # ctvae/main_ct_vae.py:478 reduce_mean(loss_M_VAE) / 1e5 = mean_b(KL term) - loglik, where loglik already sums
         # over the batch.  Written so that the ranks' losses ADD UP to the global one (gradients are summed over ranks):
@@ -489,7 +492,7 @@ class PVAETrainer:
             sl = slice(k, k + nb)
             loss_vec, _, _, recon = find_loss_vae_unsup(self.proj_samples[sl], self.masks[sl], self.input_encode[sl], self.enc,
                                                         self.dec, self.pnm, self.sqrt_reg, self.kl_anneal, a.klm,
-                                                        num_samples=a.ns, theta=self.theta, angles_i=None, pad=self.pad,
+                                                        num_samples=a.ns, theta=self.theta_host, angles_i=None, pad=self.pad,
                                                         deterministic=a.deterministic)
             losses.append(loss_vec.mean() / 1e5)
             recons.append(recon.permute(0, 2, 3, 1))

@@ -23,6 +23,10 @@
  *                                              ctvae/main_ct_vae.py:471-481) and its exact transpose
  *   ctpvae_rotate_plan_* / _planned_f32        the same two operators, batched: index arithmetic hoisted
  *                                              out of the per-object work (no counterpart in the reference)
+ *   ctpvae_rotate_transforms_host_f32          the same table for a host-resident theta (the dataset's angle list,
+ *                                              ctvae/main_ct_vae.py:152), evaluated on the host
+ *   ctpvae_rotate_*_sel_*                      the per-step angle subset of calculate_log_prob_M_given_R,
+ *                                              ctvae/helper_functions.py:350-357 (tf.gather of theta / mask / proj_sample)
  *   ctpvae_rotate_fwd_planned_loglik_f32       project_tf_fast + the Normal log_prob of calculate_log_prob_M_given_R
  *                                              ctvae/helper_functions.py:359-368, one launch
  *   ctpvae_rotate_bwd{,_planned}_scaled_f32    the gradient of the same caller w.r.t. the reconstruction (autodiff of
@@ -60,6 +64,14 @@ int ctpvae_abi_version(void);
 const char *ctpvae_last_error(void);
 /* Number of visible HIP devices, or a negative error code. */
 int ctpvae_device_count(void);
+/* Developer knobs (tools/ sweeps, tests that force one code path against another); none changes results.  The launch
+ * path never reads the environment: the registry is filled once, when the library is loaded, from CTPVAE_TUNE_<NAME>
+ * (and CTPVAE_NO_PLAN / CTPVAE_FORCE_GENERIC), and changed afterwards only here.  name: "NS", "G", "WAVES", "BNS",
+ * "BW", "SEG_NS", "SEG_CHUNK", "SEG_PPT", "TILED_NS", "TILED_G", "SIDDON_NS", "SIDDON_THREADS", "SIDDON_PPB",
+ * "SIDDON_BWD_THREADS", "MAX_SLICES", "NO_PLAN", "FORCE_GENERIC"; value < 0 unsets; name "*" unsets every knob.
+ * _active: how many knobs are set (bench.py prints it next to its numbers). */
+int ctpvae_tune_set(const char *name, int value);
+int ctpvae_tune_active(void);
 
 /* ---- a1: pad_phantom size rule (host arithmetic only) ------------------------------------- */
 int ctpvae_num_proj_pix(int nx, int ny);
@@ -72,6 +84,12 @@ int ctpvae_pad_amounts(int n, int P, int *lo, int *hi);
  * gradient uses (fp32 3x3 inverse, divided by its [2][2] element). */
 int ctpvae_rotate_transforms_f32(const float *theta_dev, int A, int H, int W, float *T8_dev,
                                  float *Tinv8_dev, ctpvae_stream_t stream);
+/* The same tables for a HOST-resident angle set, computed on the host (all pointers are host memory): cos/sin through
+ * the C library's fp64 functions rounded once to fp32, then the same unfused fp32 expressions -- the very bits any other
+ * host code gets from those expressions ("trig tables are computed by the caller on host in fp32 so CPU and
+ * GPU see identical bits").  The device kernel above differs from it only where the device library's cos/sin round a
+ * double differently (rare 1-ulp cases); it is kept for angle sets that exist only on the device. */
+int ctpvae_rotate_transforms_host_f32(const float *theta, int A, int H, int W, float *T8, float *Tinv8);
 
 /* ---- a2/a5: rotate-and-sum forward ---------------------------------------------------------
  * img_dev  [S][H][W] fp32, contiguous: the UNPADDED slices.  The PH x PW zero canvas with the
@@ -141,6 +159,28 @@ int ctpvae_rotate_fwd_planned_loglik_f32(const float *img_dev, int S, int H, int
                                          const void *fwd_plan_dev, const float *mask_dev, const float *meas_dev,
                                          const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
                                          float *dlp_dev, ctpvae_stream_t stream);
+/* Angle subsets of a DENSE plan (the training loop projects `api` random angles of the dataset's 180 per step,
+ * ctvae/helper_functions.py:350-357): the plan and tables are built ONCE for all A angles; angle_idx_dev [n_idx] int32 on
+ * the device (1 <= n_idx <= 256; values are clamped into [0, A)) selects the plan angles a launch projects, in that
+ * order: sino / lp / dlp are [S][n_idx][PW].  No plan or table kernel runs per step.  dense_inputs != 0: mask_dev and
+ * meas_dev are the DENSE [S][A] / [S][A][PW] arrays and are read at the selected plan angles (the caller's gathers
+ * mask[:, angles_i], proj_sample[:, angles_i] folded into the load); 0: they are [S][n_idx] / [S][n_idx][PW]. */
+int ctpvae_rotate_fwd_planned_sel_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                      const void *fwd_plan_dev, const int *angle_idx_dev, int n_idx, float *sino_dev,
+                                      ctpvae_stream_t stream);
+int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A,
+                                             const void *fwd_plan_dev, const int *angle_idx_dev, int n_idx,
+                                             const float *mask_dev, const float *meas_dev, int dense_inputs,
+                                             const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
+                                             float *dlp_dev, ctpvae_stream_t stream);
+/* ... and the TF_COMPAT / NEAREST backward of such a subset: gsino_dev [S][n_idx][PW], Tinv8_dev the DENSE inverted table
+ * [A_plan][8]; row k of a cotangent uses table row angle_idx_dev[k].  Same bits as ctpvae_rotate_bwd_scaled_f32 on the
+ * gathered table (scale_dev may be NULL). */
+int ctpvae_rotate_bwd_sel_scaled_f32(const float *gsino_dev, int S, int A_plan, int PH, int PW, const float *Tinv8_dev,
+                                     const int *angle_idx_dev, int n_idx, int H, int W, int py, int px,
+                                     const float *scale_dev, long long scale_stride, float *gimg_dev,
+                                     ctpvae_stream_t stream);
+
 /* (Which backward: both give the same bits.  The planned one wins except for large batches at few angles -- S >= 80
  * and A <= 64 -- where ctpvae_rotate_bwd_f32's segment kernel, which streams no indices, is up to 25 % faster.) */
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,

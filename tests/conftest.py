@@ -23,3 +23,12 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_knobs():
+    """Developer knobs of the library (ctpvae_tune_set) never leak from one test into the next."""
+    yield
+    from ct_pvae_amd import _lib
+    if os.path.exists(_lib.LIB_PATH):
+        _lib.tune("*")

@@ -73,3 +73,48 @@ def test_phantoms_are_seeded_and_in_range():
     assert a.dtype == np.float32 and a.min() >= 0 and a.max() <= 1 and 0.05 < a.mean() < 0.8
     assert list(phantoms.sparse_angle_indices(180, 20)) == list(range(0, 180, 9))
     np.testing.assert_allclose(phantoms.dense_theta(180), np.pi * np.arange(180) / 180)
+
+
+def test_host_transform_tables_are_the_oracle_bits(oracle):
+    """the tables of a host-resident angle set are built on the host -- ctpvae_rotate_transforms_host_f32 and
+    the oracle (oracle/radon_oracle.c:65-79, :109-117) give the same bits, forward rows and inverted rows."""
+    from ct_pvae_amd import phantoms
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    theta = np.concatenate([phantoms.dense_theta(180), [-1.0, 4.0, 0.3], rng.uniform(-10, 10, 2000)]).astype(np.float32)
+    for H, W in ((184, 184), (16, 12), (2, 2), (728, 728)):
+        T, Ti = np.empty((theta.size, 8), np.float32), np.empty((theta.size, 8), np.float32)
+        assert lib.ctpvae_rotate_transforms_host_f32(theta.ctypes.data, theta.size, H, W, T.ctypes.data, Ti.ctypes.data) == 0
+        T0 = oracle.rotate_transforms(theta, H, W)
+        np.testing.assert_array_equal(T, T0)
+        np.testing.assert_array_equal(Ti, oracle.invert_transforms(T0))
+    assert lib.ctpvae_rotate_transforms_host_f32(None, 3, 4, 4, T.ctypes.data, None) == _lib.EINVAL
+
+
+def test_developer_knobs_are_a_registry_not_the_environment(monkeypatch):
+    lib = _lib.load()
+    _lib.tune("*")
+    assert lib.ctpvae_tune_active() == 0
+    _lib.tune("NS", 2)
+    _lib.tune("MAX_SLICES", 5)
+    assert lib.ctpvae_tune_active() == 2
+    monkeypatch.setenv("CTPVAE_TUNE_G", "7")          # read at load time only: a later setenv changes nothing
+    assert lib.ctpvae_tune_active() == 2
+    _lib.tune("NS")
+    assert lib.ctpvae_tune_active() == 1
+    with pytest.raises(ValueError, match="unknown knob"):
+        _lib.tune("NOT_A_KNOB", 1)
+    _lib.tune("*")
+    assert lib.ctpvae_tune_active() == 0
+
+
+def test_angle_index_operand_checks():
+    idx = ff.as_angle_index([3, 1, 2], torch.device("cpu"))
+    assert idx.dtype == torch.int32 and idx.tolist() == [3, 1, 2]
+    assert ff.as_angle_index(np.array([5], dtype=np.int64), torch.device("cpu")).dtype == torch.int32
+    with pytest.raises(ValueError):
+        ff.as_angle_index([], torch.device("cpu"))
+    with pytest.raises(ValueError):
+        ff.as_angle_index([[1, 2]], torch.device("cpu"))
+    with pytest.raises(TypeError):
+        ff.as_angle_index([0.5], torch.device("cpu"))

@@ -3,7 +3,7 @@ CTPVAE_TUNE_BNS / _BW; segment: CTPVAE_TUNE_SEG_NS / _SEG_PPT / _SEG_CHUNK), fro
 the library's own choices are printed first."""
 import itertools, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from ct_pvae_amd import phantoms
+from ct_pvae_amd import _lib, phantoms
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 B, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 50), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
@@ -29,11 +29,11 @@ print("library: %.2f us (%s);  planned default %s us, segment default %.2f us" %
     t_us(auto), "planned" if auto.backward_uses_plan(B) else "segment", ("%.2f" % t_us(planned)) if has_plan else "n/a", t_us(seg)))
 res = []
 for ns, w in (itertools.product((1, 2), (2, 4, 8, 16)) if has_plan else ()):
-    os.environ.update(CTPVAE_TUNE_BNS=str(ns), CTPVAE_TUNE_BW=str(w))
+    _lib.tune("BNS", ns); _lib.tune("BW", w)
     res.append((t_us(planned), "planned NS=%d waves=%2d" % (ns, w)))
-for k in ("CTPVAE_TUNE_BNS", "CTPVAE_TUNE_BW"): os.environ.pop(k, None)
+for k in ("BNS", "BW"): _lib.tune(k)
 for ns, ppt, ch in itertools.product((1, 2), (4, 8), (24, 48, 96)):
-    os.environ.update(CTPVAE_TUNE_SEG_NS=str(ns), CTPVAE_TUNE_SEG_PPT=str(ppt), CTPVAE_TUNE_SEG_CHUNK=str(ch))
+    _lib.tune("SEG_NS", ns); _lib.tune("SEG_PPT", ppt); _lib.tune("SEG_CHUNK", ch)
     res.append((t_us(seg), "segment NS=%d ppt=%d chunk=%2d" % (ns, ppt, ch)))
 for t, name in sorted(res)[:8]:
     print("%-32s %.2f us" % (name, t))

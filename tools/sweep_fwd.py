@@ -2,7 +2,7 @@
 HIP-graph replays of 200 launches; prints the library's own choice (no knobs) first."""
 import itertools, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-from ct_pvae_amd import phantoms
+from ct_pvae_amd import _lib, phantoms
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 B, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 50), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
@@ -23,7 +23,7 @@ def t_us():
 print("library choice: %.2f us" % t_us())
 res = []
 for ns, G, w in itertools.product((1, 2), (1, 2, 3, 4, 5, 6, 8, 10), (8, 12, 16)):
-    os.environ.update(CTPVAE_TUNE_NS=str(ns), CTPVAE_TUNE_G=str(G), CTPVAE_TUNE_WAVES=str(w))
+    _lib.tune("NS", ns); _lib.tune("G", G); _lib.tune("WAVES", w)
     try:
         res.append((t_us(), ns, G, w))
     except Exception as e:

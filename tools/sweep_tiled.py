@@ -1,6 +1,7 @@
 """Developer sweep: the tiled forward (slices larger than LDS) over CTPVAE_TUNE_NS / _G at one size (graph replays)."""
 import itertools, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from ct_pvae_amd import _lib
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 B, A, N = (int(sys.argv[1]) if len(sys.argv) > 1 else 8), (int(sys.argv[2]) if len(sys.argv) > 2 else 90), (int(sys.argv[3]) if len(sys.argv) > 3 else 512)
@@ -22,7 +23,7 @@ print("library choice: %.1f us (tile kernel + reduce)" % t_us())
 res = []
 for ns, G in itertools.product((1, 2, 4), (1, 2, 3, 4, 6, 8)):
     if ns > B: continue
-    os.environ.update(CTPVAE_TUNE_NS=str(ns), CTPVAE_TUNE_G=str(G))
+    _lib.tune("TILED_NS", ns); _lib.tune("TILED_G", G)
     res.append((t_us(), ns, G))
 for ns in (1, 2, 4):
     best = sorted(r for r in res if r[1] == ns)[:2]

@@ -18,12 +18,12 @@ out = torch.empty((B, 90, plan.PW), device=dev); gx = torch.empty_like(x)
 print(f"N=512 A=90 B={B} tiled={plan.tiled} fwd %.0f us bwd %.0f us" % (timeit(lambda: plan.forward(x, out=out)), timeit(lambda: plan.backward(g, out=gx))))
 if len(sys.argv) > 2:
     for G in (1, 2, 3, 4, 6, 8):
-        os.environ["CTPVAE_TUNE_G"] = str(G)
+        _lib.tune("TILED_G", G)
         print(f"  G={G}: fwd %.0f us" % timeit(lambda: plan.forward(x, out=out)))
 if len(sys.argv) > 3:
-    os.environ.pop("CTPVAE_TUNE_G", None)
+    _lib.tune("TILED_G")
     for ns in (1, 2, 4):
-        os.environ["CTPVAE_TUNE_NS"] = str(ns)
+        _lib.tune("TILED_NS", ns)
         for G in (1, 2):
-            os.environ["CTPVAE_TUNE_G"] = str(G)
+            _lib.tune("TILED_G", G)
             print(f"  NS={ns} G={G}: fwd %.0f us" % timeit(lambda: plan.forward(x, out=out)))
