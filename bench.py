@@ -39,6 +39,12 @@ def parse():
     ap.add_argument("--angles", type=int, default=A_SPARSE, help="20 (headline) or 180 (dense evaluation set)")
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="objects per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-ms", type=float, default=50.0,
+                    help="the K-step timed region is repeated until this much time has been measured in all; the median "
+                         "region is reported (steps stays K)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the all-cores CPU baseline (0: the cores this process may run on, at most 16 -- the "
+                         "CPU share of a one-GPU box)")
     ap.add_argument("--mode", choices=["projector", "train", "siddon", "n512"], default="projector",
                     help="projector: the headline fwd+adj metric, BASELINE config 2 (default; --angles 180 = config 4's "
                          "per-GPU share); train: config 3, P-VAE steps/s; siddon: config 1, TomoPy-style forward; "
@@ -53,10 +59,30 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run around it: start the N ranks as CHILDREN
+    (python -m torch.distributed.run ... bench.py <same arguments>), before this process has touched the GPU -- a process
+    that has initialised HIP must never exec or fork GPU work -- pass their output through and exit with their code.
+    On a box with fewer than N GPUs the ranks rehearse on device 0 over gloo (CTPVAE_REHEARSE_ONE_GPU, sharding.py)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if torch.cuda.device_count() < n_gpus:        # counting devices does not initialise the GPU
+        env["CTPVAE_REHEARSE_ONE_GPU"] = "1"
+        print(f"[bench] {torch.cuda.device_count()} GPU(s) visible for --gpus {n_gpus}: rehearsing all ranks on device 0 "
+              "over gloo (not a scaling measurement)", file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def dist_setup(n_gpus):
     world, rank, local = sharding.init_from_env()      # one process per GPU; "nccl" = RCCL
     if world != n_gpus:
-        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
     return world, rank, local
 
 
@@ -100,26 +126,56 @@ def max_over_ranks(seconds, world):
     return sharding.max_over_ranks(seconds)
 
 
-def cpu_baseline(imgs, theta, g, budget_s=12.0):
-    """The CPU restatement (oracle/, kind 'port') of the SAME fwd+adj pair, one thread, on a bounded sample of the
-    workload; plus the TomoPy-style (siddon) forward the reference uses on the CPU for dataset generation."""
+def cpu_baseline(imgs, theta, g, threads=0):
+    """CPU figures for the SAME fwd+adj pair on a bounded sample of the workload (about 25 s in all), after the template
+    of ctvae/tomopy_forward_compare.py:51-67 (three timings side by side):
+      * the CPU restatement (oracle/, kind 'port'), ONE thread -- `value`: what the reference's per-image Python loop gets
+        from a one-slice call (scripts/images_to_sinograms.py:62-66; TomoPy parallelises over slices only);
+      * the same restatement, one object per thread on `cores_all` threads -- the best case of a multi-slice stack;
+      * PyTorch's CPU grid_sample rotate-and-sum with autograd (oracle/torch_gridsample.py) -- the framework-op
+        implementation comparable to the reference's TensorFlow graph on a CPU;
+      * the TomoPy-style (siddon) forward the reference uses on the CPU for dataset generation, one thread."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import radon_oracle as orc
+    from oracle import torch_gridsample as tg
     orc.build()
     geom = orc.Geometry(imgs.shape[1], imgs.shape[2], True)
     T = orc.rotate_transforms(theta, geom.PH, geom.PW)
     Tinv = orc.invert_transforms(T)
-    A = len(theta)
-    n_obj, t_rot = 0, 0.0
-    while t_rot < budget_s * 0.6:
-        k = n_obj % imgs.shape[0]
-        t0 = time.perf_counter()
+    A, B = len(theta), imgs.shape[0]
+
+    def one_object(k):
         orc.rotate_fwd(imgs[k:k + 1], geom, T, orc.NEAREST)
         orc.rotate_bwd_tfcompat(g[k:k + 1], geom, Tinv, orc.NEAREST)
+
+    n_obj, t_rot = 0, 0.0
+    while t_rot < 6.0:
+        t0 = time.perf_counter()
+        one_object(n_obj % B)
         t_rot += time.perf_counter() - t0
         n_obj += 1
+    # all cores: ctypes releases the GIL, so threads run the C restatement in parallel; one object per thread per round
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores_all = threads if threads > 0 else max(1, min(avail, 16))
+    rounds = max(1, int(round(5.0 / (t_rot / n_obj))))         # ~5 s: every thread does `rounds` objects
+    with ThreadPoolExecutor(cores_all) as pool:
+        list(pool.map(one_object, range(cores_all)))            # threads up, caches warm
+        t0 = time.perf_counter()
+        list(pool.map(lambda w: [one_object((w + r) % B) for r in range(rounds)], range(cores_all)))
+        t_all = time.perf_counter() - t0
+    # torch-CPU: nearest forward + autograd gradient (the true transpose of grid_sample's forward; TF's gradient is the
+    # re-sampling tf_compat restates -- same amount of work), default intra-op threads
+    nt, t_torch, n_torch = torch.get_num_threads(), 0.0, 0
+    tg.fwd_and_grad(imgs[:1], theta, g[:1], pad=True, mode="nearest")
+    while t_torch < 5.0:
+        k = n_torch % B
+        t0 = time.perf_counter()
+        tg.fwd_and_grad(imgs[k:k + 1], theta, g[k:k + 1], pad=True, mode="nearest")
+        t_torch += time.perf_counter() - t0
+        n_torch += 1
     n_sid, t_sid = 0, 0.0
-    while t_sid < budget_s * 0.4:
-        k = n_sid % imgs.shape[0]
+    while t_sid < 4.0:
+        k = n_sid % B
         t0 = time.perf_counter()
         orc.siddon_project(imgs[k:k + 1], theta, pad=True)
         t_sid += time.perf_counter() - t0
@@ -128,10 +184,16 @@ def cpu_baseline(imgs, theta, g, budget_s=12.0):
         "value": n_obj * A / t_rot, "unit": "projections/s (fwd+adj)", "cores": 1, "kind": "port",
         "sample": f"{n_obj} objects x {A} angles, rotate nearest fwd + tf_compat bwd, oracle/radon_oracle.c -O2, "
                   f"1 thread, {t_rot:.1f} s",
+        "all_cores": {"value": cores_all * rounds * A / t_all, "unit": "projections/s (fwd+adj)", "cores": cores_all,
+                      "kind": "port", "sample": f"{cores_all} threads x {rounds} objects x {A} angles, one object per "
+                                                f"thread, same restatement, {t_all:.1f} s"},
+        "torch_cpu": {"value": n_torch * A / t_torch, "unit": "projections/s (fwd+adj)", "cores": nt, "kind": "port",
+                      "sample": f"{n_torch} objects x {A} angles, torch {torch.__version__} CPU affine_grid + grid_sample "
+                                f"(nearest) + autograd backward, {nt} intra-op threads, {t_torch:.1f} s"},
         "siddon_fwd_projections_per_s": n_sid * A / t_sid,
         "siddon_sample": f"{n_sid} objects x {A} angles, TomoPy project.c restatement (forward only), 1 thread, "
                          f"{t_sid:.1f} s",
-        "host_cores": os.cpu_count(),
+        "host_cores": os.cpu_count(), "cores_available": avail,
     }
 
 
@@ -252,6 +314,8 @@ def n512_mode(args, world, rank, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world, rank, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     if args.mode == "train":
@@ -292,13 +356,24 @@ def main():
     if not args.no_graph and bucket is None and args.steps >= chunk:
         graph = capture_graph(lambda: [step() for _ in range(chunk)])
     n_replay, n_eager = divmod(args.steps, chunk) if graph is not None else (0, args.steps)
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for _ in range(n_replay):
-        graph.replay()
-    for _ in range(n_eager):
-        step()
-    elapsed = close_timed_region(t0, world)
+
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize on both sides; the maximum over ranks."""
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        for _ in range(n_replay):
+            graph.replay()
+        for _ in range(n_eager):
+            step()
+        return close_timed_region(t0, world)
+
+    # One region of K = 20 steps lasts 0.3 ms: too short to hang a headline on.  The region is therefore repeated until
+    # --min-ms of measured time has accumulated (every rank takes the same decision: the region times are already
+    # maxima over ranks) and the MEDIAN region is reported; `steps` stays K, `repeats` says how many regions were timed.
+    regions = [timed_region()]
+    while sum(regions) * 1e3 < args.min_ms and len(regions) < 10000:
+        regions.append(timed_region())
+    elapsed = float(np.median(regions))
 
     # ---- per-kernel durations, HIP events on the launch stream (torch's current stream) -------------------
     # One event pair brackets n_ev back-to-back launches of ONE kernel: the average duration of a launch in a stream of
@@ -370,20 +445,32 @@ def main():
     bwd_name = "rotate_bwd_planned_kernel" if plan.backward_uses_plan(B) else "rotate_bwd_tfcompat_seg_kernel"
     dom = (fwd_name, t_fwd) if t_fwd >= t_bwd else (bwd_name, t_bwd)
     achieved = bytes_dir / dom[1] / 1e9
-    traffic = None   # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
+    # HBM-side bytes per launch of the dominant kernel: a COMMITTED measurement (separate rocprofv3 --pmc passes of this
+    # command, tools/collect_profiles.sh -> profiles/rNN_traffic_pmc.json), not something this run can observe itself
+    traffic, traffic_source = None, None
     try:
         if (B, N, A) != (50, N_PIX, 20):
             raise LookupError("the committed counters are for the default workload only")
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")))["kernels"]
-        traffic = next(v["traffic_bytes_per_launch"] for k, v in pmc.items() if dom[0] in k)
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")))[-1]
+        pmc = json.load(open(newest))
+        traffic = next(v["traffic_bytes_per_launch"] for k, v in pmc["kernels"].items() if dom[0] in k)
+        traffic_source = f"profiles/{os.path.basename(newest)}" + (f" (commit {pmc['commit']})" if "commit" in pmc else "")
     except Exception:
         pass
+    from ct_pvae_amd import _lib
+    tune_env = {k: v for k, v in os.environ.items() if k.startswith("CTPVAE_")}
     proj_per_s = world * B * A * args.steps / elapsed
     out = {
         "metric": "projections/sec (fwd+adj) 128x128 foam, 20 angles; fraction of HBM roofline",
         "value": proj_per_s, "unit": "projections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "repeats": len(regions),
+        "region_ms": {"min": min(regions) * 1e3, "median": elapsed * 1e3, "max": max(regions) * 1e3,
+                      "what": f"{len(regions)} timed regions of exactly {args.steps} steps each (barrier + synchronize on both "
+                              "sides, max over ranks); value and ms_per_step are from the median region"},
+        "developer_knobs": {"library_knobs_set": _lib.load().ctpvae_tune_active(), "env": tune_env},
         "config": {"workload": f"batch={B}/GPU {N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
                    "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}",
                    "grad_allreduce_bytes_per_step": 4 * 711164 if args.grad_allreduce else 0,
@@ -393,7 +480,7 @@ def main():
         "hbm_fraction_whole_step": (2 * bytes_dir / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                     "traffic": traffic, "algorithmic_bytes_per_launch": bytes_dir,
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_dir,
                      "kernel_us": {"rotate_fwd": t_fwd * 1e6, "rotate_bwd_tfcompat": t_bwd * 1e6},
                      "note": "object lives in LDS for all angles; the launch is bound by dispatch + L2->CU bytes (indices, fills) + per-task LDS latency chains, so the HBM fraction is small by construction (DESIGN.md section 6)"},
         "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
@@ -403,7 +490,7 @@ def main():
                 "what": "project_tf_fast(...).backward() through torch.autograd, same workload, 1 GPU"},
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(imgs, theta, g_host)
+        out["cpu_baseline"] = cpu_baseline(imgs, theta, g_host, args.cpu_threads)
     print(json.dumps(out))
 
 
