@@ -165,6 +165,7 @@ def cpu_baseline(imgs, theta, g, threads=0):
         t_all = time.perf_counter() - t0
     # torch-CPU: nearest forward + autograd gradient (the true transpose of grid_sample's forward; TF's gradient is the
     # re-sampling tf_compat restates -- same amount of work), default intra-op threads
+    torch.set_num_threads(cores_all)          # the same cores as the all-cores figure (the default is every host core)
     nt, t_torch, n_torch = torch.get_num_threads(), 0.0, 0
     tg.fwd_and_grad(imgs[:1], theta, g[:1], pad=True, mode="nearest")
     while t_torch < 5.0:
@@ -210,18 +211,29 @@ def train_mode(args, world, rank, dev):
     for _ in range(args.steps):
         t.train_step(sync=False)
     elapsed = close_timed_region(t0, world)
-    # projector share: the same 2 x (fwd + bwd) on 5 objects x 20 angles per step, timed alone
-    from ct_pvae_amd.forward_functions import RotatePlan as RP
-    theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
-    plan = RP(theta, 128, 128, True, dev)
-    x = torch.rand((5, 128, 128), device=dev)
-    g = torch.rand((5, 20, plan.PW), device=dev)
+    # Projector share: EXACTLY what a step does with the projector, everything per-step included -- a fresh 20-angle
+    # subset drawn on the host and uploaded, calculate_log_prob_M_given_R on the ns * b = 10 sample-objects against the
+    # trainer's own dense 180-angle plan (angle-index operand: no table, plan or gather kernel per step), the per-object
+    # sums and backward() -- timed alone on the host clock with the GPU drained at both ends.
+    from ct_pvae_amd.helper_functions import calculate_log_prob_M_given_R
+    nobj = targs.ns * (targs.batch_size // world)
+    xs = torch.rand((nobj, 128, 128, 1), device=dev, requires_grad=True)
+    mask10, meas10 = t.masks[:nobj].contiguous(), t.proj_samples[:nobj].contiguous()
+    w10 = torch.full((nobj,), -1e-5, device=dev)
+
+    def projector_part():
+        ai = t._to_device(t.angles.next().astype(np.int32))
+        xs.grad = None
+        lp = calculate_log_prob_M_given_R(xs, mask10, meas10, t.pnm, t.sqrt_reg, theta=t.theta_host, angles_i=ai, pad=t.pad)
+        with torch.autograd.set_multithreading_enabled(False):
+            lp.sum(dim=(1, 2, 3)).backward(w10)
+
     for _ in range(20):
-        plan.backward(g); plan.forward(x)
+        projector_part()
     torch.cuda.synchronize()
     tp = time.perf_counter()
     for _ in range(200):
-        plan.forward(x); plan.backward(g); plan.forward(x); plan.backward(g)
+        projector_part()
     torch.cuda.synchronize()
     proj_s = (time.perf_counter() - tp) / 200
     if rank == 0:
@@ -231,7 +243,10 @@ def train_mode(args, world, rank, dev):
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "P-VAE step: encoder + 2 samples x (decoder, TruncatedNormal sample, HIP "
                                                  "projector fwd, log-likelihood) + backward + Adam; 5 objects/GPU, 20 of 180 angles"},
-                          "projector_ms_per_step": proj_s * 1e3, "projector_share": proj_s / (elapsed / args.steps)}))
+                          "projector_ms_per_step": proj_s * 1e3, "projector_share": proj_s / (elapsed / args.steps),
+                          "projector_what": "host time of the step's whole projector call (angle-subset upload, "
+                                            "calculate_log_prob_M_given_R fwd on the dense plan, per-object sums, backward), "
+                                            "timed alone; includes all per-step set-up"}))
 
 
 def _time_loop(fn, steps, warmup, world):
@@ -420,23 +435,57 @@ def main():
     step_us = np.array([e0.elapsed_time(e1) * 1e3 for e0, e1 in ev])
 
     # ---- the same step through the public autograd API (secondary) -----------------------------------------
-    x4 = x[..., None].clone().requires_grad_(True)
-    g4 = g[..., None]
-    n_api = min(args.steps, 200)
+    # project_tf_fast(...).backward() and calculate_log_prob_M_given_R(...).backward() -- what the reference's callers
+    # use (ctvae/helper_functions.py:359) -- against the raw operator pair launched from Python, at this batch and at the
+    # training batch (5).  Host-bound: PyTorch's autograd machinery around ONE custom node costs ~25 us, and its default
+    # multi-threaded engine adds a ~50 us hand-off to the device thread per backward() call, which a training step pays
+    # once for its whole graph -- `single_thread_engine` is the same call under
+    # torch.autograd.set_multithreading_enabled(False), as ct_pvae_amd/trainer.py runs its backward.
+    from ct_pvae_amd.helper_functions import calculate_log_prob_M_given_R
+    n_api = min(max(args.steps, 50), 300)
 
-    def api_step():
-        x4.grad = None
-        out = project_tf_fast(x4, theta, pad=True, dim=2, integrate_vae=True)
-        out.backward(g4)
+    def host_rate(fn, n_obj):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(n_api):
+            fn()
+        torch.cuda.synchronize()
+        return n_obj * A * n_api / (time.perf_counter() - ta)
 
-    for _ in range(10):
-        api_step()
-    torch.cuda.synchronize()
-    ta = time.perf_counter()
-    for _ in range(n_api):
-        api_step()
-    torch.cuda.synchronize()
-    api_elapsed = time.perf_counter() - ta
+    api = {"unit": "projections/s", "what": "fwd+bwd through torch.autograd, launched from Python, 1 GPU; raw = "
+                                            "RotatePlan.forward/backward launched from Python with preallocated outputs"}
+    eps32 = float(np.finfo(np.float32).eps)
+    for nb in sorted({B, 5}):
+        x4 = x[:nb, :, :, None].clone().requires_grad_(True)
+        g4 = g[:nb, :, :, None].contiguous()
+        xs, gs = x[:nb].contiguous(), g[:nb].contiguous()
+        so, go = torch.empty_like(gs), torch.empty_like(xs)
+        mask = torch.full((nb, A), 1.0 / A, device=dev)
+        meas = torch.rand((nb, A, P), device=dev)
+        pnm = torch.tensor(1e4, device=dev)
+        w = torch.full((nb,), -1.0 / nb, device=dev)
+
+        def raw_step():
+            plan.forward(xs, out=so)
+            plan.backward(gs, out=go)
+
+        def api_step():
+            x4.grad = None
+            project_tf_fast(x4, theta, pad=True, dim=2, integrate_vae=True).backward(g4)
+
+        def lik_step():
+            x4.grad = None
+            calculate_log_prob_M_given_R(x4, mask, meas, pnm, eps32, theta=theta, pad=True).sum(dim=(1, 2, 3)).backward(w)
+
+        ent = {"raw": host_rate(raw_step, nb), "project_tf_fast": host_rate(api_step, nb),
+               "calculate_log_prob_M_given_R": host_rate(lik_step, nb)}
+        with torch.autograd.set_multithreading_enabled(False):
+            ent["single_thread_engine"] = {"project_tf_fast": host_rate(api_step, nb),
+                                           "calculate_log_prob_M_given_R": host_rate(lik_step, nb)}
+        api[f"batch_{nb}"] = ent
+    api["value"] = api[f"batch_{B}"]["project_tf_fast"]
 
     if rank != 0:
         return
@@ -486,8 +535,7 @@ def main():
         "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
         "step_us_event_pairs": {"p10": float(np.percentile(step_us, 10)), "median": float(np.median(step_us)),
                                 "p90": float(np.percentile(step_us, 90)), "n": len(step_us)},
-        "api": {"value": B * A * n_api / api_elapsed, "unit": "projections/s",
-                "what": "project_tf_fast(...).backward() through torch.autograd, same workload, 1 GPU"},
+        "api": api,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(imgs, theta, g_host, args.cpu_threads)

@@ -448,18 +448,63 @@ class RotatePlan:
         return out
 
     def apply(self, img):
-        return _RotateProject.apply(img, self)
+        """Differentiable projection of slices [S][H][W] -> [S][A][PW]."""
+        return _RotateProject.apply(img, self, 0)
+
+
+_LAYOUT_SLICES, _LAYOUT_VAE, _LAYOUT_DIM3, _LAYOUT_DIM2 = 0, 1, 2, 3
 
 
 class _RotateProject(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, img, plan):
-        ctx.plan = plan
-        return plan.forward(img)
+    """ONE autograd node from the caller's tensor, in the reference's layout, to the result in the reference's layout
+    (ctvae/forward_functions.py:102-121): the [..., 0] / permute / unsqueeze re-layouts happen inside, as views, so that
+    the backward pass runs one function -- no select_backward (a zero fill and a copy of the whole batch) around it."""
 
     @staticmethod
-    def backward(ctx, gsino):
-        return ctx.plan.backward(gsino.contiguous()), None
+    def forward(ctx, phantom, plan, layout):
+        ctx.plan, ctx.layout, ctx.in_dtype = plan, layout, phantom.dtype
+        if layout == _LAYOUT_VAE:            # [B][X][Y][1]
+            x = phantom.reshape(phantom.shape[0], phantom.shape[1], phantom.shape[2])
+        elif layout == _LAYOUT_DIM3:         # [X][Y][Z]
+            x = phantom.permute(2, 0, 1)
+        elif layout == _LAYOUT_DIM2:         # [X][Y]
+            x = phantom[None]
+        else:
+            x = phantom
+        if x.dtype is not torch.float32:     # the reference keeps float64 pixel data (coordinates are fp32 either way)
+            x = x.to(torch.float32)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        sino = plan.forward(x)               # [S][A][PW]
+        if layout == _LAYOUT_VAE:
+            out = sino.unsqueeze(-1)         # batch x angles x P x 1   (ctvae/forward_functions.py:116-121)
+        elif layout in (_LAYOUT_DIM3, _LAYOUT_DIM2):
+            out = sino.permute(1, 2, 0)      # angles x P x Z          (ctvae/forward_functions.py:111-114)
+        else:
+            out = sino
+        return out if ctx.in_dtype is torch.float32 else out.to(ctx.in_dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        layout, plan = ctx.layout, ctx.plan
+        if layout == _LAYOUT_VAE:
+            g = gout.reshape(gout.shape[0], gout.shape[1], gout.shape[2])
+        elif layout in (_LAYOUT_DIM3, _LAYOUT_DIM2):
+            g = gout.permute(2, 0, 1)
+        else:
+            g = gout
+        if g.dtype is not torch.float32:
+            g = g.to(torch.float32)
+        if not g.is_contiguous():
+            g = g.contiguous()
+        gimg = plan.backward(g)              # [S][H][W]
+        if layout == _LAYOUT_VAE:
+            gimg = gimg.unsqueeze(-1)
+        elif layout == _LAYOUT_DIM3:
+            gimg = gimg.permute(1, 2, 0)
+        elif layout == _LAYOUT_DIM2:
+            gimg = gimg[0]
+        return (gimg if ctx.in_dtype is torch.float32 else gimg.to(ctx.in_dtype)), None, None
 
 
 _PLAN_CACHE = {}
@@ -467,6 +512,7 @@ _PLAN_CACHE_MAX = 16
 
 
 _DEV_THETA_PLANS = {}   # id(theta tensor) -> (weakref, version, {geometry key: plan})
+_HOST_THETA_PLANS = {}  # id(theta ndarray) -> (weakref, bytes snapshot, {geometry key: plan})
 
 
 def _cached_plan(theta, H, W, pad, device, interp, backward):
@@ -492,10 +538,26 @@ def _cached_plan(theta, H, W, pad, device, interp, backward):
             ent = _DEV_THETA_PLANS[id(theta)] = (weakref.ref(theta), theta._version, {})
         plan = ent[2][geo] = RotatePlan(theta, H, W, pad, device, interp=interp, backward=backward)
         return plan
+    if type(theta) is np.ndarray:
+        # the same array object as last time (a script's or a trainer's fixed theta): compare its bytes with the snapshot
+        # taken when the plan was built (an in-place edit is seen) -- no conversion, no hashing of a new key
+        ent = _HOST_THETA_PLANS.get(id(theta))
+        if ent is not None and ent[0]() is theta and ent[1] == theta.tobytes():
+            plan = ent[2].get((H, W, pad, device, interp, backward))
+            if plan is not None:
+                return plan
     host = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
                                            dtype=np.float32))
     key = (host.tobytes(), H, W, bool(pad), str(device), interp, backward)
     plan = _PLAN_CACHE.get(key)
+    if type(theta) is np.ndarray and plan is not None:
+        ent = _HOST_THETA_PLANS.get(id(theta))
+        snap = theta.tobytes()
+        if ent is None or ent[0]() is not theta or ent[1] != snap:
+            if len(_HOST_THETA_PLANS) >= 4 * _PLAN_CACHE_MAX:
+                _HOST_THETA_PLANS.clear()
+            ent = _HOST_THETA_PLANS[id(theta)] = (weakref.ref(theta), snap, {})
+        ent[2][(H, W, pad, device, interp, backward)] = plan
     if plan is None:
         plan = RotatePlan(host, H, W, pad, device, interp=interp, backward=backward)
         if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
@@ -504,48 +566,35 @@ def _cached_plan(theta, H, W, pad, device, interp, backward):
     return plan
 
 
-def _as_slices(x):
-    """fp32, contiguous [S][H][W] on the current HIP device; returns (slices, original dtype)."""
-    if not isinstance(x, torch.Tensor):
-        raise TypeError(f"phantom must be a torch.Tensor on a HIP device (got {type(x).__name__})")
-    if x.device.type != "cuda":
-        raise _lib.RadonLibraryError(
-            f"phantom lives on {x.device}: the projector runs on a HIP device only; there is no CPU path")
-    if not x.dtype.is_floating_point:
-        raise TypeError(f"phantom must be floating point (got {x.dtype})")
-    # The reference keeps float64 pixel data (coordinates are fp32 either way); here sums are fp32.
-    return x.to(torch.float32).contiguous(), x.dtype
-
-
 def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
     if not isinstance(phantom, torch.Tensor):
         raise TypeError(f"phantom must be a torch.Tensor on a HIP device (got {type(phantom).__name__})")
+    if phantom.device.type != "cuda":
+        raise _lib.RadonLibraryError(
+            f"phantom lives on {phantom.device}: the projector runs on a HIP device only; there is no CPU path")
+    if not phantom.dtype.is_floating_point:
+        raise TypeError(f"phantom must be floating point (got {phantom.dtype})")
     if integrate_vae:
         if phantom.dim() != 4 or phantom.shape[3] != 1:
             raise ValueError("integrate_vae=True expects batch_size x img_size_x x img_size_y x 1 "
                              f"(got {tuple(phantom.shape)})")
-        slices, dt = _as_slices(phantom[..., 0])
+        layout, H, W = _LAYOUT_VAE, phantom.shape[1], phantom.shape[2]
     elif dim == 3:
         if phantom.dim() != 3:
             raise ValueError(f"dim=3 expects img_size_x x img_size_y x img_size_z (got {tuple(phantom.shape)})")
-        slices, dt = _as_slices(phantom.permute(2, 0, 1))
+        layout, H, W = _LAYOUT_DIM3, phantom.shape[0], phantom.shape[1]
     elif dim == 2:
         if phantom.dim() != 2:
             raise ValueError(f"dim=2 expects img_size_x x img_size_y (got {tuple(phantom.shape)})")
-        slices, dt = _as_slices(phantom[None])
+        layout, H, W = _LAYOUT_DIM2, phantom.shape[0], phantom.shape[1]
     else:
         raise ValueError(f"dim must be 2 or 3 (got {dim})")
-    plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, interp, backward)
-    if slices.device.index == torch.cuda.current_device():
-        sino = plan.apply(slices)  # [S][A][PW]
-    else:
-        with torch.cuda.device(slices.device):
-            sino = plan.apply(slices)
-    if integrate_vae:
-        out = sino.unsqueeze(-1)  # batch x angles x P x 1   (ctvae/forward_functions.py:116-121)
-    else:
-        out = sino.permute(1, 2, 0)  # angles x P x Z          (ctvae/forward_functions.py:111-114)
-    return out if dt == torch.float32 else out.to(dt)
+    dev = phantom.device
+    plan = _cached_plan(theta, H, W, pad, dev, interp, backward)
+    if dev.index == _current_device():
+        return _RotateProject.apply(phantom, plan, layout)
+    with torch.cuda.device(dev):
+        return _RotateProject.apply(phantom, plan, layout)
 
 
 def project_tf_fast(phantom, theta, pad=False, dim=3, integrate_vae=False, *, interp="nearest",

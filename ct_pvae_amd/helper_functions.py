@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .forward_functions import _cached_plan, _stream_ptr, as_angle_index, project_tf_fast
+from .forward_functions import _cached_plan, _current_device, _stream_ptr, as_angle_index, project_tf_fast
 
 __all__ = ["create_sinogram", "create_sinograms", "calculate_log_prob_M_given_R", "gaussian_poisson_log_prob"]
 
@@ -162,7 +162,10 @@ class _ProjectLogLik(torch.autograd.Function):
     [B][A] / [B][A][P] arrays (dense_inputs) and nothing is gathered, rebuilt or re-planned per step."""
 
     @staticmethod
-    def forward(ctx, slices, plan, mask, x, pnm, eps, angles_i=None):
+    def forward(ctx, sample, plan, mask, x, pnm, eps, angles_i=None):
+        # sample: the caller's [B][X][Y][1] tensor (float32, contiguous); re-laid out here, as views, so that the
+        # backward pass is this one node (no select_backward: a zero fill and a copy of the whole batch)
+        slices = sample.view(sample.shape[0], sample.shape[1], sample.shape[2])
         ctx.plan, ctx.eps, ctx.angles_i = plan, eps, angles_i
         dense = angles_i is not None
         ctx.fused_bwd = ctx.needs_input_grad[0] and not ctx.needs_input_grad[4] and plan.supports_scale
@@ -175,16 +178,19 @@ class _ProjectLogLik(torch.autograd.Function):
                 idx = angles_i.long()
                 mask, x = mask.index_select(1, idx).contiguous(), x.index_select(1, idx).contiguous()
             ctx.save_for_backward(sino, mask, x, pnm)
-        return lp
+        return lp.unsqueeze(-1)
 
     @staticmethod
     def backward(ctx, gout):
         ai = ctx.angles_i
+        gout = gout.squeeze(-1)
         if ctx.fused_bwd:
             dlp, = ctx.saved_tensors
             if gout.stride(1) == 0 and gout.stride(2) == 0:
-                return ctx.plan.backward(dlp, scale=gout[:, 0, 0], angles_i=ai), None, None, None, None, None, None
-            return ctx.plan.backward(gout * dlp, angles_i=ai), None, None, None, None, None, None
+                gimg = ctx.plan.backward(dlp, scale=gout[:, 0, 0], angles_i=ai)
+            else:
+                gimg = ctx.plan.backward(gout * dlp, angles_i=ai)
+            return gimg.unsqueeze(-1), None, None, None, None, None, None
         lib = _lib.load()
         sino, mask, x, pnm = ctx.saved_tensors
         B, A, P = sino.shape
@@ -196,7 +202,7 @@ class _ProjectLogLik(torch.autograd.Function):
                                                  B, A, P, pnm.data_ptr(), ctypes.c_float(ctx.eps),
                                                  gproj.data_ptr(), gpnm.data_ptr() if gpnm is not None else None,
                                                  _stream_ptr()), "loglik_bwd")
-            gimg = ctx.plan.backward(gproj, angles_i=ai) if ctx.needs_input_grad[0] else None
+            gimg = ctx.plan.backward(gproj, angles_i=ai).unsqueeze(-1) if ctx.needs_input_grad[0] else None
         return gimg, None, None, None, (gpnm.reshape(pnm.shape) if gpnm is not None else None), None, None
 
 
@@ -216,10 +222,10 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
     fast = (isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[3] == 1 and x.device.type == "cuda"
             and x.dtype == torch.float32 and x.shape[0] > 0)
     if fast:
-        slices = x[..., 0]
-        if not slices.is_contiguous():
-            slices = slices.contiguous()
-        plan = _cached_plan(theta, slices.shape[1], slices.shape[2], pad, slices.device, "nearest", "tf_compat")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        slices = x       # (shapes below: [B][X][Y][1])
+        plan = _cached_plan(theta, x.shape[1], x.shape[2], pad, x.device, "nearest", "tf_compat")
         if plan.planned[0] or plan.tiled:
             sel = None
             if angles_i is not None:
@@ -242,9 +248,10 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
                 mask = mask.to(torch.float32).contiguous()
             if proj_sample.dtype is not torch.float32 or not proj_sample.is_contiguous():
                 proj_sample = proj_sample.to(torch.float32).contiguous()
+            if x.device.index == _current_device():
+                return _ProjectLogLik.apply(x, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
             with torch.cuda.device(x.device):
-                logp = _ProjectLogLik.apply(slices, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
-            return logp.unsqueeze(-1)
+                return _ProjectLogLik.apply(x, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
     if angles_i is not None:
         angles_i = torch.as_tensor(angles_i, device=output_sample.device).long()
         theta = torch.as_tensor(theta, device=output_sample.device)[angles_i].to(torch.float32)

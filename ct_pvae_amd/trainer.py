@@ -394,7 +394,10 @@ class PVAETrainer:
         del loss_vec
         loss = ((kl_anneal * a.klm * kl).sum() / a.batch_size - loglik) / 1e5
         self.opt.zero_grad(set_to_none=True)
-        loss.backward()
+        # one calling-thread pass over the graph: the default engine hands every backward() to a per-device worker thread
+        # (~50 us of hand-off, and the Python backward of the projector node then runs behind the GIL of that thread)
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward()
         grads = [p.grad for p in self.opt.param_groups[0]["params"] if p.grad is not None]
         sharding.allreduce_flat_(grads, average=False)                     # ONE bucket, one all-reduce
         # tf.where(is_nan, 0, grad), then tf.clip_by_norm(g, norm) per tensor (ctvae/main_ct_vae.py:482-484) -- in one

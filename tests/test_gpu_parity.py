@@ -554,7 +554,7 @@ def test_fused_loglik_backward_is_one_launch_and_matches_two_steps(B, N, A, upst
         x = torch.from_numpy(rng_img(B, N)).to(d).requires_grad_(True)
         if fused:
             lp = cp.calculate_log_prob_M_given_R(x, mask, meas, 1e3, eps, theta=theta, pad=True)
-            assert type(lp.grad_fn.next_functions[0][0]).__name__.startswith("_ProjectLogLik")
+            assert type(lp.grad_fn).__name__.startswith("_ProjectLogLik")      # ONE autograd node for the whole call
         else:
             proj = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
             lp = gaussian_poisson_log_prob(proj[..., 0], mask, meas, 1e3, eps).unsqueeze(-1)
