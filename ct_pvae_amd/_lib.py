@@ -62,6 +62,8 @@ SIGNATURES = {
     "ctpvae_fbp_filter_f64": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp]),
     "ctpvae_fbp_backproject_f64": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp]),
     "ctpvae_loglik_fwd_f32": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_float, _vp, _vp]),
+    "ctpvae_poisson_measure_f32": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_float, ctypes.c_ulonglong, _vp, _vp]),
+    "ctpvae_philox4x32_10": (_c_int, [_vp, _vp, _vp]),
     "ctpvae_loglik_bwd_f32": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_float, _vp, _vp, _vp]),
 }
 

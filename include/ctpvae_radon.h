@@ -37,6 +37,7 @@
  *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
  *   ctpvae_loglik_fwd_f32 / _bwd_f32           calculate_log_prob_M_given_R
  *                                              ctvae/helper_functions.py:360-368
+ *   ctpvae_poisson_measure_f32                 create_all_masks' noisy sparse sinograms  ctvae/create_masks.py:80-103
  */
 #ifndef CTPVAE_RADON_H
 #define CTPVAE_RADON_H
@@ -220,6 +221,17 @@ int ctpvae_loglik_fwd_f32(const float *proj_dev, const float *mask_dev, const fl
 int ctpvae_loglik_bwd_f32(const float *proj_dev, const float *mask_dev, const float *x_dev,
                           const float *gout_dev, int B, int A, int P, const float *pnm_dev, float eps,
                           float *gproj_dev, float *gpnm_dev, ctpvae_stream_t stream);
+
+/* ---- f2: sparse noisy measurements (the step that feeds the training loop) -------------------------------------
+ * ctvae/create_masks.py:80-103 in one launch: out[s][a][j] = Poisson(max(sino[s][a][j], 0) * mask[s][a] * pnm) / pnm.
+ * sino_dev, out_dev [S][A][P]; mask_dev [S][A].  Counter-based and fully specified (csrc/poisson.hip): element e draws
+ * from Philox4x32-10(counter = (e, block), key = seed), multiplication method below rate 10, transformed rejection
+ * (PTRS) from there, exp / log by fixed double-precision series -- the same counts on any device or host for a seed,
+ * whatever the launch shape.  The reference draws with tfd.Poisson(...).sample(): same distribution, other bits. */
+int ctpvae_poisson_measure_f32(const float *sino_dev, const float *mask_dev, int S, int A, int P, float pnm,
+                               unsigned long long seed, float *out_dev, ctpvae_stream_t stream);
+/* Host-side known-answer hook for the generator: the four words of Philox4x32-10(counter4, key2) (host pointers). */
+int ctpvae_philox4x32_10(const unsigned *counter4, const unsigned *key2, unsigned *out4);
 
 #ifdef __cplusplus
 }

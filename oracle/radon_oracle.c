@@ -519,3 +519,124 @@ void oracle_loglik(const float *proj, const float *mask, const float *x, int B, 
             }
         }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * f2: the Poisson-noise forward model of ctvae/create_masks.py:80-103,
+ *   out[s][a][j] = Poisson( max(sino, 0) * mask[s][a] * pnm ) / pnm        (:32 clamp, :82 mask, :94-95 draw)
+ * The reference draws with tfd.Poisson(rate).sample() -- TensorFlow's generator, whose bits nothing pins; what it defines
+ * is the DISTRIBUTION.  The build's sampler is counter-based and specified in full (ct_pvae_amd/csrc/poisson.hip header);
+ * this is its CPU twin, written from that specification: same Philox4x32-10 blocks per element, multiplication method
+ * below rate 10, Hormann's transformed rejection (PTRS) from there, exp / log by the same fixed double series -- so every
+ * count can be compared exactly, and the distribution itself is tested against scipy (tests/test_oracle.py).
+ * ------------------------------------------------------------------------------------------- */
+static void oracle_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void oracle_philox4x32_10(const uint32_t *ctr4, const uint32_t *key2, uint32_t *out4) { oracle_philox(ctr4, key2, out4); }
+
+static double oracle_series_log(double x)
+{
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    b = (b & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m;
+    memcpy(&m, &b, 8);
+    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+    const double s = (m - 1.0) / (m + 1.0), z = s * s;
+    double p = 1.0 / 23.0;
+    for (int d = 21; d >= 3; d -= 2) p = p * z + 1.0 / (double)d;
+    p = p * z + 1.0;
+    return (double)e * 0.6931471805599453 + 2.0 * s * p;
+}
+
+static double oracle_series_exp_neg(double x)
+{
+    static const double inv_fact[15] = { 1.0, 1.0, 0.5, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 720.0, 1.0 / 5040.0,
+                                         1.0 / 40320.0, 1.0 / 362880.0, 1.0 / 3628800.0, 1.0 / 39916800.0,
+                                         1.0 / 479001600.0, 1.0 / 6227020800.0, 1.0 / 87178291200.0 };
+    if (x < -700.0) return 0.0;
+    const double kf = (double)(long long)(x * 1.4426950408889634 - 0.5);
+    const double r = (x - kf * 0.693147180369123816490) - kf * 1.90821492927058770002e-10;
+    double p = inv_fact[14];
+    for (int d = 13; d >= 0; --d) p = p * r + inv_fact[d];
+    const uint64_t sb = (uint64_t)((long long)kf + 1023) << 52;
+    double scale;
+    memcpy(&scale, &sb, 8);
+    return p * scale;
+}
+
+static double oracle_log_factorial(double k)
+{
+    static const double small[10] = { 0.0, 0.0, 0.6931471805599453, 1.791759469228055, 3.1780538303479458,
+                                      4.787491742782046, 6.579251212010101, 8.525161361065415, 10.60460290274525,
+                                      12.801827480081469 };
+    if (k < 10.0) return small[(int)k];
+    const double n = k + 1.0, i = 1.0 / n, i2 = i * i;
+    return (n - 0.5) * oracle_series_log(n) - n + 0.9189385332046727 +
+           i * (1.0 / 12.0 - i2 * (1.0 / 360.0 - i2 * (1.0 / 1260.0 - i2 * (1.0 / 1680.0))));
+}
+
+static double oracle_u01(uint32_t w) { return ((double)w + 0.5) * 2.3283064365386963e-10; }
+
+double oracle_poisson_count(double lam, uint64_t e, uint64_t seed)
+{
+    const uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
+    uint32_t ctr[4] = { (uint32_t)e, (uint32_t)(e >> 32), 0u, 0u }, w[4];
+    if (!(lam > 0.0)) return 0.0;
+    if (lam < 10.0) {           /* multiplication method: uniforms word by word from blocks 0, 1, ... */
+        const double enlam = oracle_series_exp_neg(-lam);
+        double prod = 1.0, count = 0.0;
+        for (;; ++ctr[2]) {
+            oracle_philox(ctr, key, w);
+            for (int i = 0; i < 4; ++i) {
+                prod = prod * oracle_u01(w[i]);
+                if (!(prod > enlam)) return count;
+                count = count + 1.0;
+            }
+        }
+    }
+    /* PTRS (Hormann 1993): iteration t draws U, V from block t */
+    const double slam = sqrt(lam), loglam = oracle_series_log(lam);
+    const double b = 0.931 + 2.53 * slam;
+    const double a = -0.059 + 0.02483 * b;
+    const double invalpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double vr = 0.9277 - 3.6224 / (b - 2.0);
+    for (;; ++ctr[2]) {
+        oracle_philox(ctr, key, w);
+        const double U = oracle_u01(w[0]) - 0.5, V = oracle_u01(w[1]);
+        const double us = 0.5 - fabs(U);
+        const double k = floor((2.0 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0.0 || (us < 0.013 && V > us)) continue;
+        if (oracle_series_log(V) + oracle_series_log(invalpha) - oracle_series_log(a / (us * us) + b) <=
+            -lam + k * loglam - oracle_log_factorial(k))
+            return k;
+        if (ctr[2] == 0xffffffffu) return k;
+    }
+}
+
+void oracle_poisson_measure(const float *sino, const float *mask, int S, int A, int P, float pnm, uint64_t seed,
+                            float *out)
+{
+    const size_t n = (size_t)S * A * P;
+    for (size_t e = 0; e < n; ++e) {
+        const float loc = fmaxf(sino[e], 0.0f) * mask[e / (size_t)P];
+        const float rate = loc * pnm;
+        out[e] = rate < 1.0e15f ? (float)oracle_poisson_count((double)rate, (uint64_t)e, seed) / pnm : loc;
+    }
+}
+
+/* the two series against libm, for the tests (they must agree to ~1e-15 relative; bits need not) */
+double oracle_series_log_public(double x) { return oracle_series_log(x); }
+double oracle_series_exp_neg_public(double x) { return oracle_series_exp_neg(x); }

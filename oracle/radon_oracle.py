@@ -52,6 +52,13 @@ def lib():
         L.oracle_fbp_backproject.argtypes = [_f64p, _i, _i, _i, _f64p, _i, _i, _f64p]
         L.oracle_iradon.argtypes = [_f64p, _i, _i, _i, _f64p, _i, _i, _f64p, ctypes.c_void_p, _f64p]
         L.oracle_loglik.argtypes = [_f32p, _f32p, _f32p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _f32p]
+        L.oracle_philox4x32_10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.oracle_poisson_count.restype = ctypes.c_double
+        L.oracle_poisson_count.argtypes = [ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64]
+        L.oracle_poisson_measure.argtypes = [_f32p, _f32p, _i, _i, _i, ctypes.c_float, ctypes.c_uint64, _f32p]
+        for name in ("oracle_series_log_public", "oracle_series_exp_neg_public"):
+            getattr(L, name).restype = ctypes.c_double
+            getattr(L, name).argtypes = [ctypes.c_double]
         _lib = L
     return _lib
 
@@ -198,4 +205,25 @@ def loglik(proj, mask, x, pnm, eps):
     B, A, P = proj.shape
     out = np.empty_like(proj)
     lib().oracle_loglik(proj, mask, x, B, A, P, pnm, eps, out)
+    return out
+
+
+# ---- f2 -----------------------------------------------------------------------------------------------
+def philox4x32_10(counter4, key2):
+    c, k = np.asarray(counter4, np.uint32), np.asarray(key2, np.uint32)
+    out = np.zeros(4, np.uint32)
+    lib().oracle_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out
+
+
+def poisson_count(lam, element, seed):
+    return lib().oracle_poisson_count(float(lam), int(element), int(seed))
+
+
+def poisson_measure(sino, mask, pnm, seed):
+    """Poisson(max(sino, 0) * mask * pnm) / pnm with the build's specified sampler (ctvae/create_masks.py:80-103)."""
+    sino, mask = _c32(sino), _c32(mask)
+    S, A, P = sino.shape
+    out = np.empty_like(sino)
+    lib().oracle_poisson_measure(sino, mask, S, A, P, pnm, int(seed), out)
     return out

@@ -779,6 +779,37 @@ def test_hip_against_the_independent_resampler_fixture(golden_dir):
     assert rel_err(grad, z["grad_bilinear"]) <= 5e-5
 
 
+def test_poisson_sampler_kernel_equals_its_cpu_twin(oracle, tmp_path):
+    """Poisson(max(sino, 0) * mask * pnm) / pnm as one HIP kernel (ctvae/create_masks.py:80-103).  The sampler
+    is counter-based and fully specified, so the CPU twin reproduces EVERY count -- rates from 0 through the algorithm
+    switch at 10 to 1e6, negative inputs, zero masks; the launch shape does not matter (grid-stride over elements)."""
+    from ct_pvae_amd.create_masks import create_all_masks, poisson_measure
+    d = dev()
+    rng = np.random.default_rng(12)
+    S, A, P = 7, 12, 184
+    rates = np.concatenate([[0.0, 1e-3, 0.5, 9.99, 10.0, 10.01, 1e2, 1e4, 6e4, 1e6], 10 ** rng.uniform(-3, 6, 200)])
+    sino = rng.choice(rates, size=(S, A, P)).astype(np.float32)
+    sino[0, 0, :20] = -rng.random(20).astype(np.float32)                     # negatives are clamped to zero first
+    mask = (rng.random((S, A)) > 0.3).astype(np.float32) * rng.choice([1.0, 0.5, 1 / 20], size=(S, A)).astype(np.float32)
+    for pnm, seed in ((1.0, 0), (1e4, 2 ** 40 + 17)):
+        got = to_np(poisson_measure(torch.from_numpy(sino).to(d), torch.from_numpy(mask).to(d), pnm, seed))
+        np.testing.assert_array_equal(got, oracle.poisson_measure(sino, mask, pnm, seed))
+    # distribution on the device itself: 400k draws at one rate per decade
+    for lam in (0.3, 4.0, 25.0, 1e3, 5e4):
+        x = torch.full((1, 1, 400000), lam, device=d)
+        k = to_np(poisson_measure(x, torch.ones((1, 1), device=d), 1.0, 5))[0, 0].astype(np.float64)
+        assert abs(k.mean() - lam) <= 5 * np.sqrt(lam / k.size) and abs(k.var() / lam - 1) <= 0.02
+    # through create_all_masks: files written, measured angles only, counts are integers / pnm
+    sino_t = torch.from_numpy(np.abs(sino)).to(d)
+    masks, samples = create_all_masks(sino_t, A, save_path=str(tmp_path), poisson_noise_multiplier=1e3, num_sparse_angles=4,
+                                      random=True, train=True, truncate_dataset=5)
+    assert tuple(masks.shape) == (5, A) and tuple(samples.shape) == (5, A, P) and samples.device == sino_t.device
+    np.testing.assert_array_equal(to_np(samples), oracle.poisson_measure(np.abs(sino[:5]), to_np(masks), 1e3, 0))
+    assert float(samples[masks == 0].abs().max()) == 0.0
+    m2, s2 = create_all_masks(None, A, save_path=str(tmp_path), train=False, device=d)
+    assert torch.equal(m2, masks) and torch.equal(s2, samples)
+
+
 def test_backward_scale_operand_checks():
     d = dev()
     theta = np.linspace(0, np.pi, 6, endpoint=False)

@@ -369,3 +369,77 @@ def test_restatement_agrees_with_an_independent_resampler(oracle, golden_dir):
     assert err_bil <= 1e-5
     assert differing == int(z["nearest_differing_ray_sums"]) == 18 and err_near <= 5e-3
     assert err_grad <= 5e-5
+
+
+# ---- f2: the Poisson sampler's CPU twin -------------------------------------------------------------------------
+PHILOX_KAT = [  # Random123's published known answers for philox4x32-10 (counter, key) -> output
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def test_philox_known_answers(oracle):
+    """The generator under the Poisson sampler is Philox4x32-10: the oracle's rounds AND the library's host hook
+    reproduce the known-answer vectors published with the algorithm (Random123 kat_vectors)."""
+    import ctypes  # noqa: F401
+    from ct_pvae_amd import _lib
+    lib = _lib.load()
+    for ctr, key, want in PHILOX_KAT:
+        assert [int(v) for v in oracle.philox4x32_10(ctr, key)] == want
+        c, k, o = np.array(ctr, np.uint32), np.array(key, np.uint32), np.zeros(4, np.uint32)
+        assert lib.ctpvae_philox4x32_10(c.ctypes.data, k.ctypes.data, o.ctypes.data) == 0
+        assert [int(v) for v in o] == want
+
+
+def test_series_exp_and_log_match_libm(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    for x in np.concatenate([rng.uniform(1e-12, 1e9, 500), [1.0, 2.0, 0.5, 1e-10, math.sqrt(2), math.sqrt(0.5)]]):
+        assert abs(L.oracle_series_log_public(x) - math.log(x)) <= 4e-16 * max(abs(math.log(x)), 1.0)
+    for x in rng.uniform(-60, 0, 500):
+        assert abs(L.oracle_series_exp_neg_public(x) - math.exp(x)) <= 1e-15 * math.exp(x)
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.05, 0.7, 3.0, 9.99, 10.0, 37.0, 1e3, 1e4, 6e4, 1e6])
+def test_poisson_sampler_distribution(oracle, lam):
+    """Mean, variance and a chi-square goodness of fit against scipy's Poisson pmf, per rate decade -- rate 0, both sides
+    of the algorithm switch at 10, and the config-5 range (pnm = 1e4: rates up to ~6e4)."""
+    from scipy import stats
+    n = 60000
+    k = np.array([oracle.poisson_count(lam, e, 99) for e in range(n)])
+    assert (k == np.floor(k)).all() and k.min() >= 0
+    if lam == 0.0:
+        assert k.max() == 0
+        return
+    assert abs(k.mean() - lam) <= 5 * math.sqrt(lam / n)
+    assert abs(k.var() / lam - 1) <= 0.05
+    # chi-square over bins of >= ~50 expected counts
+    lo, hi = stats.poisson.ppf(1e-3, lam), stats.poisson.ppf(1 - 1e-3, lam)
+    edges = np.unique(np.round(np.linspace(lo, hi + 1, 25)))
+    cdf = stats.poisson.cdf(edges - 1, lam)
+    p = np.diff(np.concatenate([[0.0], cdf, [1.0]]))
+    obs = np.histogram(k, bins=np.concatenate([[-0.5], edges - 0.5, [np.inf]]))[0]
+    keep = p * n >= 20
+    chi2 = ((obs[keep] - p[keep] * n) ** 2 / (p[keep] * n)).sum()
+    assert chi2 <= stats.chi2.ppf(1 - 1e-4, keep.sum() - 1), (lam, chi2, keep.sum())
+
+
+def test_poisson_measure_model(oracle):
+    """oracle_poisson_measure = ctvae/create_masks.py:32,82,94-95: negatives to zero, dose mask, Poisson(rate * pnm) / pnm;
+    element streams are independent of the array's shape (counter = element index), different seeds differ."""
+    rng = np.random.default_rng(3)
+    sino = (rng.random((3, 6, 40)) * 8 - 0.5).astype(np.float32)
+    mask = np.zeros((3, 6), np.float32)
+    mask[:, ::2] = 0.5
+    out = oracle.poisson_measure(sino, mask, 1e2, 7)
+    assert out.shape == sino.shape and (out[:, 1::2] == 0).all() and (out >= 0).all()
+    counts = out * 1e2
+    np.testing.assert_allclose(counts, np.round(counts), atol=1e-3)
+    assert (out[sino < 0] == 0).all()
+    loc = np.maximum(sino, 0) * mask[..., None]
+    z = (out - loc)[loc > 0] / np.sqrt(loc[loc > 0] / 1e2)
+    assert abs(z.mean()) < 0.25 and 0.8 < z.std() < 1.2
+    # the stream of an element depends on its flat index only: the same data viewed as one object of 18 angles
+    np.testing.assert_array_equal(out.reshape(-1), oracle.poisson_measure(sino.reshape(1, 18, 40), mask.reshape(1, 18), 1e2, 7).reshape(-1))
+    assert not np.array_equal(out, oracle.poisson_measure(sino, mask, 1e2, 8))
