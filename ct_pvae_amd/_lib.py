@@ -59,8 +59,13 @@ SIGNATURES = {
     "ctpvae_siddon_tables_f32": (_c_int, [_vp, _c_int, _vp, _vp, _vp]),
     "ctpvae_siddon_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp,
                                        _vp]),
+    "ctpvae_siddon_bwd_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_siddon_bwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp]),
+    "ctpvae_siddon_rownorm_f32": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp]),
     "ctpvae_fbp_filter_f64": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp]),
     "ctpvae_fbp_backproject_f64": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_fbp_backproject_geom_f64": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, ctypes.c_double,
+                                                 ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "ctpvae_loglik_fwd_f32": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_float, _vp, _vp]),
     "ctpvae_poisson_measure_f32": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_float, ctypes.c_ulonglong, _vp, _vp]),
     "ctpvae_philox4x32_10": (_c_int, [_vp, _vp, _vp]),

@@ -56,14 +56,17 @@ __device__ __forceinline__ double interp_regular_1d(const double *__restrict__ y
 __global__ __launch_bounds__(256) void fbp_backproject_kernel(const double *__restrict__ filt, int B, int A,
                                                               int P, const double *__restrict__ cos_t,
                                                               const double *__restrict__ sin_t, int X, int Y,
+                                                              double x0, double y0, double t0,
                                                               double *__restrict__ recon)
 {
+    // pixel (i, j) sits at (i - x0, j - y0); detector sample k at k - t0.  The reference's iradon
+    // (ctvae/fbp_tensorflow.py:52-70): x0 = X / 2, y0 = Y / 2, t0 = P / 2.
     const int b = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= X * Y) return;
     const int i = p / Y, j = p - i * Y;
-    const double xpr = (double)i - X / 2.0, ypr = (double)j - Y / 2.0;
-    const double x_min = 0.0 - P / 2.0, x_max = (double)(P - 1) - P / 2.0;
+    const double xpr = (double)i - x0, ypr = (double)j - y0;
+    const double x_min = 0.0 - t0, x_max = (double)(P - 1) - t0;
     const double *f = filt + (size_t)b * A * P;
     double acc = 0.0;
     for (int a = 0; a < A; ++a) {
@@ -95,6 +98,13 @@ int ctpvae_fbp_filter_f64(const double *sino_dev, int R, int P, const double *hk
 int ctpvae_fbp_backproject_f64(const double *filt_dev, int B, int A, int P, const double *cos_dev,
                                const double *sin_dev, int X, int Y, double *recon_dev, ctpvae_stream_t stream)
 {
+    return ctpvae_fbp_backproject_geom_f64(filt_dev, B, A, P, cos_dev, sin_dev, X, Y, X / 2.0, Y / 2.0, P / 2.0, recon_dev, stream);
+}
+
+int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P, const double *cos_dev,
+                                    const double *sin_dev, int X, int Y, double x0, double y0, double t0,
+                                    double *recon_dev, ctpvae_stream_t stream)
+{
     CTPVAE_REQUIRE(filt_dev && cos_dev && sin_dev && recon_dev, "fbp_backproject: null pointer");
     CTPVAE_REQUIRE(B > 0 && A > 0 && P > 1 && X > 0 && Y > 0,
                    "fbp_backproject: bad sizes (B=%d A=%d P=%d X=%d Y=%d)", B, A, P, X, Y);
@@ -102,7 +112,8 @@ int ctpvae_fbp_backproject_f64(const double *filt_dev, int B, int A, int P, cons
     for (int b0 = 0; b0 < B; b0 += chunk) {   // sinograms are indexed with a grid dimension: longer batches go in chunks
         const int n = B - b0 < chunk ? B - b0 : chunk;
         hipLaunchKernelGGL(fbp_backproject_kernel, dim3(ceil_div(X * Y, 256), n), dim3(256), 0, (hipStream_t)stream,
-                           filt_dev + (size_t)b0 * A * P, n, A, P, cos_dev, sin_dev, X, Y, recon_dev + (size_t)b0 * X * Y);
+                           filt_dev + (size_t)b0 * A * P, n, A, P, cos_dev, sin_dev, X, Y, x0, y0, t0,
+                           recon_dev + (size_t)b0 * X * Y);
         CTPVAE_LAUNCH_CHECK("fbp_backproject_kernel");
     }
     return CTPVAE_OK;

@@ -21,6 +21,114 @@ struct SidGeom {
     float mov;
 };
 
+// One ray of libtomo's project(): calc_coords -> trim_coords -> sort_intersections -> calc_dist, as a walk with two cursors
+// (no per-ray arrays).  `segment(ix, iy, dist)` is called for every segment n = 0 .. csize-2 in libtomo's order with the pixel
+// its midpoint falls in and its length -- the forward projector adds model[pixel] * dist, the back-projector adds
+// data * dist into the pixel, SIRT's row norm adds dist * dist: the SAME fp32 expressions in all three, so the
+// back-projector is the forward's transpose by construction.
+template <class F>
+__device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, float cos_p, int quadrant, int d, F &&segment)
+{
+    const int ox = g.ox, oz = g.oz;
+    const float gx0 = -ox * 0.5f, gy0 = -oz * 0.5f;  // gridx[n] = gx0 + n, gridy[n] = gy0 + n
+    const float gx_gt = gx0 + 0.01f, gx_le = (gx0 + ox) - 0.01f;
+    const float gy_gt = gy0 + 0.01f, gy_le = (gy0 + oz) - 0.01f;
+    const float hx = ox * 0.5f, hz = oz * 0.5f;
+    const float xi = (float)(-ox - oz);
+    const float yi = (1 - g.dx) / 2.0f + d + g.mov;
+    const float srcx = xi * cos_p - yi * sin_p, srcy = xi * sin_p + yi * cos_p;
+    const float detx = -xi * cos_p - yi * sin_p, dety = -xi * sin_p + yi * cos_p;
+    const float slope = (srcy - dety) / (srcx - detx);
+    const float islope = (srcx - detx) / (srcy - dety);
+
+    // list a: crossings with y = gridy[n], x = coordx(n) = islope * (gridy[n] - srcy) + srcx, kept iff
+    // gx_gt <= x <= gx_le; list b: crossings with x = gridx[n], y = coordy(n), kept iff gy_gt <= y <= gy_le.
+    // Every fp32 step of coord(n) is monotone in n, so the kept n form one contiguous run whose ends are found by
+    // bisection on the SAME expression (libtomo scans all n; same set).  A non-finite slope (a ray exactly along
+    // a grid direction) keeps the scan.
+    int a_lo = 0, a_cnt = 0, b_lo = 0, b_cnt = 0;
+    auto kept_run = [](float sl, float g0, float src_u, float src_v, float lo, float hi, int N, int &first, int &cnt) {
+        auto coord = [&](int n) { return sl * ((g0 + n) - src_u) + src_v; };
+        first = 0;
+        cnt = 0;
+        if (!(fabsf(sl) <= 3.0e38f)) {   // inf / NaN
+            for (int n = 0; n <= N; ++n) {
+                const float c = coord(n);
+                if (c >= lo && c <= hi) {
+                    if (cnt == 0) first = n;
+                    ++cnt;
+                }
+            }
+            return;
+        }
+        const bool inc = coord(0) <= coord(N);
+        // smallest n whose coordinate has entered [lo, hi] from its low side, smallest n that has left it
+        int l = 0, r = N + 1;      // first n with  (inc ? c >= lo : c <= hi)
+        while (l < r) {
+            const int m = (l + r) >> 1;
+            const float c = coord(m);
+            if (inc ? c >= lo : c <= hi) r = m; else l = m + 1;
+        }
+        const int n_in = l;
+        l = n_in, r = N + 1;       // first n >= n_in with (inc ? c > hi : c < lo)
+        while (l < r) {
+            const int m = (l + r) >> 1;
+            const float c = coord(m);
+            if (inc ? c > hi : c < lo) r = m; else l = m + 1;
+        }
+        first = n_in;
+        cnt = l - n_in;
+    };
+    kept_run(islope, gy0, srcy, srcx, gx_gt, gx_le, oz, a_lo, a_cnt);
+    kept_run(slope, gx0, srcx, srcy, gy_gt, gy_le, ox, b_lo, b_cnt);
+    const int csize = a_cnt + b_cnt;
+    // The merge of libtomo's two sorted lists, with two cursors.  List a runs over its kept n upwards in
+    // quadrant 1 and downwards otherwise; gridy[n] = gy0 + n is exact in fp32, so a running +-1.0f gives the same
+    // values as int -> float.  An exhausted list shows +inf as its key: "a_key < b_key" then reproduces
+    // sort_intersections' choice (a first only if strictly smaller; the other list once one has run out).
+    const float kInf = __builtin_inff();
+    const float da = quadrant ? 1.0f : -1.0f;
+    float a_y = gy0 + (float)(quadrant ? a_lo : a_lo + a_cnt - 1);
+    float a_x = islope * (a_y - srcy) + srcx;
+    float a_key = a_cnt > 0 ? a_x : kInf;
+    int a_rem = a_cnt;
+    float b_x = gx0 + (float)b_lo;
+    float b_y = slope * (b_x - srcx) + srcy;
+    float b_key = b_cnt > 0 ? b_x : kInf;
+    int b_rem = b_cnt;
+    float px_prev = 0.0f, py_prev = 0.0f;
+    for (int k = 0; k < csize; ++k) {
+        const bool take_a = a_key < b_key;
+        const float cx = take_a ? a_x : b_x;
+        const float cy = take_a ? a_y : b_y;
+        {   // advance the list that was taken (selects, not a branch: the lanes of a wave disagree all the time)
+            const float na_y = a_y + da, na_x = islope * (na_y - srcy) + srcx;
+            const float nb_x = b_x + 1.0f, nb_y = slope * (nb_x - srcx) + srcy;
+            const int na_rem = a_rem - 1, nb_rem = b_rem - 1;
+            const float na_key = na_rem > 0 ? na_x : kInf, nb_key = nb_rem > 0 ? nb_x : kInf;
+            a_y = take_a ? na_y : a_y;
+            a_x = take_a ? na_x : a_x;
+            a_key = take_a ? na_key : a_key;
+            a_rem = take_a ? na_rem : a_rem;
+            b_x = take_a ? b_x : nb_x;
+            b_y = take_a ? b_y : nb_y;
+            b_key = take_a ? b_key : nb_key;
+            b_rem = take_a ? b_rem : nb_rem;
+        }
+        if (k > 0) {
+            const float diffx = cx - px_prev, diffy = cy - py_prev;
+            const float dist = sqrtf(diffx * diffx + diffy * diffy);
+            const float midx = (cx + px_prev) * 0.5f, midy = (cy + py_prev) * 0.5f;
+            // libtomo: i1 = (int)x1; indx = i1 - (i1 > x1)  ==  floor(x1)
+            const int indx = (int)floorf(midx + hx), indy = (int)floorf(midy + hz);
+            // libtomo reads model[indy + indx*oz] unchecked; midpoints lie strictly inside the grid
+            segment(min(max(indx, 0), ox - 1), min(max(indy, 0), oz - 1), dist);
+        }
+        px_prev = cx;
+        py_prev = cy;
+    }
+}
+
 // NS = 2: two slices per workgroup, interleaved as float2 in LDS -- the crossings, segment lengths and pixel indices of
 // a ray depend on the geometry only, so one walk serves both slices (the loop is VALU-bound on exactly that arithmetic).
 typedef float sid_f32x2 __attribute__((ext_vector_type(2)));
@@ -52,118 +160,20 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
         }
         __syncthreads();
     }
-    const int ox = g.ox, oz = g.oz;
-    const float gx0 = -ox * 0.5f, gy0 = -oz * 0.5f;  // gridx[n] = gx0 + n, gridy[n] = gy0 + n
-    const float gx_gt = gx0 + 0.01f, gx_le = (gx0 + ox) - 0.01f;
-    const float gy_gt = gy0 + 0.01f, gy_le = (gy0 + oz) - 0.01f;
-    const float hx = ox * 0.5f, hz = oz * 0.5f;
-
+    const int oz = g.oz;
     for (int ray = threadIdx.x; ray < np * g.dx; ray += blockDim.x) {
         const int pl = ray / g.dx;
         const int d = ray - pl * g.dx;
         const int p = p0 + pl;
-        const float sin_p = sin_t[p], cos_p = cos_t[p];
-        const int quadrant = quad_t[p];
-        const float xi = (float)(-ox - oz);
-        const float yi = (1 - g.dx) / 2.0f + d + g.mov;
-        const float srcx = xi * cos_p - yi * sin_p, srcy = xi * sin_p + yi * cos_p;
-        const float detx = -xi * cos_p - yi * sin_p, dety = -xi * sin_p + yi * cos_p;
-        const float slope = (srcy - dety) / (srcx - detx);
-        const float islope = (srcx - detx) / (srcy - dety);
-
-        // list a: crossings with y = gridy[n], x = coordx(n) = islope * (gridy[n] - srcy) + srcx, kept iff
-        // gx_gt <= x <= gx_le; list b: crossings with x = gridx[n], y = coordy(n), kept iff gy_gt <= y <= gy_le.
-        // Every fp32 step of coord(n) is monotone in n, so the kept n form one contiguous run whose ends are found by
-        // bisection on the SAME expression (libtomo scans all n; same set).  A non-finite slope (a ray exactly along
-        // a grid direction) keeps the scan.
-        int a_lo = 0, a_cnt = 0, b_lo = 0, b_cnt = 0;
-        auto kept_run = [](float sl, float g0, float src_u, float src_v, float lo, float hi, int N, int &first, int &cnt) {
-            auto coord = [&](int n) { return sl * ((g0 + n) - src_u) + src_v; };
-            first = 0;
-            cnt = 0;
-            if (!(fabsf(sl) <= 3.0e38f)) {   // inf / NaN
-                for (int n = 0; n <= N; ++n) {
-                    const float c = coord(n);
-                    if (c >= lo && c <= hi) {
-                        if (cnt == 0) first = n;
-                        ++cnt;
-                    }
-                }
-                return;
-            }
-            const bool inc = coord(0) <= coord(N);
-            // smallest n whose coordinate has entered [lo, hi] from its low side, smallest n that has left it
-            int l = 0, r = N + 1;      // first n with  (inc ? c >= lo : c <= hi)
-            while (l < r) {
-                const int m = (l + r) >> 1;
-                const float c = coord(m);
-                if (inc ? c >= lo : c <= hi) r = m; else l = m + 1;
-            }
-            const int n_in = l;
-            l = n_in, r = N + 1;       // first n >= n_in with (inc ? c > hi : c < lo)
-            while (l < r) {
-                const int m = (l + r) >> 1;
-                const float c = coord(m);
-                if (inc ? c > hi : c < lo) r = m; else l = m + 1;
-            }
-            first = n_in;
-            cnt = l - n_in;
-        };
-        kept_run(islope, gy0, srcy, srcx, gx_gt, gx_le, oz, a_lo, a_cnt);
-        kept_run(slope, gx0, srcx, srcy, gy_gt, gy_le, ox, b_lo, b_cnt);
-        const int csize = a_cnt + b_cnt;
         vec_t acc = 0.0f;
-        // The merge of libtomo's two sorted lists, with two cursors.  List a runs over its kept n upwards in
-        // quadrant 1 and downwards otherwise; gridy[n] = gy0 + n is exact in fp32, so a running +-1.0f gives the same
-        // values as int -> float.  An exhausted list shows +inf as its key: "a_key < b_key" then reproduces
-        // sort_intersections' choice (a first only if strictly smaller; the other list once one has run out).
-        const float kInf = __builtin_inff();
-        const float da = quadrant ? 1.0f : -1.0f;
-        float a_y = gy0 + (float)(quadrant ? a_lo : a_lo + a_cnt - 1);
-        float a_x = islope * (a_y - srcy) + srcx;
-        float a_key = a_cnt > 0 ? a_x : kInf;
-        int a_rem = a_cnt;
-        float b_x = gx0 + (float)b_lo;
-        float b_y = slope * (b_x - srcx) + srcy;
-        float b_key = b_cnt > 0 ? b_x : kInf;
-        int b_rem = b_cnt;
-        float px_prev = 0.0f, py_prev = 0.0f;
-        for (int k = 0; k < csize; ++k) {
-            const bool take_a = a_key < b_key;
-            const float cx = take_a ? a_x : b_x;
-            const float cy = take_a ? a_y : b_y;
-            {   // advance the list that was taken (selects, not a branch: the lanes of a wave disagree all the time)
-                const float na_y = a_y + da, na_x = islope * (na_y - srcy) + srcx;
-                const float nb_x = b_x + 1.0f, nb_y = slope * (nb_x - srcx) + srcy;
-                const int na_rem = a_rem - 1, nb_rem = b_rem - 1;
-                const float na_key = na_rem > 0 ? na_x : kInf, nb_key = nb_rem > 0 ? nb_x : kInf;
-                a_y = take_a ? na_y : a_y;
-                a_x = take_a ? na_x : a_x;
-                a_key = take_a ? na_key : a_key;
-                a_rem = take_a ? na_rem : a_rem;
-                b_x = take_a ? b_x : nb_x;
-                b_y = take_a ? b_y : nb_y;
-                b_key = take_a ? b_key : nb_key;
-                b_rem = take_a ? b_rem : nb_rem;
-            }
-            if (k > 0) {
-                const float diffx = cx - px_prev, diffy = cy - py_prev;
-                const float dist = sqrtf(diffx * diffx + diffy * diffy);
-                const float midx = (cx + px_prev) * 0.5f, midy = (cy + py_prev) * 0.5f;
-                // libtomo: i1 = (int)x1; indx = i1 - (i1 > x1)  ==  floor(x1)
-                const int indx = (int)floorf(midx + hx), indy = (int)floorf(midy + hz);
-                // libtomo reads model[indy + indx*oz] unchecked; midpoints lie strictly inside the grid
-                const int ix = min(max(indx, 0), ox - 1), iy = min(max(indy, 0), oz - 1);
-                vec_t m;
-                if constexpr (NS == 1)
-                    m = USE_LDS ? lds[ix * pitch + iy] : model_g[(size_t)ix * oz + iy];
-                else
-                    m = reinterpret_cast<const vec_t *>(lds)[ix * pitch + iy];
-                acc += m * dist;
-            }
-            px_prev = cx;
-            py_prev = cy;
-        }
+        siddon_walk_ray(g, sin_t[p], cos_t[p], quad_t[p], d, [&](int ix, int iy, float dist) {
+            vec_t m;
+            if constexpr (NS == 1)
+                m = USE_LDS ? lds[ix * pitch + iy] : model_g[(size_t)ix * oz + iy];
+            else
+                m = reinterpret_cast<const vec_t *>(lds)[ix * pitch + iy];
+            acc += m * dist;
+        });
         if constexpr (NS == 1) {
             data[((size_t)s * g.dt + p) * g.dx + d] = acc;
         } else {
@@ -171,6 +181,76 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
             if (has2) data[((size_t)(s + 1) * g.dt + p) * g.dx + d] = acc.y;
         }
     }
+}
+
+// Back-projector: the transpose of the forward, recon[s][pixel] = sum over rays of data[s][p][d] * dist(p, d, pixel) -- what
+// libtomo's fbp.c accumulates (recon[indi[n]] += data[ind_data] * dist[n]) and the A^T of sirt.c's update.  Atomic-free
+// and bit-reproducible: a workgroup owns one slice and a group of angles; lane = ray.  Two rays of the SAME parity of d
+// are two detector pitches apart, further than a pixel's diagonal, so they never add into the same pixel: per angle the
+// even rays add (plain read-add-write into the workgroup's image: LDS when the slice fits, the partial image in global
+// memory otherwise), a barrier, then the odd rays, a barrier.  Every pixel therefore receives its terms in a fixed order
+// (angles ascending; even ray before odd ray) whatever the launch; angle groups write partial images that
+// siddon_reduce_groups_kernel adds in ascending group order.  Rays whose datum is 0 are skipped (x + 0 * dist == x): the
+// sparse sinograms and dose masks this is fed (ctvae/helper_functions.py:489-516) are zero at most angles.
+template <bool USE_LDS>
+__global__ __launch_bounds__(1024) void siddon_bwd_kernel(const float *__restrict__ data, SidGeom g,
+                                                         const float *__restrict__ sin_t, const float *__restrict__ cos_t,
+                                                         const int *__restrict__ quad_t, int p_per_grp, int n_grp,
+                                                         float *__restrict__ partial)
+{
+    extern __shared__ float lds[];
+    const int s = blockIdx.y, grp = blockIdx.x;
+    const int p0 = grp * p_per_grp;
+    const int np = min(p_per_grp, g.dt - p0);
+    const int npix = g.ox * g.oz;
+    float *out = partial + ((size_t)s * n_grp + grp) * npix;
+    const int pitch = USE_LDS ? g.oz + ((1 - (g.oz & 31)) & 31) : g.oz;
+    float *img = USE_LDS ? lds : out;
+    for (int t = threadIdx.x; t < g.ox * pitch; t += blockDim.x) img[t] = 0.0f;
+    __syncthreads();
+    const float *row = data + ((size_t)s * g.dt + p0) * g.dx;
+    for (int pl = 0; pl < np; ++pl, row += g.dx) {
+        const int p = p0 + pl;
+        const float sin_p = sin_t[p], cos_p = cos_t[p];
+        const int quadrant = quad_t[p];
+#pragma unroll 1
+        for (int par = 0; par < 2; ++par) {
+            for (int d = 2 * (int)threadIdx.x + par; d < g.dx; d += 2 * blockDim.x) {
+                const float v = row[d];
+                if (v != 0.0f)
+                    siddon_walk_ray(g, sin_p, cos_p, quadrant, d,
+                                    [&](int ix, int iy, float dist) { img[ix * pitch + iy] += v * dist; });
+            }
+            __syncthreads();   // (workgroup-scope release / acquire of the image, LDS or global)
+        }
+    }
+    if (USE_LDS)
+        for (int t = threadIdx.x; t < npix; t += blockDim.x) out[t] = lds[(t / g.oz) * pitch + (t % g.oz)];
+}
+
+// recon[s][pix] = sum over angle groups, ascending
+__global__ __launch_bounds__(256) void siddon_reduce_groups_kernel(const float *__restrict__ partial, int n_grp, long long npix,
+                                                                  long long total, float *__restrict__ recon)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long s = e / npix, q = e - s * npix;
+        float acc = 0.0f;
+        for (int gq = 0; gq < n_grp; ++gq) acc += partial[(s * n_grp + gq) * npix + q];
+        recon[e] = acc;
+    }
+}
+
+// SIRT's row weights (libtomo sirt.c: sum_dist2 = sum of dist[n]^2 over a ray's segments): geometry only, [dt][dx]
+__global__ __launch_bounds__(256) void siddon_rownorm_kernel(SidGeom g, const float *__restrict__ sin_t,
+                                                            const float *__restrict__ cos_t, const int *__restrict__ quad_t,
+                                                            float *__restrict__ rn2)
+{
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= g.dt * g.dx) return;
+    const int p = ray / g.dx, d = ray - p * g.dx;
+    float acc = 0.0f;
+    siddon_walk_ray(g, sin_t[p], cos_t[p], quad_t[p], d, [&](int, int, float dist) { acc += dist * dist; });
+    rn2[ray] = acc;
 }
 
 }  // namespace ctpvae
@@ -209,6 +289,7 @@ int ctpvae_siddon_tables_f32(const float *theta, int dt, float *sin_out, float *
 static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
                           const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
                           float *data_dev, ctpvae_stream_t stream);
+static float siddon_mov(int dx, float center);
 
 // slices are indexed with a grid dimension (<= 65535): a longer stack goes in chunks, back to back on the stream
 int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
@@ -234,11 +315,7 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
     CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
                    "siddon_fwd: sizes must be positive (oy=%d ox=%d oz=%d dt=%d dx=%d)", oy, ox, oz, dt, dx);
     CTPVAE_REQUIRE(oy <= 65535, "siddon_fwd: at most 65535 slices per call (got %d)", oy);
-    // utils.c preprocessing(): detector shift
-    float mov = ((float)dx - 1) * 0.5f - center;
-    if (mov - std::floor(mov) < 0.01f) mov += 0.01f;
-    mov += 0.5f;
-    const SidGeom g{oy, ox, oz, dt, dx, mov};
+    const SidGeom g{oy, ox, oz, dt, dx, siddon_mov(dx, center)};
     const size_t lds_one = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
     const bool use_lds = lds_one <= (size_t)kMaxLdsBytes;
     // two slices per workgroup when the pair fits LDS and the call has slices to pair
@@ -265,6 +342,84 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
     };
     if (!use_lds) return launch(siddon_fwd_kernel<false, 1>, 0);
     return ns == 2 ? launch(siddon_fwd_kernel<true, 2>, lds_bytes) : launch(siddon_fwd_kernel<true, 1>, lds_bytes);
+}
+
+// ---- back-projector (transpose) and SIRT row weights -----------------------------------------------------------
+static float siddon_mov(int dx, float center)
+{
+    float mov = ((float)dx - 1) * 0.5f - center;   // utils.c preprocessing(): detector shift
+    if (mov - std::floor(mov) < 0.01f) mov += 0.01f;
+    return mov + 0.5f;
+}
+
+// angle groups per slice: enough workgroups to fill the chip (~512), at least 4 angles each
+static int siddon_bwd_groups(int oy, int dt)
+{
+    const int want = ceil_div(512, std::max(1, oy));
+    return std::max(1, std::min(want, ceil_div(dt, 4)));
+}
+
+long long ctpvae_siddon_bwd_workspace_bytes(int oy, int ox, int oz, int dt)
+{
+    if (oy <= 0 || ox <= 0 || oz <= 0 || dt <= 0) return fail(CTPVAE_EINVAL, "siddon_bwd_workspace_bytes: bad sizes");
+    const int n_grp = siddon_bwd_groups(std::min(oy, 65535), dt);
+    return n_grp > 1 ? (long long)std::min(oy, 65535) * n_grp * ox * oz * (long long)sizeof(float) : 0;
+}
+
+int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                          const int *quad_dev, int dt, int dx, float center, void *workspace_dev, float *recon_dev,
+                          ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(data_dev && sin_dev && cos_dev && quad_dev && recon_dev, "siddon_bwd: null pointer");
+    CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
+                   "siddon_bwd: sizes must be positive (oy=%d ox=%d oz=%d dt=%d dx=%d)", oy, ox, oz, dt, dx);
+    const int chunk = std::min(65535, max_slices_per_launch());
+    const SidGeom g0{0, ox, oz, dt, dx, siddon_mov(dx, center)};
+    const size_t lds_bytes = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
+    const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
+    int threads = std::min(1024, ceil_div(ceil_div(dx, 2), 64) * 64);
+    if (knob(kKnobSiddonBwdThreads) > 0) threads = std::max(64, std::min(1024, knob(kKnobSiddonBwdThreads) / 64 * 64));
+    const long long npix = (long long)ox * oz;
+    for (int s0 = 0; s0 < oy; s0 += chunk) {
+        const int n = std::min(chunk, oy - s0);
+        const int n_grp = siddon_bwd_groups(std::min(oy, 65535), dt);   // one rule for every chunk: the workspace was sized with it
+        CTPVAE_REQUIRE(n_grp == 1 || workspace_dev, "siddon_bwd: %d angle groups need the workspace", n_grp);
+        const int p_per_grp = ceil_div(dt, n_grp);
+        const int groups = ceil_div(dt, p_per_grp);
+        SidGeom g = g0;
+        g.oy = n;
+        float *partial = groups > 1 ? (float *)workspace_dev : recon_dev + (size_t)s0 * npix;
+        const float *data = data_dev + (size_t)s0 * dt * dx;
+        auto launch = [&](auto kernel, size_t shmem) -> int {
+            static std::atomic<unsigned long long> attr_set{0};
+            if (shmem > 64 * 1024) CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
+            hipLaunchKernelGGL(kernel, dim3(groups, n), dim3(threads), shmem, (hipStream_t)stream, data, g, sin_dev, cos_dev,
+                               quad_dev, p_per_grp, groups, partial);
+            CTPVAE_LAUNCH_CHECK("siddon_bwd_kernel");
+            return CTPVAE_OK;
+        };
+        if (int rc = use_lds ? launch(siddon_bwd_kernel<true>, lds_bytes) : launch(siddon_bwd_kernel<false>, 0)) return rc;
+        if (groups > 1) {
+            const long long total = (long long)n * npix;
+            const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256ll * 32);
+            hipLaunchKernelGGL(siddon_reduce_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, groups, npix,
+                               total, recon_dev + (size_t)s0 * npix);
+            CTPVAE_LAUNCH_CHECK("siddon_reduce_groups_kernel");
+        }
+    }
+    return CTPVAE_OK;
+}
+
+int ctpvae_siddon_rownorm_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt, int dx,
+                              float center, float *rn2_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(sin_dev && cos_dev && quad_dev && rn2_dev, "siddon_rownorm: null pointer");
+    CTPVAE_REQUIRE(ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_rownorm: sizes must be positive");
+    const SidGeom g{1, ox, oz, dt, dx, siddon_mov(dx, center)};
+    hipLaunchKernelGGL(siddon_rownorm_kernel, dim3(ceil_div(dt * dx, 256)), dim3(256), 0, (hipStream_t)stream, g, sin_dev,
+                       cos_dev, quad_dev, rn2_dev);
+    CTPVAE_LAUNCH_CHECK("siddon_rownorm_kernel");
+    return CTPVAE_OK;
 }
 
 }  // extern "C"

@@ -29,8 +29,12 @@ def _cached(key, make):
     return val
 
 
-def iradon(sinogram, theta, x_size, y_size, filter_1d):
-    """sinogram [batch][angles][num_proj_pix] -> reconstruction [batch][x_size][y_size] (float64)."""
+def iradon(sinogram, theta, x_size, y_size, filter_1d, *, tomopy_geometry=False):
+    """sinogram [batch][angles][num_proj_pix] -> reconstruction [batch][x_size][y_size] (float64).
+
+    tomopy_geometry (keyword-only extension): sample the sinogram on tomopy's ray-driven grid -- pixel centres at half-
+    integers, detector bin d at d - (P - 1) / 2 -- instead of the reference iradon's (pixel i at i - X / 2, sample k at
+    k - P / 2): the right geometry for sinograms made by create_sinogram / tomopy.project."""
     lib = _lib.load()
     if not isinstance(sinogram, torch.Tensor) or sinogram.device.type != "cuda":
         raise _lib.RadonLibraryError("iradon expects a sinogram tensor on a HIP device; there is no CPU path")
@@ -66,9 +70,10 @@ def iradon(sinogram, theta, x_size, y_size, filter_1d):
     with torch.cuda.device(dev):
         _lib.check(lib.ctpvae_fbp_filter_f64(sino.data_ptr(), B * A, P, hker.data_ptr(), filtered.data_ptr(),
                                              _stream_ptr()), "fbp_filter")
-        _lib.check(lib.ctpvae_fbp_backproject_f64(filtered.data_ptr(), B, A, P, cos_t.data_ptr(), sin_t.data_ptr(),
-                                                  int(x_size), int(y_size), recon.data_ptr(), _stream_ptr()),
-                   "fbp_backproject")
+        X, Y = int(x_size), int(y_size)
+        x0, y0, t0 = ((X - 1) / 2.0, (Y - 1) / 2.0, (P - 1) / 2.0) if tomopy_geometry else (X / 2.0, Y / 2.0, P / 2.0)
+        _lib.check(lib.ctpvae_fbp_backproject_geom_f64(filtered.data_ptr(), B, A, P, cos_t.data_ptr(), sin_t.data_ptr(), X, Y,
+                                                       x0, y0, t0, recon.data_ptr(), _stream_ptr()), "fbp_backproject")
     return recon
 
 
@@ -89,25 +94,25 @@ def ramp_filter(P):
 def iradon_all(all_proj_samples, all_masks, num_proj_pix, theta, algorithms, sqrt_reg, x_size, y_size, save_path=None,
                train=False, **kwargs):
     """Initial reconstructions that feed the encoder (ctvae/helper_functions.py:477-529): one channel per entry of
-    `algorithms` from the dose-normalised sparse sinogram, plus the unfiltered back-projection of the mask.
-
-    The reference calls tomopy.recon (CPU) per algorithm; this build has the GPU filtered back-projection only, so
-    every entry of `algorithms` must be "fbp" (ramp filter, the reference's own iradon alternative at :507-510) --
-    gridrec / SIRT / TV are outside the projector path.  Returns [n][x_size][y_size][len(algorithms) + 1] float32 on
-    the sinograms' device and, like the reference, writes / reads ``all_input_encode.npy`` under `save_path`."""
+    `algorithms` -- tomopy.recon(proj_sample_expand, theta, center=None, sinogram_order=True, algorithm=...) cropped to
+    x_size x y_size (:503-505) -- plus the un-filtered back-projection of the dose mask (algorithm='fbp',
+    filter_name='none', :514-515).  The reconstructions run on the GPU (ct_pvae_amd/recon.py: 'fbp', 'sirt' on the
+    TomoPy-style operator pair, 'gridrec' as ramp-filtered back-projection on the same grid; 'tv' is not built).
+    Returns [n][x_size][y_size][len(algorithms) + 1] float32 on the sinograms' device and, like the reference, writes /
+    reads ``all_input_encode.npy`` under `save_path`."""
     import os
+    from .recon import crop, recon
     if not train:
         arr = np.load(os.path.join(save_path, "all_input_encode.npy"))
         dev = all_proj_samples.device if isinstance(all_proj_samples, torch.Tensor) else torch.device("cuda", 0)
         return torch.from_numpy(np.asarray(arr, np.float32)).to(dev)
-    for alg in algorithms:
-        if alg != "fbp":
-            raise NotImplementedError(f"iradon_all: algorithm {alg!r} is not part of this build (GPU 'fbp' only)")
     P = int(num_proj_pix)
     mask_expand = all_masks[..., None].expand(-1, -1, P)
     expand = torch.where(mask_expand > sqrt_reg, all_proj_samples / mask_expand.clamp_min(1e-30), all_proj_samples)
-    chans = [iradon(expand.contiguous(), theta, x_size, y_size, ramp_filter(P)) for _ in algorithms]
-    chans.append(iradon(mask_expand.contiguous(), theta, x_size, y_size, np.ones(P)))   # filter_name='none'
+    chans = [crop(recon(expand.contiguous(), theta, center=None, sinogram_order=True, algorithm=alg), x_size, y_size,
+                  ignore_dim_0=True) for alg in algorithms]
+    chans.append(crop(recon(mask_expand.contiguous(), theta, center=None, sinogram_order=True, algorithm="fbp",
+                            filter_name="none"), x_size, y_size, ignore_dim_0=True))
     out = torch.stack(chans, dim=-1).to(torch.float32)
     if save_path is not None:
         os.makedirs(save_path, exist_ok=True)

@@ -1,0 +1,152 @@
+"""Initial reconstructions on the GPU: the `tomopy.recon` calls of CT_PVAE's setup path.
+
+The reference makes the encoder's input channels with TomoPy on the CPU (ctvae/helper_functions.py:477-529):
+
+    tomopy.recon(proj_sample_expand, theta, center=None, sinogram_order=True, algorithm=algorithm)       # :503, per algorithm
+    tomopy.recon(mask_expand, theta, center=None, sinogram_order=True, algorithm='fbp', filter_name='none')   # :514
+
+with `algorithm` one of 'gridrec' (the default, ctvae/main_ct_vae.py:111-112), 'sirt', 'tv', 'fbp' (README.md:80,221).
+Here `recon` takes the same arguments and runs on the hand-written kernels behind include/ctpvae_radon.h:
+
+    'fbp'      libtomo's fbp.c: the ray-driven back-projection of the sinogram = the TRANSPOSE of tomopy.project
+               (ctpvae_siddon_bwd_f32), after an optional row filter; 'none' (tomopy's default filter_name) is what the
+               reference asks for the mask channel.  [3P-recalled: TomoPy 1.11.0]
+    'sirt'     libtomo's sirt.c update rule on the same operator pair (ctpvae_siddon_fwd_f32 / _bwd_f32 / _rownorm_f32):
+               recon += (A^T ((data - A recon) / sum_dist2)) / sum_dist, tomopy's defaults num_iter=1, init 1e-6.
+    'gridrec'  STAND-IN, flagged: gridrec is a Fourier-gridding inversion (gridrec.c: PSWF convolution kernel, 2-D FFT) of
+               which only the operator it approximates -- ramp-filtered back-projection, filter_name 'none' = plain ramp -- is
+               restated here, as the float64 FBP of csrc/fbp.hip on the same grid.  Same reconstruction up to discretisation;
+               not TomoPy's bits.
+    'tv'       not built (tv.c's Chambolle-Pock normalisation is not restated): raises NotImplementedError.
+
+Grid and centre follow tomopy: num_gridx = num_gridy = detector width, center = width / 2; callers crop
+(ctvae/helper_functions.py:420-430, `crop`).  There is no CPU path."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .fbp import iradon, ramp_filter
+from .forward_functions import _stream_ptr
+from .helper_functions import _siddon_tables
+
+__all__ = ["recon", "siddon_backproject", "crop", "ALGORITHMS"]
+
+ALGORITHMS = ("fbp", "sirt", "gridrec")
+
+
+def crop(img, final_x, final_y, ignore_dim_0=False):
+    """ctvae/helper_functions.py:420-430 (works on tensors and arrays alike)."""
+    x, y = img.shape[-2], img.shape[-1]
+    rx, ry = final_x % 2, final_y % 2
+    sl = (slice(x // 2 - final_x // 2, x // 2 + final_x // 2 + rx), slice(y // 2 - final_y // 2, y // 2 + final_y // 2 + ry))
+    return img[(slice(None),) + sl] if ignore_dim_0 else img[sl]
+
+
+def _as_device_f32(t, what):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise _lib.RadonLibraryError(f"{what} must be a tensor on a HIP device; there is no CPU path")
+    return t.to(torch.float32).contiguous()
+
+
+def _project(x, tables, dx):
+    """A x: [oy][gx][gy] -> [oy][dt][dx] (tomopy.project on the reconstruction grid, center = dx / 2)."""
+    lib = _lib.load()
+    sin_t, cos_t, quad = tables
+    oy, gx, gy = x.shape
+    out = torch.empty((oy, sin_t.numel(), dx), dtype=torch.float32, device=x.device)
+    _lib.check(lib.ctpvae_siddon_fwd_f32(x.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(),
+                                         sin_t.numel(), dx, ctypes.c_float(dx / 2.0), out.data_ptr(), _stream_ptr()),
+               "siddon_fwd")
+    return out
+
+
+def _backproject(data, tables, gx, gy):
+    """A^T y: [oy][dt][dx] -> [oy][gx][gy]."""
+    lib = _lib.load()
+    sin_t, cos_t, quad = tables
+    oy, dt, dx = data.shape
+    need = lib.ctpvae_siddon_bwd_workspace_bytes(oy, gx, gy, dt)
+    _lib.check(need, "siddon_bwd_workspace_bytes")
+    ws = torch.empty(int(need), dtype=torch.uint8, device=data.device) if need else None
+    out = torch.empty((oy, gx, gy), dtype=torch.float32, device=data.device)
+    _lib.check(lib.ctpvae_siddon_bwd_f32(data.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
+                                         ctypes.c_float(dx / 2.0), ws.data_ptr() if ws is not None else None, out.data_ptr(),
+                                         _stream_ptr()), "siddon_bwd")
+    return out
+
+
+def siddon_backproject(data, theta, num_gridx=None, num_gridy=None):
+    """The transpose of create_sinograms: data [slices][angles][dx] -> [slices][num_gridx][num_gridy] (default: dx x dx),
+    i.e. tomopy.recon(data, theta, center=None, sinogram_order=True, algorithm='fbp', filter_name='none') without its 1e-6."""
+    data = _as_device_f32(data, "data")
+    if data.dim() != 3:
+        raise ValueError(f"expected slices x angles x dx (got {tuple(data.shape)})")
+    if data.shape[1] != len(theta):
+        raise ValueError("The given ``theta`` does not match the number of projections in ``data``.")
+    dx = data.shape[2]
+    gx, gy = int(num_gridx or dx), int(num_gridy or dx)
+    if data.shape[0] == 0:
+        return data.new_empty((0, gx, gy))
+    with torch.cuda.device(data.device):
+        return _backproject(data, _siddon_tables(theta, data.device), gx, gy)
+
+
+def _sirt(data, tables, gx, gy, num_iter, init):
+    lib = _lib.load()
+    sin_t, cos_t, quad = tables
+    oy, dt, dx = data.shape
+    rn2 = torch.empty((dt, dx), dtype=torch.float32, device=data.device)
+    _lib.check(lib.ctpvae_siddon_rownorm_f32(gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
+                                             ctypes.c_float(dx / 2.0), rn2.data_ptr(), _stream_ptr()), "siddon_rownorm")
+    live_ray = rn2 != 0
+    rn2_safe = torch.where(live_ray, rn2, torch.ones_like(rn2))
+    colsum = _backproject(torch.ones((1, dt, dx), dtype=torch.float32, device=data.device), tables, gx, gy)[0]   # sum_dist
+    live_pix = colsum != 0
+    colsum_safe = torch.where(live_pix, colsum, torch.ones_like(colsum))
+    x = init
+    for _ in range(int(num_iter)):
+        resid = torch.where(live_ray, (data - _project(x, tables, dx)) / rn2_safe, torch.zeros_like(data))
+        upd = _backproject(resid, tables, gx, gy)
+        x = x + torch.where(live_pix, upd / colsum_safe, torch.zeros_like(upd))
+    return x
+
+
+def recon(tomo, theta, center=None, sinogram_order=False, algorithm=None, init_recon=None, num_gridx=None, num_gridy=None,
+          num_iter=1, filter_name="none", **kwargs):
+    """tomopy.recon's call shape for the algorithms above.  tomo: [angles][slices][dx] (sinogram_order=False) or
+    [slices][angles][dx] (True), a float tensor on a HIP device.  Returns [slices][num_gridx][num_gridy] float32."""
+    if algorithm not in ALGORITHMS:
+        if algorithm == "tv":
+            raise NotImplementedError("recon: algorithm 'tv' is not part of this build (TomoPy's tv.c is not restated); "
+                                      f"available: {ALGORITHMS}")
+        raise ValueError(f"recon: unknown algorithm {algorithm!r}; available: {ALGORITHMS}")
+    data = _as_device_f32(tomo, "tomo")
+    if data.dim() != 3:
+        raise ValueError(f"tomo must be 3-D (got {tuple(data.shape)})")
+    if not sinogram_order:
+        data = data.permute(1, 0, 2).contiguous()
+    oy, dt, dx = data.shape
+    if dt != len(theta):
+        raise ValueError("The given ``theta`` does not match the number of projections in ``tomo``.")
+    if center is not None and float(center) != dx / 2.0:
+        raise NotImplementedError("recon: only center=None (the detector's middle, as every reference call passes) is built")
+    gx, gy = int(num_gridx or dx), int(num_gridy or dx)
+    if oy == 0:
+        return data.new_empty((0, gx, gy))
+    with torch.cuda.device(data.device):
+        if algorithm == "gridrec":
+            if filter_name != "none":
+                raise NotImplementedError("recon: the gridrec stand-in has the plain ramp (filter_name='none') only")
+            return iradon(data.to(torch.float64), np.asarray(theta, dtype=np.float64), gx, gy, ramp_filter(dx),
+                          tomopy_geometry=True).to(torch.float32)
+        tables = _siddon_tables(theta, data.device)
+        if algorithm == "fbp":
+            if filter_name != "none":
+                raise NotImplementedError("recon: 'fbp' is built with filter_name='none' (the reference's only use of it)")
+            out = _backproject(data, tables, gx, gy)
+            return out if init_recon is None else out + init_recon
+        init = torch.full((oy, gx, gy), 1e-6, dtype=torch.float32, device=data.device) if init_recon is None else \
+            _as_device_f32(init_recon, "init_recon")
+        return _sirt(data, tables, gx, gy, num_iter, init)

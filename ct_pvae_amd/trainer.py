@@ -548,9 +548,10 @@ def get_args(argv=None):
     p.add_argument("--miopen_find", action="store_true",
                    help="search MIOpen's convolution algorithms once (torch.backends.cudnn.benchmark); not in the reference")
     p.add_argument("--td", type=int, dest="td", default=100)
-    p.add_argument("--algorithms", nargs="+", default=["fbp"],
-                   help="initial reconstructions fed to the encoder, one channel each (ctvae/main_ct_vae.py:111-112; the "
-                        "reference's default is TomoPy's gridrec -- this build has the GPU 'fbp' only)")
+    p.add_argument("--algorithms", nargs="+", default=["gridrec"],
+                   help="initial reconstructions fed to the encoder, one channel each (ctvae/main_ct_vae.py:111-112, same "
+                        "default); on the GPU: gridrec (ramp-filtered back-projection stand-in), sirt, fbp "
+                        "(ct_pvae_amd/recon.py); tv is not built")
     p.add_argument("--train", action="store_true")
     # synthetic-data knobs (the reference reads these from its dataset folder)
     p.add_argument("--n_pixel", type=int, default=128)

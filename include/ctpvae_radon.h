@@ -34,6 +34,8 @@
  *                                              :305-312), one launch
  *   ctpvae_siddon_tables_f32 / _fwd_f32        create_sinogram -> tomopy.project
  *                                              ctvae/helper_functions.py:33-38
+ *   ctpvae_siddon_bwd_f32 / _rownorm_f32       tomopy.recon(algorithm='fbp' | 'sirt') behind iradon_all / evaluate_sinogram
+ *                                              ctvae/helper_functions.py:445-457,503,514
  *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
  *   ctpvae_loglik_fwd_f32 / _bwd_f32           calculate_log_prob_M_given_R
  *                                              ctvae/helper_functions.py:360-368
@@ -201,6 +203,20 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
                           const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
                           float *data_dev, ctpvae_stream_t stream);
 
+/* The transpose of ctpvae_siddon_fwd_f32 -- what libtomo's fbp.c accumulates (recon[indi[n]] += data * dist[n]; with
+ * filter_name 'none', as ctvae/helper_functions.py:514 asks for the mask channel, that IS tomopy.recon(algorithm='fbp')) and
+ * the A^T of its sirt.c (helper_functions.py:503 with algorithm='sirt').  data_dev [oy][dt][dx] -> recon_dev [oy][ox][oz]
+ * (overwritten).  Same ray walk, same fp32 expressions as the forward: <A x, y> = <x, A^T y> to rounding.  Atomic-free and
+ * bit-reproducible (even rays, barrier, odd rays per angle; angle groups summed in ascending order).  workspace_dev:
+ * ctpvae_siddon_bwd_workspace_bytes() bytes of device memory (0: none needed).
+ * _rownorm: rn2_dev [dt][dx] = sum of squared segment lengths of every ray (sirt.c's sum_dist2; geometry only). */
+long long ctpvae_siddon_bwd_workspace_bytes(int oy, int ox, int oz, int dt);
+int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                          const int *quad_dev, int dt, int dx, float center, void *workspace_dev, float *recon_dev,
+                          ctpvae_stream_t stream);
+int ctpvae_siddon_rownorm_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt,
+                              int dx, float center, float *rn2_dev, ctpvae_stream_t stream);
+
 /* ---- a6: filtered back-projection (float64, as the reference runs it) -----------------------
  * filter: circular convolution of every sinogram row with hker_dev [P] = Re(ifft(filter_1d)), which
  * equals Re(ifft(fft(row) * filter_1d)).  sino_dev, out_dev [R][P].
@@ -210,6 +226,13 @@ int ctpvae_fbp_filter_f64(const double *sino_dev, int R, int P, const double *hk
 int ctpvae_fbp_backproject_f64(const double *filt_dev, int B, int A, int P, const double *cos_dev,
                                const double *sin_dev, int X, int Y, double *recon_dev,
                                ctpvae_stream_t stream);
+/* ... with the sampling geometry spelled out: pixel (i, j) at (i - x0, j - y0), detector sample k at k - t0.  The reference's
+ * iradon is x0 = X / 2, y0 = Y / 2, t0 = P / 2 (the entry point above); tomopy's ray-driven grid -- pixel centres at half-
+ * integers, bin d at d - (P - 1) / 2 (libtomo utils.c preprocessing / calc_coords) -- is x0 = (X - 1) / 2, y0 = (Y - 1) / 2,
+ * t0 = (P - 1) / 2: what the gridrec stand-in of ct_pvae_amd/recon.py uses on sinograms made by create_sinogram. */
+int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P, const double *cos_dev,
+                                    const double *sin_dev, int X, int Y, double x0, double y0, double t0,
+                                    double *recon_dev, ctpvae_stream_t stream);
 
 /* ---- a8: Gaussian-approximated Poisson log-likelihood epilogue ------------------------------
  * proj_dev, x_dev, out_dev [B][A][P]; mask_dev [B][A]; pnm_dev points at ONE fp32 on the device (the

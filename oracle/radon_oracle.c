@@ -323,92 +323,194 @@ static int siddon_quadrant(float theta_p)
                ? 1 : 0;
 }
 
+/* Work arrays of one ray walk (libtomo allocates the same set per call). */
+typedef struct {
+    int ox, oz, dx;
+    float mov;
+    float *gridx, *gridy, *coordx, *coordy, *ax, *ay, *bx, *by, *coorx, *coory, *dist;
+    int *indi;
+} siddon_work;
+
+static void siddon_work_init(siddon_work *w, int ox, int oz, int dx, float center)
+{
+    w->ox = ox; w->oz = oz; w->dx = dx;
+    w->gridx = (float *)malloc((ox + 1) * sizeof(float));
+    w->gridy = (float *)malloc((oz + 1) * sizeof(float));
+    w->coordx = (float *)malloc((oz + 1) * sizeof(float));
+    w->coordy = (float *)malloc((ox + 1) * sizeof(float));
+    w->ax = (float *)malloc((ox + oz + 2) * sizeof(float));
+    w->ay = (float *)malloc((ox + oz + 2) * sizeof(float));
+    w->bx = (float *)malloc((ox + oz + 2) * sizeof(float));
+    w->by = (float *)malloc((ox + oz + 2) * sizeof(float));
+    w->coorx = (float *)malloc((ox + oz + 2) * sizeof(float));
+    w->coory = (float *)malloc((ox + oz + 2) * sizeof(float));
+    w->dist = (float *)malloc((ox + oz + 1) * sizeof(float));
+    w->indi = (int *)malloc((ox + oz + 1) * sizeof(int));
+    /* utils.c preprocessing */
+    for (int i = 0; i <= ox; ++i) w->gridx[i] = -ox * 0.5f + i;
+    for (int i = 0; i <= oz; ++i) w->gridy[i] = -oz * 0.5f + i;
+    float mov = ((float)dx - 1) * 0.5f - center;
+    if (mov - floorf(mov) < 0.01f) mov += 0.01f;
+    w->mov = mov + 0.5f;
+}
+
+static void siddon_work_free(siddon_work *w)
+{
+    free(w->gridx); free(w->gridy); free(w->coordx); free(w->coordy); free(w->ax); free(w->ay); free(w->bx);
+    free(w->by); free(w->coorx); free(w->coory); free(w->dist); free(w->indi);
+}
+
+/* One ray (angle sin_p / cos_p / quadrant, detector bin d): utils.c calc_coords -> trim_coords -> sort_intersections ->
+ * calc_dist.  Fills w->dist[n], w->indi[n] for n < (return value) = csize - 1 segments. */
+static int siddon_ray(siddon_work *w, float sin_p, float cos_p, int quadrant, int d)
+{
+    const int ox = w->ox, oz = w->oz, dx = w->dx;
+    const float *gridx = w->gridx, *gridy = w->gridy;
+    float *coordx = w->coordx, *coordy = w->coordy, *ax = w->ax, *ay = w->ay, *bx = w->bx, *by = w->by;
+    float *coorx = w->coorx, *coory = w->coory;
+    const float xi = (float)(-ox - oz);
+    const float yi = (1 - dx) / 2.0f + d + w->mov;
+    /* calc_coords */
+    const float srcx = xi * cos_p - yi * sin_p, srcy = xi * sin_p + yi * cos_p;
+    const float detx = -xi * cos_p - yi * sin_p, dety = -xi * sin_p + yi * cos_p;
+    const float slope = (srcy - dety) / (srcx - detx);
+    const float islope = (srcx - detx) / (srcy - dety);
+    for (int n = 0; n <= oz; ++n) coordx[n] = islope * (gridy[n] - srcy) + srcx;
+    for (int n = 0; n <= ox; ++n) coordy[n] = slope * (gridx[n] - srcx) + srcy;
+    /* trim_coords */
+    int asize = 0, bsize = 0;
+    const float gx_gt = gridx[0] + 0.01f, gx_le = gridx[ox] - 0.01f;
+    for (int n = 0; n <= oz; ++n)
+        if (coordx[n] >= gx_gt && coordx[n] <= gx_le) {
+            ax[asize] = coordx[n]; ay[asize] = gridy[n]; ++asize;
+        }
+    const float gy_gt = gridy[0] + 0.01f, gy_le = gridy[oz] - 0.01f;
+    for (int n = 0; n <= ox; ++n)
+        if (coordy[n] >= gy_gt && coordy[n] <= gy_le) {
+            bx[bsize] = gridx[n]; by[bsize] = coordy[n]; ++bsize;
+        }
+    /* sort_intersections */
+    int i = 0, j = 0, k = 0;
+    while (i < asize && j < bsize) {
+        const int a_ind = quadrant ? i : (asize - 1 - i);
+        if (ax[a_ind] < bx[j]) { coorx[k] = ax[a_ind]; coory[k] = ay[a_ind]; ++i; }
+        else { coorx[k] = bx[j]; coory[k] = by[j]; ++j; }
+        ++k;
+    }
+    while (i < asize) {
+        const int a_ind = quadrant ? i : (asize - 1 - i);
+        coorx[k] = ax[a_ind]; coory[k] = ay[a_ind]; ++i; ++k;
+    }
+    while (j < bsize) { coorx[k] = bx[j]; coory[k] = by[j]; ++j; ++k; }
+    const int csize = asize + bsize;
+    /* calc_dist */
+    for (int n = 0; n < csize - 1; ++n) {
+        const float diffx = coorx[n + 1] - coorx[n], diffy = coory[n + 1] - coory[n];
+        w->dist[n] = sqrtf(diffx * diffx + diffy * diffy);
+        const float midx = (coorx[n + 1] + coorx[n]) * 0.5f;
+        const float midy = (coory[n + 1] + coory[n]) * 0.5f;
+        const float x1 = midx + ox * 0.5f, x2 = midy + oz * 0.5f;
+        const int i1 = (int)x1, i2 = (int)x2;
+        const int indx = i1 - (i1 > x1), indy = i2 - (i2 > x2);
+        w->indi[n] = indy + indx * oz;
+    }
+    return csize > 0 ? csize - 1 : 0;
+}
+
 void oracle_siddon_project(const float *obj, int oy, int ox, int oz, const float *theta, int dt,
                            int dx, float center, float *data)
 {
-    float *gridx = (float *)malloc((ox + 1) * sizeof(float));
-    float *gridy = (float *)malloc((oz + 1) * sizeof(float));
-    float *coordx = (float *)malloc((oz + 1) * sizeof(float));
-    float *coordy = (float *)malloc((ox + 1) * sizeof(float));
-    float *ax = (float *)malloc((ox + oz + 2) * sizeof(float));
-    float *ay = (float *)malloc((ox + oz + 2) * sizeof(float));
-    float *bx = (float *)malloc((ox + oz + 2) * sizeof(float));
-    float *by = (float *)malloc((ox + oz + 2) * sizeof(float));
-    float *coorx = (float *)malloc((ox + oz + 2) * sizeof(float));
-    float *coory = (float *)malloc((ox + oz + 2) * sizeof(float));
-    float *dist = (float *)malloc((ox + oz + 1) * sizeof(float));
-    int *indi = (int *)malloc((ox + oz + 1) * sizeof(int));
-
+    siddon_work w;
+    siddon_work_init(&w, ox, oz, dx, center);
     memset(data, 0, (size_t)oy * dt * dx * sizeof(float));
-
-    /* utils.c preprocessing */
-    for (int i = 0; i <= ox; ++i) gridx[i] = -ox * 0.5f + i;
-    for (int i = 0; i <= oz; ++i) gridy[i] = -oz * 0.5f + i;
-    float mov = ((float)dx - 1) * 0.5f - center;
-    if (mov - floorf(mov) < 0.01f) mov += 0.01f;
-    mov += 0.5f;
-
     for (int p = 0; p < dt; ++p) {
         const float theta_p = fmodf(theta[p], 2.0f * (float)M_PI);
         const int quadrant = siddon_quadrant(theta_p);
         const float sin_p = sinf(theta_p), cos_p = cosf(theta_p);
         for (int d = 0; d < dx; ++d) {
-            const float xi = (float)(-ox - oz);
-            const float yi = (1 - dx) / 2.0f + d + mov;
-            /* calc_coords */
-            const float srcx = xi * cos_p - yi * sin_p, srcy = xi * sin_p + yi * cos_p;
-            const float detx = -xi * cos_p - yi * sin_p, dety = -xi * sin_p + yi * cos_p;
-            const float slope = (srcy - dety) / (srcx - detx);
-            const float islope = (srcx - detx) / (srcy - dety);
-            for (int n = 0; n <= oz; ++n) coordx[n] = islope * (gridy[n] - srcy) + srcx;
-            for (int n = 0; n <= ox; ++n) coordy[n] = slope * (gridx[n] - srcx) + srcy;
-            /* trim_coords */
-            int asize = 0, bsize = 0;
-            const float gx_gt = gridx[0] + 0.01f, gx_le = gridx[ox] - 0.01f;
-            for (int n = 0; n <= oz; ++n)
-                if (coordx[n] >= gx_gt && coordx[n] <= gx_le) {
-                    ax[asize] = coordx[n]; ay[asize] = gridy[n]; ++asize;
-                }
-            const float gy_gt = gridy[0] + 0.01f, gy_le = gridy[oz] - 0.01f;
-            for (int n = 0; n <= ox; ++n)
-                if (coordy[n] >= gy_gt && coordy[n] <= gy_le) {
-                    bx[bsize] = gridx[n]; by[bsize] = coordy[n]; ++bsize;
-                }
-            /* sort_intersections */
-            int i = 0, j = 0, k = 0;
-            while (i < asize && j < bsize) {
-                const int a_ind = quadrant ? i : (asize - 1 - i);
-                if (ax[a_ind] < bx[j]) { coorx[k] = ax[a_ind]; coory[k] = ay[a_ind]; ++i; }
-                else { coorx[k] = bx[j]; coory[k] = by[j]; ++j; }
-                ++k;
-            }
-            while (i < asize) {
-                const int a_ind = quadrant ? i : (asize - 1 - i);
-                coorx[k] = ax[a_ind]; coory[k] = ay[a_ind]; ++i; ++k;
-            }
-            while (j < bsize) { coorx[k] = bx[j]; coory[k] = by[j]; ++j; ++k; }
-            const int csize = asize + bsize;
-            /* calc_dist */
-            for (int n = 0; n < csize - 1; ++n) {
-                const float diffx = coorx[n + 1] - coorx[n], diffy = coory[n + 1] - coory[n];
-                dist[n] = sqrtf(diffx * diffx + diffy * diffy);
-                const float midx = (coorx[n + 1] + coorx[n]) * 0.5f;
-                const float midy = (coory[n + 1] + coory[n]) * 0.5f;
-                const float x1 = midx + ox * 0.5f, x2 = midy + oz * 0.5f;
-                const int i1 = (int)x1, i2 = (int)x2;
-                const int indx = i1 - (i1 > x1), indy = i2 - (i2 > x2);
-                indi[n] = indy + indx * oz;
-            }
+            const int nseg = siddon_ray(&w, sin_p, cos_p, quadrant, d);
             /* calc_simdata, every slice */
             for (int s = 0; s < oy; ++s) {
                 const float *model = obj + (size_t)s * ox * oz;
                 float *out = data + ((size_t)s * dt + p) * dx + d;
-                for (int n = 0; n < csize - 1; ++n) *out += model[indi[n]] * dist[n];
+                for (int n = 0; n < nseg; ++n) *out += model[w.indi[n]] * w.dist[n];
             }
         }
     }
-    free(gridx); free(gridy); free(coordx); free(coordy); free(ax); free(ay); free(bx); free(by);
-    free(coorx); free(coory); free(dist); free(indi);
+    siddon_work_free(&w);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * tomopy.recon(..., algorithm='fbp', filter_name='none')  [3P-recalled: TomoPy 1.11.0 libtomo/recon/fbp.c], the call
+ * ctvae/helper_functions.py:514 makes for the encoder's mask channel: for every slice s, angle p, detector bin d, in
+ * that order, the ray's segments add data[s][p][d] * dist[n] into recon[s][indi[n]] -- the transpose of project.c's
+ * calc_simdata.  data [oy][dt][dx] (libtomo's order), recon [oy][ngridx][ngridy], ADDED to its initial contents
+ * (tomopy initialises it; the caller passes zeros or 1e-6 as it wishes).
+ * ------------------------------------------------------------------------------------------- */
+void oracle_siddon_backproject(const float *data, int oy, int dt, int dx, const float *theta, float center, int ngridx,
+                               int ngridy, float *recon)
+{
+    siddon_work w;
+    siddon_work_init(&w, ngridx, ngridy, dx, center);
+    for (int s = 0; s < oy; ++s)
+        for (int p = 0; p < dt; ++p) {
+            const float theta_p = fmodf(theta[p], 2.0f * (float)M_PI);
+            const int quadrant = siddon_quadrant(theta_p);
+            const float sin_p = sinf(theta_p), cos_p = cosf(theta_p);
+            for (int d = 0; d < dx; ++d) {
+                const int nseg = siddon_ray(&w, sin_p, cos_p, quadrant, d);
+                const float v = data[((size_t)s * dt + p) * dx + d];
+                float *img = recon + (size_t)s * ngridx * ngridy;
+                for (int n = 0; n < nseg; ++n) img[w.indi[n]] += v * w.dist[n];
+            }
+        }
+    siddon_work_free(&w);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * tomopy.recon(..., algorithm='sirt')  [3P-recalled: TomoPy 1.11.0 libtomo/recon/sirt.c], reached from
+ * ctvae/helper_functions.py:445-457,503 and the README recipe (README.md:221).  Per iteration and slice:
+ *   simdata = A recon (project.c's calc_simdata);  for every ray:  sum_dist2 = sum dist[n]^2,
+ *   sum_dist[indi[n]] += dist[n];  if sum_dist2 != 0:  upd = (data - simdata) / sum_dist2,  update[indi[n]] += upd * dist[n];
+ *   then  recon[pix] += update[pix] / sum_dist[pix]  where sum_dist[pix] != 0.
+ * tomopy's default is num_iter = 1 and an initial recon of 1e-6 everywhere (the caller passes both).
+ * ------------------------------------------------------------------------------------------- */
+void oracle_sirt(const float *data, int oy, int dt, int dx, const float *theta, float center, int ngridx, int ngridy,
+                 int num_iter, float *recon)
+{
+    siddon_work w;
+    siddon_work_init(&w, ngridx, ngridy, dx, center);
+    const size_t npix = (size_t)ngridx * ngridy;
+    float *sum_dist = (float *)malloc(npix * sizeof(float));
+    float *update = (float *)malloc(npix * sizeof(float));
+    for (int it = 0; it < num_iter; ++it)
+        for (int s = 0; s < oy; ++s) {
+            float *img = recon + (size_t)s * npix;
+            memset(sum_dist, 0, npix * sizeof(float));
+            memset(update, 0, npix * sizeof(float));
+            for (int p = 0; p < dt; ++p) {
+                const float theta_p = fmodf(theta[p], 2.0f * (float)M_PI);
+                const int quadrant = siddon_quadrant(theta_p);
+                const float sin_p = sinf(theta_p), cos_p = cosf(theta_p);
+                for (int d = 0; d < dx; ++d) {
+                    const int nseg = siddon_ray(&w, sin_p, cos_p, quadrant, d);
+                    float sim = 0.0f, sum_dist2 = 0.0f;
+                    for (int n = 0; n < nseg; ++n) sim += img[w.indi[n]] * w.dist[n];
+                    for (int n = 0; n < nseg; ++n) {
+                        sum_dist2 += w.dist[n] * w.dist[n];
+                        sum_dist[w.indi[n]] += w.dist[n];
+                    }
+                    if (sum_dist2 != 0.0f) {
+                        const float upd = (data[((size_t)s * dt + p) * dx + d] - sim) / sum_dist2;
+                        for (int n = 0; n < nseg; ++n) update[w.indi[n]] += upd * w.dist[n];
+                    }
+                }
+            }
+            for (size_t q = 0; q < npix; ++q)
+                if (sum_dist[q] != 0.0f) img[q] += update[q] / sum_dist[q];
+        }
+    free(sum_dist); free(update);
+    siddon_work_free(&w);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -52,6 +52,8 @@ def lib():
         L.oracle_fbp_backproject.argtypes = [_f64p, _i, _i, _i, _f64p, _i, _i, _f64p]
         L.oracle_iradon.argtypes = [_f64p, _i, _i, _i, _f64p, _i, _i, _f64p, ctypes.c_void_p, _f64p]
         L.oracle_loglik.argtypes = [_f32p, _f32p, _f32p, _i, _i, _i, ctypes.c_float, ctypes.c_float, _f32p]
+        L.oracle_siddon_backproject.argtypes = [_f32p, _i, _i, _i, _f32p, ctypes.c_float, _i, _i, _f32p]
+        L.oracle_sirt.argtypes = [_f32p, _i, _i, _i, _f32p, ctypes.c_float, _i, _i, _i, _f32p]
         L.oracle_philox4x32_10.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.oracle_poisson_count.restype = ctypes.c_double
         L.oracle_poisson_count.argtypes = [ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64]
@@ -184,6 +186,27 @@ def siddon_project(obj, theta, pad=True):
 def create_sinogram(img, theta, pad=True):
     """ctvae/helper_functions.py:33-38."""
     return np.squeeze(siddon_project(np.asarray(img)[None], theta, pad=pad), axis=1)
+
+
+def siddon_backproject(data, theta, ngridx=None, ngridy=None, init=0.0):
+    """tomopy.recon(data, theta, center=None, sinogram_order=True, algorithm='fbp', filter_name='none'): data [oy][dt][dx]
+    (one sinogram per slice) -> [oy][ngridx][ngridy], grid = detector width by default, added to `init`."""
+    data, theta = _c32(data), _c32(theta)
+    oy, dt, dx = data.shape
+    gx, gy = int(ngridx or dx), int(ngridy or dx)
+    recon = np.full((oy, gx, gy), init, np.float32)
+    lib().oracle_siddon_backproject(data, oy, dt, dx, theta, dx / 2.0, gx, gy, recon)
+    return recon
+
+
+def sirt(data, theta, num_iter=1, ngridx=None, ngridy=None, init=1e-6):
+    """tomopy.recon(data, theta, center=None, sinogram_order=True, algorithm='sirt', num_iter=num_iter)."""
+    data, theta = _c32(data), _c32(theta)
+    oy, dt, dx = data.shape
+    gx, gy = int(ngridx or dx), int(ngridy or dx)
+    recon = np.full((oy, gx, gy), init, np.float32)
+    lib().oracle_sirt(data, oy, dt, dx, theta, dx / 2.0, gx, gy, int(num_iter), recon)
+    return recon
 
 
 # ---- a6 -----------------------------------------------------------------------------------------------

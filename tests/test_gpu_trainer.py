@@ -103,28 +103,29 @@ def test_setup_chain_on_the_device(tmp_path):
     masks, samples = create_all_masks(sino, 180, save_path=str(tmp_path), poisson_noise_multiplier=1e3,
                                       num_sparse_angles=20, train=True, truncate_dataset=4)
     assert masks.device.type == "cuda" and samples.shape == (4, 180, 184)
-    enc = iradon_all(samples, masks, 184, theta, ["fbp"], float(np.finfo(np.float32).eps), 128, 128,
+    enc = iradon_all(samples, masks, 184, theta, ["gridrec"], float(np.finfo(np.float32).eps), 128, 128,
                      save_path=str(tmp_path), train=True)
     assert enc.shape == (4, 128, 128, 2) and enc.dtype == torch.float32 and torch.isfinite(enc).all()
-    # the FBP channel resembles the phantom (sparse, noisy: loose), the mask channel is the same for uniform masks
+    # the gridrec channel resembles the phantom (sparse, noisy: loose), the mask channel is the same for uniform masks
     c = np.corrcoef(enc[0, ..., 0].cpu().numpy().ravel(), imgs[0].cpu().numpy().ravel())[0, 1]
     assert c > 0.6
     assert torch.allclose(enc[0, ..., 1], enc[3, ..., 1])
-    again = iradon_all(samples, masks, 184, theta, ["fbp"], 1e-7, 128, 128, save_path=str(tmp_path), train=False)
+    again = iradon_all(samples, masks, 184, theta, ["gridrec"], 1e-7, 128, 128, save_path=str(tmp_path), train=False)
     assert torch.equal(again, enc)
     with pytest.raises(NotImplementedError):
-        iradon_all(samples, masks, 184, theta, ["sirt"], 1e-7, 128, 128, train=True)
+        iradon_all(samples, masks, 184, theta, ["tv"], 1e-7, 128, 128, train=True)
 
 
 def test_algorithms_flag_sets_the_encoder_channels():
     """--algorithms (ctvae/main_ct_vae.py:111-112): one encoder input channel per initial reconstruction, plus the mask's
-    back-projection; anything but the GPU 'fbp' is refused by name."""
+    back-projection -- the README's list (README.md:221) minus tv, which is refused by name."""
+    assert tr.get_args([]).algorithms == ["gridrec"]                 # the reference's default
     args = tr.get_args("--nsa 20 --td 6 -b 3 --ns 2 --api 10 --pnm 1e4 --random --normal -i 2 --train "
-                       "--algorithms fbp fbp".split())
+                       "--algorithms sirt gridrec".split())
     t = tr.PVAETrainer(args, torch.device("cuda", 0))
     assert tuple(t.input_encode.shape) == (6, 3, 128, 128)
     assert math.isfinite(t.train_step())
-    bad = tr.get_args("--nsa 20 --td 6 -b 3 --train --algorithms gridrec".split())
+    bad = tr.get_args("--nsa 20 --td 6 -b 3 --train --algorithms tv".split())
     with pytest.raises(NotImplementedError):
         tr.PVAETrainer(bad, torch.device("cuda", 0))
 
