@@ -85,12 +85,14 @@ static FwdLayout fwd_layout(const PlanGeom &g)
 }
 // Backward taps are detector bins: one BYTE per (angle, pixel), 255 = dead.  A cotangent row is staged as 257 dwords
 // (== 1 mod 32): bins 0..PW-1, then zeros up to cell 256, so a dead tap reads row cell 255 = 0.0f and needs no select.
-static BwdLayout bwd_layout(const PlanGeom &g)
+// dup = 2: the EXACT-transpose plan -- two taps per (angle, pixel), stored as "virtual angles" 2a and 2a + 1 that both read
+// the staged cotangent row of angle a (see rotate_exact_plan_kernel)
+static BwdLayout bwd_layout(const PlanGeom &g, int dup = 1)
 {
     BwdLayout L;
     L.nXB = ceil_div(g.W, 64);
     L.Wpad = L.nXB * 64;
-    L.NA16 = ceil_div(g.A, 16);
+    L.NA16 = ceil_div(g.A * dup, 16);
     L.pitchg = kBwdPitch;
     L.chunkA = std::min(L.NA16 * 16, kBwdChunk);
     L.bytes = (long long)L.NA16 * g.H * L.Wpad * 16;
@@ -224,6 +226,45 @@ __global__ __launch_bounds__(64) void rotate_bwd_plan_kernel(PlanGeom g, const f
         w[e >> 2] |= v << (8 * (e & 3));
     }
     idx[((size_t)a16 * g.H + yrow) * L.Wpad + xcol] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Exact-transpose plan.  The forward adds img[tap(a, i, j)] into sino[a][j]; its transpose adds g[a][j] into every pixel
+// that is the tap of a canvas sample (i, j).  A rotation followed by rounding sends at most two samples of an angle to one
+// pixel (the rotated unit lattice has at most two points in a pixel's rounding cell), so the transpose is a GATHER of at
+// most two bins per (angle, pixel): the plan stores them as bytes (255 = none) in the order the scatter would have added
+// them (canvas row i ascending, then bin j), as "virtual angles" 2a (first hit) and 2a + 1 (second).  The hits are found
+// among the 3 x 3 canvas samples around the pixel's inverse-rotated position by evaluating the FORWARD tap exactly.  A pixel
+// with more than two hits (not a rotation) raises *overflow: the caller then keeps the scatter kernel.
+__global__ __launch_bounds__(64) void rotate_exact_plan_kernel(PlanGeom g, const float *__restrict__ T8,
+                                                               const float *__restrict__ Tinv8, BwdLayout L,
+                                                               unsigned char *__restrict__ idx, int *__restrict__ overflow)
+{
+    const int xb = blockIdx.x, yrow = blockIdx.y, a = blockIdx.z, lane = threadIdx.x;
+    const int xcol = xb * 64 + lane;
+    unsigned hit0 = 255u, hit1 = 255u;
+    if (xcol < g.W) {
+        const float *ti = Tinv8 + 8 * a, *t = T8 + 8 * a;
+        const float fx = (float)(xcol + g.px), fy = (float)(yrow + g.py);
+        const int jc = (int)__builtin_roundf((ti[0] * fx + ti[1] * fy) + ti[2]);
+        const int ic = (int)__builtin_roundf((ti[3] * fx + ti[4] * fy) + ti[5]);
+        int n = 0;
+        for (int i = ic - 1; i <= ic + 1; ++i)
+            for (int j = jc - 1; j <= jc + 1; ++j) {
+                if ((unsigned)i >= (unsigned)g.PH || (unsigned)j >= (unsigned)g.PW) continue;
+                const float x = (t[0] * (float)j + t[1] * (float)i) + t[2];
+                const float y = (t[3] * (float)j + t[4] * (float)i) + t[5];
+                if ((int)__builtin_roundf(x) - g.px == xcol && (int)__builtin_roundf(y) - g.py == yrow) {
+                    if (n == 0) hit0 = (unsigned)j;
+                    if (n == 1) hit1 = (unsigned)j;
+                    ++n;
+                }
+            }
+        if (n > 2) atomicOr(overflow, 1);
+    }
+    // byte (2a) & 15 and (2a + 1) & 15 of the uint4 of virtual-angle group (2a) >> 4
+    unsigned char *cell = idx + (((size_t)((2 * a) >> 4) * g.H + yrow) * L.Wpad + xcol) * 16 + ((2 * a) & 15);
+    cell[0] = (unsigned char)hit0;
+    cell[1] = (unsigned char)hit1;
 }
 
 // ---- executing a plan -------------------------------------------------------------------------------------------
@@ -532,9 +573,10 @@ template <int NS> __device__ __forceinline__ typename SliceVec<NS>::type lds_at_
 }
 // the 16 taps of `q` are staged rows AL0 .. AL0+15: the row offset is a compile-time ds_read immediate, the address
 // VGPR is just the SDWA-extracted bin * cell size -- no address arithmetic per tap
-template <int AL0, int NS>
+template <int AL0, int NS, int DUP = 1>
 __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_live, typename SliceVec<NS>::type (&v)[16])
 {
+    // DUP = 2 (exact-transpose plan): taps AL0 + e are "virtual angles"; virtual angle v reads staged row v / 2
     // n_live (wave-uniform): staged rows AL0 .. AL0+n_live-1 exist; a partial last group skips whole dwords of taps
     constexpr int ROW = kBwdPitch * 4 * NS;   // bytes per staged row
     const unsigned w[4] = {q.x, q.y, q.z, q.w};
@@ -543,10 +585,10 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
         if (4 * d < n_live) {
             int b0, b1, b2, b3;
             unpack4<NS == 1 ? 2 : 3>(w[d], b0, b1, b2, b3);
-            v[4 * d + 0] = lds_at_vec<NS>(lds, b0 + (AL0 + 4 * d + 0) * ROW);
-            v[4 * d + 1] = lds_at_vec<NS>(lds, b1 + (AL0 + 4 * d + 1) * ROW);
-            v[4 * d + 2] = lds_at_vec<NS>(lds, b2 + (AL0 + 4 * d + 2) * ROW);
-            v[4 * d + 3] = lds_at_vec<NS>(lds, b3 + (AL0 + 4 * d + 3) * ROW);
+            v[4 * d + 0] = lds_at_vec<NS>(lds, b0 + ((AL0 + 4 * d + 0) / DUP) * ROW);
+            v[4 * d + 1] = lds_at_vec<NS>(lds, b1 + ((AL0 + 4 * d + 1) / DUP) * ROW);
+            v[4 * d + 2] = lds_at_vec<NS>(lds, b2 + ((AL0 + 4 * d + 2) / DUP) * ROW);
+            v[4 * d + 3] = lds_at_vec<NS>(lds, b3 + ((AL0 + 4 * d + 3) / DUP) * ROW);
         } else {
             v[4 * d + 0] = v[4 * d + 1] = v[4 * d + 2] = v[4 * d + 3] = 0.0f;
         }
@@ -559,7 +601,9 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
 // NS = 2: two slices per workgroup, their cotangent rows fetched together and interleaved as float2 -- one index
 // stream, one SDWA unpack and one ds_read_b64 per tap serve both (rows are then 2056 B, so a chunk is 32 angles to keep
 // the row offsets immediates).
-template <int PPT, int MAXT, int NS>
+// DUP = 2: the exact-transpose plan (two taps per angle and pixel, as virtual angles 2a, 2a + 1 reading staged row a): the same
+// kernel with twice the index vectors per staged row; sums are added in virtual-angle order = the scatter's order.
+template <int PPT, int MAXT, int NS, int DUP = 1>
 __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y, int g_S,
                                                                  SliceScale scale, float *__restrict__ gimg)
@@ -607,7 +651,8 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     };
     load_group(0);       // index loads fly while the cotangent rows land
 
-    const int chunk = min(L.NA16 * 16, kChunk);
+    const int VA = g.A * DUP;                            // virtual angles (= angles unless DUP = 2)
+    const int chunk = min(L.NA16 * 16, kChunk * DUP);    // virtual angles per staged chunk (a multiple of 16)
     // Pairs in 16-wave workgroups (many angles, several chunks): the cotangent rows of chunk c + 1 are requested into
     // registers (two units per lane) before the gathers of chunk c and written to LDS after them -- each chunk's load
     // round trip hides behind the previous chunk's gather phase instead of standing between two barriers.
@@ -619,12 +664,15 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
         srcs[0] = gs + (size_t)ac * g.PW;
         if constexpr (NS == 2) srcs[1] = gs + (has2 ? (size_t)g.A * g.PW : 0) + (size_t)ac * g.PW;
     };
-    for (int ac = 0; ac < g.A; ac += chunk) {
-        const int na = min(chunk, g.A - ac);
-        const int na4 = (na + 3) & ~3;              // taps are consumed a dword (4 angles) at a time
-        if (ac > 0) __syncthreads();
+    for (int acv = 0; acv < VA; acv += chunk) {
+        const int nav = min(chunk, VA - acv);
+        const int na4 = (nav + 3) & ~3;             // taps are consumed a dword (4 virtual angles) at a time
+        const int ac = acv / DUP;                   // first staged (real) angle of the chunk
+        const int na = (nav + DUP - 1) / DUP;       // staged rows
+        const int na_z = (na4 + DUP - 1) / DUP;     // rows a tap of this chunk may name
+        if (acv > 0) __syncthreads();
         // a dead tap is byte 255: only cell 255 of every row (never a bin: PW <= 255) must hold 0.0f
-        for (int t = threadIdx.x; t < na4 * NS; t += blockDim.x) lds[((t / NS) * kBwdPitch + 255) * NS + (t % NS)] = 0.0f;
+        for (int t = threadIdx.x; t < na_z * NS; t += blockDim.x) lds[((t / NS) * kBwdPitch + 255) * NS + (t % NS)] = 0.0f;
         if (ahead_valid) {
             ahead.commit(lds, kBwdPitch);           // requested during the previous chunk's gathers
         } else if constexpr (NS == 1) {
@@ -635,20 +683,20 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
             stage_rows_interleaved<2>(lds, srcs, na, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
         }
         ahead_valid = false;
-        if (kPipe && ac + chunk < g.A) {            // wave-uniform
+        if (kPipe && acv + chunk < VA) {            // wave-uniform
             const float *srcs[NS];
-            chunk_srcs(ac + chunk, srcs);
-            const int nna = min(chunk, g.A - (ac + chunk));
+            chunk_srcs(ac + chunk / DUP, srcs);
+            const int nna = (min(chunk, VA - (acv + chunk)) + DUP - 1) / DUP;
             if (StagedRows<NS, kPipe ? kAheadUnits : 1>::fits(srcs, nna, g.PW, g.PW, nwaves)) {
                 ahead.issue(srcs, nna, g.PW, g.PW, lane, wave, nwaves);
                 ahead_valid = true;
             }
         }
         __syncthreads();
-        // up to four groups of sixteen staged angles, unrolled so that every row offset is an immediate
+        // up to four (eight with DUP = 2) groups of sixteen virtual angles, unrolled so that every row offset is an immediate
         auto group = [&](auto al_tag) {
             constexpr int AL = decltype(al_tag)::value;
-            if constexpr (AL < kChunk) {
+            if constexpr (AL < kChunk * DUP) {
                 if (AL >= na4) return;                       // wave-uniform
                 const int n_live = min(16, na4 - AL);
                 vec_t v[PPT][16];
@@ -657,9 +705,9 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
                 for (int k = 0; k < PPT; ++k)   // timing only: no gathers, the index words stand in for the taps
                     for (int e = 0; e < 16; ++e) v[k][e] = __uint_as_float((&q[k].x)[e & 3] & 0x3fffffu);
 #else
-                for (int k = 0; k < PPT; ++k) gather16<AL, NS>(lds, q[k], n_live, v[k]);
+                for (int k = 0; k < PPT; ++k) gather16<AL, NS, DUP>(lds, q[k], n_live, v[k]);
 #endif
-                const int next = (ac + AL) / 16 + 1;         // all index vectors of this group consumed: prefetch the next
+                const int next = (acv + AL) / 16 + 1;        // all index vectors of this group consumed: prefetch the next
                 if (next < L.NA16) load_group(next);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -672,6 +720,10 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
         group(std::integral_constant<int, 16>{});
         group(std::integral_constant<int, 32>{});
         group(std::integral_constant<int, 48>{});
+        group(std::integral_constant<int, 64>{});
+        group(std::integral_constant<int, 80>{});
+        group(std::integral_constant<int, 96>{});
+        group(std::integral_constant<int, 112>{});
     }
     if (xcol < g.W) {
 #pragma unroll
@@ -887,16 +939,17 @@ int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, i
     return ctpvae_rotate_bwd_planned_scaled_f32(gsino_dev, S, H, W, PH, PW, A, bwd_plan_dev, nullptr, 0, gimg_dev, stream);
 }
 
-int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
-                                         const void *bwd_plan_dev, const float *scale_dev, long long scale_stride,
-                                         float *gimg_dev, ctpvae_stream_t stream)
+// dup = 1: the TF-compatible plan (one tap per angle and pixel); dup = 2: the exact-transpose plan (two)
+static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A, const void *bwd_plan_dev,
+                              const float *scale_dev, long long scale_stride, float *gimg_dev, int dup,
+                              ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(gsino_dev && bwd_plan_dev && gimg_dev, "rotate_bwd_planned: null pointer");
     CTPVAE_REQUIRE(S > 0, "rotate_bwd_planned: need at least one slice");
     if (int rc = check_plan_geom("rotate_bwd_planned", H, W, PH, PW, 0, 0, A)) return rc;
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd_planned: the backward plan stores bins as bytes (PW=%d > 255)", PW);
-    const BwdLayout L = bwd_layout(g);
+    const BwdLayout L = bwd_layout(g, dup);
     // Two slices per workgroup (one index stream, one unpack and one ds_read_b64 per tap serve both; each lane then
     // owns 2 rows instead of 4) once the batch is large enough to still fill the chip: measured B=50: 7.6 -> 6.4 us at
     // A=20, 16.5 -> 13.8 us at A=90, 28.3 -> 25.4 us at A=180.  Small batches pair up too, in short 4-wave tiles
@@ -906,15 +959,16 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
     const int ppt = ns == 2 ? 2 : 4;
     const int units = ceil_div(S, ns);
     // staged chunk: up to 64 rows of one slice, or 32 rows of an interleaved pair
-    const size_t shmem = (size_t)std::min(L.NA16 * 16, kBwdChunk / ns) * L.pitchg * sizeof(float) * ns;
+    const size_t shmem = (size_t)std::min(ceil_div(L.NA16 * 16, dup), kBwdChunk / ns) * L.pitchg * sizeof(float) * ns;
     // Tile = 64 columns x (waves x ppt) rows.  Every workgroup of a slice stages ALL the slice's cotangent rows: with many
     // angles taller tiles amortise that staging (measured, B=50 A=180: 44 -> 28 us from 4 to 16 waves); with few angles
     // the staging is small and short tiles win, because four small workgroups per CU overlap each other's staging and
     // barrier waits while one 16-wave workgroup (114 VGPRs: one per CU) cannot (B=400 A=20: 34 us vs 45 us).
+    const int Aeff = A * dup;
     int waves = 4;
     if (ns == 2)   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many; half as tall below 32 slices (sweeps)
-        waves = A >= 64 ? (S >= 32 ? 16 : 8) : (S > 16 ? 8 : 4);
-    else if (A >= 32)
+        waves = Aeff >= 64 ? (S >= 32 ? 16 : 8) : (S > 16 ? 8 : 4);
+    else if (Aeff >= 32)
         while (waves < 16 && (long long)units * L.nXB * ceil_div(H, 2 * waves * ppt) >= 200 && waves * ppt < H) waves *= 2;
     while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has
     if (knob(kKnobBw) > 0) waves = std::min(16, knob(kKnobBw));
@@ -930,13 +984,71 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
         return CTPVAE_OK;
     };
     int rc;
-    if (ns == 2)
+    if (dup == 2) {
+        if (ns == 2)
+            rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<2, 256, 2, 2>) : launch(rotate_bwd_planned_kernel<2, 1024, 2, 2>);
+        else
+            rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<4, 256, 1, 2>) : launch(rotate_bwd_planned_kernel<4, 1024, 1, 2>);
+    } else if (ns == 2) {
         rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<2, 256, 2>) : launch(rotate_bwd_planned_kernel<2, 1024, 2>);
-    else
+    } else {
         rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<4, 256, 1>) : launch(rotate_bwd_planned_kernel<4, 1024, 1>);
+    }
     if (rc) return rc;
     CTPVAE_LAUNCH_CHECK("rotate_bwd_planned_kernel");
     return CTPVAE_OK;
+}
+
+int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                         const void *bwd_plan_dev, const float *scale_dev, long long scale_stride,
+                                         float *gimg_dev, ctpvae_stream_t stream)
+{
+    return launch_bwd_planned(gsino_dev, S, H, W, PH, PW, A, bwd_plan_dev, scale_dev, scale_stride, gimg_dev, 1, stream);
+}
+
+// ---- exact transpose through a plan (NEAREST): deterministic gather, see rotate_exact_plan_kernel ----------------------
+long long ctpvae_rotate_exact_plan_bytes(int H, int W, int PH, int PW, int A)
+{
+    if (H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_exact_plan_bytes: bad sizes");
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    if (!bwd_plan_fits(g) || knob(kKnobNoPlan) >= 0) return 0;      // bins do not fit a byte: keep the scatter kernel
+    return bwd_layout(g, 2).bytes + 256;                              // + the overflow word, on its own line
+}
+
+int ctpvae_rotate_exact_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
+                                       int py, int px, void *plan_dev, ctpvae_stream_t stream)
+{
+    if (int rc = check_plan_geom("rotate_exact_plan_build", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(T8_dev && Tinv8_dev && plan_dev, "rotate_exact_plan_build: null pointer");
+    const PlanGeom g{H, W, PH, PW, py, px, A};
+    CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_exact_plan_build: the plan stores bins as bytes (PW=%d > 255)", PW);
+    CTPVAE_REQUIRE(H <= 65535 && A <= 65535, "rotate_exact_plan_build: at most 65535 rows and angles");
+    const BwdLayout L = bwd_layout(g, 2);
+    // 255 everywhere first: the padding columns and the virtual angles behind 2A must be dead taps
+    CTPVAE_HIP(hipMemsetAsync(plan_dev, 0xff, (size_t)L.bytes, (hipStream_t)stream));
+    CTPVAE_HIP(hipMemsetAsync((char *)plan_dev + L.bytes, 0, 256, (hipStream_t)stream));
+    hipLaunchKernelGGL(rotate_exact_plan_kernel, dim3(L.nXB, H, A), dim3(64), 0, (hipStream_t)stream, g, T8_dev, Tinv8_dev, L,
+                       (unsigned char *)plan_dev, (int *)((char *)plan_dev + L.bytes));
+    CTPVAE_LAUNCH_CHECK("rotate_exact_plan_kernel");
+    return CTPVAE_OK;
+}
+
+// 1 if some pixel had more than two hits (the rows are not a rotation): use the scatter kernel.  SYNCHRONISES the stream.
+int ctpvae_rotate_exact_plan_overflowed(const void *plan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(plan_dev && H > 0 && W > 0 && A > 0, "rotate_exact_plan_overflowed: bad arguments");
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    const BwdLayout L = bwd_layout(g, 2);
+    int flag = 0;
+    CTPVAE_HIP(hipMemcpyAsync(&flag, (const char *)plan_dev + L.bytes, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CTPVAE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return flag ? 1 : 0;
+}
+
+int ctpvae_rotate_bwd_exact_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                        const void *exact_plan_dev, float *gimg_dev, ctpvae_stream_t stream)
+{
+    return launch_bwd_planned(gsino_dev, S, H, W, PH, PW, A, exact_plan_dev, nullptr, 0, gimg_dev, 2, stream);
 }
 
 }  // extern "C"

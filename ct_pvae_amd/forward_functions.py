@@ -187,8 +187,10 @@ class RotatePlan:
         self._lib = _lib.load()
         # Gather plans (NEAREST): tap indices computed once for this geometry, shared by every slice of every call.
         # The forward plan is built now, the backward plan on the first backward.
-        self._fwd_plan = self._bwd_plan = None
+        self._fwd_plan = self._bwd_plan = self._exact_plan = None
         self._want_bwd_plan = False
+        # exact transpose (nearest): a deterministic gather through an inverse plan, built on the first backward
+        self._want_exact_plan = bool(use_plan and self.mode == _lib.BWD_EXACT and self.interp == _lib.NEAREST)
         self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
         self._tile_ws = None
         if use_plan:
@@ -208,6 +210,25 @@ class RotatePlan:
                 buf.data_ptr() if which == 0 else None, buf.data_ptr() if which == 1 else None, _stream_ptr()),
                 "rotate_plan_build")
         return buf
+
+    def _build_exact_plan(self):
+        """Inverse plan of the nearest forward (<= 2 hitting bins per angle and pixel).  Falls back to the scatter kernel
+        (atomics) when the geometry does not fit byte taps or the rows are not a rotation."""
+        self._want_exact_plan = False
+        nbytes = self._lib.ctpvae_rotate_exact_plan_bytes(self.H, self.W, self.PH, self.PW, self.A)
+        _lib.check(nbytes, "rotate_exact_plan_bytes")
+        if nbytes == 0:
+            return
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctpvae_rotate_exact_plan_build_f32(self.T8.data_ptr(), self.Tinv8.data_ptr(), self.A, self.H,
+                                                                    self.W, self.PH, self.PW, self.py, self.px, buf.data_ptr(),
+                                                                    _stream_ptr()), "rotate_exact_plan_build")
+            over = self._lib.ctpvae_rotate_exact_plan_overflowed(buf.data_ptr(), self.H, self.W, self.PH, self.PW, self.A,
+                                                                 _stream_ptr())
+        _lib.check(over, "rotate_exact_plan_overflowed")
+        if over == 0:
+            self._exact_plan = buf
 
     @property
     def planned(self):
@@ -432,6 +453,15 @@ class RotatePlan:
             rc = self._lib.ctpvae_rotate_bwd_sel_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, self.Tinv8.data_ptr(),
                                                             angles_i.data_ptr(), n, self.H, self.W, self.py, self.px,
                                                             sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
+            if rc:
+                _lib.check(rc, "rotate_bwd_sel")
+            return out
+        if self._want_exact_plan:            # first exact backward of a nearest plan: build the inverse plan
+            self._build_exact_plan()
+        if self._exact_plan is not None:
+            rc = self._lib.ctpvae_rotate_bwd_exact_planned_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                               self._exact_plan.data_ptr(), out.data_ptr(),
+                                                               _stream_ptr(self._dev_index))
         elif self.backward_uses_plan(S):
             if self._bwd_plan is None:
                 self._bwd_plan = self._build_plan(1)

@@ -193,6 +193,20 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
                                          const void *bwd_plan_dev, const float *scale_dev, long long scale_stride,
                                          float *gimg_dev, ctpvae_stream_t stream);
 
+/* Exact transpose of the NEAREST forward as a deterministic gather (no atomics, bit-reproducible): a rotation followed by
+ * rounding sends at most two canvas samples of an angle to one pixel, so the plan stores, per (angle, pixel), the <= 2
+ * detector bins whose cotangent the scatter would have added, in the scatter's order (canvas row, then bin), and the
+ * planned backward kernel gathers them -- the same sums, bit for bit, as ctpvae_rotate_bwd_f32(mode EXACT) would produce
+ * if its atomic adds arrived in order.  _bytes: size of the caller-owned plan buffer (256-byte aligned), 0 if the geometry
+ * does not fit (PW > 255: keep ctpvae_rotate_bwd_f32).  _build needs both tables.  _overflowed (synchronises): 1 if
+ * some pixel had more than two hits -- the rows were not a rotation -- and the plan must not be used. */
+long long ctpvae_rotate_exact_plan_bytes(int H, int W, int PH, int PW, int A);
+int ctpvae_rotate_exact_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
+                                       int py, int px, void *plan_dev, ctpvae_stream_t stream);
+int ctpvae_rotate_exact_plan_overflowed(const void *plan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream);
+int ctpvae_rotate_bwd_exact_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                        const void *exact_plan_dev, float *gimg_dev, ctpvae_stream_t stream);
+
 /* ---- a7: TomoPy-style ray-driven projector --------------------------------------------------
  * Tables (host side, fp32): theta [dt] -> sin, cos of fmodf(theta, 2*pi) and libtomo's quadrant flag. */
 int ctpvae_siddon_dx(int ox, int oz, int pad);

@@ -895,6 +895,39 @@ def test_sirt_and_the_encoder_channels(oracle, tmp_path):
     assert torch.equal(again.to(d), enc)
 
 
+@pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 50), ((128, 128), True, 180, 3), ((40, 100), True, 33, 3),
+                                          ((65, 31), False, 9, 1), ((2, 2), False, 2, 2), ((130, 70), True, 70, 17)])
+def test_exact_transpose_is_a_deterministic_gather(oracle, shape, pad, A, S):
+    """backward='exact' (nearest): the inverse plan (<= 2 hitting bins per angle and pixel, in the scatter's order) makes the
+    true transpose a gather -- BIT-EQUAL to the oracle's in-order scatter (oracle_rotate_bwd_exact), identical from run to
+    run, single slices and pairs, and still the adjoint of the forward."""
+    d = dev()
+    rng = np.random.default_rng(A * 11 + S)
+    theta = rng.uniform(-1.0, 4.0, A)
+    theta[: min(A, 3)] = [0.0, np.pi / 2, np.pi / 4][: min(A, 3)]
+    plan = RotatePlan(theta, shape[0], shape[1], pad, d, backward="exact")
+    g = rng.standard_normal((S, A, plan.PW)).astype(np.float32)
+    gt = torch.from_numpy(g).to(d)
+    got = plan.backward(gt)
+    assert plan._exact_plan is not None                      # the planned gather ran, not the atomic scatter
+    geom = oracle.Geometry(shape[0], shape[1], pad)
+    n = min(S, 3)
+    np.testing.assert_array_equal(to_np(got)[:n], oracle.rotate_bwd_exact(g[:n], geom, oT(oracle, theta, plan), 0))
+    assert torch.equal(got, plan.backward(gt))
+    _lib.tune("BNS", 1)
+    one = plan.backward(gt)
+    _lib.tune("BNS", 2)
+    two = plan.backward(gt)
+    assert torch.equal(one, got) and torch.equal(two, got)
+    # the scatter kernel (atomics) agrees to rounding, and <A x, y> = <x, A^T y>
+    scatter = RotatePlan(theta, shape[0], shape[1], pad, d, backward="exact", use_plan=False).backward(gt)
+    assert rel_err(to_np(scatter), to_np(got)) <= REL
+    x = rng.standard_normal((S,) + shape).astype(np.float32)
+    lhs = float((to_np(plan.forward(torch.from_numpy(x).to(d))).astype(np.float64) * g).sum())
+    rhs = float((x.astype(np.float64) * to_np(got)).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
 def test_backward_scale_operand_checks():
     d = dev()
     theta = np.linspace(0, np.pi, 6, endpoint=False)
