@@ -37,7 +37,7 @@ def _counter_means(db_path, counter):
     per = {}
     for k, _, v in db.execute(q, (counter,)):
         per.setdefault(_short(k), []).append(v)
-    return {k: sum(v) / len(v) for k, v in per.items()}
+    return {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
 
 
 def traffic(fetch_db, write_db):
@@ -46,8 +46,9 @@ def traffic(fetch_db, write_db):
     for k in sorted(set(f) | set(w)):
         if "ctpvae" not in k:
             continue
-        fk, wk = f.get(k, 0.0), w.get(k, 0.0)
-        out["kernels"][k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "traffic_bytes_per_launch": (2 * fk + wk) * 1024}
+        (fk, nf), (wk, _) = f.get(k, (0.0, 0)), w.get(k, (0.0, 0))
+        out["kernels"][k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "traffic_bytes_per_launch": (2 * fk + wk) * 1024,
+                             "dispatches": nf}
     print(json.dumps(out, indent=1))
 
 
