@@ -340,14 +340,19 @@ class PVAETrainer:
         # with --save_path the three setup arrays are written there when training and read back when not (the
         # reference's train / restore split, ctvae/create_masks.py:70,101-103, ctvae/helper_functions.py:523-526)
         drawing = bool(a.train) or not a.save_path
-        masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=a.save_path, poisson_noise_multiplier=a.pnm,
+        # every rank draws the same arrays (same seeds); only rank 0 writes them -- concurrent np.save of one path from
+        # several ranks is a truncate-and-write race
+        save_here = a.save_path if (self.rank == 0 or not drawing) else None
+        masks, self.proj_samples = create_all_masks(sino, a.num_angles, save_path=save_here, poisson_noise_multiplier=a.pnm,
                                                     num_sparse_angles=a.nsa, random=a.random, train=drawing, real_data=a.real_data,
                                                     toy_masks=a.toy_masks,
                                                     truncate_dataset=a.td, device=dev)
         self.masks, self.truth = masks, (torch.from_numpy(imgs).to(dev) if imgs is not None else None)
         # initial reconstructions for the encoder, ctvae/helper_functions.py:477-529 with FBP on the GPU
         enc_in = iradon_all(self.proj_samples, masks, self.P, self.theta_np, list(a.algorithms), self.sqrt_reg, self.x_size,
-                            self.y_size, save_path=a.save_path, train=drawing)        # [td][X][Y][2]
+                            self.y_size, save_path=save_here, train=drawing)          # [td][X][Y][len(algorithms) + 1]
+        if self.world > 1 and drawing and a.save_path:
+            torch.distributed.barrier()                                                # files complete before anyone goes on
         self.input_encode = enc_in.permute(0, 3, 1, 2).contiguous()                   # [td][2][X][Y]
         self.theta = torch.from_numpy(self.theta_np.astype(np.float32)).to(dev)
         # the projector gets the HOST angle list: its tables and gather plan are then built once, on the host's bits, and
@@ -488,8 +493,9 @@ class PVAETrainer:
         no update; keeps every batch's loss and one sample of the output distribution per object, and writes
         loss_final.npy / reconstruction_final.npy ([n][X][Y][1]) -- the file bin/final_merit.py scores."""
         a = self.args
-        lo, hi = sharding.shard_range(a.batch_size, self.rank, self.world)
-        nb = hi - lo
+        # full batches of `-b` on every rank (the log-likelihood sums over the batch, so a sharded batch would change the
+        # per-batch losses the reference reports); the evaluation runs once and only rank 0 writes
+        nb = a.batch_size
         losses, recons = [], []
         for k in range(0, (a.td // nb) * nb, nb):
             sl = slice(k, k + nb)
