@@ -1118,9 +1118,24 @@ def test_random_geometries_against_the_oracle(oracle):
             np.testing.assert_array_equal(gb, oracle.rotate_bwd_tfcompat(g, geom, oTinv(oracle, theta, plan), 0),
                                           err_msg=f"bwd case {case}: {H}x{W} pad={pad} A={A} S={S} plan={use_plan}")
         ex = RotatePlan(theta, H, W, pad, d, backward="exact")
+        gx = to_np(ex.backward(torch.from_numpy(g).to(d)))
         lhs = float((to_np(ex.forward(torch.from_numpy(img).to(d))).astype(np.float64) * g).sum())
-        rhs = float((to_np(ex.backward(torch.from_numpy(g).to(d))).astype(np.float64) * img).sum())
+        rhs = float((gx.astype(np.float64) * img).sum())
         assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (case, lhs, rhs)
+        if ex._exact_plan is not None:          # the planned gather: the oracle's in-order scatter, bit for bit
+            np.testing.assert_array_equal(gx, oracle.rotate_bwd_exact(g, geom, oT(oracle, theta, ex), 0),
+                                          err_msg=f"exact case {case}: {H}x{W} pad={pad} A={A} S={S}")
+        # a random angle subset of the same (dense) plan, with repeats, through the index operand
+        dense = RotatePlan(theta, H, W, pad, d)
+        sub = rng.integers(0, A, int(rng.integers(1, 2 * A + 1)))
+        idx = cp.as_angle_index(sub, d)
+        T = oT(oracle, theta, dense)
+        np.testing.assert_array_equal(to_np(dense.forward(torch.from_numpy(img).to(d), angles_i=idx)),
+                                      oracle.rotate_fwd(img, geom, T[sub], 0), err_msg=f"sel fwd case {case}")
+        gs = rng.standard_normal((S, len(sub), geom.PW)).astype(np.float32)
+        np.testing.assert_array_equal(to_np(dense.backward(torch.from_numpy(gs).to(d), angles_i=idx)),
+                                      oracle.rotate_bwd_tfcompat(gs, geom, oracle.invert_transforms(T)[sub], 0),
+                                      err_msg=f"sel bwd case {case}")
 
 
 def test_tiled_forward_against_golden(golden_dir):
