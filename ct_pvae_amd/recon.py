@@ -17,7 +17,10 @@ Here `recon` takes the same arguments and runs on the hand-written kernels behin
                which only the operator it approximates -- ramp-filtered back-projection, filter_name 'none' = plain ramp -- is
                restated here, as the float64 FBP of csrc/fbp.hip on the same grid.  Same reconstruction up to discretisation;
                not TomoPy's bits.
-    'tv'       not built (tv.c's Chambolle-Pock normalisation is not restated): raises NotImplementedError.
+    'tv'       STAND-IN, flagged: total-variation regularised reconstruction on the same operator pair by the diagonally
+               preconditioned Chambolle-Pock iteration (Pock & Chambolle 2011: step sizes from the operator's own row and
+               column sums -- sirt.c's sum_dist2-free weights -- so nothing has to be tuned), reg_par[0] = the TV weight.
+               libtomo's tv.c (also a primal-dual TV scheme) is NOT restated: same family, not TomoPy's numbers.
 
 Grid and centre follow tomopy: num_gridx = num_gridy = detector width, center = width / 2; callers crop
 (ctvae/helper_functions.py:420-430, `crop`).  There is no CPU path."""
@@ -33,7 +36,7 @@ from .helper_functions import _siddon_tables
 
 __all__ = ["recon", "siddon_backproject", "crop", "ALGORITHMS"]
 
-ALGORITHMS = ("fbp", "sirt", "gridrec")
+ALGORITHMS = ("fbp", "sirt", "gridrec", "tv")
 
 
 def crop(img, final_x, final_y, ignore_dim_0=False):
@@ -113,14 +116,55 @@ def _sirt(data, tables, gx, gy, num_iter, init):
     return x
 
 
+def _tv(data, tables, gx, gy, num_iter, init, lam):
+    """min_x 1/2 |A x - b|^2 + lam TV(x) by preconditioned Chambolle-Pock (Pock & Chambolle, ICCV 2011, alpha = 1):
+    dual steps 1 / (row sums of |K|), primal steps 1 / (column sums of |K|) for K = (A; grad).  Flagged stand-in for
+    tomopy's 'tv' (see the module docstring)."""
+    oy, dt, dx = data.shape
+    dev = data.device
+    ones_img = torch.ones((1, gx, gy), dtype=torch.float32, device=dev)
+    rowsum = _project(ones_img, tables, dx)[0]                                          # sum_n dist[n] of every ray
+    colsum = _backproject(torch.ones((1, dt, dx), dtype=torch.float32, device=dev), tables, gx, gy)[0]
+    sigma_a = torch.where(rowsum > 0, 1.0 / rowsum.clamp_min(1e-30), torch.zeros_like(rowsum))
+    tau = 1.0 / (colsum + 4.0)                                                          # |grad| has column sums <= 4
+    sigma_g = 0.5                                                                       # and row sums 2
+
+    def grad(u):
+        gxu = torch.zeros_like(u)
+        gyu = torch.zeros_like(u)
+        gxu[:, :-1] = u[:, 1:] - u[:, :-1]
+        gyu[:, :, :-1] = u[:, :, 1:] - u[:, :, :-1]
+        return gxu, gyu
+
+    def div(px, py):                                                                    # -grad^T
+        out = torch.zeros_like(px)
+        out[:, :-1] += px[:, :-1]
+        out[:, 1:] -= px[:, :-1]
+        out[:, :, :-1] += py[:, :, :-1]
+        out[:, :, 1:] -= py[:, :, :-1]
+        return out
+
+    x = init.clone()
+    xbar = x.clone()
+    p = torch.zeros_like(data)
+    qx, qy = torch.zeros_like(x), torch.zeros_like(x)
+    for _ in range(int(num_iter)):
+        p = (p + sigma_a * (_project(xbar, tables, dx) - data)) / (1.0 + sigma_a)      # prox of 1/2 |. - b|^2 conjugate
+        gxu, gyu = grad(xbar)
+        qx, qy = qx + sigma_g * gxu, qy + sigma_g * gyu
+        norm = torch.sqrt(qx * qx + qy * qy).clamp_min(lam) / lam                       # project onto |q| <= lam
+        qx, qy = qx / norm, qy / norm
+        x_new = x - tau * (_backproject(p, tables, gx, gy) - div(qx, qy))      # K^T y = A^T p + grad^T q, grad^T = -div
+        xbar = 2.0 * x_new - x
+        x = x_new
+    return x
+
+
 def recon(tomo, theta, center=None, sinogram_order=False, algorithm=None, init_recon=None, num_gridx=None, num_gridy=None,
-          num_iter=1, filter_name="none", **kwargs):
+          num_iter=1, filter_name="none", reg_par=None, **kwargs):
     """tomopy.recon's call shape for the algorithms above.  tomo: [angles][slices][dx] (sinogram_order=False) or
     [slices][angles][dx] (True), a float tensor on a HIP device.  Returns [slices][num_gridx][num_gridy] float32."""
     if algorithm not in ALGORITHMS:
-        if algorithm == "tv":
-            raise NotImplementedError("recon: algorithm 'tv' is not part of this build (TomoPy's tv.c is not restated); "
-                                      f"available: {ALGORITHMS}")
         raise ValueError(f"recon: unknown algorithm {algorithm!r}; available: {ALGORITHMS}")
     data = _as_device_f32(tomo, "tomo")
     if data.dim() != 3:
@@ -149,4 +193,9 @@ def recon(tomo, theta, center=None, sinogram_order=False, algorithm=None, init_r
             return out if init_recon is None else out + init_recon
         init = torch.full((oy, gx, gy), 1e-6, dtype=torch.float32, device=data.device) if init_recon is None else \
             _as_device_f32(init_recon, "init_recon")
+        if algorithm == "tv":
+            lam = float(np.asarray(reg_par if reg_par is not None else 1.0, dtype=np.float64).reshape(-1)[0])   # tomopy: ones(10)
+            if not lam > 0:
+                raise ValueError("recon: reg_par[0] (the TV weight) must be positive")
+            return _tv(data, tables, gx, gy, num_iter, init, lam)
         return _sirt(data, tables, gx, gy, num_iter, init)

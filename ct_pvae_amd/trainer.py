@@ -557,7 +557,7 @@ def get_args(argv=None):
     p.add_argument("--algorithms", nargs="+", default=["gridrec"],
                    help="initial reconstructions fed to the encoder, one channel each (ctvae/main_ct_vae.py:111-112, same "
                         "default); on the GPU: gridrec (ramp-filtered back-projection stand-in), sirt, fbp "
-                        "(ct_pvae_amd/recon.py); tv is not built")
+                        "(ct_pvae_amd/recon.py), tv (flagged stand-in)")
     p.add_argument("--train", action="store_true")
     # synthetic-data knobs (the reference reads these from its dataset folder)
     p.add_argument("--n_pixel", type=int, default=128)

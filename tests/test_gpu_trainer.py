@@ -112,21 +112,21 @@ def test_setup_chain_on_the_device(tmp_path):
     assert torch.allclose(enc[0, ..., 1], enc[3, ..., 1])
     again = iradon_all(samples, masks, 184, theta, ["gridrec"], 1e-7, 128, 128, save_path=str(tmp_path), train=False)
     assert torch.equal(again, enc)
-    with pytest.raises(NotImplementedError):
-        iradon_all(samples, masks, 184, theta, ["tv"], 1e-7, 128, 128, train=True)
+    with pytest.raises(ValueError):
+        iradon_all(samples, masks, 184, theta, ["art"], 1e-7, 128, 128, train=True)
 
 
 def test_algorithms_flag_sets_the_encoder_channels():
     """--algorithms (ctvae/main_ct_vae.py:111-112): one encoder input channel per initial reconstruction, plus the mask's
-    back-projection -- the README's list (README.md:221) minus tv, which is refused by name."""
+    back-projection -- the README's list (README.md:221); an unknown name is refused."""
     assert tr.get_args([]).algorithms == ["gridrec"]                 # the reference's default
     args = tr.get_args("--nsa 20 --td 6 -b 3 --ns 2 --api 10 --pnm 1e4 --random --normal -i 2 --train "
                        "--algorithms sirt gridrec".split())
     t = tr.PVAETrainer(args, torch.device("cuda", 0))
     assert tuple(t.input_encode.shape) == (6, 3, 128, 128)
     assert math.isfinite(t.train_step())
-    bad = tr.get_args("--nsa 20 --td 6 -b 3 --train --algorithms tv".split())
-    with pytest.raises(NotImplementedError):
+    bad = tr.get_args("--nsa 20 --td 6 -b 3 --train --algorithms art".split())
+    with pytest.raises(ValueError):
         tr.PVAETrainer(bad, torch.device("cuda", 0))
 
 
