@@ -936,6 +936,55 @@ def test_exact_transpose_is_a_deterministic_gather(oracle, shape, pad, A, S):
     assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
 
 
+def test_angle_subsets_on_geometries_without_an_index_operand(oracle):
+    """angles_i on paths whose kernels take no angle-index operand -- a slice larger than LDS (tiled forward), bilinear
+    interpolation, the exact backward -- falls back to gathered table rows (RotatePlan.subset): same numbers as a plan built
+    for the gathered theta, through the raw operators and through calculate_log_prob_M_given_R."""
+    from ct_pvae_amd.helper_functions import gaussian_poisson_log_prob
+    d = dev()
+    rng = np.random.default_rng(9)
+    N, A = 230, 24
+    theta = rng.uniform(0, np.pi, A)
+    sub = rng.permutation(A)[:7]
+    idx = cp.as_angle_index(sub, d)
+    img = rng.random((3, N, N), dtype=np.float32)
+    x = torch.from_numpy(img).to(d)
+    geom = oracle.Geometry(N, N, True)
+    big = RotatePlan(theta, N, N, True, d)
+    assert big.tiled and not big.sel_supported(7)
+    T = oT(oracle, theta, big)
+    np.testing.assert_array_equal(to_np(big.forward(x, angles_i=idx)), oracle.rotate_fwd_tiled(img, geom, T[sub], (96, 64)))
+    g = rng.standard_normal((3, 7, big.PW)).astype(np.float32)
+    np.testing.assert_array_equal(to_np(big.backward(torch.from_numpy(g).to(d), angles_i=idx)),
+                                  oracle.rotate_bwd_tfcompat(g, geom, oracle.invert_transforms(T)[sub], 0))
+    small = rng.random((2, 40, 40), dtype=np.float32)
+    geo40 = oracle.Geometry(40, 40, True)
+    for kw, ref_b in ((dict(interp="bilinear"), lambda gg, TT: oracle.rotate_bwd_tfcompat(gg, geo40, oracle.invert_transforms(TT), 1)),
+                      (dict(backward="exact"), lambda gg, TT: oracle.rotate_bwd_exact(gg, geo40, TT, 0))):
+        plan = RotatePlan(theta, 40, 40, True, d, **kw)
+        T40 = oT(oracle, theta, plan)
+        code = 1 if "interp" in kw else 0
+        got = to_np(plan.forward(torch.from_numpy(small).to(d), angles_i=idx))
+        if code:
+            np.testing.assert_array_equal(got, oracle.rotate_fwd(small, geo40, T40[sub], code))
+        g40 = rng.standard_normal((2, 7, plan.PW)).astype(np.float32)
+        gb = to_np(plan.backward(torch.from_numpy(g40).to(d), angles_i=idx))
+        assert rel_err(gb, ref_b(g40, T40[sub])) <= REL
+    # the training call on the tiled geometry
+    mask = torch.from_numpy(((rng.random((3, A)) > 0.3) / 7).astype(np.float32)).to(d)
+    meas = torch.from_numpy((rng.random((3, A, big.PW)) * 3).astype(np.float32)).to(d)
+    xa = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+    lp = cp.calculate_log_prob_M_given_R(xa, mask, meas, 1e3, 1e-7, theta=theta, angles_i=sub, pad=True)
+    lp.sum().backward()
+    xb = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+    li = torch.from_numpy(sub).to(d)
+    proj = cp.project_tf_fast(xb, theta[sub], pad=True, dim=2, integrate_vae=True)
+    lp2 = gaussian_poisson_log_prob(proj[..., 0], mask[:, li], meas[:, li], 1e3, 1e-7)
+    lp2.sum().backward()
+    assert torch.equal(lp[..., 0].detach(), lp2.detach())
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
+
+
 def test_backward_scale_operand_checks():
     d = dev()
     theta = np.linspace(0, np.pi, 6, endpoint=False)
