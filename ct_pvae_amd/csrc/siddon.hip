@@ -26,8 +26,13 @@ struct SidGeom {
 // its midpoint falls in and its length -- the forward projector adds model[pixel] * dist, the back-projector adds
 // data * dist into the pixel, SIRT's row norm adds dist * dist: the SAME fp32 expressions in all three, so the
 // back-projector is the forward's transpose by construction.
-template <class F>
-__device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, float cos_p, int quadrant, int d, F &&segment)
+// CHUNKED: only the segments [nseg * chunk / nchunks, nseg * (chunk + 1) / nchunks) of the ray are visited -- the walk starts
+// in the middle of the merge, at the cursor pair found by a merge-path bisection on the same two key sequences (both are
+// monotone: the a-list's fp32 expression in its traversal order, the b-list's grid lines), so every visited segment has
+// exactly the points, length and pixel the whole walk gives it.
+template <bool CHUNKED = false, class F>
+__device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, float cos_p, int quadrant, int d, F &&segment,
+                                                int chunk = 0, int nchunks = 1)
 {
     const int ox = g.ox, oz = g.oz;
     const float gx0 = -ox * 0.5f, gy0 = -oz * 0.5f;  // gridx[n] = gx0 + n, gridy[n] = gy0 + n
@@ -82,22 +87,41 @@ __device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, f
     kept_run(islope, gy0, srcy, srcx, gx_gt, gx_le, oz, a_lo, a_cnt);
     kept_run(slope, gx0, srcx, srcy, gy_gt, gy_le, ox, b_lo, b_cnt);
     const int csize = a_cnt + b_cnt;
+    int k_begin = 0, k_end = csize, ia0 = 0;
+    if constexpr (CHUNKED) {
+        const int nseg = max(csize - 1, 0);
+        const int s0 = (int)((long long)nseg * chunk / nchunks), s1 = (int)((long long)nseg * (chunk + 1) / nchunks);
+        if (s1 <= s0) return;
+        k_begin = s0;
+        k_end = s1 + 1;
+        // ia0 = how many a-elements are among the first k_begin merged points ("a first only if strictly smaller")
+        int lo = max(0, k_begin - b_cnt), hi = min(k_begin, a_cnt);
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            const float ay = gy0 + (float)(quadrant ? a_lo + mid : a_lo + a_cnt - 1 - mid);
+            const float akey = islope * (ay - srcy) + srcx;
+            const float bkey = gx0 + (float)(b_lo + (k_begin - 1 - mid));
+            if (akey < bkey) lo = mid + 1; else hi = mid;
+        }
+        ia0 = lo;
+    }
+    const int ib0 = k_begin - ia0;
     // The merge of libtomo's two sorted lists, with two cursors.  List a runs over its kept n upwards in
     // quadrant 1 and downwards otherwise; gridy[n] = gy0 + n is exact in fp32, so a running +-1.0f gives the same
     // values as int -> float.  An exhausted list shows +inf as its key: "a_key < b_key" then reproduces
     // sort_intersections' choice (a first only if strictly smaller; the other list once one has run out).
     const float kInf = __builtin_inff();
     const float da = quadrant ? 1.0f : -1.0f;
-    float a_y = gy0 + (float)(quadrant ? a_lo : a_lo + a_cnt - 1);
+    float a_y = gy0 + (float)(quadrant ? a_lo + ia0 : a_lo + a_cnt - 1 - ia0);
     float a_x = islope * (a_y - srcy) + srcx;
-    float a_key = a_cnt > 0 ? a_x : kInf;
-    int a_rem = a_cnt;
-    float b_x = gx0 + (float)b_lo;
+    int a_rem = a_cnt - ia0;
+    float a_key = a_rem > 0 ? a_x : kInf;
+    float b_x = gx0 + (float)(b_lo + ib0);
     float b_y = slope * (b_x - srcx) + srcy;
-    float b_key = b_cnt > 0 ? b_x : kInf;
-    int b_rem = b_cnt;
+    int b_rem = b_cnt - ib0;
+    float b_key = b_rem > 0 ? b_x : kInf;
     float px_prev = 0.0f, py_prev = 0.0f;
-    for (int k = 0; k < csize; ++k) {
+    for (int k = k_begin; k < k_end; ++k) {
         const bool take_a = a_key < b_key;
         const float cx = take_a ? a_x : b_x;
         const float cy = take_a ? a_y : b_y;
@@ -115,7 +139,7 @@ __device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, f
             b_key = take_a ? b_key : nb_key;
             b_rem = take_a ? b_rem : nb_rem;
         }
-        if (k > 0) {
+        if (k > k_begin) {
             const float diffx = cx - px_prev, diffy = cy - py_prev;
             const float dist = sqrtf(diffx * diffx + diffy * diffy);
             const float midx = (cx + px_prev) * 0.5f, midy = (cy + py_prev) * 0.5f;
@@ -185,18 +209,22 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
 
 // Back-projector: the transpose of the forward, recon[s][pixel] = sum over rays of data[s][p][d] * dist(p, d, pixel) -- what
 // libtomo's fbp.c accumulates (recon[indi[n]] += data[ind_data] * dist[n]) and the A^T of sirt.c's update.  Atomic-free
-// and bit-reproducible: a workgroup owns one slice and a group of angles; lane = ray.  Two rays of the SAME parity of d
-// are two detector pitches apart, further than a pixel's diagonal, so they never add into the same pixel: per angle the
-// even rays add (plain read-add-write into the workgroup's image: LDS when the slice fits, the partial image in global
-// memory otherwise), a barrier, then the odd rays, a barrier.  Every pixel therefore receives its terms in a fixed order
-// (angles ascending; even ray before odd ray) whatever the launch; angle groups write partial images that
-// siddon_reduce_groups_kernel adds in ascending group order.  Rays whose datum is 0 are skipped (x + 0 * dist == x): the
+// and bit-reproducible: a workgroup owns one slice and a group of angles and adds into its own image (LDS when the slice
+// fits, the partial image in global memory otherwise) with plain read-add-writes, made conflict-free by construction:
+//   * two rays of the SAME parity of d are two detector pitches apart, further than a pixel's diagonal: they never add
+//     into the same pixel;
+//   * every ray is cut into kChunks runs of consecutive segments (merge-path start, see siddon_walk_ray), one lane each, so
+//     that a phase fills the workgroup instead of 92 lanes; a ray meets a pixel in consecutive segments only, so two runs
+//     of one ray can share a pixel only where they touch: even-numbered and odd-numbered runs go in separate phases.
+// Four phases per angle (ray parity x run parity), a barrier after each: every pixel receives its terms in a fixed order
+// (angles ascending; even rays before odd; even runs before odd) whatever the launch; angle groups write partial images
+// that siddon_reduce_groups_kernel adds in ascending group order.  Rays whose datum is 0 are skipped (x + 0 * dist == x): the
 // sparse sinograms and dose masks this is fed (ctvae/helper_functions.py:489-516) are zero at most angles.
 template <bool USE_LDS>
 __global__ __launch_bounds__(1024) void siddon_bwd_kernel(const float *__restrict__ data, SidGeom g,
                                                          const float *__restrict__ sin_t, const float *__restrict__ cos_t,
                                                          const int *__restrict__ quad_t, int p_per_grp, int n_grp,
-                                                         float *__restrict__ partial)
+                                                         int kChunks, float *__restrict__ partial)
 {
     extern __shared__ float lds[];
     const int s = blockIdx.y, grp = blockIdx.x;
@@ -209,17 +237,23 @@ __global__ __launch_bounds__(1024) void siddon_bwd_kernel(const float *__restric
     for (int t = threadIdx.x; t < g.ox * pitch; t += blockDim.x) img[t] = 0.0f;
     __syncthreads();
     const float *row = data + ((size_t)s * g.dt + p0) * g.dx;
+    const int KH = kChunks / 2;              // runs per ray and phase (kChunks is even)
+    const int half_rays = (g.dx + 1) >> 1;
     for (int pl = 0; pl < np; ++pl, row += g.dx) {
         const int p = p0 + pl;
         const float sin_p = sin_t[p], cos_p = cos_t[p];
         const int quadrant = quad_t[p];
 #pragma unroll 1
-        for (int par = 0; par < 2; ++par) {
-            for (int d = 2 * (int)threadIdx.x + par; d < g.dx; d += 2 * blockDim.x) {
+        for (int phase = 0; phase < 4; ++phase) {
+            const int par = phase >> 1, cpar = phase & 1;
+            for (int t = threadIdx.x; t < half_rays * KH; t += blockDim.x) {
+                const int rr = t / KH, d = 2 * rr + par;
+                if (d >= g.dx) continue;
                 const float v = row[d];
                 if (v != 0.0f)
-                    siddon_walk_ray(g, sin_p, cos_p, quadrant, d,
-                                    [&](int ix, int iy, float dist) { img[ix * pitch + iy] += v * dist; });
+                    siddon_walk_ray<true>(g, sin_p, cos_p, quadrant, d,
+                                          [&](int ix, int iy, float dist) { img[ix * pitch + iy] += v * dist; },
+                                          2 * (t - rr * KH) + cpar, kChunks);
             }
             __syncthreads();   // (workgroup-scope release / acquire of the image, LDS or global)
         }
@@ -377,7 +411,11 @@ int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const f
     const SidGeom g0{0, ox, oz, dt, dx, siddon_mov(dx, center)};
     const size_t lds_bytes = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
     const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
-    int threads = std::min(1024, ceil_div(ceil_div(dx, 2), 64) * 64);
+    // runs per ray: 16 (tools/time_recon.py sweep) -- more shorten a lane's chain of dependent read-add-writes but repeat the
+    // ray set-up (two bisections + the merge-path search); never more runs than a short ray has segments to share out
+    int kChunks = 16;
+    if (knob(kKnobSiddonBwdChunks) > 0) kChunks = std::max(2, std::min(64, knob(kKnobSiddonBwdChunks) / 2 * 2));
+    int threads = std::min(1024, ceil_div(ceil_div(dx, 2) * (kChunks / 2), 64) * 64);   // one lane per (ray, run) of a phase
     if (knob(kKnobSiddonBwdThreads) > 0) threads = std::max(64, std::min(1024, knob(kKnobSiddonBwdThreads) / 64 * 64));
     const long long npix = (long long)ox * oz;
     for (int s0 = 0; s0 < oy; s0 += chunk) {
@@ -394,7 +432,7 @@ int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const f
             static std::atomic<unsigned long long> attr_set{0};
             if (shmem > 64 * 1024) CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
             hipLaunchKernelGGL(kernel, dim3(groups, n), dim3(threads), shmem, (hipStream_t)stream, data, g, sin_dev, cos_dev,
-                               quad_dev, p_per_grp, groups, partial);
+                               quad_dev, p_per_grp, groups, kChunks, partial);
             CTPVAE_LAUNCH_CHECK("siddon_bwd_kernel");
             return CTPVAE_OK;
         };
