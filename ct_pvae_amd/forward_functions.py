@@ -477,6 +477,38 @@ class RotatePlan:
             _lib.check(rc, "rotate_bwd")
         return out
 
+    # The training layout [B][X][Y][1] <-> [B][A][P][1] has the memory layout of [B][X][Y] <-> [B][A][P]: the two methods
+    # below launch on the caller's 4-D tensors directly (no reshape / unsqueeze views, one check) -- the drop-in API's
+    # fast path for planned float32 geometries.  None = not applicable, take the general path.
+    def forward_vae(self, x4):
+        if (self._fwd_plan is None or x4.dtype is not torch.float32 or not x4.is_contiguous() or x4.shape[0] == 0
+                or x4.device != self._tdev or x4.shape[1] != self.H or x4.shape[2] != self.W
+                or _current_device() != self._dev_index):
+            return None
+        S = x4.shape[0]
+        out = torch.empty((S, self.A, self.PW, 1), dtype=torch.float32, device=self._tdev)
+        rc = self._lib.ctpvae_rotate_fwd_planned_f32(x4.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                     self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+        if rc:
+            _lib.check(rc, "rotate_fwd")
+        return out
+
+    def backward_vae(self, g4):
+        S = g4.shape[0]
+        if (g4.dtype is not torch.float32 or not g4.is_contiguous() or S == 0 or g4.device != self._tdev
+                or g4.shape[1] != self.A or g4.shape[2] != self.PW or _current_device() != self._dev_index
+                or self._want_exact_plan or self._exact_plan is not None or not self.backward_uses_plan(S)):
+            return None
+        if self._bwd_plan is None:
+            self._bwd_plan = self._build_plan(1)
+        out = torch.empty((S, self.H, self.W, 1), dtype=torch.float32, device=self._tdev)
+        rc = self._lib.ctpvae_rotate_bwd_planned_scaled_f32(g4.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                            self._bwd_plan.data_ptr(), None, 0, out.data_ptr(),
+                                                            _stream_ptr(self._dev_index))
+        if rc:
+            _lib.check(rc, "rotate_bwd")
+        return out
+
     def apply(self, img):
         """Differentiable projection of slices [S][H][W] -> [S][A][PW]."""
         return _RotateProject.apply(img, self, 0)
@@ -494,6 +526,9 @@ class _RotateProject(torch.autograd.Function):
     def forward(ctx, phantom, plan, layout):
         ctx.plan, ctx.layout, ctx.in_dtype = plan, layout, phantom.dtype
         if layout == _LAYOUT_VAE:            # [B][X][Y][1]
+            out = plan.forward_vae(phantom)
+            if out is not None:
+                return out
             x = phantom.reshape(phantom.shape[0], phantom.shape[1], phantom.shape[2])
         elif layout == _LAYOUT_DIM3:         # [X][Y][Z]
             x = phantom.permute(2, 0, 1)
@@ -518,6 +553,10 @@ class _RotateProject(torch.autograd.Function):
     def backward(ctx, gout):
         layout, plan = ctx.layout, ctx.plan
         if layout == _LAYOUT_VAE:
+            if ctx.in_dtype is torch.float32:
+                gimg = plan.backward_vae(gout)
+                if gimg is not None:
+                    return gimg, None, None
             g = gout.reshape(gout.shape[0], gout.shape[1], gout.shape[2])
         elif layout in (_LAYOUT_DIM3, _LAYOUT_DIM2):
             g = gout.permute(2, 0, 1)
