@@ -235,8 +235,6 @@ class RotatePlan:
         """(forward uses a plan, backward uses / will use a plan)"""
         return self._fwd_plan is not None, self._want_bwd_plan
 
-    # The library launches on the calling thread's current HIP device: make that this plan's device (the common case --
-    # it already is -- costs one cheap query).
     def subset(self, angles_i):
         """A plan over rows `angles_i` of this one's tables (two small gathers, no plan kernels): the fallback for angle
         subsets on paths whose kernels take no angle-index operand (tiled / bilinear forward, exact backward)."""
@@ -251,6 +249,8 @@ class RotatePlan:
             return self._fwd_plan is not None and 1 <= n <= self.MAX_SEL
         return self.supports_scale and n >= 1
 
+    # The library launches on the calling thread's current HIP device: the wrappers below make that this plan's device (the
+    # common case -- it already is -- costs one cheap query).
     def forward(self, img, out=None, angles_i=None):
         """slices [S][H][W] -> sinograms [S][A][PW] (raw operator, no autograd bookkeeping).
         angles_i: int32 device vector of plan angles -> sinograms [S][len(angles_i)][PW] of those angles, in that order."""

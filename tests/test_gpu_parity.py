@@ -123,6 +123,31 @@ def test_rotate_against_oracle_and_golden(oracle, golden_dir, name, interp, use_
     assert rel_err(bx, z[f"bwd_exact_{interp}"]) <= REL
 
 
+@pytest.mark.parametrize("shape,kw", [((4, 10, 7, 1), dict(integrate_vae=True)), ((10, 7, 3), dict(dim=3)),
+                                      ((128, 128), dict(dim=2)), ((50, 128, 128, 1), dict(dim=2, integrate_vae=True))])
+def test_pad_phantom_on_the_device(oracle, shape, kw):
+    """a1: the materialising pad (ctvae/forward_functions.py:18-46) on device tensors, all three layouts, against the
+    oracle's; and projecting the padded tensor WITHOUT padding again equals projecting the original with pad=True."""
+    d = dev()
+    rng = np.random.default_rng(1)
+    x = rng.random(shape, dtype=np.float32)
+    out = cp.pad_phantom(torch.from_numpy(x).to(d), **kw)
+    assert out.device.type == "cuda"
+    if kw.get("integrate_vae"):
+        slices, got = x[..., 0], to_np(out)[..., 0]
+    elif kw.get("dim") == 3:
+        slices, got = np.transpose(x, (2, 0, 1)), np.transpose(to_np(out), (2, 0, 1))
+    else:
+        slices, got = x[None], to_np(out)[None]
+    geom = oracle.Geometry(slices.shape[1], slices.shape[2], True)
+    np.testing.assert_array_equal(got, oracle.pad_phantom(slices, geom))
+    if slices.shape[1] == slices.shape[2]:          # square: the padded canvas is what pad=True projects
+        theta = np.array([0.0, 0.4, 1.3, 2.2])
+        a = cp.project_tf_fast(torch.from_numpy(x).to(d), theta, pad=True, **kw)
+        b = cp.project_tf_fast(out, theta, pad=False, **kw)
+        assert torch.equal(a, b)
+
+
 def test_toy_known_answers_through_the_public_api():
     # scripts/images_to_sinograms.py:54-59 / ctvae/toy_mcmc_v2_functions.py:41
     x = torch.from_numpy(phantoms.toy_images()).to(dev())
