@@ -95,19 +95,18 @@ int main(int argc, char **argv)
         printf("planned fwd : %.2f us\n", time_us([&] { if (ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); } }));
         printf("planned bwd : %.2f us\n", time_us([&] { if (ctpvae_rotate_bwd_planned_f32(d_g, S, N, N, P, P, A, bp, d_gimg, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); } }));
         for (int ns : {1, 2}) for (int G : {1, 2, 3, 4, 5, 6, 8, 10, 12, 16}) {
-            char b[16]; snprintf(b, 16, "%d", G); setenv("CTPVAE_TUNE_G", b, 1);
-            snprintf(b, 16, "%d", ns); setenv("CTPVAE_TUNE_NS", b, 1);
+            char b[16]; snprintf(b, 16, "%d", G); ctpvae_tune_set("G", atoi(b));
+            snprintf(b, 16, "%d", ns); ctpvae_tune_set("NS", atoi(b));
             printf("planned fwd NS=%d G=%d: %.2f us\n", ns, G, time_us([&] { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); }, 100));
         }
-        unsetenv("CTPVAE_TUNE_NS");
-        unsetenv("CTPVAE_TUNE_G");
+        ctpvae_tune_set("NS", -1);
+        ctpvae_tune_set("G", -1);
         for (int bw : {2, 4, 8, 16}) {
-            char b[16]; snprintf(b, 16, "%d", bw); setenv("CTPVAE_TUNE_BW", b, 1);
+            char b[16]; snprintf(b, 16, "%d", bw); ctpvae_tune_set("BW", atoi(b));
             printf("planned bwd waves=%d: %.2f us\n", bw, time_us([&] { ctpvae_rotate_bwd_planned_f32(d_g, S, N, N, P, P, A, bp, d_gimg, nullptr); }, 100));
         }
-        unsetenv("CTPVAE_TUNE_BW");
-        unsetenv("CTPVAE_TUNE_LDS");
-        unsetenv("CTPVAE_TUNE_G");
+        ctpvae_tune_set("BW", -1);
+        ctpvae_tune_set("G", -1);
     }
     printf("product fwd bilinear: %.2f us\n", time_us([&] { ctpvae_rotate_fwd_f32(d_img, S, N, N, P, P, pad, pad, d_T, A, 1, d_sino, nullptr); }));
     printf("product bwd bilinear: %.2f us\n", time_us([&] { ctpvae_rotate_bwd_f32(d_g, S, A, P, P, d_Ti, 1, 0, N, N, pad, pad, d_gimg, nullptr); }));
@@ -117,8 +116,8 @@ int main(int argc, char **argv)
 #ifdef CTPVAE_TUNE_STAMPS
     for (int cfg : {15, 25, 24}) {   // (slices per workgroup, groups)
         const int Gs = cfg % 10, nsl = cfg / 10;
-        char gb[16]; snprintf(gb, 16, "%d", Gs); setenv("CTPVAE_TUNE_G", gb, 1);
-        snprintf(gb, 16, "%d", nsl); setenv("CTPVAE_TUNE_NS", gb, 1);
+        char gb[16]; snprintf(gb, 16, "%d", Gs); ctpvae_tune_set("G", atoi(gb));
+        snprintf(gb, 16, "%d", nsl); ctpvae_tune_set("NS", atoi(gb));
         void *fp; CK(hipMalloc(&fp, ctpvae_rotate_plan_bytes(N, N, P, P, A, 0)));
         ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, fp, nullptr, nullptr);
         for (int rep = 0; rep < 2; ++rep) { ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr); CK(hipDeviceSynchronize()); }
