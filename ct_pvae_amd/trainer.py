@@ -227,17 +227,22 @@ def kl_normal_std(loc, scale):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# ELBO (ctvae/helper_functions.py:204-332, use_normal path)
+# ELBO (ctvae/helper_functions.py:204-332; --normal: Normal latents + TruncatedNormal output, otherwise the reference's
+# default Beta latents, Beta(0.5, 0.5) prior and Beta output, :247-252, :275-285, ctvae/main_ct_vae.py:369-372)
 # ---------------------------------------------------------------------------------------------------------
 def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_decode, poisson_noise_multiplier, sqrt_reg,
-                        kl_anneal, kl_multiplier, num_samples=2, theta=None, angles_i=None, pad=True, deterministic=False):
+                        kl_anneal, kl_multiplier, num_samples=2, theta=None, angles_i=None, pad=True, deterministic=False,
+                        use_normal=True):
     skips = model_encode(input_encode / 300)
     q = None
     if not deterministic:
         q = []
         for sk in skips:
             loc, log_scale = sk.chunk(2, dim=1)
-            q.append((loc, positive_range(log_scale) + sqrt_reg))
+            if use_normal:
+                q.append((loc, positive_range(log_scale) + sqrt_reg))
+            else:                                                   # :252 tfd.Beta(positive_range(loc), scale)
+                q.append(torch.distributions.Beta(positive_range(loc), positive_range(log_scale)))
     # The reference draws its `num_samples` latent samples in a Python loop (:263-312); they are independent, so here
     # they ride the batch axis: ONE decoder pass and ONE projector + likelihood pass over num_samples * B objects
     # (sample-major), the same estimator with half the launches at ns = 2.
@@ -245,14 +250,21 @@ def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_dec
     B = input_encode.shape[0]
     if deterministic:
         q_sample = skips
-    else:
+    elif use_normal:
         q_sample = [loc.repeat(ns, 1, 1, 1) + scale.repeat(ns, 1, 1, 1) * torch.randn((ns * B,) + tuple(loc.shape[1:]),
                                                                                       device=loc.device, dtype=loc.dtype)
                     for loc, scale in q]
+    else:                                                           # reparameterised Beta samples, sample-major
+        q_sample = [d.rsample((ns,)).reshape((ns * B,) + tuple(d.concentration1.shape[1:])) for d in q]
     alpha, beta = model_decode(q_sample)
-    dist = TruncatedNormal(positive_range(alpha), positive_range(beta), low=0.0, high=1e10)
-    output_sample = dist.rsample()                                       # [ns * B][1][X][Y]
-    log_prob_R_given_z = dist.log_prob(output_sample)
+    if use_normal:
+        dist = TruncatedNormal(positive_range(alpha), positive_range(beta), low=0.0, high=1e10)
+        output_sample = dist.rsample()                                   # [ns * B][1][X][Y]
+        log_prob_R_given_z = dist.log_prob(output_sample)
+    else:                                                           # :278-285
+        dist = torch.distributions.Beta(positive_range(alpha), positive_range(beta))
+        output_sample = dist.rsample()
+        log_prob_R_given_z = dist.log_prob(output_sample.clamp(sqrt_reg, 1 - sqrt_reg))
     lp = calculate_log_prob_M_given_R(output_sample.permute(0, 2, 3, 1), mask.repeat(ns, 1), proj_sample.repeat(ns, 1, 1),
                                       poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad)
     # :305-306 reduce_sum(..., axis=[0, 1, 2]) of the squeezed [B][A][P] and [B][X][Y] tensors: the log-likelihood of a
@@ -262,8 +274,12 @@ def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_dec
     recon = output_sample[(ns - 1) * B:]
     if deterministic:
         kl = lp.new_zeros(B)
-    else:
+    elif use_normal:
         kl = sum(kl_normal_std(loc, scale).sum(dim=(1, 2, 3)) for loc, scale in q[1:])   # the input level is unused
+    else:                                                           # prior Beta(0.5, 0.5), ctvae/main_ct_vae.py:372
+        kl = sum(torch.distributions.kl_divergence(d, torch.distributions.Beta(torch.full_like(d.concentration1, 0.5),
+                                                                             torch.full_like(d.concentration1, 0.5)))
+                 .sum(dim=(1, 2, 3)) for d in q[1:])
     loglik = log_prob_M.mean(dim=0)                                                       # scalar
     return kl_anneal * kl_multiplier * kl - loglik, kl, loglik, recon
 
@@ -392,7 +408,7 @@ class PVAETrainer:
         loss_vec, kl, loglik, _ = find_loss_vae_unsup(proj_sample, mask, input_encode, self.enc, self.dec, pnm_i,
                                                       self.sqrt_reg, kl_anneal, a.klm, num_samples=a.ns,
                                                       theta=self.theta_host, angles_i=angles_i, pad=self.pad,
-                                                      deterministic=a.deterministic)
+                                                      deterministic=a.deterministic, use_normal=a.use_normal)
         # ctvae/main_ct_vae.py:478 reduce_mean(loss_M_VAE) / 1e5 = mean_b(KL term) - loglik, where loglik already sums
         # over the batch.  Written so that the ranks' losses ADD UP to the global one (gradients are summed over ranks):
         # each rank contributes its objects' KL / global_B and its own objects' log-likelihood.
@@ -480,9 +496,17 @@ class PVAETrainer:
         """Mean decoder output on the first n examples vs. the phantoms (MSE), and the FBP input's MSE."""
         n = n or min(self.args.td, 16)
         skips = self.enc(self.input_encode[:n] / 300)
-        lat = [s.chunk(2, dim=1)[0] for s in skips] if not self.args.deterministic else skips
-        alpha, _ = self.dec(lat)
+        if self.args.deterministic:
+            lat = skips
+        elif self.args.use_normal:
+            lat = [s.chunk(2, dim=1)[0] for s in skips]                                   # the latents' means
+        else:                                                                             # Beta(a, b): a / (a + b)
+            ab = [(positive_range(s.chunk(2, dim=1)[0]), positive_range(s.chunk(2, dim=1)[1])) for s in skips]
+            lat = [a_ / (a_ + b_) for a_, b_ in ab]
+        alpha, beta = self.dec(lat)
         rec = positive_range(alpha)[:, 0]
+        if not self.args.use_normal:
+            rec = rec / (rec + positive_range(beta)[:, 0])
         if self.truth is None:                    # a dataset folder holds sinograms only
             return float("nan"), float("nan")
         return float(((rec - self.truth[:n]) ** 2).mean()), float(((self.input_encode[:n, 0] - self.truth[:n]) ** 2).mean())
@@ -502,7 +526,7 @@ class PVAETrainer:
             loss_vec, _, _, recon = find_loss_vae_unsup(self.proj_samples[sl], self.masks[sl], self.input_encode[sl], self.enc,
                                                         self.dec, self.pnm, self.sqrt_reg, self.kl_anneal, a.klm,
                                                         num_samples=a.ns, theta=self.theta_host, angles_i=None, pad=self.pad,
-                                                        deterministic=a.deterministic)
+                                                        deterministic=a.deterministic, use_normal=a.use_normal)
             losses.append(loss_vec.mean() / 1e5)
             recons.append(recon.permute(0, 2, 3, 1))
         loss_final = torch.stack(losses).cpu().numpy()
@@ -532,7 +556,9 @@ def get_args(argv=None):
     p.add_argument("--nfm", type=int, dest="nfm", default=20)
     p.add_argument("--nfmm", type=float, dest="nfmm", default=1.1)
     p.add_argument("--norm", type=float, dest="norm", default=100.0)
-    p.add_argument("--normal", action="store_true", dest="use_normal", help="accepted; the normal path is the only one built")
+    p.add_argument("--normal", action="store_true", dest="use_normal",
+                   help="Normal latents and a TruncatedNormal output distribution (every README recipe); without it the "
+                        "reference's default Beta latents / Beta(0.5, 0.5) prior / Beta output (ctvae/main_ct_vae.py:69, :369-372)")
     p.add_argument("--nsa", type=int, dest="nsa", default=10)
     p.add_argument("--api", type=int, dest="api", default=5)
     p.add_argument("--pnm", type=float, dest="pnm", default=(2 ** 16 - 1) * 0.41)

@@ -196,3 +196,20 @@ def test_train_then_restore_and_evaluate_from_the_saved_files(tmp_path):
     assert again.iter == 4 and again.latest_checkpoint().endswith("ckpt-3.pt")
     loss_final, recon = again.final_evaluation()
     assert recon.shape == (6, 64, 64, 1) and np.isfinite(loss_final).all()
+
+
+def test_beta_branch_of_the_elbo():
+    """Without --normal the reference's ELBO uses Beta latents, a Beta(0.5, 0.5) prior and a Beta output distribution
+    (ctvae/helper_functions.py:247-252, :275-285; ctvae/main_ct_vae.py:369-372 -- its argparse default): the harness runs
+    it through the same HIP physics decoder, reconstructions stay inside (0, 1), losses are finite and gradients flow."""
+    args = tr.get_args("--nsa 20 --td 6 -b 3 --ns 2 --api 10 --pnm 1e4 --random -i 3 --train".split())
+    assert args.use_normal is False
+    t = tr.PVAETrainer(args, torch.device("cuda", 0))
+    before = [p.detach().clone() for p in t.params[:3]]
+    losses = [t.train_step() for _ in range(3)]
+    assert all(math.isfinite(v) for v in losses)
+    assert any(not torch.equal(a, b) for a, b in zip(before, t.params[:3]))
+    loss_final, recon = t.final_evaluation(None)
+    assert recon.shape == (6, 128, 128, 1) and (recon > 0).all() and (recon < 1).all()
+    mse, _ = t.evaluate()
+    assert math.isfinite(mse)
