@@ -189,7 +189,7 @@ class RotatePlan:
         # The forward plan is built now, the backward plan on the first backward.
         self._fwd_plan = self._bwd_plan = self._exact_plan = None
         self._want_bwd_plan = False
-        # exact transpose (nearest): a deterministic gather through an inverse plan, built on the first backward
+        # exact transpose (nearest): a deterministic gather through an inverse plan
         self._want_exact_plan = bool(use_plan and self.mode == _lib.BWD_EXACT and self.interp == _lib.NEAREST)
         self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
         self._tile_ws = None
@@ -199,6 +199,10 @@ class RotatePlan:
                 self._fwd_plan = self._build_plan(0)
             self._want_bwd_plan = bool(self.mode == _lib.BWD_TF_COMPAT and
                                        self._lib.ctpvae_rotate_plan_supported(*geo, 1))
+        if self._want_exact_plan:
+            # built here, not on the first backward: reading its overflow word synchronises the stream, which must not
+            # happen inside a caller's HIP-graph capture
+            self._build_exact_plan()
 
     def _build_plan(self, which):
         nbytes = self._lib.ctpvae_rotate_plan_bytes(self.H, self.W, self.PH, self.PW, self.A, which)
