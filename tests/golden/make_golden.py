@@ -47,11 +47,33 @@ def tiled_case():
                         fwd_rowwise=orc.rotate_fwd(img, geom, T, NEAREST))
 
 
+def round2_case():
+    """Round-2 set-up-path operators: the Poisson measurement model with the build's specified sampler (f2), the ray-driven
+    back-projection and SIRT (f3) -- small shapes, fixed seeds."""
+    rng = np.random.default_rng(21)
+    sino = (10 ** rng.uniform(-3, 5, size=(2, 5, 24))).astype(np.float32)
+    sino[0, 0, :4] = [-1.0, 0.0, 9.99, 10.0]
+    mask = np.array([[1, 0, 0.5, 0.05, 1], [0.05, 0.05, 0, 1, 0.5]], np.float32)
+    out = dict(p_sino=sino, p_mask=mask, p_pnm=np.array(1e2, np.float32), p_seed=np.array(2 ** 40 + 17, np.uint64),
+               p_out=orc.poisson_measure(sino, mask, 1e2, 2 ** 40 + 17))
+    img = phantoms.foam_batch(2, 24, seed=9, supersample=2)
+    theta = np.array([0.0, 0.35, 0.9, np.pi / 2, 2.0, 2.6, 3.3, 4.4, 5.9])
+    data = np.ascontiguousarray(np.swapaxes(orc.siddon_project(img, theta, pad=True), 0, 1))       # [2][9][36]
+    out.update(r_img=img, r_theta=theta, r_data=data, r_backproject=orc.siddon_backproject(data, theta),
+               r_backproject_obj=orc.siddon_backproject(data, theta, 24, 24), r_sirt1=orc.sirt(data, theta, 1),
+               r_sirt7=orc.sirt(data, theta, 7))
+    np.savez_compressed(os.path.join(OUT, "round2_setup_path.npz"), **out)
+
+
 def main():
     orc.build(force=True)
     if sys.argv[1:] == ["tiled"]:
         tiled_case()
         return
+    if sys.argv[1:] == ["round2"]:
+        round2_case()
+        return
+    round2_case()
     tiled_case()
     rng = np.random.default_rng(0)
     # the reference's 2x2 toy set (scripts/create_toy_images.py:36-40), no padding

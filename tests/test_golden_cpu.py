@@ -62,3 +62,23 @@ def test_tiled_summation_golden(oracle, golden_dir):
     np.testing.assert_array_equal(oracle.rotate_fwd_tiled(z["img"], geom, z["T8"], (220, 190)), z["fwd_rowwise"])
     with pytest.raises(ValueError):
         oracle.rotate_fwd_tiled(z["img"], geom, z["T8"], (0, 64))
+
+
+def test_round2_setup_path_golden(oracle, golden_dir):
+    """The set-up path's operators (f2: Poisson measurements with the specified counter-based sampler; f3: ray-driven
+    back-projection and SIRT) against their committed vectors: a change of the sampler's specification or of the walk shows
+    here, on the CPU."""
+    z = load(golden_dir, "round2_setup_path")
+    np.testing.assert_array_equal(oracle.poisson_measure(z["p_sino"], z["p_mask"], float(z["p_pnm"]), int(z["p_seed"])),
+                                  z["p_out"])
+    assert z["p_out"][0, 0, 0] == 0.0 and z["p_out"][0, 0, 1] == 0.0 and (z["p_out"][0, 1] == 0).all()
+    data, theta = z["r_data"], z["r_theta"]
+    np.testing.assert_array_equal(np.swapaxes(oracle.siddon_project(z["r_img"], theta, pad=True), 0, 1), data)
+    np.testing.assert_array_equal(oracle.siddon_backproject(data, theta), z["r_backproject"])
+    np.testing.assert_array_equal(oracle.siddon_backproject(data, theta, 24, 24), z["r_backproject_obj"])
+    np.testing.assert_array_equal(oracle.sirt(data, theta, 1), z["r_sirt1"])
+    np.testing.assert_array_equal(oracle.sirt(data, theta, 7), z["r_sirt7"])
+    # <A x, y> = <x, A^T y> on the stored vectors
+    lhs = float((data.astype(np.float64) ** 2).sum())
+    rhs = float((z["r_img"].astype(np.float64) * z["r_backproject_obj"]).sum())
+    assert abs(lhs - rhs) <= 1e-5 * lhs

@@ -1010,6 +1010,24 @@ def test_angle_subsets_on_geometries_without_an_index_operand(oracle):
     assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
 
 
+def test_round2_setup_path_against_golden(golden_dir):
+    """The HIP set-up-path kernels against tests/golden/round2_setup_path.npz directly: Poisson counts bit-exact, back-
+    projection and SIRT to 1e-5 / 5e-5 of the largest value."""
+    from ct_pvae_amd.create_masks import poisson_measure
+    from ct_pvae_amd.recon import recon, siddon_backproject
+    d = dev()
+    z = np.load(os.path.join(golden_dir, "round2_setup_path.npz"))
+    got = poisson_measure(torch.from_numpy(z["p_sino"]).to(d), torch.from_numpy(z["p_mask"]).to(d), float(z["p_pnm"]),
+                          int(z["p_seed"]))
+    np.testing.assert_array_equal(to_np(got), z["p_out"])
+    data, theta = torch.from_numpy(z["r_data"]).to(d), z["r_theta"]
+    np.testing.assert_array_equal(to_np(cp.create_sinograms(torch.from_numpy(z["r_img"]).to(d), theta, pad=True)), z["r_data"])
+    assert rel_err(to_np(siddon_backproject(data, theta)), z["r_backproject"]) <= REL
+    assert rel_err(to_np(siddon_backproject(data, theta, 24, 24)), z["r_backproject_obj"]) <= REL
+    assert rel_err(to_np(recon(data, theta, sinogram_order=True, algorithm="sirt")), z["r_sirt1"]) <= REL
+    assert rel_err(to_np(recon(data, theta, sinogram_order=True, algorithm="sirt", num_iter=7)), z["r_sirt7"]) <= 5e-5
+
+
 def test_backward_scale_operand_checks():
     d = dev()
     theta = np.linspace(0, np.pi, 6, endpoint=False)
