@@ -301,7 +301,8 @@ def n512_mode(args, world, rank, dev):
     plan = RotatePlan(theta, N, N, True, dev)
     x = torch.rand((B, N, N), device=dev)
     mask = torch.full((B, A), 1.0 / A, device=dev)
-    meas = torch.poisson(plan.forward(x) * mask[..., None] * 1e4) / 1e4
+    from ct_pvae_amd.create_masks import poisson_measure
+    meas = poisson_measure(plan.forward(x), mask, 1e4, seed=rank)      # the Poisson-noise forward model, on the device
     pnm = torch.tensor(1e4, device=dev)
     eps = float(np.finfo(np.float32).eps)
     sino = torch.empty((B, A, plan.PW), device=dev)
@@ -316,15 +317,36 @@ def n512_mode(args, world, rank, dev):
 
     steps = max(args.steps // 10, 10)
     el = _time_loop(step, steps, 3, world)
+
+    def ev_time(fn, n=20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    t_fwd = ev_time(lambda: plan.forward_loglik(x, mask, meas, pnm, eps, out=sino, out_lp=lp, out_dlp=dlp))
+    t_bwd = ev_time(lambda: plan.backward(dlp, out=gx, scale=up))
     if rank == 0:
         bytes_step = 8.0 * B * (N * N + A * plan.PW)
+        bytes_fwd = 4.0 * B * (N * N + A * plan.PW)
         print(json.dumps({"metric": "projections/sec (fwd + log-lik + adj), 512x512, 90 angles, pnm 1e4",
                           "value": world * B * A * steps / el, "unit": "projections/s", "n_gpus": world, "steps": steps,
                           "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"batch={B}/GPU 512x512, 90 angles, P={plan.PW}, nearest fwd + "
                                                  "fused Gaussian-Poisson log-likelihood and its derivative, tf_compat adj with the upstream per-object factor (tiled fwd, 4 slices per workgroup; segment-staged adj)"},
-                          "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS}))
+                          "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS,
+                          "roofline": {"bound": "hbm", "kernel": "rotate_fwd_fast_kernel<tiled> + rotate_tile_reduce_kernel<loglik>",
+                                       "achieved": bytes_fwd / t_fwd / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": bytes_fwd / t_fwd / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "algorithmic_bytes_per_launch": bytes_fwd,
+                                       "kernel_us": {"tiled_fwd_plus_reduce_loglik": t_fwd * 1e6, "segment_adj_scaled": t_bwd * 1e6},
+                                       "note": "VALU-bound on the shared address arithmetic (DESIGN.md section 9), not HBM-bound"}}))
 
 
 def main():
