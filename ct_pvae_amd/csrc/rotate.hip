@@ -611,9 +611,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 }
 
 // sino[s][a][j] = sum over tiles, ascending, of the partial sums of the tiles whose slot range holds bin j.
-// Workgroup = up to 1024 bins of one (slice, angle); every wave owns 64 consecutive bins: it lists, 64 tiles at a time
-// and in ascending order, the tiles whose slot range touches its bins (about a quarter of them: ballot + popcount into
-// a per-wave LDS list), then adds their partial sums, eight loads in flight.
+// Workgroup = up to 1024 bins of one angle for kReduceSlices consecutive slices; every wave owns 64 consecutive bins: it
+// lists, 64 tiles at a time and in ascending order, the tiles whose slot range touches its bins (about a quarter of them:
+// ballot + popcount into a per-wave LDS list) -- the list depends on the angle and the bins only, so it is built ONCE and
+// serves all the workgroup's slices -- then adds their partial sums tile by tile, the slices' loads in flight together.
+// (One slice per workgroup made this pass wave-launch bound: 34.5 k waves of a dozen loads each at B=32, 27 us.)
+constexpr int kReduceSlices = 8;
 template <bool EPI>   // EPI: also write the log-probability of the measured sample under every ray-sum (loglik_math.h)
 __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
                                                                   const float *__restrict__ T8, float *__restrict__ sino,
@@ -621,13 +624,20 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
 {
     __shared__ int list_tile[16][64], list_first[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64, j = j0 + lane, a = blockIdx.y, s = blockIdx.z;
+    const int j0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 64, j = j0 + lane, a = blockIdx.y;
+    const int s0 = blockIdx.z * kReduceSlices;
     if (j0 >= g.PW) return;                         // (whole waves only: no barrier below)
     const float *t = T8 + 8 * a;
     const int nt = ts.ntx * ts.nty;
-    const float *pa = partial + ((size_t)s * nt * g.A + a) * ts.nb;   // tile stride: A * nb
-    const size_t tstride = (size_t)g.A * ts.nb;
-    float acc = 0.0f;
+    const size_t tstride = (size_t)g.A * ts.nb;     // tile stride
+    const size_t sstride = (size_t)nt * tstride;    // slice stride
+    const float *pa[kReduceSlices];
+#pragma unroll
+    for (int q = 0; q < kReduceSlices; ++q)        // slices past the batch re-read the last one, never stored
+        pa[q] = partial + (size_t)min(s0 + q, g.S - 1) * sstride + (size_t)a * ts.nb;
+    float acc[kReduceSlices];
+#pragma unroll
+    for (int q = 0; q < kReduceSlices; ++q) acc[q] = 0.0f;
     for (int base = 0; base < nt; base += 64) {
         const int tile = base + lane;
         bool rel = false;
@@ -647,26 +657,28 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
             list_first[wave][pos] = fb;
         }
         __builtin_amdgcn_wave_barrier();              // the list is this wave's own: LDS writes are in order
-        constexpr int U = 8;   // loads in flight; unconditional (slot clamped to a valid cell), the select comes after
-        for (int i0 = 0; i0 < n; i0 += U) {
-            float v[U];
-            bool ok[U];
+        for (int i = 0; i < n; ++i) {                 // tiles in ascending order; loads unconditional (slot clamped)
+            const int slot = j - list_first[wave][i];
+            const bool ok = j < g.PW && (unsigned)slot < (unsigned)ts.nb;
+            const size_t off = (size_t)list_tile[wave][i] * tstride + (ok ? slot : 0);
+            float v[kReduceSlices];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = min(i0 + u, n - 1);
-                const int slot = j - list_first[wave][i];
-                ok[u] = i0 + u < n && j < g.PW && (unsigned)slot < (unsigned)ts.nb;
-                v[u] = pa[list_tile[wave][i] * tstride + (ok[u] ? slot : 0)];
-            }
+            for (int q = 0; q < kReduceSlices; ++q) v[q] = pa[q][off];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc += ok[u] ? v[u] : 0.0f;   // + 0.0f leaves the sum unchanged
+            for (int q = 0; q < kReduceSlices; ++q) acc[q] += ok ? v[q] : 0.0f;   // + 0.0f leaves the sum unchanged
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (j >= g.PW) return;
-    const size_t o = ((size_t)s * g.A + a) * g.PW + j;
-    sino[o] = acc;
-    if constexpr (EPI) epi.write(o, o, (size_t)s * g.A + a, acc);
+#pragma unroll
+    for (int q = 0; q < kReduceSlices; ++q) {
+        const int s = s0 + q;
+        if (s < g.S) {
+            const size_t o = ((size_t)s * g.A + a) * g.PW + j;
+            sino[o] = acc[q];
+            if constexpr (EPI) epi.write(o, o, (size_t)s * g.A + a, acc[q]);
+        }
+    }
 }
 
 // ---- backward, TensorFlow-compatible (gather) -------------------------------------------------
@@ -1303,7 +1315,7 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 1>);
     if (rc) return rc;
     const int rwaves = std::min(16, ceil_div(PW, 64));   // waves per workgroup: 64 bins each
-    const dim3 rgrid(ceil_div(PW, 64 * rwaves), A, S), rblock(64 * rwaves);
+    const dim3 rgrid(ceil_div(PW, 64 * rwaves), A, ceil_div(S, kReduceSlices)), rblock(64 * rwaves);
     if (epi.lp)
         hipLaunchKernelGGL(rotate_tile_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream,
                            (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
