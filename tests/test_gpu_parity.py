@@ -1187,6 +1187,25 @@ def test_bench_under_torchrun_two_ranks():
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it (how the driver runs N = 1): the parent starts the
+    ranks itself, as children, before it touches the GPU; on this one-GPU box they rehearse on device 0 over gloo.  rc 0,
+    one JSON line from rank 0, n_gpus = 2, whole-job value."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--min-ms", "5"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["repeats"] >= 1 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 50 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
 def test_random_geometries_against_the_oracle(oracle):
     """Seeded random small geometries (odd sizes, 1-pixel slices, unpadded canvases, 1..40 angles, any angle values):
     planned or direct, whichever the geometry takes, forward and tf_compat backward are bit-exact against the oracle; the
