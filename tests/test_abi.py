@@ -99,3 +99,20 @@ def test_driver_build_entry_point():
     library and agree with it about the ABI version."""
     import __graft_entry__ as entry
     entry.build()
+
+
+def test_round2_host_only_size_rules(built_lib):
+    """Host-side size rules of the round-2 entry points (no GPU needed): the exact-transpose plan is the backward plan's
+    layout over 2A virtual angles plus one overflow line; the back-projector's workspace holds one partial image per angle
+    group; bad sizes are refused."""
+    lib = built_lib.load()
+    # 128 x 128 in a 184 x 184 canvas, 20 angles: ceil(40 / 16) = 3 groups x 128 rows x 128 padded columns x 16 B + 256
+    assert lib.ctpvae_rotate_exact_plan_bytes(128, 128, 184, 184, 20) == 3 * 128 * 128 * 16 + 256
+    assert lib.ctpvae_rotate_exact_plan_bytes(128, 128, 184, 184, 180) == 23 * 128 * 128 * 16 + 256
+    assert lib.ctpvae_rotate_exact_plan_bytes(512, 512, 728, 728, 90) == 0          # bins do not fit a byte
+    assert lib.ctpvae_rotate_exact_plan_bytes(0, 128, 184, 184, 20) == built_lib.EINVAL
+    # 50 slices x 180 angles onto 184 x 184: ceil(512 / 50) = 11 angle groups
+    assert lib.ctpvae_siddon_bwd_workspace_bytes(50, 184, 184, 180) == 50 * 11 * 184 * 184 * 4
+    assert lib.ctpvae_siddon_bwd_workspace_bytes(600, 64, 64, 16) == 0               # one group: no workspace
+    assert lib.ctpvae_siddon_bwd_workspace_bytes(1, 64, 64, 3) == 0                  # fewer than 4 angles per group
+    assert lib.ctpvae_siddon_bwd_workspace_bytes(0, 64, 64, 16) == built_lib.EINVAL
