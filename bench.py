@@ -508,6 +508,8 @@ def main():
                                            "calculate_log_prob_M_given_R": host_rate(lik_step, nb)}
         api[f"batch_{nb}"] = ent
     api["value"] = api[f"batch_{B}"]["project_tf_fast"]
+    from ct_pvae_amd import _lib as _cl
+    api["autograd_node"] = "C++ (ct_pvae_amd/csrc/torch_node.cpp)" if _cl.torch_node() is not None else "Python"
 
     if rank != 0:
         return

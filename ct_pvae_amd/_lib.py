@@ -102,6 +102,43 @@ def load():
     return _lib
 
 
+NODE_NAME = "_ctpvae_torch_node"
+NODE_DIR = os.path.join(_HERE, "_torch_node")
+NODE_PATH = os.path.join(NODE_DIR, NODE_NAME + ".so")
+_node = False
+
+
+def build_torch_node(verbose=False):
+    """Compile csrc/torch_node.cpp (host C++, no HIP) in-tree with torch's extension builder; __graft_entry__.build() calls this."""
+    from torch.utils.cpp_extension import load
+    os.makedirs(NODE_DIR, exist_ok=True)
+    return load(name=NODE_NAME, sources=[os.path.join(_HERE, "csrc", "torch_node.cpp")], build_directory=NODE_DIR,
+                extra_cflags=["-O2"], extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose)
+
+
+def torch_node():
+    """The C++ autograd node of the training layout (csrc/torch_node.cpp), bound to the loaded library; None when it was not
+    built (the Python node of forward_functions.py then makes the same two C-ABI calls, a few microseconds slower)."""
+    global _node
+    if _node is False:
+        _node = None
+        if os.path.exists(NODE_PATH):
+            import importlib.util
+            import torch  # noqa: F401  (the module links against libtorch)
+            try:
+                spec = importlib.util.spec_from_file_location(NODE_NAME, NODE_PATH)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+            except (ImportError, OSError) as e:      # built against another libtorch: say so, keep the Python nodes
+                import warnings
+                warnings.warn(f"{NODE_PATH} does not load ({e}); rebuild it with __graft_entry__.build()")
+                return None
+            load()
+            mod.bind(LIB_PATH)
+            _node = mod
+    return _node
+
+
 def tune(name, value=-1):
     """Developer knob of the library (see ctpvae_tune_set in include/ctpvae_radon.h); value < 0 unsets, name "*" unsets all."""
     check(load().ctpvae_tune_set(name.encode(), int(value)), "tune_set")

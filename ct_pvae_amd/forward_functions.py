@@ -513,12 +513,45 @@ class RotatePlan:
             _lib.check(rc, "rotate_bwd")
         return out
 
+    def project_vae_cpp(self, x4):
+        """The training layout through the C++ autograd node (csrc/torch_node.cpp): the same two C-ABI calls as
+        forward_vae / backward_vae, without the Python of torch.autograd.Function around them.  None = not applicable."""
+        node = _lib.torch_node()
+        S = x4.shape[0]
+        if (node is None or self._fwd_plan is None or x4.dtype is not torch.float32 or not x4.is_contiguous() or S == 0
+                or x4.device != self._tdev or self._want_exact_plan or self._exact_plan is not None
+                or not self.backward_uses_plan(S)):
+            return None
+        if self._bwd_plan is None:
+            self._bwd_plan = self._build_plan(1)
+        return node.rotate_vae(x4, self._fwd_plan, self._bwd_plan, self.H, self.W, self.PH, self.PW, self.A,
+                               _stream_ptr(self._dev_index))
+
+    def loglik_vae_cpp(self, x4, mask, meas, pnm, eps, angles_i):
+        """calculate_log_prob_M_given_R through the C++ autograd node (one-launch forward that stores d lp / d sino, scaled
+        backward): the calls _ProjectLogLik's fused branch makes.  The caller has checked x4 / mask / meas / pnm (float32,
+        contiguous, this device).  None = not applicable."""
+        node = _lib.torch_node()
+        if node is None or self._fwd_plan is None or not self.supports_scale:
+            return None
+        use_plan = False
+        if angles_i is None:
+            use_plan = self.backward_uses_plan(x4.shape[0])
+            if use_plan and self._bwd_plan is None:
+                self._bwd_plan = self._build_plan(1)
+        else:
+            self._check_sel(angles_i)
+        return node.rotate_loglik(x4, self._fwd_plan, self._bwd_plan if use_plan else self.Tinv8, self.Tinv8, mask, meas, pnm,
+                                  angles_i, eps, [self.H, self.W, self.PH, self.PW, self.A, self.py, self.px, int(use_plan),
+                                                  int(angles_i is not None), _stream_ptr(self._dev_index)])
+
     def apply(self, img):
         """Differentiable projection of slices [S][H][W] -> [S][A][PW]."""
         return _RotateProject.apply(img, self, 0)
 
 
 _LAYOUT_SLICES, _LAYOUT_VAE, _LAYOUT_DIM3, _LAYOUT_DIM2 = 0, 1, 2, 3
+USE_CPP_NODE = True     # tests and tools/profile_api.py switch this off to compare the two host paths
 
 
 class _RotateProject(torch.autograd.Function):
@@ -665,6 +698,10 @@ def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
     dev = phantom.device
     plan = _cached_plan(theta, H, W, pad, dev, interp, backward)
     if dev.index == _current_device():
+        if layout == _LAYOUT_VAE and USE_CPP_NODE:
+            out = plan.project_vae_cpp(phantom)
+            if out is not None:
+                return out
         return _RotateProject.apply(phantom, plan, layout)
     with torch.cuda.device(dev):
         return _RotateProject.apply(phantom, plan, layout)

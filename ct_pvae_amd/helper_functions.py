@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, forward_functions
 from .forward_functions import _cached_plan, _current_device, _stream_ptr, as_angle_index, project_tf_fast
 
 __all__ = ["create_sinogram", "create_sinograms", "calculate_log_prob_M_given_R", "gaussian_poisson_log_prob"]
@@ -249,6 +249,11 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
             if proj_sample.dtype is not torch.float32 or not proj_sample.is_contiguous():
                 proj_sample = proj_sample.to(torch.float32).contiguous()
             if x.device.index == _current_device():
+                if (forward_functions.USE_CPP_NODE and plan.planned[0] and x.requires_grad and not pnm.requires_grad
+                        and torch.is_grad_enabled()):
+                    out = plan.loglik_vae_cpp(x, mask, proj_sample, pnm, float(sqrt_reg), sel)
+                    if out is not None:
+                        return out
                 return _ProjectLogLik.apply(x, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
             with torch.cuda.device(x.device):
                 return _ProjectLogLik.apply(x, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)

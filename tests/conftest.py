@@ -21,6 +21,19 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def torch_node():
+    """The C++ autograd nodes (ct_pvae_amd/csrc/torch_node.cpp): built by __graft_entry__.build(); compiled on demand (g++,
+    under a minute) when a test session starts without them."""
+    from ct_pvae_amd import _lib
+    if _lib.torch_node() is None:
+        _lib.build_torch_node()
+        _lib._node = False
+    node = _lib.torch_node()
+    assert node is not None
+    return node
+
+
+@pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 

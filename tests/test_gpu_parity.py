@@ -579,7 +579,7 @@ def test_fused_loglik_backward_is_one_launch_and_matches_two_steps(B, N, A, upst
         x = torch.from_numpy(rng_img(B, N)).to(d).requires_grad_(True)
         if fused:
             lp = cp.calculate_log_prob_M_given_R(x, mask, meas, 1e3, eps, theta=theta, pad=True)
-            assert type(lp.grad_fn).__name__.startswith("_ProjectLogLik")      # ONE autograd node for the whole call
+            assert "ProjectLogLik" in lp.grad_fn.name() or "RotateLogLik" in lp.grad_fn.name()   # ONE autograd node for the call
         else:
             proj = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
             lp = gaussian_poisson_log_prob(proj[..., 0], mask, meas, 1e3, eps).unsqueeze(-1)
@@ -1396,3 +1396,104 @@ def test_likelihood_entry_points_check_their_operands():
                                      torch.rand((2, 5, P), device=d), 1e3, 1e-7)
     ok = cp.calculate_log_prob_M_given_R(x, torch.rand((2, 6), device=d), torch.rand((2, 6, P), device=d), 1e3, 1e-7, theta=theta)
     assert ok.shape == (2, 6, P, 1)
+
+
+def test_cpp_autograd_node_and_python_node_are_the_same_calls(oracle, torch_node):
+    """csrc/torch_node.cpp (the training layout's C++ autograd node) and the Python node make the same two C-ABI calls:
+    forward and gradient are bit-equal between them and to the oracle; inputs the C++ node does not take (float64,
+    non-contiguous, no-plan geometries) fall through to the Python node."""
+    from ct_pvae_amd import forward_functions as ff
+    d = dev()
+    theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, 20)]
+    img = phantoms.foam_batch(5, 128, seed=3, supersample=2)
+    g = np.random.default_rng(4).standard_normal((5, 20, 184, 1)).astype(np.float32)
+    res = {}
+    for use_cpp in (True, False):
+        ff.USE_CPP_NODE = use_cpp
+        try:
+            x = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+            out = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+            assert ("RotateVae" in out.grad_fn.name()) == use_cpp, out.grad_fn.name()
+            (out * torch.from_numpy(g).to(d)).sum().backward()
+            res[use_cpp] = (to_np(out), to_np(x.grad))
+        finally:
+            ff.USE_CPP_NODE = True
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    geom = oracle.Geometry(128, 128, True)
+    T = oracle.rotate_transforms(theta, geom.PH, geom.PW)
+    assert np.array_equal(res[True][0][..., 0], oracle.rotate_fwd(img, geom, T, oracle.NEAREST))
+    assert np.array_equal(res[True][1][..., 0],
+                          oracle.rotate_bwd_tfcompat(g[..., 0], geom, oracle.invert_transforms(T), oracle.NEAREST))
+    # no grad wanted: no node is recorded, same numbers
+    y = cp.project_tf_fast(torch.from_numpy(img[..., None]).to(d), theta, pad=True, dim=2, integrate_vae=True)
+    assert y.grad_fn is None and np.array_equal(to_np(y), res[True][0])
+    # float64 and non-contiguous inputs take the Python node
+    x64 = torch.from_numpy(img[..., None].astype(np.float64)).to(d).requires_grad_(True)
+    o64 = cp.project_tf_fast(x64, theta, pad=True, dim=2, integrate_vae=True)
+    assert o64.dtype is torch.float64 and "RotateVae" not in o64.grad_fn.name()
+    assert np.array_equal(to_np(o64).astype(np.float32), res[True][0])
+    xt = torch.from_numpy(np.ascontiguousarray(img.transpose(0, 2, 1))[..., None]).to(d).transpose(1, 2).requires_grad_(True)
+    ot = cp.project_tf_fast(xt, theta, pad=True, dim=2, integrate_vae=True)
+    assert "RotateVae" not in ot.grad_fn.name() and np.array_equal(to_np(ot), res[True][0])
+    # double backward is not defined for either node; a second first-order backward through a retained graph is
+    x = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+    out = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True)
+    gt = torch.from_numpy(g).to(d)
+    g1, = torch.autograd.grad((out * gt).sum(), x, retain_graph=True)
+    g2, = torch.autograd.grad((out * gt).sum(), x)
+    assert torch.equal(g1, g2) and np.array_equal(to_np(g1), res[True][1])
+
+
+@pytest.mark.parametrize("B,subset,upstream", [(5, False, "sum"), (5, True, "sum"), (6, True, "full"), (4, False, "full"),
+                                               (5, False, "scalar"), (80, False, "sum")])
+def test_cpp_loglik_node_matches_the_python_node(oracle, torch_node, B, subset, upstream):
+    """calculate_log_prob_M_given_R through csrc/torch_node.cpp's RotateLogLik against _ProjectLogLik (same C-ABI calls):
+    value and gradient bit-equal -- dense plan + angle subset or compact, the three upstream-gradient kinds (per-object sum:
+    the scaled backward; arbitrary; fully expanded scalar), and the large batch whose backward is the segment kernel."""
+    from ct_pvae_amd import forward_functions as ff
+    d = dev()
+    rng = np.random.default_rng(B * 7 + subset)
+    dense = phantoms.dense_theta(180)
+    theta = dense if subset else dense[phantoms.sparse_angle_indices(180, 20)]
+    sub = np.sort(rng.permutation(180)[:20]).astype(np.int32) if subset else None
+    A = len(theta)
+    img = phantoms.foam_batch(B, 128, seed=B, supersample=1)
+    mask = torch.from_numpy((rng.random((B, A)) * 0.1 + 0.01).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((B, A, 184)).astype(np.float32)).to(d)
+    n = 20
+    w = torch.from_numpy(rng.standard_normal(B).astype(np.float32)).to(d)
+    gfull = torch.from_numpy(rng.standard_normal((B, n, 184, 1)).astype(np.float32)).to(d)
+    res = {}
+    for use_cpp in (True, False):
+        ff.USE_CPP_NODE = use_cpp
+        try:
+            x = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+            lp = cp.calculate_log_prob_M_given_R(x, mask, meas, 1e4, 1.2e-7, theta=theta, angles_i=sub, pad=True)
+            assert lp.shape == (B, n, 184, 1) and ("RotateLogLik" in lp.grad_fn.name()) == use_cpp, lp.grad_fn.name()
+            if upstream == "sum":
+                lp.sum(dim=(1, 2, 3)).backward(w)
+            elif upstream == "scalar":
+                lp.sum().backward()
+            else:
+                lp.backward(gfull)
+            res[use_cpp] = (to_np(lp), to_np(x.grad))
+        finally:
+            ff.USE_CPP_NODE = True
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    assert np.isfinite(res[True][1]).all() and np.abs(res[True][1]).max() > 0
+    # against the oracle's projection + log-likelihood
+    geom = oracle.Geometry(128, 128, True)
+    T = oracle.rotate_transforms(theta, geom.PH, geom.PW)
+    m, y = to_np(mask), to_np(meas)
+    if subset:
+        T, m, y = T[sub], m[:, sub], y[:, sub]
+    want = oracle.loglik(oracle.rotate_fwd(img, geom, T, oracle.NEAREST), m, y, 1e4, 1.2e-7)
+    assert rel_err(res[True][0][..., 0], want) <= REL
+    # no gradient wanted / trainable pnm: the Python node (which skips dlp, or reduces d/d pnm)
+    lp = cp.calculate_log_prob_M_given_R(torch.from_numpy(img[..., None]).to(d), mask, meas, 1e4, 1.2e-7, theta=theta,
+                                         angles_i=sub, pad=True)
+    assert lp.grad_fn is None and np.array_equal(to_np(lp), res[True][0])
+    pnm = torch.tensor(1e4, device=d, requires_grad=True)
+    x = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+    lp = cp.calculate_log_prob_M_given_R(x, mask, meas, pnm, 1.2e-7, theta=theta, angles_i=sub, pad=True)
+    assert "RotateLogLik" not in lp.grad_fn.name()

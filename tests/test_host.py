@@ -118,3 +118,20 @@ def test_angle_index_operand_checks():
         ff.as_angle_index([[1, 2]], torch.device("cpu"))
     with pytest.raises(TypeError):
         ff.as_angle_index([0.5], torch.device("cpu"))
+
+
+def test_cpp_autograd_node_loads_and_binds(torch_node):
+    """csrc/torch_node.cpp is host C++ over the C ABI: it loads without a GPU, resolves the planned entry points from the
+    library, and refuses tensors it cannot launch on (no compute here)."""
+    import torch
+    from ct_pvae_amd import _lib
+    node = torch_node
+    assert hasattr(node, "rotate_vae") and hasattr(node, "rotate_loglik") and hasattr(node, "bind")
+    with pytest.raises(RuntimeError, match="cannot load"):
+        node.bind("/nonexistent/libctpvae_radon.so")
+    node.bind(_lib.LIB_PATH)
+    plan = torch.zeros(16, dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="expected a contiguous float32"):
+        node.rotate_vae(torch.zeros(2, 8, 8, 1, dtype=torch.float64), plan, plan, 8, 8, 14, 14, 3, 0)
+    with pytest.raises(RuntimeError, match="expected a contiguous float32"):
+        node.rotate_vae(torch.zeros(2, 8, 9, 1), plan, plan, 8, 8, 14, 14, 3, 0)

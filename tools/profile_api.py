@@ -60,6 +60,12 @@ def timeit(fn, name):
 for fn, name in ((raw, "raw RotatePlan fwd+bwd"), (api, "project_tf_fast(...).backward()"),
                  (api_lp, "calculate_log_prob_M_given_R(...).sum.backward()")):
     timeit(fn, name)
+from ct_pvae_amd import forward_functions as ff  # noqa: E402
+ff.USE_CPP_NODE = False
+timeit(api, "project_tf_fast(...).backward(), Python autograd node")
+with torch.autograd.set_multithreading_enabled(False):
+    timeit(api, "project_tf_fast(...).backward(), Python autograd node, single-threaded autograd engine")
+ff.USE_CPP_NODE = True
 with torch.autograd.set_multithreading_enabled(False):
     for fn, name in ((api, "project_tf_fast(...).backward(), single-threaded autograd engine"),
                      (api_lp, "calculate_log_prob_M_given_R(...).sum.backward(), single-threaded autograd engine")):
