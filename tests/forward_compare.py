@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ct_pvae_amd as cp  # noqa: E402
 from ct_pvae_amd import phantoms  # noqa: E402
 from ct_pvae_amd.recon import recon  # noqa: E402
-from oracle import radon_oracle as orc  # noqa: E402  (a developer tool may load the checker)
+from oracle import radon_oracle as orc  # noqa: E402  (the checker: this script lives under tests/)
 
 d = torch.device("cuda", 0)
 theta = np.linspace(0, np.pi, 100, endpoint=False)
