@@ -707,14 +707,81 @@ def _project(phantom, theta, pad, dim, integrate_vae, interp, backward):
         return _RotateProject.apply(phantom, plan, layout)
 
 
+class _SiddonProject(torch.autograd.Function):
+    """model="siddon": TomoPy's ray-driven projector (tomopy.project, ctvae/helper_functions.py:33-38 -- intersection
+    lengths) in project_tf_fast's layouts, differentiable: the backward is its exact transpose (libtomo fbp.c's
+    accumulation on the object grid, ct_pvae_amd/recon.py).  One node per call, like _RotateProject."""
+
+    @staticmethod
+    def forward(ctx, phantom, theta, pad, layout):
+        from .helper_functions import create_sinograms
+        ctx.theta, ctx.layout, ctx.in_dtype = theta, layout, phantom.dtype
+        if layout == _LAYOUT_VAE:
+            x = phantom.reshape(phantom.shape[0], phantom.shape[1], phantom.shape[2])
+        elif layout == _LAYOUT_DIM3:
+            x = phantom.permute(2, 0, 1)
+        else:
+            x = phantom[None]
+        ctx.grid = (x.shape[1], x.shape[2])
+        sino = create_sinograms(x, theta, pad=pad)           # [S][A][dx] (float32, contiguous inside)
+        out = sino.unsqueeze(-1) if layout == _LAYOUT_VAE else sino.permute(1, 2, 0)
+        return out if ctx.in_dtype is torch.float32 else out.to(ctx.in_dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .recon import siddon_backproject
+        g = gout.reshape(gout.shape[0], gout.shape[1], gout.shape[2]) if ctx.layout == _LAYOUT_VAE else gout.permute(2, 0, 1)
+        gimg = siddon_backproject(g, ctx.theta, ctx.grid[0], ctx.grid[1])          # [S][X][Y]
+        if ctx.layout == _LAYOUT_VAE:
+            gimg = gimg.unsqueeze(-1)
+        elif ctx.layout == _LAYOUT_DIM3:
+            gimg = gimg.permute(1, 2, 0)
+        else:
+            gimg = gimg[0]
+        return (gimg if ctx.in_dtype is torch.float32 else gimg.to(ctx.in_dtype)), None, None, None
+
+
+def _project_siddon(phantom, theta, pad, dim, integrate_vae):
+    if not isinstance(phantom, torch.Tensor):
+        raise TypeError(f"phantom must be a torch.Tensor on a HIP device (got {type(phantom).__name__})")
+    if phantom.device.type != "cuda":
+        raise _lib.RadonLibraryError(
+            f"phantom lives on {phantom.device}: the projector runs on a HIP device only; there is no CPU path")
+    if not phantom.dtype.is_floating_point:
+        raise TypeError(f"phantom must be floating point (got {phantom.dtype})")
+    if integrate_vae:
+        if phantom.dim() != 4 or phantom.shape[3] != 1:
+            raise ValueError("integrate_vae=True expects batch_size x img_size_x x img_size_y x 1 "
+                             f"(got {tuple(phantom.shape)})")
+        layout = _LAYOUT_VAE
+    elif dim in (2, 3):
+        if phantom.dim() != dim:
+            raise ValueError(f"dim={dim} expects a {dim}-D phantom (got {tuple(phantom.shape)})")
+        layout = _LAYOUT_DIM3 if dim == 3 else _LAYOUT_DIM2
+    else:
+        raise ValueError(f"dim must be 2 or 3 (got {dim})")
+    theta_host = np.ascontiguousarray(np.asarray(theta.detach().cpu() if isinstance(theta, torch.Tensor) else theta,
+                                                 dtype=np.float32))
+    with torch.cuda.device(phantom.device):
+        return _SiddonProject.apply(phantom, theta_host, bool(pad), layout)
+
+
 def project_tf_fast(phantom, theta, pad=False, dim=3, integrate_vae=False, *, interp="nearest",
-                    backward="tf_compat"):
+                    backward="tf_compat", model="rotate"):
     """Vectorised Radon forward, ctvae/forward_functions.py:80-123.
 
     phantom: img_size_x x img_size_y x img_size_z (dim=3), img_size_x x img_size_y (dim=2), or
     batch_size x img_size_x x img_size_y x 1 (integrate_vae=True).  Returns angles x P x Z, angles x P x 1, or
     batch_size x angles x P x 1.  Every slice is rotated by -theta (nearest neighbour, zero fill) and summed
-    over image rows."""
+    over image rows.
+
+    model="siddon" (keyword-only extension): the same layouts through TomoPy's ray-driven projector -- what
+    the reference's data were MADE with (scripts/images_to_sinograms.py:62-66) -- differentiable through its exact
+    transpose; `interp` and `backward` do not apply to it."""
+    if model == "siddon":
+        return _project_siddon(phantom, theta, pad, dim, integrate_vae)
+    if model != "rotate":
+        raise ValueError(f"model must be 'rotate' or 'siddon' (got {model!r})")
     return _project(phantom, theta, pad, dim, integrate_vae, interp, backward)
 
 

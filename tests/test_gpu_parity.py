@@ -1497,3 +1497,47 @@ def test_cpp_loglik_node_matches_the_python_node(oracle, torch_node, B, subset, 
     x = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
     lp = cp.calculate_log_prob_M_given_R(x, mask, meas, pnm, 1.2e-7, theta=theta, angles_i=sub, pad=True)
     assert "RotateLogLik" not in lp.grad_fn.name()
+
+
+@pytest.mark.parametrize("layout", ["vae", "dim3", "dim2"])
+def test_project_tf_fast_siddon_model_is_differentiable(oracle, layout):
+    """model="siddon" (SURVEY 8b's keyword-only extension): project_tf_fast's three layouts through the TomoPy-style
+    projector -- forward bit-equal to the oracle's restatement of project.c, backward = its transpose (oracle's
+    restatement, 1e-5; <A x, y> = <x, A^T y>), float64 in -> float64 out like the reference's xdesign phantoms."""
+    d = dev()
+    rng = np.random.default_rng(11)
+    theta = rng.uniform(0, np.pi, 13)
+    img = rng.random((3, 40, 40), dtype=np.float32)
+    want = np.swapaxes(oracle.siddon_project(img, theta, pad=True), 0, 1)           # [S][A][dx]
+    dx = want.shape[2]
+    gy = rng.standard_normal(want.shape).astype(np.float32)
+    gwant = np.zeros_like(img)
+    oracle.lib().oracle_siddon_backproject(np.ascontiguousarray(gy), 3, len(theta), dx, theta.astype(np.float32), dx / 2.0, 40, 40, gwant)
+    if layout == "vae":
+        x = torch.from_numpy(img[..., None]).to(d).requires_grad_(True)
+        out = cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True, model="siddon")
+        assert out.shape == (3, 13, dx, 1)
+        got, g = to_np(out)[..., 0], torch.from_numpy(gy[..., None]).to(d)
+        out.backward(g)
+        ggot = to_np(x.grad)[..., 0]
+    elif layout == "dim3":
+        x = torch.from_numpy(np.transpose(img, (1, 2, 0)).astype(np.float64)).to(d).requires_grad_(True)
+        out = cp.project_tf_fast(x, theta, pad=True, model="siddon")
+        assert out.shape == (13, dx, 3) and out.dtype is torch.float64
+        got = np.transpose(to_np(out), (2, 0, 1)).astype(np.float32)
+        out.backward(torch.from_numpy(np.transpose(gy, (1, 2, 0)).astype(np.float64)).to(d))
+        ggot = np.transpose(to_np(x.grad), (2, 0, 1))
+    else:
+        x = torch.from_numpy(img[0]).to(d).requires_grad_(True)
+        out = cp.project_tf_fast(x, theta, pad=True, dim=2, model="siddon")
+        assert out.shape == (13, dx, 1)
+        got, want, gwant = to_np(out)[None, ..., 0], want[:1], gwant[:1]
+        out.backward(torch.from_numpy(gy[0][..., None]).to(d))
+        ggot = to_np(x.grad)[None]
+        gy = gy[:1]
+    np.testing.assert_array_equal(got, want)
+    assert rel_err(ggot, gwant) <= REL
+    lhs, rhs = float((want.astype(np.float64) * gy).sum()), float((img[:len(ggot)].astype(np.float64) * ggot).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+    with pytest.raises(ValueError, match="model must be"):
+        cp.project_tf_fast(x, theta, pad=True, dim=x.dim() if layout != "vae" else 2, integrate_vae=layout == "vae", model="fan")
