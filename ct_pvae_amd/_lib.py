@@ -112,6 +112,9 @@ def build_torch_node(verbose=False):
     """Compile csrc/torch_node.cpp (host C++, no HIP) in-tree with torch's extension builder; __graft_entry__.build() calls this."""
     from torch.utils.cpp_extension import load
     os.makedirs(NODE_DIR, exist_ok=True)
+    lock = os.path.join(NODE_DIR, "lock")        # an interrupted earlier build leaves its baton behind: load() would wait on it
+    if os.path.exists(lock):
+        os.remove(lock)
     return load(name=NODE_NAME, sources=[os.path.join(_HERE, "csrc", "torch_node.cpp")], build_directory=NODE_DIR,
                 extra_cflags=["-O2"], extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose)
 
