@@ -506,6 +506,9 @@ def main():
         with torch.autograd.set_multithreading_enabled(False):
             ent["single_thread_engine"] = {"project_tf_fast": host_rate(api_step, nb),
                                            "calculate_log_prob_M_given_R": host_rate(lik_step, nb)}
+        ent["times_raw"] = {"project_tf_fast": ent["raw"] / ent["project_tf_fast"],
+                            "calculate_log_prob_M_given_R": ent["raw"] / ent["calculate_log_prob_M_given_R"],
+                            "single_thread_engine": {k: ent["raw"] / v for k, v in ent["single_thread_engine"].items()}}
         api[f"batch_{nb}"] = ent
     api["value"] = api[f"batch_{B}"]["project_tf_fast"]
     from ct_pvae_amd import _lib as _cl

@@ -41,6 +41,10 @@ def test_no_cpu_fallback():
         cp.project_tf_fast(x, np.array([0.0]), pad=True, dim=2)
     with pytest.raises(_lib.RadonLibraryError, match="no CPU path"):
         cp.project_tf_low_mem(torch.zeros(8, 8, 2), np.array([0.0]))
+    with pytest.raises(_lib.RadonLibraryError, match="no CPU path"):
+        cp.project_tf_fast(x, np.array([0.0]), pad=True, dim=2, model="siddon")
+    with pytest.raises(ValueError, match="model must be"):
+        cp.project_tf_fast(x, np.array([0.0]), pad=True, dim=2, model="fan")
     with pytest.raises(_lib.RadonLibraryError):
         cp.iradon(torch.zeros(1, 3, 8), np.zeros(3), 4, 4, np.ones(8))
     if not torch.cuda.is_available():
