@@ -477,7 +477,9 @@ def main():
         return n_obj * A * n_api / (time.perf_counter() - ta)
 
     api = {"unit": "projections/s", "what": "fwd+bwd through torch.autograd, launched from Python, 1 GPU; raw = "
-                                            "RotatePlan.forward/backward launched from Python with preallocated outputs"}
+                                            "RotatePlan.forward/backward launched from Python with preallocated outputs; "
+                                            "raw_loglik = forward_loglik + the caller's per-object sum + scaled backward, "
+                                            "likewise; times_raw = how many times the raw launches' time each call takes"}
     eps32 = float(np.finfo(np.float32).eps)
     for nb in sorted({B, 5}):
         x4 = x[:nb, :, :, None].clone().requires_grad_(True)
@@ -493,6 +495,13 @@ def main():
             plan.forward(xs, out=so)
             plan.backward(gs, out=go)
 
+        lpo, dlpo = torch.empty_like(gs), torch.empty_like(gs)
+
+        def raw_lik_step():      # the launches calculate_log_prob_M_given_R(...).sum(...).backward(w) ends in, from Python
+            plan.forward_loglik(xs, mask, meas, pnm, eps32, out=so, out_lp=lpo, out_dlp=dlpo)
+            lpo.sum(dim=(1, 2))
+            plan.backward(dlpo, out=go, scale=w)
+
         def api_step():
             x4.grad = None
             project_tf_fast(x4, theta, pad=True, dim=2, integrate_vae=True).backward(g4)
@@ -501,14 +510,18 @@ def main():
             x4.grad = None
             calculate_log_prob_M_given_R(x4, mask, meas, pnm, eps32, theta=theta, pad=True).sum(dim=(1, 2, 3)).backward(w)
 
-        ent = {"raw": host_rate(raw_step, nb), "project_tf_fast": host_rate(api_step, nb),
+        ent = {"raw": host_rate(raw_step, nb), "raw_loglik": host_rate(raw_lik_step, nb),
+               "project_tf_fast": host_rate(api_step, nb),
                "calculate_log_prob_M_given_R": host_rate(lik_step, nb)}
         with torch.autograd.set_multithreading_enabled(False):
             ent["single_thread_engine"] = {"project_tf_fast": host_rate(api_step, nb),
                                            "calculate_log_prob_M_given_R": host_rate(lik_step, nb)}
         ent["times_raw"] = {"project_tf_fast": ent["raw"] / ent["project_tf_fast"],
-                            "calculate_log_prob_M_given_R": ent["raw"] / ent["calculate_log_prob_M_given_R"],
-                            "single_thread_engine": {k: ent["raw"] / v for k, v in ent["single_thread_engine"].items()}}
+                            "calculate_log_prob_M_given_R": ent["raw_loglik"] / ent["calculate_log_prob_M_given_R"],
+                            "single_thread_engine": {
+                                "project_tf_fast": ent["raw"] / ent["single_thread_engine"]["project_tf_fast"],
+                                "calculate_log_prob_M_given_R":
+                                    ent["raw_loglik"] / ent["single_thread_engine"]["calculate_log_prob_M_given_R"]}}
         api[f"batch_{nb}"] = ent
     api["value"] = api[f"batch_{B}"]["project_tf_fast"]
     from ct_pvae_amd import _lib as _cl
