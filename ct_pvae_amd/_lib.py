@@ -116,7 +116,8 @@ def build_torch_node(verbose=False):
     if os.path.exists(lock):
         os.remove(lock)
     return load(name=NODE_NAME, sources=[os.path.join(_HERE, "csrc", "torch_node.cpp")], build_directory=NODE_DIR,
-                extra_cflags=["-O2"], extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose)
+                extra_include_paths=[os.path.join(os.path.dirname(_HERE), "include")], extra_cflags=["-O2"],
+                extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose)
 
 
 def torch_node():

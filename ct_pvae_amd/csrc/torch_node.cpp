@@ -1,31 +1,30 @@
-// torch_node.cpp -- the drop-in API's autograd node for the training layout, in C++.
+// torch_node.cpp -- the drop-in API's autograd nodes for the training layout, in C++.
 //
-// project_tf_fast(x [B][X][Y][1], theta, pad, dim=2, integrate_vae=True) -> [B][A][P][1] and its backward are ONE
-// torch::autograd::Function whose forward and backward each make one call into the C ABI of include/ctpvae_radon.h
-// (ctpvae_rotate_fwd_planned_f32 / ctpvae_rotate_bwd_planned_scaled_f32).  RotateLogLik: calculate_log_prob_M_given_R of a
-// planned geometry with a fixed pnm, optionally at an angle subset of a dense plan (ctvae/helper_functions.py:336-368):
-// forward = the one-launch projection + log-likelihood that also stores d lp / d sino, backward = the projector's backward
-// with the upstream per-object factor applied in its store.  Nothing is computed here: this file only removes
-// the Python that torch.autograd.Function.apply and a Python backward cost per call (~10 us of ~34).  Host code only -- no
-// HIP headers: the library is bound with dlopen / dlsym and the raw stream arrives as an integer from Python (the backward
-// runs on the stream the forward ran on, as the autograd engine arranges).  Built by __graft_entry__.build() with
-// torch.utils.cpp_extension (g++), in-tree.
+// RotateVae: project_tf_fast(x [B][X][Y][1], theta, pad, dim=2, integrate_vae=True) -> [B][A][P][1] and its backward are
+// ONE torch::autograd::Function whose forward and backward each make one call into the C ABI of include/ctpvae_radon.h
+// (ctpvae_rotate_fwd_planned_f32 / ctpvae_rotate_bwd_planned_scaled_f32).
+// RotateLogLik: calculate_log_prob_M_given_R of a planned geometry with a fixed pnm, optionally at an angle subset of a
+// dense plan (ctvae/helper_functions.py:336-368): forward = the one-launch projection + log-likelihood that also stores
+// d lp / d sino, backward = the projector's backward with the upstream per-object factor applied in its store.
+// Nothing is computed here: this file only removes the Python that torch.autograd.Function.apply and a Python backward
+// cost per call (~6 us of ~27, ~16 of ~52).  Host code only -- no HIP headers: the library is bound with dlopen / dlsym
+// (the pointer types are taken from the C header, so a changed signature does not compile) and the raw stream arrives as an
+// integer from Python (the backward runs on the stream the forward ran on, as the autograd engine arranges).  Built by
+// __graft_entry__.build() with torch.utils.cpp_extension (g++), in-tree.
 #include <dlfcn.h>
 #include <torch/extension.h>
 
+#include "ctpvae_radon.h"
+
 namespace {
 
-typedef int (*fwd_fn)(const float *, int, int, int, int, int, int, const void *, float *, void *);
-typedef int (*bwd_fn)(const float *, int, int, int, int, int, int, const void *, const float *, long long, float *, void *);
-typedef const char *(*err_fn)(void);
-typedef int (*fwd_lik_fn)(const float *, int, int, int, int, int, int, const void *, const float *, const float *, const float *,
-                          float, float *, float *, float *, void *);
-typedef int (*fwd_lik_sel_fn)(const float *, int, int, int, int, int, int, const void *, const int *, int, const float *,
-                              const float *, int, const float *, float, float *, float *, float *, void *);
-typedef int (*bwd_seg_fn)(const float *, int, int, int, int, const float *, int, int, int, int, int, int, const float *, long long,
-                          float *, void *);
-typedef int (*bwd_sel_fn)(const float *, int, int, int, int, const float *, const int *, int, int, int, int, int, const float *,
-                          long long, float *, void *);
+using fwd_fn = decltype(&ctpvae_rotate_fwd_planned_f32);
+using bwd_fn = decltype(&ctpvae_rotate_bwd_planned_scaled_f32);
+using err_fn = decltype(&ctpvae_last_error);
+using fwd_lik_fn = decltype(&ctpvae_rotate_fwd_planned_loglik_f32);
+using fwd_lik_sel_fn = decltype(&ctpvae_rotate_fwd_planned_loglik_sel_f32);
+using bwd_seg_fn = decltype(&ctpvae_rotate_bwd_scaled_f32);
+using bwd_sel_fn = decltype(&ctpvae_rotate_bwd_sel_scaled_f32);
 fwd_fn g_fwd = nullptr;
 bwd_fn g_bwd = nullptr;
 err_fn g_err = nullptr;
