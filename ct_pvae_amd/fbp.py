@@ -32,6 +32,9 @@ def _cached(key, make):
 def iradon(sinogram, theta, x_size, y_size, filter_1d, *, tomopy_geometry=False):
     """sinogram [batch][angles][num_proj_pix] -> reconstruction [batch][x_size][y_size] (float64).
 
+    Forward only: the result carries no autograd graph (the reference has no live importer of iradon and never takes its
+    gradient; its TF version is differentiable only because it is written in TF ops).
+
     tomopy_geometry (keyword-only extension): sample the sinogram on tomopy's ray-driven grid -- pixel centres at half-
     integers, detector bin d at d - (P - 1) / 2 -- instead of the reference iradon's (pixel i at i - X / 2, sample k at
     k - P / 2): the right geometry for sinograms made by create_sinogram / tomopy.project."""
