@@ -125,7 +125,7 @@ using namespace ctpvae;
 
 extern "C" {
 
-int ctpvae_abi_version(void) { return 2000; }
+int ctpvae_abi_version(void) { return 2001; }
 
 int ctpvae_tune_set(const char *name, int value)
 {

@@ -76,6 +76,56 @@ __global__ __launch_bounds__(256) void fbp_backproject_kernel(const double *__re
     recon[(size_t)b * X * Y + p] = acc * 3.14159265358979323846 / (2.0 * A);
 }
 
+// The transpose of fbp_backproject_kernel (the gradient of iradon with respect to the filtered sinogram):
+//     gfilt[b][a][k] = pi / (2A) * sum over pixels p = (i, j), ascending, of w_k(t(i, j, a)) * g[b][p],
+// w_k = the weight interp_regular_1d gives y_ref[k] (linear interpolation on the clamped index: bins 0 and P - 1 collect
+// everything beyond the detector).  One thread per (angle, bin) walks ALL pixels and evaluates its own weight -- 2 of P
+// threads have a non-zero one at a pixel -- so every output is one ordered fp64 sum: deterministic, no atomics.  A
+// set-up-path kernel (the reference never differentiates iradon): A * P * X * Y weight evaluations, shared by the kSlices
+// slices of a thread.
+constexpr int kFbpBwdSlices = 8;
+__global__ __launch_bounds__(64) void fbp_backproject_bwd_kernel(const double *__restrict__ g, int B, int A, int P,
+                                                                const double *__restrict__ cos_t,
+                                                                const double *__restrict__ sin_t, int X, int Y, double x0,
+                                                                double y0, double t0, double *__restrict__ gfilt)
+{
+    const int a = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b0 = blockIdx.z * kFbpBwdSlices;
+    const int nb = min(kFbpBwdSlices, B - b0);
+    const double c = cos_t[a], s = sin_t[a], top = (double)(P - 1);
+    const double x_min = 0.0 - t0, x_max = top - t0;
+    const double scale = top / (x_max - x_min);
+    double acc[kFbpBwdSlices];
+#pragma unroll
+    for (int n = 0; n < kFbpBwdSlices; ++n) acc[n] = 0.0;
+    const double kd = (double)k;
+    for (int i = 0; i < X; ++i) {
+        const double xs = ((double)i - x0) * s;
+        for (int j = 0; j < Y; ++j) {
+            const double t = ((double)j - y0) * c - xs;
+            double idx = (t - x_min) * scale;              // the forward's expression, bit for bit
+            idx = idx < 0.0 ? 0.0 : idx;
+            idx = idx > top ? top : idx;
+            double below = floor(idx);
+            const double above = fmin(below + 1.0, top);
+            below = fmax(above - 1.0, 0.0);
+            const double tt = idx - below;
+            const double w = (kd == above ? tt : 0.0) + (kd == below ? 1.0 - tt : 0.0);
+            if (w != 0.0 && k < P) {
+                const double *gp = g + ((size_t)b0 * X + i) * Y + j;
+#pragma unroll
+                for (int n = 0; n < kFbpBwdSlices; ++n)
+                    if (n < nb) acc[n] += w * gp[(size_t)n * X * Y];
+            }
+        }
+    }
+    if (k < P) {
+#pragma unroll
+        for (int n = 0; n < kFbpBwdSlices; ++n)
+            if (n < nb) gfilt[((size_t)(b0 + n) * A + a) * P + k] = acc[n] * 3.14159265358979323846 / (2.0 * A);
+    }
+}
+
 }  // namespace ctpvae
 
 using namespace ctpvae;
@@ -116,6 +166,20 @@ int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P,
                            recon_dev + (size_t)b0 * X * Y);
         CTPVAE_LAUNCH_CHECK("fbp_backproject_kernel");
     }
+    return CTPVAE_OK;
+}
+
+int ctpvae_fbp_backproject_bwd_f64(const double *grecon_dev, int B, int A, int P, const double *cos_dev,
+                                   const double *sin_dev, int X, int Y, double x0, double y0, double t0,
+                                   double *gfilt_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(grecon_dev && cos_dev && sin_dev && gfilt_dev, "fbp_backproject_bwd: null pointer");
+    CTPVAE_REQUIRE(B > 0 && A > 0 && P > 1 && X > 0 && Y > 0,
+                   "fbp_backproject_bwd: bad sizes (B=%d A=%d P=%d X=%d Y=%d)", B, A, P, X, Y);
+    CTPVAE_REQUIRE(A <= 65535 && ceil_div(B, kFbpBwdSlices) <= 65535, "fbp_backproject_bwd: A=%d or B=%d exceeds the grid", A, B);
+    hipLaunchKernelGGL(fbp_backproject_bwd_kernel, dim3(ceil_div(P, 64), A, ceil_div(B, kFbpBwdSlices)), dim3(64), 0,
+                       (hipStream_t)stream, grecon_dev, B, A, P, cos_dev, sin_dev, X, Y, x0, y0, t0, gfilt_dev);
+    CTPVAE_LAUNCH_CHECK("fbp_backproject_bwd_kernel");
     return CTPVAE_OK;
 }
 

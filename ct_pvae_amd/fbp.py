@@ -32,13 +32,13 @@ def _cached(key, make):
 def iradon(sinogram, theta, x_size, y_size, filter_1d, *, tomopy_geometry=False):
     """sinogram [batch][angles][num_proj_pix] -> reconstruction [batch][x_size][y_size] (float64).
 
-    Forward only: the result carries no autograd graph (the reference has no live importer of iradon and never takes its
-    gradient; its TF version is differentiable only because it is written in TF ops).
+    Differentiable with respect to the sinogram (like the reference's TF-op version; nothing in the reference takes that
+    gradient).
 
     tomopy_geometry (keyword-only extension): sample the sinogram on tomopy's ray-driven grid -- pixel centres at half-
     integers, detector bin d at d - (P - 1) / 2 -- instead of the reference iradon's (pixel i at i - X / 2, sample k at
     k - P / 2): the right geometry for sinograms made by create_sinogram / tomopy.project."""
-    lib = _lib.load()
+    _lib.load()
     if not isinstance(sinogram, torch.Tensor) or sinogram.device.type != "cuda":
         raise _lib.RadonLibraryError("iradon expects a sinogram tensor on a HIP device; there is no CPU path")
     if sinogram.dim() != 3:
@@ -67,17 +67,56 @@ def iradon(sinogram, theta, x_size, y_size, filter_1d, *, tomopy_geometry=False)
             return torch.cos(th).contiguous(), torch.sin(th).contiguous()
 
         cos_t, sin_t = _cached(("trig", th_np.tobytes(), str(dev)), make)
+    X, Y = int(x_size), int(y_size)
+    geom = ((X - 1) / 2.0, (Y - 1) / 2.0, (P - 1) / 2.0) if tomopy_geometry else (X / 2.0, Y / 2.0, P / 2.0)
+    if sinogram.requires_grad and torch.is_grad_enabled():
+        # the transposed filter: hker reversed, hker[(P - n) % P]
+        hker_t = _cached(("hker_t", filt.tobytes(), str(filt.dtype), str(dev)), lambda: torch.roll(torch.flip(hker, (0,)), 1, 0).contiguous())
+        return _IRadon.apply(sinogram, hker, hker_t, cos_t, sin_t, X, Y, geom)
+    return _iradon_forward(sinogram, hker, cos_t, sin_t, X, Y, geom)
+
+
+def _iradon_forward(sinogram, hker, cos_t, sin_t, X, Y, geom):
+    lib = _lib.load()
+    B, A, P = sinogram.shape
+    dev = sinogram.device
     sino = sinogram.to(torch.float64).contiguous()
     filtered = torch.empty_like(sino)
-    recon = torch.empty((B, int(x_size), int(y_size)), dtype=torch.float64, device=dev)
+    recon = torch.empty((B, X, Y), dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.ctpvae_fbp_filter_f64(sino.data_ptr(), B * A, P, hker.data_ptr(), filtered.data_ptr(),
                                              _stream_ptr()), "fbp_filter")
-        X, Y = int(x_size), int(y_size)
-        x0, y0, t0 = ((X - 1) / 2.0, (Y - 1) / 2.0, (P - 1) / 2.0) if tomopy_geometry else (X / 2.0, Y / 2.0, P / 2.0)
         _lib.check(lib.ctpvae_fbp_backproject_geom_f64(filtered.data_ptr(), B, A, P, cos_t.data_ptr(), sin_t.data_ptr(), X, Y,
-                                                       x0, y0, t0, recon.data_ptr(), _stream_ptr()), "fbp_backproject")
+                                                       geom[0], geom[1], geom[2], recon.data_ptr(), _stream_ptr()), "fbp_backproject")
     return recon
+
+
+class _IRadon(torch.autograd.Function):
+    """iradon with its gradient with respect to the sinogram (the reference's iradon is TF ops, hence differentiable):
+    backward = transposed back-projection (ctpvae_fbp_backproject_bwd_f64, ordered fp64 sums) then the transposed filter
+    (the same circular convolution with the kernel reversed)."""
+
+    @staticmethod
+    def forward(ctx, sinogram, hker, hker_t, cos_t, sin_t, X, Y, geom):
+        ctx.save_for_backward(hker_t, cos_t, sin_t)
+        ctx.shape, ctx.geom, ctx.in_dtype = (tuple(sinogram.shape), X, Y), geom, sinogram.dtype
+        return _iradon_forward(sinogram, hker, cos_t, sin_t, X, Y, geom)
+
+    @staticmethod
+    def backward(ctx, grecon):
+        lib = _lib.load()
+        hker_t, cos_t, sin_t = ctx.saved_tensors
+        (B, A, P), X, Y = ctx.shape
+        g = grecon.to(torch.float64).contiguous()
+        gfilt = torch.empty((B, A, P), dtype=torch.float64, device=g.device)
+        gsino = torch.empty_like(gfilt)
+        with torch.cuda.device(g.device):
+            _lib.check(lib.ctpvae_fbp_backproject_bwd_f64(g.data_ptr(), B, A, P, cos_t.data_ptr(), sin_t.data_ptr(), X, Y,
+                                                          ctx.geom[0], ctx.geom[1], ctx.geom[2], gfilt.data_ptr(), _stream_ptr()),
+                       "fbp_backproject_bwd")
+            _lib.check(lib.ctpvae_fbp_filter_f64(gfilt.data_ptr(), B * A, P, hker_t.data_ptr(), gsino.data_ptr(), _stream_ptr()),
+                       "fbp_filter")
+        return gsino.to(ctx.in_dtype), None, None, None, None, None, None, None
 
 
 def ramp_filter(P):

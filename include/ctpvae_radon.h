@@ -36,7 +36,7 @@
  *                                              ctvae/helper_functions.py:33-38
  *   ctpvae_siddon_bwd_f32 / _rownorm_f32       tomopy.recon(algorithm='fbp' | 'sirt') behind iradon_all / evaluate_sinogram
  *                                              ctvae/helper_functions.py:445-457,503,514
- *   ctpvae_fbp_filter_f64 / _backproject_f64   iradon  ctvae/fbp_tensorflow.py:14-75
+ *   ctpvae_fbp_filter_f64 / _backproject{,_bwd}_f64   iradon  ctvae/fbp_tensorflow.py:14-75
  *   ctpvae_loglik_fwd_f32 / _bwd_f32           calculate_log_prob_M_given_R
  *                                              ctvae/helper_functions.py:360-368
  *   ctpvae_poisson_measure_f32                 create_all_masks' noisy sparse sinograms  ctvae/create_masks.py:80-103
@@ -247,6 +247,13 @@ int ctpvae_fbp_backproject_f64(const double *filt_dev, int B, int A, int P, cons
 int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P, const double *cos_dev,
                                     const double *sin_dev, int X, int Y, double x0, double y0, double t0,
                                     double *recon_dev, ctpvae_stream_t stream);
+
+/* The transpose of ctpvae_fbp_backproject_geom_f64 (iradon's gradient; the reference's iradon, ctvae/fbp_tensorflow.py:14-75, is
+ * TF ops and so differentiable): grecon_dev [B][X][Y] -> gfilt_dev [B][A][P], every output one ordered fp64 sum over pixels.
+ * The transpose of ctpvae_fbp_filter_f64 is the same entry point with the kernel reversed, hker[(P - n) % P]. */
+int ctpvae_fbp_backproject_bwd_f64(const double *grecon_dev, int B, int A, int P, const double *cos_dev,
+                                   const double *sin_dev, int X, int Y, double x0, double y0, double t0,
+                                   double *gfilt_dev, ctpvae_stream_t stream);
 
 /* ---- a8: Gaussian-approximated Poisson log-likelihood epilogue ------------------------------
  * proj_dev, x_dev, out_dev [B][A][P]; mask_dev [B][A]; pnm_dev points at ONE fp32 on the device (the

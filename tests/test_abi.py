@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_binding_table_matches_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == declared_symbols()
     lib = built_lib.load()
-    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == 2000
+    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == 2001
 
 
 def test_host_only_entry_points(built_lib):

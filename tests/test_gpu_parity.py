@@ -1541,3 +1541,41 @@ def test_project_tf_fast_siddon_model_is_differentiable(oracle, layout):
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
     with pytest.raises(ValueError, match="model must be"):
         cp.project_tf_fast(x, theta, pad=True, dim=x.dim() if layout != "vae" else 2, integrate_vae=layout == "vae", model="fan")
+
+
+@pytest.mark.parametrize("tomopy_geometry", [False, True])
+def test_iradon_gradient_is_the_transpose_of_the_oracle_operator(oracle, tomopy_geometry):
+    """iradon is linear in the sinogram and (like the reference's TF-op version) differentiable: the gradient must be M^T g
+    for the matrix M the ORACLE's iradon defines -- built column by column from unit sinograms at a small size (a complex
+    filter_1d, so the transposed filter's kernel is NOT symmetric; angles beyond the detector, so the clamped edge bins
+    collect) -- and <iradon(s), g> = <s, grad> at full size, float32 in -> float32 gradient out."""
+    d = dev()
+    rng = np.random.default_rng(5)
+    A, P, X, Y = 5, 12, 9, 8                       # 9 x 8 pixels reach beyond 12 bins on the diagonal
+    theta = rng.uniform(0, np.pi, A)
+    filt = rng.standard_normal(P) + 1j * rng.standard_normal(P)
+    s = rng.standard_normal((2, A, P))
+    g = rng.standard_normal((2, X, Y))
+    st = torch.from_numpy(s).to(d).requires_grad_(True)
+    out = cp.iradon(st, theta, X, Y, filt, tomopy_geometry=tomopy_geometry)
+    out.backward(torch.from_numpy(g).to(d))
+    if not tomopy_geometry:                        # the oracle restates the reference's geometry
+        assert rel_err(to_np(out), oracle.iradon(s, theta, X, Y, filt)) <= 1e-10
+        M = oracle.iradon(np.eye(A * P).reshape(A * P, A, P), theta, X, Y, filt).reshape(A * P, X * Y)   # rows: M^T
+        want = (M @ g.reshape(2, X * Y).T).T.reshape(2, A, P)
+        assert rel_err(to_np(st.grad), want) <= 1e-10
+    lhs, rhs = float((to_np(out) * g).sum()), float((s * to_np(st.grad)).sum())
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), 1.0)
+    # full size, float32 sinogram, the ramp: adjointness in fp64 accumulators
+    theta = phantoms.dense_theta(180)[::9]
+    filt = np.abs(np.fft.fftfreq(184)) * 2
+    s32 = torch.from_numpy(rng.random((3, 20, 184)).astype(np.float32)).to(d).requires_grad_(True)
+    g = rng.standard_normal((3, 128, 128))
+    out = cp.iradon(s32, theta, 128, 128, filt, tomopy_geometry=tomopy_geometry)
+    out.backward(torch.from_numpy(g).to(d))
+    assert out.dtype is torch.float64 and s32.grad.dtype is torch.float32
+    lhs = float((to_np(out) * g).sum())
+    rhs = float((to_np(s32).astype(np.float64) * to_np(s32.grad).astype(np.float64)).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0)       # the gradient was rounded to float32
+    # no gradient wanted: no graph
+    assert cp.iradon(s32.detach(), theta, 128, 128, filt).grad_fn is None
