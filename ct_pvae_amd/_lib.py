@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
-ABI_VERSION = 2001   # ctpvae_abi_version() of the library this binding was written for
+ABI_VERSION = 3000   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -32,6 +32,12 @@ SIGNATURES = {
     "ctpvae_rotate_fwd_planned_sel_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp]),
     "ctpvae_rotate_fwd_planned_loglik_sel_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
                                                           _vp, _vp, _c_int, _vp, _c_float, _vp, _vp, _vp, _vp]),
+    "ctpvae_rotate_cplan_supported": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_rotate_cplan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_rotate_cplan_build_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_rotate_cplan_overflowed": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ctpvae_rotate_fwd_compact_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp,
+                                               _c_int, _vp, _c_float, _vp, _vp, _vp, _vp]),
     "ctpvae_rotate_bwd_sel_scaled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int,
                                                   _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
     "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
@@ -114,9 +120,16 @@ def build_torch_node(verbose=False):
     """Compile csrc/torch_node.cpp (host C++, no HIP) in-tree with torch's extension builder; __graft_entry__.build() calls this."""
     from torch.utils.cpp_extension import load
     os.makedirs(NODE_DIR, exist_ok=True)
-    lock = os.path.join(NODE_DIR, "lock")        # an interrupted earlier build leaves its baton behind: load() would wait on it
-    if os.path.exists(lock):
-        os.remove(lock)
+    # An interrupted earlier build leaves its baton behind and load() would wait on it forever -- but a LIVE lock belongs to
+    # another process that is compiling into this directory right now (two pytest sessions, a build beside a test run):
+    # removing that one makes both link the same .so.  Only a stale baton (older than any build takes) is removed.
+    lock = os.path.join(NODE_DIR, "lock")
+    try:
+        import time
+        if time.time() - os.path.getmtime(lock) > 600:
+            os.remove(lock)
+    except OSError:
+        pass
     return load(name=NODE_NAME, sources=[os.path.join(_HERE, "csrc", "torch_node.cpp")], build_directory=NODE_DIR,
                 extra_include_paths=[os.path.join(os.path.dirname(_HERE), "include")], extra_cflags=["-O2"],
                 extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose)
@@ -139,7 +152,15 @@ def torch_node():
                 import warnings
                 warnings.warn(f"{NODE_PATH} does not load ({e}); rebuild it with __graft_entry__.build()")
                 return None
-            load()
+            lib = load()
+            # the node resolves entry points by NAME: one compiled against another version of the header would call them
+            # with that version's argument list.  Compare what it was compiled for with the library that is loaded.
+            built_for = mod.compiled_abi() if hasattr(mod, "compiled_abi") else None
+            if built_for != lib.ctpvae_abi_version():
+                import warnings
+                warnings.warn(f"{NODE_PATH} was built for ABI {built_for}, {LIB_PATH} has ABI {lib.ctpvae_abi_version()}: "
+                              "using the Python autograd nodes; rebuild it with __graft_entry__.build()")
+                return None
             mod.bind(LIB_PATH)
             _node = mod
     return _node

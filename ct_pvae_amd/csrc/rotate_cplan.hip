@@ -1,0 +1,602 @@
+// rotate_cplan.hip -- COMPACT (step-coded) gather plans for the NEAREST rotate-and-sum forward (gfx950).
+//
+// rotate_plan.hip stores every tap of a geometry as a u16 LDS index: 2 B per sample, 1.9 MB at 20 angles and 17 MB at the
+// dataset's 180 -- more than an XCD's 4 MB L2, so at many angles the per-slice kernel is bound by the index stream it
+// pulls through L2 (about six times its algorithmic bytes at A = 180, profiles/r02_traffic_pmc.json).  But along a ray the tap
+// moves, from one canvas row to the next, by one of FOUR cell deltas: x_in and y_in (ctvae/forward_functions.py:113 ->
+// tfa.image.rotate -> ImageProjectiveTransformV3) are monotone in the row number with slope |t1|, |t4| <= 1,
+// so round(x_in) and round(y_in) each stay or step by one, always the same way for an angle.  A ray is therefore
+//     its first live canvas row's tap  +  2 bits per row  (bit 0: the column steps, bit 1: the row steps),
+// and its live rows are one interval.  The plan kernel below still evaluates the reference arithmetic EXACTLY (unfused
+// fp32, std::round, zero fill) -- it only stores the differences: 1/3 B per sample, 0.3 MB at 20 angles, 2.3 MB at 180.
+//
+// Decoding: one code BYTE holds the steps of THREE rows (6 bits) and indexes a 64-entry table in LDS whose entry holds the
+// cumulative byte offsets (i16) after one, two and three of those steps; an SDWA add with a sign-extended word select both
+// extracts an offset and adds it to the ray's running address.  Per three taps: 1 SDWA move (table address), 1 ds_read_b64
+// (table entry), 3 SDWA adds -- against 3 SDWA shifts for u16 taps.  The table is kept in 32 copies, one per lane of a
+// half-wave (entry e of copy l at byte e * 256 + l * 8): whatever entries the 32 lanes of a ds_read_b64 group ask for,
+// they sit in 32 different bank pairs, so a table read is always one LDS pass.  (Round 3, measured: with four rows per
+// byte and ONE 2 KB table the lanes' different entries collided -- 5.3 LDS cycles per table read, 64 % more LDS cycles
+// than the u16 kernel, which made the kernel LDS-bound and 3-10 % slower than the u16 plan at every large shape;
+// 256 entries x 32 copies would not fit beside a slice pair, 64 x 32 x 8 B = 16 KB does.)
+//
+// Rows behind a ray's last live row must add +0.0f.  The slice is staged with a ONE-CELL ZERO BORDER (a zero row above and
+// below, the spare column(s) of the odd row pitch as the gutter between rows): the step that leaves the core lands on a
+// border cell, and all later codes of the ray are 0 (stay).  Rays of a 64-bin block start at their own first live row
+// (as in rotate_plan.hip), all walk 6 * ng rows, ng = the block's longest ray in groups of six (two code bytes).
+//
+// Same taps, same ascending row order => bit-identical to rotate_plan.hip, rotate.hip and the oracle.  A geometry
+// whose steps do not fit the code (rows that are not a rotation, a ray still inside the core at the canvas' last row,
+// rounding ties that make a coordinate jump by two) raises the plan's overflow word; the caller then keeps the u16 plan.
+#include <algorithm>
+#include <atomic>
+#include <type_traits>
+
+#include "common.h"
+#include "lds_stage.h"
+#include "loglik_math.h"
+#include "rotate_plan.h"
+
+namespace ctpvae {
+
+constexpr int kLutBytes = 64 * 32 * 8;   // 64 entries x 32 lane copies x (3 x i16 + pad), at LDS offset 0
+constexpr int kRowsPerChunk = 48;       // a uint4 of codes: 16 bytes x 3 rows
+constexpr int kRowsPerGroup = 6;        // rows gathered per step of the walk: two code bytes
+constexpr int kCSelRounds = 4;    // angle subsets hold <= 64 * kCSelRounds angles
+
+struct CLayout {
+    int nJB, PWpad, NQ, pitch, cells;
+    long long off_cls, off_clist, off_ng, off_start, off_codes, off_flag, bytes;
+};
+
+static CLayout c_layout(const PlanGeom &g)
+{
+    CLayout L;
+    L.nJB = num_bin_blocks(g.PW);
+    L.PWpad = L.nJB * 64;
+    L.NQ = ceil_div(g.PH, kRowsPerChunk);           // uint4 code chunks per ray: 48 rows each
+    L.pitch = pitch_mod32_is_1(g.W + 1);            // >= W + 1: at least one gutter column
+    L.cells = 1 + (g.H + 2) * L.pitch + 1;          // guard cell, border row, H rows, border row, guard
+    auto up = [](long long v) { return (v + 255) / 256 * 256; };
+    L.off_cls = 0;                                   // per angle: bit 0 = mirror class (see rotate_plan.hip), bit 1 = sigma < 0
+    L.off_clist = (long long)g.A * 4;                // two lists of (count, angles...)
+    L.off_ng = up(L.off_clist + 2ll * (g.A + 1) * 4);          // [A][nJB]: row groups (of 6) a task walks
+    L.off_start = up(L.off_ng + (long long)g.A * L.nJB * 4);   // [A][PWpad]: first tap's cell in the bordered image
+    L.off_codes = up(L.off_start + (long long)g.A * L.PWpad * 4);
+    L.off_flag = L.off_codes + (long long)g.A * L.NQ * L.PWpad * 16;
+    L.bytes = L.off_flag + 256;
+    return L;
+}
+static size_t c_lds_bytes(const CLayout &L, int ns) { return (size_t)kLutBytes + (size_t)L.cells * 4 * ns + 16; }
+static bool cplan_fits(const PlanGeom &g, int ns = 1)
+{
+    const CLayout L = c_layout(g);
+    // three steps of at most one row each must fit the table's i16 byte offsets
+    return c_lds_bytes(L, ns) <= (size_t)kMaxLdsBytes && 12ll * L.pitch * ns <= 32767;
+}
+
+// ---- plan builder ------------------------------------------------------------------------------------------------
+struct RawTap {
+    int ix, iy;   // rounded source column / row relative to the core's origin (may lie outside the core)
+};
+// ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round -- the expressions of rotate_plan.hip's fwd_tap
+__device__ __forceinline__ RawTap raw_tap(const PlanGeom &g, float xj, float yj, float t1, float t2, float t4, float t5, int i)
+{
+    const float fi = (float)i;
+    const float x = (xj + t1 * fi) + t2;
+    const float y = (yj + t4 * fi) + t5;
+    return RawTap{(int)__builtin_roundf(x) - g.px, (int)__builtin_roundf(y) - g.py};
+}
+__device__ __forceinline__ bool in_core(const PlanGeom &g, RawTap t)
+{
+    return (unsigned)t.ix < (unsigned)g.W && (unsigned)t.iy < (unsigned)g.H;
+}
+// cell of (ix, iy), ix in [-1, W], iy in [-1, H], in the bordered (and, for class 0, column-mirrored) image
+__device__ __forceinline__ int c_cell(const PlanGeom &g, const CLayout &L, bool plus, RawTap t)
+{
+    return 1 + (t.iy + 1) * L.pitch + (plus ? t.ix : g.W - 1 - t.ix);
+}
+
+// one wave per (bin block, angle)
+__global__ __launch_bounds__(64) void rotate_cplan_kernel(PlanGeom g, const float *__restrict__ T8, CLayout L,
+                                                          char *__restrict__ plan)
+{
+    const int a = blockIdx.y, jb = blockIdx.x, lane = threadIdx.x;
+    const int j = lane_to_bin(g.PW, jb, lane);
+    const float *t = T8 + 8 * a;
+    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
+    const int sigma = t4 < 0.0f ? -1 : 1;   // the kernel's convention: a step moves the cell by sigma * (by * pitch - bx)
+    int *cls = reinterpret_cast<int *>(plan + L.off_cls);
+    int *ngt = reinterpret_cast<int *>(plan + L.off_ng);
+    unsigned *start = reinterpret_cast<unsigned *>(plan + L.off_start);
+    uint4 *codes = reinterpret_cast<uint4 *>(plan + L.off_codes);
+    int *flag = reinterpret_cast<int *>(plan + L.off_flag);
+    if (jb == 0 && lane == 0) cls[a] = (plus ? 1 : 0) | (sigma < 0 ? 2 : 0);
+    const float xj = t0 * (float)j, yj = t3 * (float)j;
+    const bool valid = (unsigned)j < (unsigned)g.PW;
+
+    int first = g.PH, last = -1, cnt = 0;
+    if (valid)
+        for (int i = 0; i < g.PH; ++i)
+            if (in_core(g, raw_tap(g, xj, yj, t1, t2, t4, t5, i))) {
+                first = min(first, i);
+                last = i;
+                ++cnt;
+            }
+    bool bad = cnt > 0 && cnt != last - first + 1;   // live rows must be one interval
+    const int n = cnt;
+    const int ng = (wave_max_i(n) + kRowsPerGroup - 1) / kRowsPerGroup, R = kRowsPerGroup * ng;
+    if (lane == 0) ngt[a * L.nJB + jb] = ng;
+
+    RawTap cur{0, 0};
+    int curcell = 0;   // a ray that misses the core stands on the guard cell (0.0f) with all codes 0
+    if (n > 0) {
+        cur = raw_tap(g, xj, yj, t1, t2, t4, t5, first);
+        curcell = c_cell(g, L, plus, cur);
+    }
+    start[(size_t)a * L.PWpad + jb * 64 + lane] = (unsigned)curcell;
+    for (int q = 0; q < L.NQ; ++q) {
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+        for (int e = 0; e < kRowsPerChunk; ++e) {
+            const int r = kRowsPerChunk * q + e;   // the step from row first + r to row first + r + 1
+            const bool inner = r + 1 < n, leave = r + 1 == n && n < R;
+            if (inner || leave) {
+                const RawTap nxt = raw_tap(g, xj, yj, t1, t2, t4, t5, first + r + 1);   // (row PH: the same arithmetic)
+                const int bx = nxt.ix != cur.ix, by = nxt.iy != cur.iy;
+                if (leave && (in_core(g, nxt) || nxt.ix < -1 || nxt.ix > g.W || nxt.iy < -1 || nxt.iy > g.H)) {
+                    bad = true;   // the ray cannot step onto the border
+                } else {
+                    const int nc = c_cell(g, L, plus, nxt);
+                    if (nc - curcell != sigma * (by * L.pitch - bx)) bad = true;
+                    w[e / 12] |= (unsigned)(bx | (by << 1)) << (8 * ((e % 12) / 3) + 2 * (e % 3));   // byte e / 3, step e % 3
+                    cur = nxt;
+                    curcell = nc;
+                }
+            }
+        }
+        codes[((size_t)a * L.NQ + q) * L.PWpad + jb * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+// clist[c] = (count, the angles of mirror class c in ascending order)
+__global__ __launch_bounds__(64) void rotate_cplan_class_list_kernel(int A, CLayout L, char *__restrict__ plan)
+{
+    const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
+    int *clist = reinterpret_cast<int *>(plan + L.off_clist);
+    const int lane = threadIdx.x;
+    for (int c = 0; c < 2; ++c) {
+        int *list = clist + c * (A + 1);
+        int n = 0;
+        for (int a0 = 0; a0 < A; a0 += 64) {
+            const bool in = a0 + lane < A && (cls[a0 + lane] & 1) == c;
+            const unsigned long long m = __ballot(in);
+            if (in) list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
+            n += __popcll(m);
+        }
+        if (lane == 0) list[0] = n;
+    }
+}
+
+// ---- executing a compact plan ---------------------------------------------------------------------------------------
+// table address of code byte BYTE of `w` for this lane: byte * 256 + (lane & 31) * 8.  `la` holds (lane & 31) * 8 in its
+// byte 0; one SDWA move writes the code into byte 1 and preserves the rest.
+template <int BYTE> __device__ __forceinline__ void lut_addr(int &la, unsigned w)
+{
+    if constexpr (BYTE == 0)
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(la) : "v"(w));
+    else if constexpr (BYTE == 1)
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(la) : "v"(w));
+    else if constexpr (BYTE == 2)
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(la) : "v"(w));
+    else
+        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(la) : "v"(w));
+}
+// base +- the sign-extended 16-bit half HALF of `pk`: one SDWA op
+template <bool NEG, int HALF> __device__ __forceinline__ int step16(int base, unsigned pk)
+{
+    int r;
+    if constexpr (!NEG && HALF == 0)
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(base), "v"(pk));
+    else if constexpr (!NEG && HALF == 1)
+        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(pk));
+    else if constexpr (NEG && HALF == 0)
+        asm("v_sub_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(base), "v"(pk));
+    else
+        asm("v_sub_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(pk));
+    return r;
+}
+// group GG (six rows = two code bytes) of the chunk pair (c0: groups 0..7, c1: groups 8..15): its code dword and byte pair
+template <int GG> __device__ __forceinline__ unsigned group_dword(const uint4 &c0, const uint4 &c1)
+{
+    constexpr int d = GG >> 1;
+    if constexpr (d == 0) return c0.x;
+    else if constexpr (d == 1) return c0.y;
+    else if constexpr (d == 2) return c0.z;
+    else if constexpr (d == 3) return c0.w;
+    else if constexpr (d == 4) return c1.x;
+    else if constexpr (d == 5) return c1.y;
+    else if constexpr (d == 6) return c1.z;
+    else return c1.w;
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct LutPair {
+    u32x2 e0, e1;   // the table entries of a group's two code bytes: (c1 | c2 << 16, c3) each
+};
+// LDS is addressed by absolute 32-bit byte addresses here: the kernel has no static LDS, so its dynamic LDS -- the table
+// first -- starts at address 0 (checked once per workgroup), and a table address is just code byte * 8.
+typedef const __attribute__((address_space(3))) u32x2 *lds_u2_cptr;
+template <int GG> __device__ __forceinline__ LutPair lut_issue(int &la0, int &la1, const uint4 &c0, const uint4 &c1)
+{
+    const unsigned w = group_dword<GG>(c0, c1);
+    constexpr int b = (GG & 1) * 2;
+    LutPair p;
+    lut_addr<b>(la0, w);
+    p.e0 = *(lds_u2_cptr)(size_t)(unsigned)la0;
+    lut_addr<b + 1>(la1, w);
+    p.e1 = *(lds_u2_cptr)(size_t)(unsigned)la1;
+    return p;
+}
+// the six tap addresses of a group from the ray's running address and the group's two table entries
+template <bool NEG> __device__ __forceinline__ void group_addr(int &adr, const LutPair &p, int (&a)[6])
+{
+    a[0] = adr;
+    a[1] = step16<NEG, 0>(adr, p.e0.x);
+    a[2] = step16<NEG, 1>(adr, p.e0.x);
+    const int mid = step16<NEG, 0>(adr, p.e0.y);
+    a[3] = mid;
+    a[4] = step16<NEG, 0>(mid, p.e1.x);
+    a[5] = step16<NEG, 1>(mid, p.e1.x);
+    adr = step16<NEG, 0>(mid, p.e1.y);
+}
+template <int NS> __device__ __forceinline__ void group_gather(const int (&a)[6], typename SliceVec<NS>::type (&v)[6])
+{
+    typedef const __attribute__((address_space(3))) typename SliceVec<NS>::type *lds_vec_cptr;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) v[e] = *(lds_vec_cptr)(size_t)(unsigned)a[e];   // a[e]: absolute LDS byte address
+}
+
+// One ray-sum per lane: walks ng groups of six rows from byte address adr0.  c0 / c1: the ray's code chunks 0 and 1 (48 rows
+// each; chunks behind the plan's NQ-th are zeros: stay); chunk q + 2 is loaded from pc (chunk 2 on) while chunk q is walked.
+// The table entries of group n + 3 and the gathers of group n + 1 are in flight while group n is added.
+template <int NS, bool NEG>
+__device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, int lane8, uint4 c0, uint4 c1, const uint4 *pc,
+                                                              size_t st, int NQ)
+{
+    typedef typename SliceVec<NS>::type vec_t;
+    vec_t acc = 0.0f;
+    vec_t va[6], vb[6];
+    int an[6];
+    int la0 = lane8, la1 = lane8;   // table address registers: byte 0 = (lane & 31) * 8, byte 1 = the code
+    LutPair l0 = lut_issue<0>(la0, la1, c0, c1), l1 = lut_issue<1>(la0, la1, c0, c1);
+    const LutPair l2 = lut_issue<2>(la0, la1, c0, c1);
+    __builtin_amdgcn_sched_barrier(0);   // all six table reads of the first three groups in flight together
+    group_addr<NEG>(adr, l0, an);
+    group_gather<NS>(an, va);
+    group_addr<NEG>(adr, l1, an);
+    l0 = l2;
+    int n = 0;   // first group of the current chunk
+    for (int q = 0;; ++q) {
+        const bool more = q + 2 < NQ && n + 8 < ng;   // wave-uniform: chunk q + 2 exists and may be walked
+        uint4 c2;
+        if (more) c2 = pc[(size_t)q * st];
+#define CTPVAE_CSTEP(G, VCUR, VNXT, LNEW, LUSE)                                                    \
+        group_gather<NS>(an, VNXT);                        /* group n + G + 1 */             \
+        LNEW = lut_issue<G + 3>(la0, la1, c0, c1);        /* table entries of group n + G + 3 */ \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* group n + G */          \
+        if (n + G + 1 >= ng) break;                                                                \
+        group_addr<NEG>(adr, LUSE, an);                          /* addresses of group n + G + 2 */
+        CTPVAE_CSTEP(0, va, vb, l1, l0)
+        CTPVAE_CSTEP(1, vb, va, l0, l1)
+        CTPVAE_CSTEP(2, va, vb, l1, l0)
+        CTPVAE_CSTEP(3, vb, va, l0, l1)
+        CTPVAE_CSTEP(4, va, vb, l1, l0)
+        CTPVAE_CSTEP(5, vb, va, l0, l1)
+        CTPVAE_CSTEP(6, va, vb, l1, l0)
+        CTPVAE_CSTEP(7, vb, va, l0, l1)
+#undef CTPVAE_CSTEP
+        n += 8;
+        c0 = c1;
+        c1 = more ? c2 : uint4{0u, 0u, 0u, 0u};
+    }
+    return acc;
+}
+
+// Forward.  Workgroup = (slice or slice pair, mirror class, task group), placed as in rotate_fwd_planned_kernel; stages the
+// unit with its zero border, builds the step table, then its waves take (angle, bin block) tasks.
+// EPI: 0 = ray-sums only; 1 = + log-probabilities (and d lp / d ray-sum) of the measured samples.
+// SEL: the launch projects a subset of the plan's angles (see rotate_fwd_planned_kernel).
+template <int NS, int EPI, bool SEL>
+__global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *__restrict__ img, PlanGeom g, CLayout L,
+                                                                  const char *__restrict__ plan, int wgs_per_slice, int g_S,
+                                                                  float *__restrict__ sino, LogLikEpilogue epi,
+                                                                  const int *__restrict__ sel, int n_sel)
+{
+    typedef typename SliceVec<NS>::type vec_t;
+    extern __shared__ float lds[];
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();   // see lut_issue
+    float *image = lds + kLutBytes / 4;   // cell c of slice n: image[c * NS + n]
+    const int units = (g_S + NS - 1) / NS;
+    int u, wg;
+    {
+        const int per8 = 8 * wgs_per_slice, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
+        if ((octet + 1) * 8 <= units) {
+            wg = rem >> 3;
+            u = octet * 8 + (rem & 7);
+        } else {   // the last, partial octet is laid out unit-major
+            u = octet * 8 + rem / wgs_per_slice;
+            wg = rem % wgs_per_slice;
+        }
+    }
+    const int s = u * NS;
+    const bool has2 = NS == 2 && s + 1 < g_S;     // an odd batch ends with a half-empty pair (slice s staged twice)
+    const int c = wg & 1, gi = wg >> 1, G = wgs_per_slice >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const float *im = img + (size_t)s * g.H * g.W;
+
+    const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
+    const int *clist = reinterpret_cast<const int *>(plan + L.off_clist) + c * (g.A + 1);
+    const int *ngt = reinterpret_cast<const int *>(plan + L.off_ng);
+    const unsigned *start = reinterpret_cast<const unsigned *>(plan + L.off_start);
+    const uint4 *codes = reinterpret_cast<const uint4 *>(plan + L.off_codes);
+    const int A_out = SEL ? n_sel : g.A;   // rows of an output sinogram
+    int sel_a[kCSelRounds], sel_rank[kCSelRounds], sel_cum[kCSelRounds + 1], sel_neg[kCSelRounds];
+    int ncls;
+    if constexpr (SEL) {
+        sel_cum[0] = 0;
+#pragma unroll
+        for (int r = 0; r < kCSelRounds; ++r) {
+            const int k = 64 * r + lane;
+            int a = 0, cl = -1, w = 0;
+            if (k < n_sel) {
+                a = min(max(sel[k], 0), g.A - 1);   // a bad index cannot leave the plan
+                w = cls[a];
+                cl = w & 1;
+            }
+            const unsigned long long m = __ballot(cl == c);
+            sel_a[r] = a;
+            sel_neg[r] = w >> 1;
+            sel_rank[r] = cl == c ? (int)__popcll(m & ((1ull << lane) - 1ull)) : -1;
+            sel_cum[r + 1] = sel_cum[r] + (int)__popcll(m);
+        }
+        ncls = sel_cum[kCSelRounds];
+    } else {
+        ncls = clist[0];
+    }
+    const int ntask = ncls * L.nJB;
+    const size_t st = (size_t)L.PWpad;
+    struct Task {
+        bool valid, neg;
+        int a, k, j, ng, adr;   // plan angle, output row, bin, row groups, first tap's LDS byte address
+        const uint4 *p;         // the ray's chunk 2
+        uint4 c0, c1;
+    };
+    auto prepare = [&](int m) -> Task {
+        Task t;
+        t.valid = m < ntask;
+        t.neg = false;
+        t.a = t.k = t.j = t.ng = 0;
+        t.adr = kLutBytes;
+        t.p = codes;
+        t.c0 = t.c1 = uint4{0u, 0u, 0u, 0u};
+        if (t.valid) {   // wave-uniform
+            const int jb = m / ncls, ai = m - jb * ncls;
+            if constexpr (SEL) {
+#pragma unroll
+                for (int r = 0; r < kCSelRounds; ++r)
+                    if (ai >= sel_cum[r] && ai < sel_cum[r + 1]) {   // wave-uniform
+                        const unsigned long long hit = __ballot(sel_rank[r] == ai - sel_cum[r]);
+                        const int l = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)hit) - 1);
+                        t.a = __builtin_amdgcn_readlane(sel_a[r], l);
+                        t.neg = __builtin_amdgcn_readlane(sel_neg[r], l) != 0;
+                        t.k = 64 * r + l;
+                    }
+            } else {
+                t.k = t.a = clist[1 + ai];
+                t.neg = (cls[t.a] >> 1) != 0;
+            }
+            t.a = __builtin_amdgcn_readfirstlane(t.a);
+            t.k = __builtin_amdgcn_readfirstlane(t.k);
+            t.ng = __builtin_amdgcn_readfirstlane(ngt[t.a * L.nJB + jb]);
+            t.j = lane_to_bin(g.PW, jb, lane);
+            t.adr = kLutBytes + (int)start[(size_t)t.a * L.PWpad + jb * 64 + lane] * (4 * NS);
+            const uint4 *p = codes + (size_t)t.a * L.NQ * L.PWpad + jb * 64 + lane;
+            t.c0 = p[0];
+            if (L.NQ > 1) t.c1 = p[st];
+            t.p = p + 2 * st;
+        }
+        return t;
+    };
+    Task cur = prepare(gi + G * wave);
+    int *next_task = reinterpret_cast<int *>(image + (size_t)L.cells * NS);
+    if (threadIdx.x == 0) *next_task = nwaves;
+
+    // step table: entry e = the cumulative byte offsets after 1..3 of the steps coded in e (bit 2m: column, 2m+1: row), one
+    // copy per lane of a half-wave at byte e * 256 + l * 8
+    for (int t = threadIdx.x; t < 64 * 32; t += blockDim.x) {
+        const int e = t >> 5;
+        int acc = 0;
+        unsigned short cum[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            acc += (((e >> (2 * m + 1)) & 1) * L.pitch - ((e >> (2 * m)) & 1)) * (4 * NS);
+            cum[m] = (unsigned short)(short)acc;
+        }
+        reinterpret_cast<uint2 *>(lds)[t] = make_uint2(cum[0] | ((unsigned)cum[1] << 16), cum[2]);
+    }
+    // zero border: guard + row -1 (cells 0 .. pitch), row H + guard, and the gutter columns W .. pitch-1 of rows 0..H-1
+    {
+        const int nthreads = blockDim.x, gut = L.pitch - g.W;
+        for (int t = threadIdx.x; t < (L.pitch + 1) * NS; t += nthreads) image[t] = 0.0f;
+        for (int t = threadIdx.x; t < (L.pitch + 1) * NS; t += nthreads) image[(size_t)(1 + (g.H + 1) * L.pitch) * NS + t] = 0.0f;
+        for (int t = threadIdx.x; t < g.H * gut * NS; t += nthreads) {
+            const int row = t / (gut * NS), k = t - row * (gut * NS);
+            image[(size_t)(1 + (row + 1) * L.pitch + g.W) * NS + k] = 0.0f;
+        }
+    }
+    float *core = image + (size_t)(1 + L.pitch) * NS;   // cell of (iy = 0, column 0)
+    if constexpr (NS == 1) {
+        stage_rows(core, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+    } else {   // both slices of the pair in one load round trip, written as float2
+        const float *srcs[2] = {im, im + (has2 ? (size_t)g.H * g.W : 0)};
+        stage_rows_interleaved<2>(core, srcs, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+    }
+    __syncthreads();
+
+    while (cur.valid) {
+        int m = 0;
+        if (lane == 0) m = atomicAdd(next_task, 1);
+        const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m) * G + gi);
+
+        vec_t acc = 0.0f;
+        const int ng = __builtin_amdgcn_readfirstlane(cur.ng);
+        const bool neg = __builtin_amdgcn_readfirstlane((int)cur.neg) != 0;
+        if (ng > 0)
+            acc = neg ? cwalk<NS, true>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ)
+                      : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
+        if ((unsigned)cur.j < (unsigned)g.PW) {
+            auto store = [&](int sl, float v) {
+                const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
+                sino[o] = v;
+                if constexpr (EPI == 1) {
+                    // measured samples and masks: compact like the outputs, or the dense arrays read at the plan angle
+                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + cur.a : (size_t)sl * A_out + cur.k;
+                    epi.write(o, sa * g.PW + cur.j, sa, v);
+                }
+            };
+            if constexpr (NS == 1) {
+                store(s, acc);
+            } else {
+                store(s, acc.x);
+                if (has2) store(s + 1, acc.y);
+            }
+        }
+        cur = nxt;
+    }
+}
+
+}  // namespace ctpvae
+
+using namespace ctpvae;
+
+extern "C" {
+
+int ctpvae_rotate_cplan_supported(int H, int W, int PH, int PW, int A, int interp)
+{
+    if (interp != CTPVAE_NEAREST || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return 0;
+    if (knob(kKnobNoPlan) >= 0 || knob(kKnobNoCompact) >= 0) return 0;
+    return cplan_fits(PlanGeom{H, W, PH, PW, 0, 0, A}) ? 1 : 0;
+}
+
+long long ctpvae_rotate_cplan_bytes(int H, int W, int PH, int PW, int A)
+{
+    if (H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_cplan_bytes: bad sizes");
+    return c_layout(PlanGeom{H, W, PH, PW, 0, 0, A}).bytes;
+}
+
+int ctpvae_rotate_cplan_build_f32(const float *T8_dev, int A, int H, int W, int PH, int PW, int py, int px, void *cplan_dev,
+                                  ctpvae_stream_t stream)
+{
+    if (int rc = check_plan_geom("rotate_cplan_build", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(T8_dev && cplan_dev, "rotate_cplan_build: null pointer");
+    const PlanGeom g{H, W, PH, PW, py, px, A};
+    CTPVAE_REQUIRE(cplan_fits(g), "rotate_cplan_build: a %dx%d slice does not fit the compact plan's LDS image", H, W);
+    CTPVAE_REQUIRE(A <= 65535, "rotate_cplan_build: at most 65535 angles");
+    const CLayout L = c_layout(g);
+    CTPVAE_HIP(hipMemsetAsync((char *)cplan_dev + L.off_flag, 0, 256, (hipStream_t)stream));
+    hipLaunchKernelGGL(rotate_cplan_kernel, dim3(L.nJB, A), dim3(64), 0, (hipStream_t)stream, g, T8_dev, L, (char *)cplan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_cplan_kernel");
+    hipLaunchKernelGGL(rotate_cplan_class_list_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, L, (char *)cplan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_cplan_class_list_kernel");
+    return CTPVAE_OK;
+}
+
+// 1 if some ray's steps do not fit the code: keep the u16 plan (ctpvae_rotate_plan_build_f32).  SYNCHRONISES the stream.
+int ctpvae_rotate_cplan_overflowed(const void *cplan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(cplan_dev && H > 0 && W > 0 && A > 0 && PH >= H && PW >= W, "rotate_cplan_overflowed: bad arguments");
+    const CLayout L = c_layout(PlanGeom{H, W, PH, PW, 0, 0, A});
+    int flag = 0;
+    CTPVAE_HIP(hipMemcpyAsync(&flag, (const char *)cplan_dev + L.off_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CTPVAE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return flag ? 1 : 0;
+}
+
+int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *cplan_dev,
+                                  const int *angle_idx_dev, int n_idx, const float *mask_dev, const float *meas_dev,
+                                  int dense_inputs, const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
+                                  float *dlp_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(img_dev && cplan_dev && sino_dev, "rotate_fwd_compact: null pointer");
+    CTPVAE_REQUIRE(S > 0, "rotate_fwd_compact: need at least one slice");
+    if (int rc = check_plan_geom("rotate_fwd_compact", H, W, PH, PW, 0, 0, A)) return rc;
+    const int *sel_dev = angle_idx_dev;
+    CTPVAE_REQUIRE(sel_dev == nullptr || (n_idx >= 1 && n_idx <= 64 * kCSelRounds),
+                   "rotate_fwd_compact: an angle subset holds 1..%d angles (got %d); build a plan for larger ones",
+                   64 * kCSelRounds, n_idx);
+    const bool lik = lp_dev != nullptr;
+    CTPVAE_REQUIRE(!lik || (mask_dev && meas_dev && pnm_dev), "rotate_fwd_compact: the likelihood epilogue needs mask, meas and pnm");
+    CTPVAE_REQUIRE(lik || dlp_dev == nullptr, "rotate_fwd_compact: dlp without lp");
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    CTPVAE_REQUIRE(cplan_fits(g), "rotate_fwd_compact: a %dx%d slice does not fit the compact plan's LDS image", H, W);
+    const CLayout L = c_layout(g);
+    const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0}
+                                   : LogLikEpilogue{};
+    const int A_run = sel_dev ? n_idx : A;      // angles this launch projects
+    const int T = A_run * L.nJB;                // (angle, bin block) tasks per slice
+    // Launch shape.  With 0.25 B of plan per sample the index stream no longer counts; what a workgroup costs is the fill of
+    // its unit (a slice, or a pair of slices interleaved as float2) and its tasks, which are bound by the CU's LDS pipe when
+    // all 16 waves gather (10 LDS instructions of ~3.7 cycles per group of eight rows, the same for one slice or a pair)
+    // and by the latency of a wave's chain of dependent row groups when few waves do (measured on the MI355X, round 3:
+    // B=50 A=20 pairs G=5 7.4 us, G=4 7.8, G=3 8.1, singles 9.1; A=180 pairs G=5 22.5, G=4 26.2, G=10 26.3).  In microseconds:
+    const bool pairs_fit = cplan_fits(g, 2) && S >= 2;
+    int ns = 1, G = 1;
+    {
+        const double ngroups = 0.6 * ceil_div(PH, 8);             // row groups (of eight) of an average task
+        const double task_lds_us = ngroups * 0.0176, chain_us = ngroups * 0.075;
+        double best = 0.0;
+        for (int cand_ns = 1; cand_ns <= (pairs_fit ? 2 : 1); ++cand_ns) {
+            const double fill_us = 0.6 + 0.011 * ((double)g.H * g.W * 4.0 * cand_ns / 1024.0);
+            const long long cand_units = (S + cand_ns - 1) / cand_ns;
+            for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
+                const long long wgs = 2ll * cand_units * cand;
+                const double tasks_wg = T / (2.0 * cand);
+                const double cost = (double)((wgs + 255) / 256) *
+                                    (fill_us + std::max(tasks_wg * task_lds_us, std::ceil(tasks_wg / 16.0) * chain_us));
+                if (best == 0.0 || cost < best) {
+                    best = cost;
+                    ns = cand_ns;
+                    G = cand;
+                }
+            }
+        }
+    }
+    if (knob(kKnobNs) >= 0) ns = (knob(kKnobNs) == 2 && pairs_fit) ? 2 : 1;
+    if (knob(kKnobG) > 0) G = knob(kKnobG);
+    const size_t shmem = c_lds_bytes(L, ns);
+    const int units = (S + ns - 1) / ns;
+    // never fewer waves than stage the unit in ONE batch of eight 16-byte loads per lane (see launch_fwd_planned)
+    const int stage_waves = (int)std::min<size_t>(16, ceil_div((int)((size_t)g.H * g.W * 4 * ns / 1024), 8));
+    int waves = std::min(16, std::max(stage_waves, (T + 2 * G - 1) / (2 * G)));
+    if (knob(kKnobWaves) > 0) waves = std::min(16, std::max(1, knob(kKnobWaves)));
+    const int wgs_per_slice = 2 * G;
+    CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_compact: too many slices");
+    auto launch = [&](auto kernel) -> int {
+        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
+                           img_dev, g, L, (const char *)cplan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_idx);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_compact_kernel");
+        return CTPVAE_OK;
+    };
+    if (sel_dev) {
+        if (lik) return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 1, true>) : launch(rotate_fwd_compact_kernel<1, 1, true>);
+        return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 0, true>) : launch(rotate_fwd_compact_kernel<1, 0, true>);
+    }
+    if (lik) return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 1, false>) : launch(rotate_fwd_compact_kernel<1, 1, false>);
+    return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 0, false>) : launch(rotate_fwd_compact_kernel<1, 0, false>);
+}
+
+}  // extern "C"

@@ -34,12 +34,9 @@
 #include "common.h"
 #include "lds_stage.h"
 #include "loglik_math.h"
+#include "rotate_plan.h"
 
 namespace ctpvae {
-
-struct PlanGeom {
-    int H, W, PH, PW, py, px, A;
-};
 
 struct FwdLayout {
     int nJB, PWpad, NG, Galloc, pitch, zero;
@@ -51,20 +48,6 @@ struct BwdLayout {
     int nXB, Wpad, NA16, pitchg, chunkA;   // chunkA: angles staged per pass (multiple of 16)
     long long bytes;
 };
-
-__host__ __device__ inline int pitch_mod32_is_1(int w) { return w + ((1 - (w & 31)) & 31); }
-
-// Detector bins are dealt to 64-lane blocks in two 32-bin bands mirrored about the detector centre: block k holds
-// bins [c - 32(k+1), c - 32k) in lanes 0..31 and [c + 32k, c + 32(k+1)) in lanes 32..63, c = PW / 2.  Rays at equal
-// distance from the centre have equal chords through the slice, so a wave's 64 rays need nearly the same rows
-// (a contiguous 64-bin block mixes long central chords with short outer ones: 147 vs 134 visited rows per task at
-// N = 128).  Each 32-lane half is still a contiguous run of bins, which is what the LDS bank argument needs.
-__host__ __device__ inline int lane_to_bin(int PW, int jb, int lane)
-{
-    const int c = PW >> 1;
-    return lane < 32 ? c - 32 * (jb + 1) + lane : c + 32 * jb + (lane - 32);   // may fall outside [0, PW): dead lane
-}
-__host__ __device__ inline int num_bin_blocks(int PW) { return (PW - (PW >> 1) + 31) / 32; }
 
 static FwdLayout fwd_layout(const PlanGeom &g)
 {
@@ -104,23 +87,6 @@ static bool fwd_plan_fits(const PlanGeom &g)
     return L.zero < 65535 && (size_t)(L.zero + 1) * 4 + 16 <= (size_t)kMaxLdsBytes;   // image, zero cell, task counter
 }
 static bool bwd_plan_fits(const PlanGeom &g) { return g.PW <= 255; }
-
-typedef const __attribute__((address_space(3))) float *lds_cptr;
-typedef __attribute__((address_space(3))) float *lds_ptr;
-typedef const __attribute__((address_space(1))) float *glb_cptr;
-
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
-    return v;
-}
 
 // ---- plan builders: the reference arithmetic, evaluated exactly, once per geometry ---------------------------
 // The taps of a ray are stored from ITS OWN first live row on: group g of ray (a, j) holds canvas rows
@@ -282,10 +248,6 @@ __device__ __forceinline__ float lds_at(const float *lds, int byte_off)
 {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + byte_off);
 }
-// NS slices interleaved in LDS (float or float2 per pixel): byte offset = index * 4 * NS, one ds_read_b32 / _b64 per tap
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int NS> struct SliceVec { typedef float type; };
-template <> struct SliceVec<2> { typedef f32x2 type; };
 __device__ __forceinline__ void unpack2x8(unsigned pk, int &lo8, int &hi8)
 {
     asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
@@ -739,15 +701,6 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
             }
         }
     }
-}
-
-static int check_plan_geom(const char *who, int H, int W, int PH, int PW, int py, int px, int A)
-{
-    CTPVAE_REQUIRE(H > 0 && W > 0 && A > 0, "%s: sizes must be positive (H=%d W=%d A=%d)", who, H, W, A);
-    CTPVAE_REQUIRE(py >= 0 && px >= 0 && PH >= H + py && PW >= W + px,
-                   "%s: the %dx%d slice at (%d,%d) does not fit the %dx%d canvas", who, H, W, py, px, PH, PW);
-    CTPVAE_REQUIRE((long long)PH * PW < (1ll << 24), "%s: canvas too large for fp32 index arithmetic", who);
-    return CTPVAE_OK;
 }
 
 }  // namespace ctpvae

@@ -25,6 +25,8 @@ using fwd_lik_fn = decltype(&ctpvae_rotate_fwd_planned_loglik_f32);
 using fwd_lik_sel_fn = decltype(&ctpvae_rotate_fwd_planned_loglik_sel_f32);
 using bwd_seg_fn = decltype(&ctpvae_rotate_bwd_scaled_f32);
 using bwd_sel_fn = decltype(&ctpvae_rotate_bwd_sel_scaled_f32);
+using fwd_compact_fn = decltype(&ctpvae_rotate_fwd_compact_f32);
+using abi_fn = decltype(&ctpvae_abi_version);
 fwd_fn g_fwd = nullptr;
 bwd_fn g_bwd = nullptr;
 err_fn g_err = nullptr;
@@ -32,11 +34,21 @@ fwd_lik_fn g_fwd_lik = nullptr;
 fwd_lik_sel_fn g_fwd_lik_sel = nullptr;
 bwd_seg_fn g_bwd_seg = nullptr;
 bwd_sel_fn g_bwd_sel = nullptr;
+fwd_compact_fn g_fwd_compact = nullptr;
+
+// The ABI this node was COMPILED against (the header's macro) must be the ABI of the library it binds at run time: the
+// entry points are resolved by name only, so a node left over from an older build would otherwise call them with an old
+// argument list.  Returns the library's version; the Python side (ct_pvae_amd/_lib.py torch_node()) compares and falls back
+// to the Python nodes on a mismatch.
+int64_t compiled_abi() { return CTPVAE_ABI_VERSION; }
 
 void bind(const std::string &lib_path)
 {
     void *h = dlopen(lib_path.c_str(), RTLD_NOW | RTLD_GLOBAL);
     TORCH_CHECK(h != nullptr, "cannot load ", lib_path, ": ", dlerror());
+    abi_fn abi = (abi_fn)dlsym(h, "ctpvae_abi_version");
+    TORCH_CHECK(abi != nullptr && abi() == CTPVAE_ABI_VERSION, "ct_pvae_amd torch node was built for ABI ", CTPVAE_ABI_VERSION,
+                " but ", lib_path, " has ABI ", abi ? abi() : -1, ": rebuild the node (__graft_entry__.build())");
     g_fwd = (fwd_fn)dlsym(h, "ctpvae_rotate_fwd_planned_f32");
     g_bwd = (bwd_fn)dlsym(h, "ctpvae_rotate_bwd_planned_scaled_f32");
     g_err = (err_fn)dlsym(h, "ctpvae_last_error");
@@ -44,7 +56,8 @@ void bind(const std::string &lib_path)
     g_fwd_lik_sel = (fwd_lik_sel_fn)dlsym(h, "ctpvae_rotate_fwd_planned_loglik_sel_f32");
     g_bwd_seg = (bwd_seg_fn)dlsym(h, "ctpvae_rotate_bwd_scaled_f32");
     g_bwd_sel = (bwd_sel_fn)dlsym(h, "ctpvae_rotate_bwd_sel_scaled_f32");
-    TORCH_CHECK(g_fwd && g_bwd && g_err && g_fwd_lik && g_fwd_lik_sel && g_bwd_seg && g_bwd_sel, lib_path,
+    g_fwd_compact = (fwd_compact_fn)dlsym(h, "ctpvae_rotate_fwd_compact_f32");
+    TORCH_CHECK(g_fwd && g_bwd && g_err && g_fwd_lik && g_fwd_lik_sel && g_bwd_seg && g_bwd_sel && g_fwd_compact, lib_path,
                 " does not export the planned projector entry points");
 }
 
@@ -57,7 +70,8 @@ void check(int rc, const char *what)
 
 struct RotateVae : public torch::autograd::Function<RotateVae> {
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &x4, const at::Tensor &fwd_plan,
-                              const at::Tensor &bwd_plan, int64_t H, int64_t W, int64_t PH, int64_t PW, int64_t A, int64_t stream)
+                              const at::Tensor &bwd_plan, int64_t H, int64_t W, int64_t PH, int64_t PW, int64_t A, int64_t stream,
+                              int64_t compact)
     {
         TORCH_CHECK(g_fwd != nullptr, "ct_pvae_amd torch node: bind() was not called");
         TORCH_CHECK(x4.is_cuda() && x4.dim() == 4 && x4.size(1) == H && x4.size(2) == W && x4.size(3) == 1 && x4.size(0) > 0 &&
@@ -65,8 +79,11 @@ struct RotateVae : public torch::autograd::Function<RotateVae> {
                     "project_tf_fast: expected a contiguous float32 [B][", H, "][", W, "][1] tensor on ", fwd_plan.device());
         const int64_t S = x4.size(0);
         at::Tensor out = at::empty({S, A, PW, 1}, x4.options());
-        const int rc = g_fwd(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
-                             out.data_ptr<float>(), (void *)stream);
+        const int rc = compact ? g_fwd_compact(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A,
+                                               fwd_plan.data_ptr(), nullptr, 0, nullptr, nullptr, 0, nullptr, 0.0f,
+                                               out.data_ptr<float>(), nullptr, nullptr, (void *)stream)
+                               : g_fwd(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
+                                       out.data_ptr<float>(), (void *)stream);
         check(rc, "rotate_fwd");
         ctx->saved_data["bwd_plan"] = bwd_plan;
         ctx->saved_data["geo"] = std::vector<int64_t>{H, W, PH, PW, A, stream};
@@ -85,18 +102,21 @@ struct RotateVae : public torch::autograd::Function<RotateVae> {
         const int rc = g_bwd(g.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, bwd_plan.data_ptr(), nullptr, 0,
                              gimg.data_ptr<float>(), (void *)geo[5]);
         check(rc, "rotate_bwd");
-        return {gimg, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+        torch::autograd::tensor_list out(10);
+        out[0] = gimg;
+        return out;
     }
 };
 
-// geo = {H, W, PH, PW, A_plan, py, px, backward_uses_plan, dense_inputs, stream}; angles: int32 [n] on the device or undefined
+// geo = {H, W, PH, PW, A_plan, py, px, backward_uses_plan, dense_inputs, stream, compact forward plan}; angles: int32 [n] on
+// the device or undefined
 struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &x4, const at::Tensor &fwd_plan,
                               const at::Tensor &bwd_plan, const at::Tensor &Tinv8, const at::Tensor &mask, const at::Tensor &meas,
                               const at::Tensor &pnm, const c10::optional<at::Tensor> &angles, double eps, std::vector<int64_t> geo)
     {
         TORCH_CHECK(g_fwd_lik != nullptr, "ct_pvae_amd torch node: bind() was not called");
-        const int64_t H = geo[0], W = geo[1], PH = geo[2], PW = geo[3], A = geo[4], dense = geo[8], stream = geo[9];
+        const int64_t H = geo[0], W = geo[1], PH = geo[2], PW = geo[3], A = geo[4], dense = geo[8], stream = geo[9], compact = geo[10];
         const bool sel = angles.has_value() && angles->defined();
         const int64_t n = sel ? angles->numel() : A, n_in = (sel && !dense) ? n : A;
         auto f32c = [&](const at::Tensor &t) { return t.is_cuda() && t.scalar_type() == at::kFloat && t.is_contiguous() && t.device() == x4.device(); };
@@ -114,7 +134,12 @@ struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
         at::Tensor lp = at::empty({S, n, PW, 1}, x4.options());
         at::Tensor dlp = at::empty({S, n, PW}, x4.options());
         int rc;
-        if (sel)
+        if (compact)
+            rc = g_fwd_compact(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
+                               sel ? angles->data_ptr<int>() : nullptr, sel ? (int)n : 0, mask.data_ptr<float>(),
+                               meas.data_ptr<float>(), (int)dense, pnm.data_ptr<float>(), (float)eps, sino.data_ptr<float>(),
+                               lp.data_ptr<float>(), dlp.data_ptr<float>(), (void *)stream);
+        else if (sel)
             rc = g_fwd_lik_sel(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
                                angles->data_ptr<int>(), (int)n, mask.data_ptr<float>(), meas.data_ptr<float>(), (int)dense,
                                pnm.data_ptr<float>(), (float)eps, sino.data_ptr<float>(), lp.data_ptr<float>(),
@@ -175,20 +200,21 @@ at::Tensor rotate_loglik(const at::Tensor &x4, const at::Tensor &fwd_plan, const
                          const at::Tensor &mask, const at::Tensor &meas, const at::Tensor &pnm, const c10::optional<at::Tensor> &angles,
                          double eps, std::vector<int64_t> geo)
 {
-    TORCH_CHECK(geo.size() == 10, "geo = {H, W, PH, PW, A, py, px, backward_uses_plan, dense_inputs, stream}");
+    TORCH_CHECK(geo.size() == 11, "geo = {H, W, PH, PW, A, py, px, backward_uses_plan, dense_inputs, stream, compact}");
     return RotateLogLik::apply(x4, fwd_plan, bwd_plan, Tinv8, mask, meas, pnm, angles, eps, geo);
 }
 
 at::Tensor rotate_vae(const at::Tensor &x4, const at::Tensor &fwd_plan, const at::Tensor &bwd_plan, int64_t H, int64_t W, int64_t PH,
-                      int64_t PW, int64_t A, int64_t stream)
+                      int64_t PW, int64_t A, int64_t stream, int64_t compact)
 {
-    return RotateVae::apply(x4, fwd_plan, bwd_plan, H, W, PH, PW, A, stream);
+    return RotateVae::apply(x4, fwd_plan, bwd_plan, H, W, PH, PW, A, stream, compact);
 }
 
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    m.def("compiled_abi", &compiled_abi, "CTPVAE_ABI_VERSION of the header this node was compiled against");
     m.def("bind", &bind, "dlopen libctpvae_radon.so and resolve the planned projector entry points");
     m.def("rotate_loglik", &rotate_loglik,
           "calculate_log_prob_M_given_R for [B][X][Y][1] float32 through a gather plan: projection + log-likelihood in one launch");

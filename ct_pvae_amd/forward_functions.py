@@ -160,8 +160,18 @@ class RotatePlan:
     `forward` / `backward` are the raw operator pair (no autograd bookkeeping); `apply` is differentiable."""
 
     MAX_SEL = 256   # angles per subset launch of a dense plan (kSelRounds * 64 in rotate_plan.hip)
+    # Forward plan format (nearest).  "u16": 2 B per sample (csrc/rotate_plan.hip); "compact": first tap + 2 bits per row,
+    # 1/3 B per sample (csrc/rotate_cplan.hip) -- the same bits either way.  "auto" takes what was measured faster on the
+    # MI355X (round 3, tools/time_compact_shapes.py, tools/time_sel.py): the compact plan for many-angle plans, whose 17 MB
+    # of u16 taps at the dataset's 180 angles overflow an XCD's 4 MB L2 (B=400 A=180: 145 vs 155 us; a 20-angle subset of the
+    # dense plan, the training call: 7.8 vs 8.9 us), the u16 plan for few angles, where its taps are L2-resident anyway and
+    # its shorter per-task prologue wins (B=50 A=20: 7.3 vs 7.65 us).
+    COMPACT_MIN_ANGLES = 64
 
-    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True, _tables=None):
+    def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True, _tables=None,
+                 plan_format="auto"):
+        if plan_format not in ("auto", "compact", "u16"):
+            raise ValueError(f"plan_format must be 'auto', 'compact' or 'u16' (got {plan_format!r})")
         if interp not in _INTERP:
             raise ValueError(f"interp must be one of {sorted(_INTERP)} (got {interp!r})")
         if backward not in _BACKWARD:
@@ -193,9 +203,14 @@ class RotatePlan:
         self._want_exact_plan = bool(use_plan and self.mode == _lib.BWD_EXACT and self.interp == _lib.NEAREST)
         self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
         self._tile_ws = None
+        self._compact = False      # the forward plan is a compact (step-coded) one: ctpvae_rotate_fwd_compact_f32 runs it
         if use_plan:
             geo = (self.H, self.W, self.PH, self.PW, self.A, self.interp)
-            if self._lib.ctpvae_rotate_plan_supported(*geo, 0):
+            want_compact = plan_format == "compact" or (plan_format == "auto" and self.A >= self.COMPACT_MIN_ANGLES)
+            if want_compact and self._lib.ctpvae_rotate_cplan_supported(*geo):
+                self._fwd_plan = self._build_compact_plan()
+                self._compact = self._fwd_plan is not None
+            if self._fwd_plan is None and self._lib.ctpvae_rotate_plan_supported(*geo, 0):
                 self._fwd_plan = self._build_plan(0)
             self._want_bwd_plan = bool(self.mode == _lib.BWD_TF_COMPAT and
                                        self._lib.ctpvae_rotate_plan_supported(*geo, 1))
@@ -214,6 +229,22 @@ class RotatePlan:
                 buf.data_ptr() if which == 0 else None, buf.data_ptr() if which == 1 else None, _stream_ptr()),
                 "rotate_plan_build")
         return buf
+
+    def _build_compact_plan(self):
+        """Step-coded forward plan (first tap + 2 bits per row: csrc/rotate_cplan.hip), or None when some ray's steps do not
+        fit the code (unpadded canvases at oblique angles, rows that are not a rotation): the u16 plan is built then.
+        Reading the overflow word synchronises -- here, at construction, never inside a caller's graph capture."""
+        nbytes = self._lib.ctpvae_rotate_cplan_bytes(self.H, self.W, self.PH, self.PW, self.A)
+        _lib.check(nbytes, "rotate_cplan_bytes")
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctpvae_rotate_cplan_build_f32(self.T8.data_ptr(), self.A, self.H, self.W, self.PH, self.PW,
+                                                               self.py, self.px, buf.data_ptr(), _stream_ptr()),
+                       "rotate_cplan_build")
+            over = self._lib.ctpvae_rotate_cplan_overflowed(buf.data_ptr(), self.H, self.W, self.PH, self.PW, self.A,
+                                                            _stream_ptr())
+        _lib.check(over, "rotate_cplan_overflowed")
+        return buf if over == 0 else None
 
     def _build_exact_plan(self):
         """Inverse plan of the nearest forward (<= 2 hitting bins per angle and pixel).  Falls back to the scatter kernel
@@ -238,6 +269,19 @@ class RotatePlan:
     def planned(self):
         """(forward uses a plan, backward uses / will use a plan)"""
         return self._fwd_plan is not None, self._want_bwd_plan
+
+    @property
+    def compact(self):
+        """True if the forward plan is the compact (step-coded) form."""
+        return self._compact
+
+    def _run_compact(self, img_ptr, S, out_ptr, angles_i=None, n=0, mask=None, meas=None, dense=0, pnm=None, eps=0.0,
+                     lp_ptr=None, dlp_ptr=None):
+        return self._lib.ctpvae_rotate_fwd_compact_f32(
+            img_ptr, S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(),
+            angles_i.data_ptr() if angles_i is not None else None, n, mask.data_ptr() if mask is not None else None,
+            meas.data_ptr() if meas is not None else None, dense, pnm.data_ptr() if pnm is not None else None,
+            ctypes.c_float(eps), out_ptr, lp_ptr, dlp_ptr, _stream_ptr(self._dev_index))
 
     def subset(self, angles_i):
         """A plan over rows `angles_i` of this one's tables (two small gathers, no plan kernels): the fallback for angle
@@ -355,6 +399,11 @@ class RotatePlan:
             self._check(out, (n, self.PW), "out")
             if out.shape[0] != S:
                 raise ValueError(f"out holds {out.shape[0]} sinograms for {S} slices")
+        if self._compact:
+            rc = self._run_compact(img.data_ptr(), S, out.data_ptr(), angles_i, n if angles_i is not None else 0)
+            if rc:
+                _lib.check(rc, "rotate_fwd_compact")
+            return out
         if angles_i is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_sel_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                              self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
@@ -409,7 +458,10 @@ class RotatePlan:
                 if out_dlp.shape[0] != S:
                     raise ValueError("out_dlp must hold one sinogram per slice")
         dlp_ptr = out_dlp.data_ptr() if out_dlp is not None else None
-        if angles_i is not None:
+        if self._compact:
+            rc = self._run_compact(img.data_ptr(), S, out.data_ptr(), angles_i, n if angles_i is not None else 0, mask, meas,
+                                   1 if dense_inputs else 0, pnm, eps, out_lp.data_ptr(), dlp_ptr)
+        elif angles_i is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_loglik_sel_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
                 mask.data_ptr(), meas.data_ptr(), 1 if dense_inputs else 0, pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
@@ -491,8 +543,11 @@ class RotatePlan:
             return None
         S = x4.shape[0]
         out = torch.empty((S, self.A, self.PW, 1), dtype=torch.float32, device=self._tdev)
-        rc = self._lib.ctpvae_rotate_fwd_planned_f32(x4.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
-                                                     self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+        if self._compact:
+            rc = self._run_compact(x4.data_ptr(), S, out.data_ptr())
+        else:
+            rc = self._lib.ctpvae_rotate_fwd_planned_f32(x4.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                         self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
         if rc:
             _lib.check(rc, "rotate_fwd")
         return out
@@ -525,7 +580,7 @@ class RotatePlan:
         if self._bwd_plan is None:
             self._bwd_plan = self._build_plan(1)
         return node.rotate_vae(x4, self._fwd_plan, self._bwd_plan, self.H, self.W, self.PH, self.PW, self.A,
-                               _stream_ptr(self._dev_index))
+                               _stream_ptr(self._dev_index), int(self._compact))
 
     def loglik_vae_cpp(self, x4, mask, meas, pnm, eps, angles_i):
         """calculate_log_prob_M_given_R through the C++ autograd node (one-launch forward that stores d lp / d sino, scaled
@@ -543,7 +598,7 @@ class RotatePlan:
             self._check_sel(angles_i)
         return node.rotate_loglik(x4, self._fwd_plan, self._bwd_plan if use_plan else self.Tinv8, self.Tinv8, mask, meas, pnm,
                                   angles_i, eps, [self.H, self.W, self.PH, self.PW, self.A, self.py, self.px, int(use_plan),
-                                                  int(angles_i is not None), _stream_ptr(self._dev_index)])
+                                                  int(angles_i is not None), _stream_ptr(self._dev_index), int(self._compact)])
 
     def apply(self, img):
         """Differentiable projection of slices [S][H][W] -> [S][A][PW]."""

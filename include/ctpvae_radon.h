@@ -23,6 +23,7 @@
  *                                              ctvae/main_ct_vae.py:471-481) and its exact transpose
  *   ctpvae_rotate_plan_* / _planned_f32        the same two operators, batched: index arithmetic hoisted
  *                                              out of the per-object work (no counterpart in the reference)
+ *   ctpvae_rotate_cplan_* / _fwd_compact_f32   the planned forward with step-coded (2 bits per sample) plans
  *   ctpvae_rotate_transforms_host_f32          the same table for a host-resident theta (the dataset's angle list,
  *                                              ctvae/main_ct_vae.py:152), evaluated on the host
  *   ctpvae_rotate_*_sel_*                      the per-step angle subset of calculate_log_prob_M_given_R,
@@ -61,7 +62,10 @@ extern "C" {
 
 typedef void *ctpvae_stream_t;
 
-/* Version of this ABI: major * 1000 + minor. */
+/* Version of this ABI: major * 1000 + minor.  CTPVAE_ABI_VERSION is what THIS header describes: host code compiled against
+ * it (csrc/torch_node.cpp, a maintainer's own binding) compares the macro with ctpvae_abi_version() of the library it loaded
+ * and refuses a mismatch -- an entry point called with another version's argument list is a silent wrong-argument call. */
+#define CTPVAE_ABI_VERSION 3000
 int ctpvae_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *ctpvae_last_error(void);
@@ -71,7 +75,7 @@ int ctpvae_device_count(void);
  * path never reads the environment: the registry is filled once, when the library is loaded, from CTPVAE_TUNE_<NAME>
  * (and CTPVAE_NO_PLAN / CTPVAE_FORCE_GENERIC), and changed afterwards only here.  name: "NS", "G", "WAVES", "BNS",
  * "BW", "SEG_NS", "SEG_CHUNK", "SEG_PPT", "TILED_NS", "TILED_G", "SIDDON_NS", "SIDDON_THREADS", "SIDDON_PPB",
- * "SIDDON_BWD_THREADS", "SIDDON_BWD_CHUNKS", "MAX_SLICES", "NO_PLAN", "FORCE_GENERIC"; value < 0 unsets; name "*" unsets every knob.
+ * "SIDDON_BWD_THREADS", "SIDDON_BWD_CHUNKS", "MAX_SLICES", "NO_PLAN", "NO_COMPACT", "FORCE_GENERIC"; value < 0 unsets; name "*" unsets every knob.
  * _active: how many knobs are set (bench.py prints it next to its numbers). */
 int ctpvae_tune_set(const char *name, int value);
 int ctpvae_tune_active(void);
@@ -176,6 +180,28 @@ int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H,
                                              const float *mask_dev, const float *meas_dev, int dense_inputs,
                                              const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
                                              float *dlp_dev, ctpvae_stream_t stream);
+/* COMPACT forward plans (round 3): the same taps as the u16 plan above, stored as the ray's first tap + 2 bits per canvas
+ * row (does the source column step? does the source row step? -- x_in and y_in of ImageProjectiveTransformV3 are monotone in
+ * the row number with slope <= 1, so their rounded values stay or step by one): 0.25 B instead of 2 B per sample, 1.8 MB
+ * instead of 17 MB at the dataset's 180 angles, L2-resident on every XCD.  The plan kernel evaluates the reference
+ * arithmetic exactly as the u16 plan's does; ctpvae_rotate_fwd_compact_f32 computes the SAME sums, bit for bit, as
+ * ctpvae_rotate_fwd_planned{,_sel,_loglik,_loglik_sel}_f32 -- one entry point, optional operands:
+ *   angle_idx_dev  NULL = all A plan angles; else the n_idx (1..256) plan angles to project, outputs [S][n_idx][PW]
+ *   lp_dev         NULL = ray-sums only; else the log-likelihood epilogue of ctpvae_rotate_fwd_planned_loglik_f32
+ *                  (mask_dev, meas_dev, pnm_dev required; dense_inputs as in the _sel entry point; dlp_dev may be NULL)
+ * _supported: 1 if the slice with its one-cell zero border fits LDS (interp NEAREST).  _overflowed (SYNCHRONISES): 1 if some
+ * ray's steps do not fit the code (rows that are not a rotation, a ray still inside the slice at the canvas' last row, a
+ * rounding tie that makes a coordinate jump by two) -- the plan must then not be used: keep the u16 plan. */
+int ctpvae_rotate_cplan_supported(int H, int W, int PH, int PW, int A, int interp);
+long long ctpvae_rotate_cplan_bytes(int H, int W, int PH, int PW, int A);
+int ctpvae_rotate_cplan_build_f32(const float *T8_dev, int A, int H, int W, int PH, int PW, int py, int px, void *cplan_dev,
+                                  ctpvae_stream_t stream);
+int ctpvae_rotate_cplan_overflowed(const void *cplan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream);
+int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *cplan_dev,
+                                  const int *angle_idx_dev, int n_idx, const float *mask_dev, const float *meas_dev,
+                                  int dense_inputs, const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
+                                  float *dlp_dev, ctpvae_stream_t stream);
+
 /* ... and the TF_COMPAT / NEAREST backward of such a subset: gsino_dev [S][n_idx][PW], Tinv8_dev the DENSE inverted table
  * [A_plan][8]; row k of a cotangent uses table row angle_idx_dev[k].  Same bits as ctpvae_rotate_bwd_scaled_f32 on the
  * gathered table (scale_dev may be NULL). */

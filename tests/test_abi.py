@@ -41,7 +41,31 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_binding_table_matches_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == declared_symbols()
     lib = built_lib.load()
-    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == 2001
+    macro = int(re.search(r"#define\s+CTPVAE_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3000
+
+
+def test_torch_node_refuses_a_library_of_another_abi(built_lib, monkeypatch):
+    """the C++ autograd node resolves entry points by name, so it must compare the ABI it was compiled for with the
+    library it binds -- a stale node falls back to the Python nodes with a warning instead of calling with old arguments."""
+    import warnings
+    if not os.path.exists(built_lib.NODE_PATH):
+        pytest.skip("torch node not built")
+    lib = built_lib.load()
+
+    class Other:
+        def __getattr__(self, name):
+            return getattr(lib, name)
+
+        def ctpvae_abi_version(self):
+            return 2001
+    monkeypatch.setattr(built_lib, "_node", False)
+    monkeypatch.setattr(built_lib, "_lib", Other())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert built_lib.torch_node() is None
+    assert any("built for ABI" in str(x.message) for x in w)
+    monkeypatch.setattr(built_lib, "_node", False)
 
 
 def test_host_only_entry_points(built_lib):

@@ -1579,3 +1579,82 @@ def test_iradon_gradient_is_the_transpose_of_the_oracle_operator(oracle, tomopy_
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0)       # the gradient was rounded to float32
     # no gradient wanted: no graph
     assert cp.iradon(s32.detach(), theta, 128, 128, filt).grad_fn is None
+
+
+# ---- round 3: compact (step-coded) forward plans, csrc/rotate_cplan.hip ---------------------------------------------------
+@pytest.mark.parametrize("shape,A,S", [((128, 128), 20, 50), ((128, 128), 180, 5), ((64, 64), 7, 3), ((33, 47), 12, 4),
+                                       ((150, 150), 9, 2), ((6, 5), 5, 3), ((128, 128), 20, 1)])
+def test_compact_plan_equals_u16_plan_and_oracle(oracle, shape, A, S):
+    """The compact plan stores the u16 plan's taps as first tap + 2 bits per row: same taps, same row order -> the same
+    bits, at every launch shape (pairs, singles, few or many task groups)."""
+    d = dev()
+    rng = np.random.default_rng(A * 1000 + S)
+    img = rng.random((S,) + shape, dtype=np.float32)
+    theta = rng.uniform(-4.0, 7.0, A).astype(np.float32) if A != 180 else phantoms.dense_theta(180)
+    plan = RotatePlan(theta, shape[0], shape[1], True, d, plan_format="compact")
+    assert plan.compact and plan.planned[0]
+    x = torch.from_numpy(img).to(d)
+    got = plan.forward(x)
+    want = oracle.rotate_fwd(img, oracle.Geometry(shape[0], shape[1], True), oT(oracle, theta, plan), 0)
+    np.testing.assert_array_equal(to_np(got), want)
+    plan16 = RotatePlan(theta, shape[0], shape[1], True, d, plan_format="u16")
+    assert not plan16.compact and plan16.planned[0]
+    assert torch.equal(plan16.forward(x), got)
+    assert RotatePlan(theta, shape[0], shape[1], True, d).compact == (A >= RotatePlan.COMPACT_MIN_ANGLES)   # "auto"
+    _lib.tune("NO_COMPACT", 1)
+    assert not RotatePlan(theta, shape[0], shape[1], True, d, plan_format="compact").compact   # the knob wins
+    _lib.tune("NO_COMPACT", -1)
+    for ns, G, w in ((1, 1, 4), (2, 3, 16), (1, 7, 8), (2, 12, 5)):
+        _lib.tune("NS", ns), _lib.tune("G", G), _lib.tune("WAVES", w)
+        assert torch.equal(plan.forward(x), got), (ns, G, w)
+
+
+def test_compact_plan_falls_back_where_the_code_does_not_fit(oracle):
+    """An unpadded canvas at an oblique angle has rays that are still inside the slice at the canvas' last row: no border cell
+    to step onto -> the plan's overflow word is raised and the u16 plan is used; results are the oracle's either way."""
+    d = dev()
+    rng = np.random.default_rng(3)
+    img = rng.random((3, 40, 40), dtype=np.float32)
+    theta = np.array([0.0, 0.4, 0.79, 1.3, np.pi / 2, 2.5], np.float32)
+    plan = RotatePlan(theta, 40, 40, False, d, plan_format="compact")
+    assert plan.planned[0] and not plan.compact
+    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))),
+                                  oracle.rotate_fwd(img, oracle.Geometry(40, 40, False), oT(oracle, theta, plan), 0))
+    # axis-aligned angles only: every ray leaves through the canvas edge with the slice -> nothing to step onto either,
+    # unless the ray is exactly as long as its block's walk; whichever the builder decides, the sums are the oracle's
+    theta2 = np.array([0.0, np.pi / 2, np.pi], np.float32)
+    plan2 = RotatePlan(theta2, 40, 40, False, d, plan_format="compact")
+    np.testing.assert_array_equal(to_np(plan2.forward(torch.from_numpy(img).to(d))),
+                                  oracle.rotate_fwd(img, oracle.Geometry(40, 40, False), oT(oracle, theta2, plan2), 0))
+
+
+def test_compact_plan_subsets_and_likelihood(oracle):
+    """Angle subsets of a dense compact plan and the fused likelihood epilogue against the oracle."""
+    d = dev()
+    rng = np.random.default_rng(11)
+    S, N = 6, 128
+    img = rng.random((S, N, N), dtype=np.float32)
+    theta = phantoms.dense_theta(180)
+    plan = RotatePlan(theta, N, N, True, d)
+    assert plan.compact
+    geom = oracle.Geometry(N, N, True)
+    T = oT(oracle, theta, plan)
+    x = torch.from_numpy(img).to(d)
+    for n in (1, 20, 64, 65, 200):
+        sub = rng.integers(0, 180, n).astype(np.int32)
+        ai = torch.from_numpy(sub).to(d)
+        np.testing.assert_array_equal(to_np(plan.forward(x, angles_i=ai)), oracle.rotate_fwd(img, geom, T[sub], 0))
+    sub = rng.permutation(180)[:20].astype(np.int32)
+    ai = torch.from_numpy(sub).to(d)
+    mask = rng.uniform(0.01, 0.1, (S, 180)).astype(np.float32)
+    meas = rng.random((S, 180, plan.PW), dtype=np.float32)
+    pnm = torch.tensor([1e4], device=d)
+    sino, lp, dlp = plan.forward_loglik(x, torch.from_numpy(mask).to(d), torch.from_numpy(meas).to(d), pnm, 1.2e-7,
+                                        with_dlp=True, angles_i=ai, dense_inputs=True)
+    want = oracle.rotate_fwd(img, geom, T[sub], 0)
+    np.testing.assert_array_equal(to_np(sino), want)
+    assert rel_err(to_np(lp), oracle.loglik(want, mask[:, sub], meas[:, sub], 1e4, 1.2e-7)) <= REL
+    p16 = RotatePlan(theta, N, N, True, d, plan_format="u16")
+    s16, lp16, dlp16 = p16.forward_loglik(x, torch.from_numpy(mask).to(d), torch.from_numpy(meas).to(d), pnm, 1.2e-7,
+                                          with_dlp=True, angles_i=ai, dense_inputs=True)
+    assert torch.equal(s16, sino) and torch.equal(lp16, lp) and torch.equal(dlp16, dlp)

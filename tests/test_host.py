@@ -131,11 +131,12 @@ def test_cpp_autograd_node_loads_and_binds(torch_node):
     from ct_pvae_amd import _lib
     node = torch_node
     assert hasattr(node, "rotate_vae") and hasattr(node, "rotate_loglik") and hasattr(node, "bind")
+    assert node.compiled_abi() == _lib.ABI_VERSION
     with pytest.raises(RuntimeError, match="cannot load"):
         node.bind("/nonexistent/libctpvae_radon.so")
     node.bind(_lib.LIB_PATH)
     plan = torch.zeros(16, dtype=torch.uint8)
     with pytest.raises(RuntimeError, match="expected a contiguous float32"):
-        node.rotate_vae(torch.zeros(2, 8, 8, 1, dtype=torch.float64), plan, plan, 8, 8, 14, 14, 3, 0)
+        node.rotate_vae(torch.zeros(2, 8, 8, 1, dtype=torch.float64), plan, plan, 8, 8, 14, 14, 3, 0, 0)
     with pytest.raises(RuntimeError, match="expected a contiguous float32"):
-        node.rotate_vae(torch.zeros(2, 8, 9, 1), plan, plan, 8, 8, 14, 14, 3, 0)
+        node.rotate_vae(torch.zeros(2, 8, 9, 1), plan, plan, 8, 8, 14, 14, 3, 0, 0)
