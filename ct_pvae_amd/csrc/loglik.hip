@@ -1,7 +1,10 @@
 // loglik.hip -- Gaussian-approximated Poisson log-likelihood of a sinogram (a8,
 // ctvae/helper_functions.py:360-368) and its backward.  Elementwise over [B][A][P]; HBM-bound.
+#include <algorithm>
+
 #include "common.h"
 #include "loglik_math.h"
+#include "rotate_plan.h"
 
 namespace ctpvae {
 
@@ -41,6 +44,33 @@ __global__ __launch_bounds__(256) void loglik_bwd_kernel(const float *__restrict
     }
 }
 
+// Per-object sums of a stored log-probability array in the fixed order of the fused epilogues (LogLikEpilogue::part):
+// a slice's [A][PW] values are cut into 64-lane tasks -- partition 0: the planned kernels' (angle, bin block) tasks, two
+// 32-bin bands mirrored about the detector centre (lane_to_bin); partition 1: the tiled reduce pass's contiguous 64-bin
+// blocks -- each task is added by the xor butterfly (lanes without a bin add +0.0f), and the task sums are added in
+// ascending (angle, task) order.  One workgroup per slice; the task sums wait in LDS.
+__global__ __launch_bounds__(256) void loglik_object_sums_kernel(const float *__restrict__ lp, int A, int PW, int partition,
+                                                                 int tasks_per_row, float *__restrict__ out)
+{
+    extern __shared__ float part[];
+    const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int NT = A * tasks_per_row;
+    const float *row0 = lp + (size_t)s * A * PW;
+    for (int t = wave; t < NT; t += nwaves) {
+        const int a = t / tasks_per_row, jb = t - a * tasks_per_row;
+        const int j = partition == 0 ? lane_to_bin(PW, jb, lane) : 64 * jb + lane;
+        const float v = (unsigned)j < (unsigned)PW ? row0[(size_t)a * PW + j] : 0.0f;
+        const float tot = wave_sum(v);
+        if (lane == 0) part[t] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float acc = 0.0f;
+        for (int t = 0; t < NT; ++t) acc += part[t];
+        out[s] = acc;
+    }
+}
+
 }  // namespace ctpvae
 
 using namespace ctpvae;
@@ -72,6 +102,30 @@ int ctpvae_loglik_bwd_f32(const float *proj_dev, const float *mask_dev, const fl
     hipLaunchKernelGGL(loglik_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, proj_dev, mask_dev, x_dev,
                        gout_dev, n, P, pnm_dev, eps, gproj_dev, gpnm_dev);
     CTPVAE_LAUNCH_CHECK("loglik_bwd_kernel");
+    return CTPVAE_OK;
+}
+
+int ctpvae_loglik_tasks_per_row(int PW, int partition)
+{
+    if (PW <= 0 || (partition != 0 && partition != 1)) return fail(CTPVAE_EINVAL, "loglik_tasks_per_row: bad arguments");
+    return partition == 0 ? num_bin_blocks(PW) : ceil_div(PW, 64);
+}
+
+int ctpvae_loglik_object_sums_f32(const float *lp_dev, int S, int A, int PW, int partition, float *out_dev,
+                                  ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(lp_dev && out_dev, "loglik_object_sums: null pointer");
+    CTPVAE_REQUIRE(S > 0 && A > 0 && PW > 0 && (partition == 0 || partition == 1),
+                   "loglik_object_sums: bad arguments (S=%d A=%d PW=%d partition=%d)", S, A, PW, partition);
+    const int tpr = partition == 0 ? num_bin_blocks(PW) : ceil_div(PW, 64);
+    const long long NT = (long long)A * tpr;
+    CTPVAE_REQUIRE(NT * 4 <= 64 * 1024, "loglik_object_sums: %lld task sums per slice do not fit LDS", NT);
+    for (int s0 = 0; s0 < S; s0 += 65535) {
+        const int n = std::min(65535, S - s0);
+        hipLaunchKernelGGL(loglik_object_sums_kernel, dim3(n), dim3(256), (size_t)NT * 4, (hipStream_t)stream,
+                           lp_dev + (size_t)s0 * A * PW, A, PW, partition, tpr, out_dev + s0);
+        CTPVAE_LAUNCH_CHECK("loglik_object_sums_kernel");
+    }
     return CTPVAE_OK;
 }
 

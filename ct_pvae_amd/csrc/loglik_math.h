@@ -42,6 +42,11 @@ struct LogLikEpilogue {
     // angle (the caller's gather mask[:, angles_i], proj_sample[:, angles_i] -- ctvae/helper_functions.py:356-357 --
     // folded into the load); 0: they are compact like the outputs
     int dense = 0;
+    // per-object sums ("reduction to per-object log-lik", ctvae/helper_functions.py:305-312): when `part` is set
+    // the kernel writes ONE partial sum per 64-lane task into part[(s * A_out + k) * tasks_per_row + task] (lanes added by
+    // the xor butterfly 32, 16, 8, 4, 2, 1; lanes without a bin add +0.0f) and lp / the ray-sum store become optional; a
+    // second, tiny launch adds a slice's partials in ascending slot order (wave_sum / loglik.hip).
+    float *part = nullptr;
 
     // o: offset of the ray-sum in the outputs; om / sa: offsets of its measured sample and its mask entry
     __device__ __forceinline__ void write(size_t o, size_t om, size_t sa, float raysum) const
@@ -53,6 +58,39 @@ struct LogLikEpilogue {
             dlp[o] = gaussian_poisson_dlogp(raysum, m, x, pnm_v, eps, unused);
         }
     }
+    // the same, returning the log-probability; lp (and dlp) are stored only where a buffer was given
+    __device__ __forceinline__ float eval(size_t o, size_t om, size_t sa, float raysum) const
+    {
+        const float m = mask[sa], x = meas[om], pnm_v = *pnm;
+        const float v = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
+        if (lp) lp[o] = v;
+        if (dlp) {
+            float unused;
+            dlp[o] = gaussian_poisson_dlogp(raysum, m, x, pnm_v, eps, unused);
+        }
+        return v;
+    }
 };
+
+// The fixed order of a 64-lane task's partial sum: xor butterfly, every lane ends with the same value (a + b == b + a bit
+// for bit, so both partners of a step compute the same sum).  oracle/radon_oracle.py loglik_object_sums restates it.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// lp_sum[s] = the NT partial sums of slice s added in ascending slot order (one thread per slice)
+[[maybe_unused]] static __global__ __launch_bounds__(64) void loglik_sum_partials_kernel(const float *__restrict__ part, int S, int NT,
+                                                                 float *__restrict__ out)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const float *p = part + (size_t)s * NT;
+    float acc = 0.0f;
+    for (int t = 0; t < NT; ++t) acc += p[t];
+    out[s] = acc;
+}
 
 }  // namespace ctpvae

@@ -306,7 +306,9 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
 
 // Forward.  Workgroup = (slice or slice pair, mirror class, task group), placed as in rotate_fwd_planned_kernel; stages the
 // unit with its zero border, builds the step table, then its waves take (angle, bin block) tasks.
-// EPI: 0 = ray-sums only; 1 = + log-probabilities (and d lp / d ray-sum) of the measured samples.
+// EPI: 0 = ray-sums only; 1 = + log-probabilities (and d lp / d ray-sum) of the measured samples; 2 = the
+// log-probabilities are REDUCED: one partial sum per task into epi.part (see LogLikEpilogue), d lp / d ray-sum stored for the
+// backward, the ray-sum and log-probability stores only where buffers were given.
 // SEL: the launch projects a subset of the plan's angles (see rotate_fwd_planned_kernel).
 template <int NS, int EPI, bool SEL>
 __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *__restrict__ img, PlanGeom g, CLayout L,
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
     const size_t st = (size_t)L.PWpad;
     struct Task {
         bool valid, neg;
-        int a, k, j, ng, adr;   // plan angle, output row, bin, row groups, first tap's LDS byte address
+        int a, k, j, jb, ng, adr;   // plan angle, output row, bin, bin block, row groups, first tap's LDS byte address
         const uint4 *p;         // the ray's chunk 2
         uint4 c0, c1;
     };
@@ -377,12 +379,13 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
         Task t;
         t.valid = m < ntask;
         t.neg = false;
-        t.a = t.k = t.j = t.ng = 0;
+        t.a = t.k = t.j = t.jb = t.ng = 0;
         t.adr = kLutBytes;
         t.p = codes;
         t.c0 = t.c1 = uint4{0u, 0u, 0u, 0u};
         if (t.valid) {   // wave-uniform
             const int jb = m / ncls, ai = m - jb * ncls;
+            t.jb = jb;
             if constexpr (SEL) {
 #pragma unroll
                 for (int r = 0; r < kCSelRounds; ++r)
@@ -456,7 +459,26 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
         if (ng > 0)
             acc = neg ? cwalk<NS, true>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ)
                       : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
-        if ((unsigned)cur.j < (unsigned)g.PW) {
+        if constexpr (EPI == 2) {
+            const bool live = (unsigned)cur.j < (unsigned)g.PW;
+            auto reduce = [&](int sl, float v) {
+                float lpv = 0.0f;
+                if (live) {
+                    const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
+                    if (sino) sino[o] = v;
+                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + cur.a : (size_t)sl * A_out + cur.k;
+                    lpv = epi.eval(o, sa * g.PW + cur.j, sa, v);
+                }
+                const float tot = wave_sum(lpv);
+                if (lane == 0) epi.part[((size_t)sl * A_out + cur.k) * L.nJB + cur.jb] = tot;
+            };
+            if constexpr (NS == 1) {
+                reduce(s, acc);
+            } else {
+                reduce(s, acc.x);
+                if (has2) reduce(s + 1, acc.y);
+            }
+        } else if ((unsigned)cur.j < (unsigned)g.PW) {
             auto store = [&](int sl, float v) {
                 const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
                 sino[o] = v;
@@ -527,22 +549,25 @@ int ctpvae_rotate_cplan_overflowed(const void *cplan_dev, int H, int W, int PH, 
 int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *cplan_dev,
                                   const int *angle_idx_dev, int n_idx, const float *mask_dev, const float *meas_dev,
                                   int dense_inputs, const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
-                                  float *dlp_dev, ctpvae_stream_t stream)
+                                  float *dlp_dev, float *lp_part_dev, float *lp_sum_dev, ctpvae_stream_t stream)
 {
-    CTPVAE_REQUIRE(img_dev && cplan_dev && sino_dev, "rotate_fwd_compact: null pointer");
+    const bool red = lp_sum_dev != nullptr;
+    CTPVAE_REQUIRE(img_dev && cplan_dev && (sino_dev || red), "rotate_fwd_compact: null pointer");
+    CTPVAE_REQUIRE(!red || lp_part_dev, "rotate_fwd_compact: per-object sums need the partial-sum workspace");
     CTPVAE_REQUIRE(S > 0, "rotate_fwd_compact: need at least one slice");
     if (int rc = check_plan_geom("rotate_fwd_compact", H, W, PH, PW, 0, 0, A)) return rc;
     const int *sel_dev = angle_idx_dev;
     CTPVAE_REQUIRE(sel_dev == nullptr || (n_idx >= 1 && n_idx <= 64 * kCSelRounds),
                    "rotate_fwd_compact: an angle subset holds 1..%d angles (got %d); build a plan for larger ones",
                    64 * kCSelRounds, n_idx);
-    const bool lik = lp_dev != nullptr;
+    const bool lik = lp_dev != nullptr || red;
     CTPVAE_REQUIRE(!lik || (mask_dev && meas_dev && pnm_dev), "rotate_fwd_compact: the likelihood epilogue needs mask, meas and pnm");
     CTPVAE_REQUIRE(lik || dlp_dev == nullptr, "rotate_fwd_compact: dlp without lp");
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     CTPVAE_REQUIRE(cplan_fits(g), "rotate_fwd_compact: a %dx%d slice does not fit the compact plan's LDS image", H, W);
     const CLayout L = c_layout(g);
-    const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0}
+    const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0,
+                                                    red ? lp_part_dev : nullptr}
                                    : LogLikEpilogue{};
     const int A_run = sel_dev ? n_idx : A;      // angles this launch projects
     const int T = A_run * L.nJB;                // (angle, bin block) tasks per slice
@@ -591,6 +616,16 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
         CTPVAE_LAUNCH_CHECK("rotate_fwd_compact_kernel");
         return CTPVAE_OK;
     };
+    if (red) {
+        int rc;
+        if (sel_dev) rc = ns == 2 ? launch(rotate_fwd_compact_kernel<2, 2, true>) : launch(rotate_fwd_compact_kernel<1, 2, true>);
+        else rc = ns == 2 ? launch(rotate_fwd_compact_kernel<2, 2, false>) : launch(rotate_fwd_compact_kernel<1, 2, false>);
+        if (rc) return rc;
+        hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S,
+                           A_run * L.nJB, lp_sum_dev);
+        CTPVAE_LAUNCH_CHECK("loglik_sum_partials_kernel");
+        return CTPVAE_OK;
+    }
     if (sel_dev) {
         if (lik) return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 1, true>) : launch(rotate_fwd_compact_kernel<1, 1, true>);
         return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 0, true>) : launch(rotate_fwd_compact_kernel<1, 0, true>);

@@ -81,7 +81,7 @@ struct RotateVae : public torch::autograd::Function<RotateVae> {
         at::Tensor out = at::empty({S, A, PW, 1}, x4.options());
         const int rc = compact ? g_fwd_compact(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A,
                                                fwd_plan.data_ptr(), nullptr, 0, nullptr, nullptr, 0, nullptr, 0.0f,
-                                               out.data_ptr<float>(), nullptr, nullptr, (void *)stream)
+                                               out.data_ptr<float>(), nullptr, nullptr, nullptr, nullptr, (void *)stream)
                                : g_fwd(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
                                        out.data_ptr<float>(), (void *)stream);
         check(rc, "rotate_fwd");
@@ -138,7 +138,7 @@ struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
             rc = g_fwd_compact(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
                                sel ? angles->data_ptr<int>() : nullptr, sel ? (int)n : 0, mask.data_ptr<float>(),
                                meas.data_ptr<float>(), (int)dense, pnm.data_ptr<float>(), (float)eps, sino.data_ptr<float>(),
-                               lp.data_ptr<float>(), dlp.data_ptr<float>(), (void *)stream);
+                               lp.data_ptr<float>(), dlp.data_ptr<float>(), nullptr, nullptr, (void *)stream);
         else if (sel)
             rc = g_fwd_lik_sel(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
                                angles->data_ptr<int>(), (int)n, mask.data_ptr<float>(), meas.data_ptr<float>(), (int)dense,

@@ -276,12 +276,53 @@ class RotatePlan:
         return self._compact
 
     def _run_compact(self, img_ptr, S, out_ptr, angles_i=None, n=0, mask=None, meas=None, dense=0, pnm=None, eps=0.0,
-                     lp_ptr=None, dlp_ptr=None):
+                     lp_ptr=None, dlp_ptr=None, part_ptr=None, sum_ptr=None):
         return self._lib.ctpvae_rotate_fwd_compact_f32(
             img_ptr, S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(),
             angles_i.data_ptr() if angles_i is not None else None, n, mask.data_ptr() if mask is not None else None,
             meas.data_ptr() if meas is not None else None, dense, pnm.data_ptr() if pnm is not None else None,
-            ctypes.c_float(eps), out_ptr, lp_ptr, dlp_ptr, _stream_ptr(self._dev_index))
+            ctypes.c_float(eps), out_ptr, lp_ptr, dlp_ptr, part_ptr, sum_ptr, _stream_ptr(self._dev_index))
+
+    def forward_loglik_sums(self, img, mask, meas, pnm, eps, angles_i=None, dense_inputs=False, with_dlp=True):
+        """Per-object log-likelihood sums (ctvae/helper_functions.py:305-312: reduce_sum of the log-probabilities over
+        angles and bins) -> (sums [S], d lp / d ray-sum [S][n][PW] or None), in the library's fixed order
+        (ctpvae_loglik_object_sums_f32 / oracle.loglik_object_sums).  On a compact plan the reduction happens INSIDE the
+        projector launch: neither the sinogram nor the log-probabilities are written to HBM, only dlp (the
+        backward's operand) and one partial per (object, angle, 64-bin task).  Other planned / tiled geometries write the
+        log-probabilities and reduce them with the same-order kernel."""
+        if angles_i is not None and not self.sel_supported(angles_i.numel()):
+            if dense_inputs:
+                idx = angles_i.long()
+                mask, meas = mask.index_select(1, idx).contiguous(), meas.index_select(1, idx).contiguous()
+            return self.subset(angles_i).forward_loglik_sums(img, mask, meas, pnm, eps, with_dlp=with_dlp)
+        with torch.cuda.device(self._dev_index):
+            S = img.shape[0]
+            sums = torch.empty((S,), dtype=torch.float32, device=self._tdev)
+            if not self._compact:
+                res = self._forward_loglik(img, mask, meas, pnm, eps, with_dlp=with_dlp, angles_i=angles_i,
+                                           dense_inputs=dense_inputs)
+                lp = res[1]
+                partition = 0 if self._fwd_plan is not None else 1
+                _lib.check(self._lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), S, lp.shape[1], self.PW, partition,
+                                                                   sums.data_ptr(), _stream_ptr(self._dev_index)),
+                           "loglik_object_sums")
+                return sums, (res[2] if with_dlp else None)
+            self._check(img, (self.H, self.W), "img")
+            n = self.A if angles_i is None else self._check_sel(angles_i)
+            n_in = self.A if (angles_i is None or dense_inputs) else n
+            self._check(meas, (n_in, self.PW), "meas")
+            self._check(mask, (n_in,), "mask")
+            if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
+                raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
+            dlp = torch.empty((S, n, self.PW), dtype=torch.float32, device=self._tdev) if with_dlp else None
+            tpr = self._lib.ctpvae_loglik_tasks_per_row(self.PW, 0)
+            part = torch.empty((S * n * tpr,), dtype=torch.float32, device=self._tdev)
+            rc = self._run_compact(img.data_ptr(), S, None, angles_i, n if angles_i is not None else 0, mask, meas,
+                                   1 if dense_inputs else 0, pnm, eps, None, dlp.data_ptr() if dlp is not None else None,
+                                   part.data_ptr(), sums.data_ptr())
+            if rc:
+                _lib.check(rc, "rotate_fwd_compact")
+            return sums, dlp
 
     def subset(self, angles_i):
         """A plan over rows `angles_i` of this one's tables (two small gathers, no plan kernels): the fallback for angle

@@ -206,10 +206,59 @@ class _ProjectLogLik(torch.autograd.Function):
         return gimg, None, None, None, (gpnm.reshape(pnm.shape) if gpnm is not None else None), None, None
 
 
+class _ProjectLogLikSums(torch.autograd.Function):
+    """a2 + a8 + the per-object reduce_sum of ctvae/helper_functions.py:305-312 as ONE node: forward = the projector launch
+    that reduces the log-probabilities itself (plan.forward_loglik_sums) and stores only d lp / d ray-sum; backward = the
+    projector's backward with the upstream gradient of the sums as its per-slice factor.  Reconstruction gradient only
+    (a fixed pnm): a trainable pnm takes the two-step path."""
+
+    @staticmethod
+    def forward(ctx, sample, plan, mask, x, pnm, eps, angles_i=None):
+        slices = sample.view(sample.shape[0], sample.shape[1], sample.shape[2])
+        sums, dlp = plan.forward_loglik_sums(slices, mask, x, pnm, eps, angles_i=angles_i, dense_inputs=angles_i is not None,
+                                             with_dlp=ctx.needs_input_grad[0])
+        ctx.plan, ctx.angles_i = plan, angles_i
+        if dlp is not None:
+            ctx.save_for_backward(dlp)
+        return sums
+
+    @staticmethod
+    def backward(ctx, gout):
+        dlp, = ctx.saved_tensors
+        scale = gout if gout.dtype is torch.float32 else gout.to(torch.float32)
+        gimg = ctx.plan.backward(dlp, scale=scale, angles_i=ctx.angles_i)
+        return gimg.unsqueeze(-1), None, None, None, None, None, None
+
+
+class _ObjectSums(torch.autograd.Function):
+    """lp [B][A][P][1] -> [B] in the library's fixed order (ctpvae_loglik_object_sums_f32); backward = a broadcast."""
+
+    @staticmethod
+    def forward(ctx, lp4, partition):
+        lib = _lib.load()
+        lp = lp4.reshape(lp4.shape[0], lp4.shape[1], lp4.shape[2]).to(torch.float32).contiguous()
+        ctx.shape, ctx.dtype = tuple(lp4.shape), lp4.dtype
+        out = torch.empty((lp.shape[0],), dtype=torch.float32, device=lp.device)
+        if lp.shape[0]:
+            with torch.cuda.device(lp.device):
+                _lib.check(lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), lp.shape[0], lp.shape[1], lp.shape[2], partition,
+                                                             out.data_ptr(), _stream_ptr()), "loglik_object_sums")
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        return gout.to(ctx.dtype).view(-1, 1, 1, 1).expand(ctx.shape), None
+
+
 def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise_multiplier, sqrt_reg,
-                                 theta=None, angles_i=None, pad=True):
+                                 theta=None, angles_i=None, pad=True, *, reduce=None):
     """ctvae/helper_functions.py:336-368.  output_sample [B][X][Y][1], mask [B][angles], proj_sample
     [B][angles][P]; returns the log-probabilities [B][angles_used][P][1].
+
+    reduce="per_object" (keyword-only extension; default None = the reference's return value): returns the [B] per-object
+    sums over angles and bins that find_loss_vae_unsup takes next (ctvae/helper_functions.py:305-312), reduced inside the
+    projector launch on a compact plan -- the [B][A][P] sinogram and log-probabilities never reach HBM -- and
+    always in the library's fixed summation order (oracle.loglik_object_sums), whichever path computes them.
 
     When the geometry takes the planned or the tiled forward (nearest) the projection and the log-probability are
     one launch (the same numbers, bit for bit, as project_tf_fast followed by gaussian_poisson_log_prob).
@@ -218,6 +267,8 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
     ONCE for the whole `theta` (host-resident: on the host, so they are the bits the CPU oracle computes) and the kernels
     take `angles_i` as an index operand -- nothing is gathered or rebuilt per step, and mask / proj_sample are read at
     the selected angles by the kernel itself."""
+    if reduce not in (None, "per_object"):
+        raise ValueError(f"reduce must be None or 'per_object' (got {reduce!r})")
     x = output_sample
     fast = (isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[3] == 1 and x.device.type == "cuda"
             and x.dtype == torch.float32 and x.shape[0] > 0)
@@ -248,6 +299,12 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
                 mask = mask.to(torch.float32).contiguous()
             if proj_sample.dtype is not torch.float32 or not proj_sample.is_contiguous():
                 proj_sample = proj_sample.to(torch.float32).contiguous()
+            if reduce == "per_object":
+                with torch.cuda.device(x.device):
+                    if not pnm.requires_grad and plan.supports_scale:
+                        return _ProjectLogLikSums.apply(x, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
+                    lp4 = _ProjectLogLik.apply(x, plan, mask, proj_sample, pnm, float(sqrt_reg), sel)
+                    return _ObjectSums.apply(lp4, 0 if plan.planned[0] else 1)
             if x.device.index == _current_device():
                 if (forward_functions.USE_CPP_NODE and plan.planned[0] and x.requires_grad and not pnm.requires_grad
                         and torch.is_grad_enabled()):
@@ -264,4 +321,6 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
         proj_sample = proj_sample[:, angles_i]
     proj = project_tf_fast(output_sample, theta, pad=pad, dim=2, integrate_vae=True)
     logp = gaussian_poisson_log_prob(proj[..., 0], mask, proj_sample, poisson_noise_multiplier, sqrt_reg)
+    if reduce == "per_object":
+        return _ObjectSums.apply(logp.unsqueeze(-1), 0)
     return logp.unsqueeze(-1)

@@ -265,12 +265,14 @@ def find_loss_vae_unsup(proj_sample, mask, input_encode, model_encode, model_dec
         dist = torch.distributions.Beta(positive_range(alpha), positive_range(beta))
         output_sample = dist.rsample()
         log_prob_R_given_z = dist.log_prob(output_sample.clamp(sqrt_reg, 1 - sqrt_reg))
+    # per-object sums of the log-probabilities, reduced inside the projector launch
     lp = calculate_log_prob_M_given_R(output_sample.permute(0, 2, 3, 1), mask.repeat(ns, 1), proj_sample.repeat(ns, 1, 1),
-                                      poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad)
+                                      poisson_noise_multiplier, sqrt_reg, theta=theta, angles_i=angles_i, pad=pad,
+                                      reduce="per_object")
     # :305-306 reduce_sum(..., axis=[0, 1, 2]) of the squeezed [B][A][P] and [B][X][Y] tensors: the log-likelihood of a
     # sample is ONE number for the whole batch (the batch axis is summed too), the KL below is per object; :329-330 then
     # broadcast-subtract, and train_step takes the mean over the batch -- i.e. mean_b(KL_b) - sum_b(loglik_b).
-    log_prob_M = (lp.sum(dim=(1, 2, 3)) + log_prob_R_given_z.sum(dim=(1, 2, 3))).view(ns, B).sum(dim=1)    # [ns]
+    log_prob_M = (lp + log_prob_R_given_z.sum(dim=(1, 2, 3))).view(ns, B).sum(dim=1)    # [ns]
     recon = output_sample[(ns - 1) * B:]
     if deterministic:
         kl = lp.new_zeros(B)

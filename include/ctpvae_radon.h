@@ -189,6 +189,12 @@ int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H,
  *   angle_idx_dev  NULL = all A plan angles; else the n_idx (1..256) plan angles to project, outputs [S][n_idx][PW]
  *   lp_dev         NULL = ray-sums only; else the log-likelihood epilogue of ctpvae_rotate_fwd_planned_loglik_f32
  *                  (mask_dev, meas_dev, pnm_dev required; dense_inputs as in the _sel entry point; dlp_dev may be NULL)
+ *   lp_sum_dev     NULL, or [S]: the PER-OBJECT log-likelihood sums the loss takes (ctvae/helper_functions.py:305-312),
+ *                  reduced inside the launch: every (angle, 64-bin) task adds its log-probabilities by a
+ *                  fixed xor butterfly and writes one partial into lp_part_dev (workspace of
+ *                  S * angles * ctpvae_loglik_tasks_per_row(PW, 0) floats), a second tiny launch adds a slice's partials
+ *                  in ascending order -- the bits of ctpvae_loglik_object_sums_f32(lp, partition 0).  sino_dev and lp_dev
+ *                  may then be NULL (nothing but dlp [S][n][PW] and the sums leaves the kernel).
  * _supported: 1 if the slice with its one-cell zero border fits LDS (interp NEAREST).  _overflowed (SYNCHRONISES): 1 if some
  * ray's steps do not fit the code (rows that are not a rotation, a ray still inside the slice at the canvas' last row, a
  * rounding tie that makes a coordinate jump by two) -- the plan must then not be used: keep the u16 plan. */
@@ -200,7 +206,7 @@ int ctpvae_rotate_cplan_overflowed(const void *cplan_dev, int H, int W, int PH, 
 int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *cplan_dev,
                                   const int *angle_idx_dev, int n_idx, const float *mask_dev, const float *meas_dev,
                                   int dense_inputs, const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
-                                  float *dlp_dev, ctpvae_stream_t stream);
+                                  float *dlp_dev, float *lp_part_dev, float *lp_sum_dev, ctpvae_stream_t stream);
 
 /* ... and the TF_COMPAT / NEAREST backward of such a subset: gsino_dev [S][n_idx][PW], Tinv8_dev the DENSE inverted table
  * [A_plan][8]; row k of a cotangent uses table row angle_idx_dev[k].  Same bits as ctpvae_rotate_bwd_scaled_f32 on the
@@ -280,6 +286,16 @@ int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P,
 int ctpvae_fbp_backproject_bwd_f64(const double *grecon_dev, int B, int A, int P, const double *cos_dev,
                                    const double *sin_dev, int X, int Y, double x0, double y0, double t0,
                                    double *gfilt_dev, ctpvae_stream_t stream);
+
+/* Per-object sums of a log-probability array lp_dev [S][A][PW] -> out_dev [S] (reduce_sum over angles and bins,
+ * ctvae/helper_functions.py:305-306), in a FIXED order so that every path gives the same bits: the [A][PW] values of a slice
+ * are cut into 64-lane tasks (partition 0: the planned kernels' tasks -- angle a, bin block jb = the two 32-bin bands
+ * [c - 32 (jb + 1), c - 32 jb) and [c + 32 jb, c + 32 (jb + 1)), c = PW / 2, lanes 0..31 and 32..63; partition 1: the tiled
+ * reduce pass's contiguous 64-bin blocks), a task's values are added by the xor butterfly 32, 16, 8, 4, 2, 1 (lanes
+ * without a bin add +0.0f), and the task sums are added in ascending (angle, task) order.  _tasks_per_row: tasks per angle. */
+int ctpvae_loglik_tasks_per_row(int PW, int partition);
+int ctpvae_loglik_object_sums_f32(const float *lp_dev, int S, int A, int PW, int partition, float *out_dev,
+                                  ctpvae_stream_t stream);
 
 /* ---- a8: Gaussian-approximated Poisson log-likelihood epilogue ------------------------------
  * proj_dev, x_dev, out_dev [B][A][P]; mask_dev [B][A]; pnm_dev points at ONE fp32 on the device (the

@@ -233,6 +233,41 @@ def loglik(proj, mask, x, pnm, eps):
     return out
 
 
+def loglik_task_bins(PW, partition=0):
+    """The 64-lane tasks a detector row is cut into (list of 64 bin numbers each; a bin outside [0, PW) = an idle lane).
+    partition 0: the planned projector kernels' (angle, bin block) tasks -- block k = the two 32-bin bands mirrored about the
+    detector centre c = PW // 2: lanes 0..31 = bins c - 32 (k + 1) + l, lanes 32..63 = bins c + 32 k + (l - 32).
+    partition 1: the tiled reduce pass's contiguous 64-bin blocks."""
+    if partition == 0:
+        c = PW // 2
+        nblk = (PW - c + 31) // 32
+        return [np.concatenate([c - 32 * (k + 1) + np.arange(32), c + 32 * k + np.arange(32)]) for k in range(nblk)]
+    return [64 * k + np.arange(64) for k in range((PW + 63) // 64)]
+
+
+def loglik_object_sums(lp, partition=0):
+    """Per-object log-likelihood sums, reduce_sum over angles and bins of lp [S][A][PW] (ctvae/helper_functions.py:305-306) --
+    TensorFlow does not fix the order of that sum; the build does, so that every path gives the same bits:
+    a task's 64 values (idle lanes: +0.0) are added by the xor butterfly -- for off in 32, 16, 8, 4, 2, 1: v[l] = v[l] +
+    v[l ^ off] in fp32 -- and the task sums are added one by one in ascending (angle, task) order, starting from +0.0."""
+    lp = _c32(lp)
+    S, A, PW = lp.shape
+    tasks = loglik_task_bins(PW, partition)
+    out = np.zeros(S, np.float32)
+    lanes = np.arange(64)
+    for s in range(S):
+        acc = np.float32(0.0)
+        for a in range(A):
+            for bins in tasks:
+                ok = (bins >= 0) & (bins < PW)
+                v = np.where(ok, lp[s, a, np.clip(bins, 0, PW - 1)], np.float32(0.0)).astype(np.float32)
+                for off in (32, 16, 8, 4, 2, 1):
+                    v = (v + v[lanes ^ off]).astype(np.float32)
+                acc = np.float32(acc + v[0])
+        out[s] = acc
+    return out
+
+
 # ---- f2 -----------------------------------------------------------------------------------------------
 def philox4x32_10(counter4, key2):
     c, k = np.asarray(counter4, np.uint32), np.asarray(key2, np.uint32)

@@ -1658,3 +1658,59 @@ def test_compact_plan_subsets_and_likelihood(oracle):
     s16, lp16, dlp16 = p16.forward_loglik(x, torch.from_numpy(mask).to(d), torch.from_numpy(meas).to(d), pnm, 1.2e-7,
                                           with_dlp=True, angles_i=ai, dense_inputs=True)
     assert torch.equal(s16, sino) and torch.equal(lp16, lp) and torch.equal(dlp16, dlp)
+
+
+# ---- round 3: per-object log-likelihood sums inside the projector launch -------------------------------------
+@pytest.mark.parametrize("fmt,subset", [("compact", True), ("compact", False), ("u16", True), ("u16", False)])
+def test_per_object_loglik_sums_are_the_ordered_sum_of_the_two_step_path(oracle, fmt, subset):
+    """reduce_sum over angles and bins (ctvae/helper_functions.py:305-312) in the library's fixed order: the fused epilogue of
+    the compact kernel (partials per task + ordered pass), the standalone same-order kernel and the oracle's statement of the
+    order give the same bits on the two-step path's log-probabilities."""
+    d = dev()
+    rng = np.random.default_rng(5)
+    S, N = 7, 128
+    img = rng.random((S, N, N), dtype=np.float32)
+    theta = phantoms.dense_theta(180)
+    plan = RotatePlan(theta, N, N, True, d, plan_format=fmt)
+    x = torch.from_numpy(img).to(d)
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, 180)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((S, 180, plan.PW), dtype=np.float32)).to(d)
+    pnm = torch.tensor([1e4], device=d)
+    ai = torch.from_numpy(rng.permutation(180)[:20].astype(np.int32)).to(d) if subset else None
+    sino, lp, dlp = plan.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True, angles_i=ai, dense_inputs=subset)
+    sums, dlp2 = plan.forward_loglik_sums(x, mask, meas, pnm, 1.2e-7, angles_i=ai, dense_inputs=subset)
+    want = oracle.loglik_object_sums(to_np(lp), 0)
+    np.testing.assert_array_equal(to_np(sums), want)
+    assert torch.equal(dlp2, dlp)
+    lib = _lib.load()
+    out = torch.empty(S, device=d)
+    assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), S, lp.shape[1], plan.PW, 0, out.data_ptr(), None) == 0
+    np.testing.assert_array_equal(to_np(out), want)
+    assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), S, lp.shape[1], plan.PW, 1, out.data_ptr(), None) == 0
+    np.testing.assert_array_equal(to_np(out), oracle.loglik_object_sums(to_np(lp), 1))
+
+
+@pytest.mark.parametrize("subset", [True, False])
+def test_calculate_log_prob_reduce_per_object(oracle, subset):
+    """The drop-in call with reduce='per_object': values = the ordered sum of the unreduced call's log-probabilities, and its
+    gradient = the unreduced call's gradient under the same per-object weights (one scaled backward launch either way)."""
+    d = dev()
+    rng = np.random.default_rng(8)
+    B, N = 6, 128
+    theta = phantoms.dense_theta(180)
+    x0 = torch.from_numpy(rng.random((B, N, N, 1), dtype=np.float32)).to(d)
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (B, 180)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((B, 180, 184), dtype=np.float32)).to(d)
+    sub = rng.permutation(180)[:20] if subset else None
+    w = torch.from_numpy(rng.standard_normal(B).astype(np.float32)).to(d)
+    xa = x0.clone().requires_grad_(True)
+    lp = cp.calculate_log_prob_M_given_R(xa, mask, meas, 1e4, 1.2e-7, theta=theta, angles_i=sub, pad=True)
+    (lp.sum(dim=(1, 2, 3)) * w).sum().backward()
+    xb = x0.clone().requires_grad_(True)
+    sums = cp.calculate_log_prob_M_given_R(xb, mask, meas, 1e4, 1.2e-7, theta=theta, angles_i=sub, pad=True, reduce="per_object")
+    assert sums.shape == (B,)
+    np.testing.assert_array_equal(to_np(sums), oracle.loglik_object_sums(to_np(lp)[..., 0], 0))
+    (sums * w).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    with pytest.raises(ValueError, match="reduce must be"):
+        cp.calculate_log_prob_M_given_R(xb, mask, meas, 1e4, 1.2e-7, theta=theta, reduce="mean")

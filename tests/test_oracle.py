@@ -477,3 +477,20 @@ def test_siddon_lengths_are_exact_chords(oracle):
             want = np.array([_chord_through_unit_square(-N / 2 + ix, -N / 2 + iy, th, d - (dx - 1) / 2) for d in range(dx)])
             # (axis-aligned rays run along pixel centres here -- dx is even -- so no ray lies on a grid line)
             assert np.abs(sino[a] - want).max() <= 2e-5, (ix, iy, a, float(np.abs(sino[a] - want).max()))
+
+
+def test_object_sum_order_covers_every_bin_once(oracle):
+    """The fixed order of the per-object log-likelihood sum: both partitions of a detector row into 64-lane
+    tasks cover every bin exactly once, and the ordered fp32 sum agrees with the fp64 sum to rounding."""
+    rng = np.random.default_rng(0)
+    for PW in (184, 728, 2, 63, 64, 65, 130):
+        for part in (0, 1):
+            bins = np.concatenate(oracle.loglik_task_bins(PW, part))
+            live = bins[(bins >= 0) & (bins < PW)]
+            assert sorted(live.tolist()) == list(range(PW)), (PW, part)
+    lp = (-5.0 * rng.random((3, 20, 184))).astype(np.float32)
+    for part in (0, 1):
+        got = oracle.loglik_object_sums(lp, part)
+        want = lp.astype(np.float64).sum(axis=(1, 2))
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    assert not np.array_equal(oracle.loglik_object_sums(lp, 0), lp.sum(axis=(1, 2)))   # it IS an order of its own
