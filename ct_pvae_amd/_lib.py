@@ -36,12 +36,16 @@ SIGNATURES = {
     "ctpvae_rotate_cplan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctpvae_rotate_cplan_build_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     "ctpvae_rotate_cplan_overflowed": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
-    "ctpvae_rotate_fwd_compact_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _vp, _vp,
-                                               _c_int, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ctpvae_rotate_fwd_compact_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp,
+                                               _vp, _c_int, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctpvae_loglik_tasks_per_row": (_c_int, [_c_int, _c_int]),
     "ctpvae_loglik_object_sums_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     "ctpvae_rotate_bwd_sel_scaled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int,
                                                   _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
+    "ctpvae_rotate_bwd4_plan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_rotate_bwd4_plan_build_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_rotate_bwd_planned_sel_scaled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int,
+                                                          _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
     "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                        _c_int, _vp, _vp]),
     "ctpvae_rotate_fwd_tiled_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),

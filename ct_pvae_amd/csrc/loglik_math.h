@@ -81,16 +81,20 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// lp_sum[s] = the NT partial sums of slice s added in ascending slot order (one thread per slice)
+// lp_sum[s] = the NT partial sums of slice s added in ascending slot order.  One wave per slice: 64 partials per coalesced
+// load, then added one by one through readlane (every lane keeps the same running sum).
 [[maybe_unused]] static __global__ __launch_bounds__(64) void loglik_sum_partials_kernel(const float *__restrict__ part, int S, int NT,
-                                                                 float *__restrict__ out)
+                                                                                       float *__restrict__ out)
 {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
+    const int s = blockIdx.x, lane = threadIdx.x;
     const float *p = part + (size_t)s * NT;
     float acc = 0.0f;
-    for (int t = 0; t < NT; ++t) acc += p[t];
-    out[s] = acc;
+    for (int t0 = 0; t0 < NT; t0 += 64) {
+        const float v = t0 + lane < NT ? p[t0 + lane] : 0.0f;
+        const int m = min(64, NT - t0);
+        for (int t = 0; t < m; ++t) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+    }
+    if (lane == 0) out[s] = acc;
 }
 
 }  // namespace ctpvae

@@ -309,13 +309,15 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
 // EPI: 0 = ray-sums only; 1 = + log-probabilities (and d lp / d ray-sum) of the measured samples; 2 = the
 // log-probabilities are REDUCED: one partial sum per task into epi.part (see LogLikEpilogue), d lp / d ray-sum stored for the
 // backward, the ray-sum and log-probability stores only where buffers were given.
-// SEL: the launch projects a subset of the plan's angles (see rotate_fwd_planned_kernel).
-template <int NS, int EPI, bool SEL>
+// SELM: 0 = all plan angles; 1 = the launch projects a subset of the plan's angles (see rotate_fwd_planned_kernel), read
+// from device memory (sel); 2 = the subset arrived in host memory and travels in the kernel arguments (selh).
+template <int NS, int EPI, int SELM>
 __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *__restrict__ img, PlanGeom g, CLayout L,
                                                                   const char *__restrict__ plan, int wgs_per_slice, int g_S,
                                                                   float *__restrict__ sino, LogLikEpilogue epi,
-                                                                  const int *__restrict__ sel, int n_sel)
+                                                                  const int *__restrict__ sel, int n_sel, SelHost selh)
 {
+    constexpr bool SEL = SELM != 0;
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
     if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();   // see lut_issue
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
             const int k = 64 * r + lane;
             int a = 0, cl = -1, w = 0;
             if (k < n_sel) {
-                a = min(max(sel[k], 0), g.A - 1);   // a bad index cannot leave the plan
+                a = min(max(SELM == 2 ? selh.get(k) : sel[k], 0), g.A - 1);   // a bad index cannot leave the plan
                 w = cls[a];
                 cl = w & 1;
             }
@@ -547,16 +549,17 @@ int ctpvae_rotate_cplan_overflowed(const void *cplan_dev, int H, int W, int PH, 
 }
 
 int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *cplan_dev,
-                                  const int *angle_idx_dev, int n_idx, const float *mask_dev, const float *meas_dev,
-                                  int dense_inputs, const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
-                                  float *dlp_dev, float *lp_part_dev, float *lp_sum_dev, ctpvae_stream_t stream)
+                                  const int *angle_idx, int n_idx, int idx_on_host, const float *mask_dev,
+                                  const float *meas_dev, int dense_inputs, const float *pnm_dev, float eps, float *sino_dev,
+                                  float *lp_dev, float *dlp_dev, float *lp_part_dev, float *lp_sum_dev, ctpvae_stream_t stream)
 {
+    const int *angle_idx_dev = angle_idx;
     const bool red = lp_sum_dev != nullptr;
     CTPVAE_REQUIRE(img_dev && cplan_dev && (sino_dev || red), "rotate_fwd_compact: null pointer");
     CTPVAE_REQUIRE(!red || lp_part_dev, "rotate_fwd_compact: per-object sums need the partial-sum workspace");
     CTPVAE_REQUIRE(S > 0, "rotate_fwd_compact: need at least one slice");
     if (int rc = check_plan_geom("rotate_fwd_compact", H, W, PH, PW, 0, 0, A)) return rc;
-    const int *sel_dev = angle_idx_dev;
+    const int *sel_dev = angle_idx_dev;   // (host memory when idx_on_host)
     CTPVAE_REQUIRE(sel_dev == nullptr || (n_idx >= 1 && n_idx <= 64 * kCSelRounds),
                    "rotate_fwd_compact: an angle subset holds 1..%d angles (got %d); build a plan for larger ones",
                    64 * kCSelRounds, n_idx);
@@ -566,10 +569,16 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     CTPVAE_REQUIRE(cplan_fits(g), "rotate_fwd_compact: a %dx%d slice does not fit the compact plan's LDS image", H, W);
     const CLayout L = c_layout(g);
+    SelHost selh = {};
+    const int selm = sel_dev == nullptr ? 0 : (idx_on_host ? 2 : 1);
+    if (selm == 2) {   // host indices: clamped here, carried in the kernel arguments
+        for (int k = 0; k < n_idx; ++k) selh.set(k, std::min(std::max(sel_dev[k], 0), A - 1));
+        sel_dev = nullptr;
+    }
     const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0,
                                                     red ? lp_part_dev : nullptr}
                                    : LogLikEpilogue{};
-    const int A_run = sel_dev ? n_idx : A;      // angles this launch projects
+    const int A_run = selm != 0 ? n_idx : A;    // angles this launch projects
     const int T = A_run * L.nJB;                // (angle, bin block) tasks per slice
     // Launch shape.  With 0.25 B of plan per sample the index stream no longer counts; what a workgroup costs is the fill of
     // its unit (a slice, or a pair of slices interleaved as float2) and its tasks, which are bound by the CU's LDS pipe when
@@ -612,26 +621,28 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
         static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)cplan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_idx);
+                           img_dev, g, L, (const char *)cplan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_idx, selh);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_compact_kernel");
         return CTPVAE_OK;
     };
+    // (slices per workgroup, epilogue, subset mode) -> instantiation
+    auto by_sel = [&](auto ns_tag, auto epi_tag) -> int {
+        constexpr int NS_ = decltype(ns_tag)::value, EPI_ = decltype(epi_tag)::value;
+        if (selm == 0) return launch(rotate_fwd_compact_kernel<NS_, EPI_, 0>);
+        if (selm == 1) return launch(rotate_fwd_compact_kernel<NS_, EPI_, 1>);
+        return launch(rotate_fwd_compact_kernel<NS_, EPI_, 2>);
+    };
+    auto by_ns = [&](auto epi_tag) -> int {
+        return ns == 2 ? by_sel(std::integral_constant<int, 2>{}, epi_tag) : by_sel(std::integral_constant<int, 1>{}, epi_tag);
+    };
     if (red) {
-        int rc;
-        if (sel_dev) rc = ns == 2 ? launch(rotate_fwd_compact_kernel<2, 2, true>) : launch(rotate_fwd_compact_kernel<1, 2, true>);
-        else rc = ns == 2 ? launch(rotate_fwd_compact_kernel<2, 2, false>) : launch(rotate_fwd_compact_kernel<1, 2, false>);
-        if (rc) return rc;
-        hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(ceil_div(S, 64)), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S,
+        if (int rc = by_ns(std::integral_constant<int, 2>{})) return rc;
+        hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S,
                            A_run * L.nJB, lp_sum_dev);
         CTPVAE_LAUNCH_CHECK("loglik_sum_partials_kernel");
         return CTPVAE_OK;
     }
-    if (sel_dev) {
-        if (lik) return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 1, true>) : launch(rotate_fwd_compact_kernel<1, 1, true>);
-        return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 0, true>) : launch(rotate_fwd_compact_kernel<1, 0, true>);
-    }
-    if (lik) return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 1, false>) : launch(rotate_fwd_compact_kernel<1, 1, false>);
-    return ns == 2 ? launch(rotate_fwd_compact_kernel<2, 0, false>) : launch(rotate_fwd_compact_kernel<1, 0, false>);
+    return lik ? by_ns(std::integral_constant<int, 1>{}) : by_ns(std::integral_constant<int, 0>{});
 }
 
 }  // extern "C"

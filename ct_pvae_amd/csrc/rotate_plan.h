@@ -46,6 +46,14 @@ __device__ __forceinline__ int wave_max_i(int v)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NS> struct SliceVec { typedef float type; };
 template <> struct SliceVec<2> { typedef f32x2 type; };
+// An angle subset handed over in HOST memory travels in the kernel arguments (<= 256 plan angles, 512 B): no upload, no
+// device-side copy to wait for -- the kernels read it like any other argument.
+constexpr int kMaxSelAngles = 256;
+struct SelHost {
+    unsigned w[kMaxSelAngles / 2];   // two 16-bit plan angles per dword: a wave-uniform index reads them with SCALAR loads
+    __host__ __device__ void set(int k, int a) { w[k >> 1] = (w[k >> 1] & ~(0xffffu << (16 * (k & 1)))) | ((unsigned)a << (16 * (k & 1))); }
+    __device__ __forceinline__ int get(int k) const { return (int)((w[k >> 1] >> (16 * (k & 1))) & 0xffffu); }
+};
 inline int check_plan_geom(const char *who, int H, int W, int PH, int PW, int py, int px, int A)
 {
     CTPVAE_REQUIRE(H > 0 && W > 0 && A > 0, "%s: sizes must be positive (H=%d W=%d A=%d)", who, H, W, A);

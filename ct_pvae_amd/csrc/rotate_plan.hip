@@ -703,6 +703,146 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     }
 }
 
+// ---- angle-selecting planned backward ("bwd4" plan) ---------------------------------------------------------------------
+// The 16-angles-per-vector plan above cannot project a SUBSET of its angles (the training loop's per-step `api` random
+// angles, ctvae/helper_functions.py:350-357): a selected angle would drag its fifteen neighbours' taps along.  The bwd4 plan
+// stores the same byte taps as idx4[a][y / 4][x] = one DWORD = the bins angle a reads for pixels (4q .. 4q + 3, x): a lane
+// that owns four consecutive rows of one column loads exactly one dword per selected angle.
+__global__ __launch_bounds__(64) void rotate_bwd4_plan_kernel(PlanGeom g, const float *__restrict__ Tinv8, int Wpad, int HQ,
+                                                              unsigned *__restrict__ idx4)
+{
+    const int xb = blockIdx.x, yq = blockIdx.y, a = blockIdx.z, lane = threadIdx.x;
+    const int xcol = xb * 64 + lane;
+    const float *t = Tinv8 + 8 * a;
+    const float fx = (float)(xcol + g.px);
+    unsigned w = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int yrow = 4 * yq + e;
+        unsigned v = 255u;
+        if (yrow < g.H && xcol < g.W) {   // the expressions of rotate_bwd_plan_kernel
+            const float fy = (float)(yrow + g.py);
+            const float x = (t[0] * fx + t[1] * fy) + t[2];
+            const float y = (t[3] * fx + t[4] * fy) + t[5];
+            const int ix = (int)__builtin_roundf(x), iy = (int)__builtin_roundf(y);
+            if ((unsigned)ix < (unsigned)g.PW && (unsigned)iy < (unsigned)g.PH) v = (unsigned)ix;
+        }
+        w |= v << (8 * e);
+    }
+    idx4[((size_t)a * HQ + yq) * Wpad + xcol] = w;
+}
+
+// Workgroup = (slice or slice pair, 64 columns x 4 * waves rows); lane = column, a wave owns four consecutive rows.  The
+// subset's n cotangent rows are staged in chunks (257-cell rows as in rotate_bwd_planned_kernel: a dead tap, byte 255,
+// reads 0.0f); row k of the cotangent belongs to plan angle sel[k] and the sum runs over k ascending -- the order of
+// ctpvae_rotate_bwd_sel_scaled_f32 and of the oracle on the gathered table.
+// HOSTSEL: the subset arrived in host memory and travels in the kernel arguments (selh) instead of device memory (sel).
+template <int NS, bool HOSTSEL>
+__global__ __launch_bounds__(256) void rotate_bwd_planned_sel_kernel(const float *__restrict__ gsino, PlanGeom g, int Wpad,
+                                                                     int HQ, const unsigned *__restrict__ idx4,
+                                                                     const int *__restrict__ sel, int n_sel, int tiles_y,
+                                                                     int g_S, SliceScale scale, float *__restrict__ gimg,
+                                                                     SelHost selh)
+{
+    typedef typename SliceVec<NS>::type vec_t;
+    constexpr int kChunk = kBwdChunk / NS;          // staged rows per pass: row offsets stay ds_read immediates
+    constexpr int ROW = kBwdPitch * 4 * NS;         // bytes per staged row
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int nXB = Wpad >> 6, tiles = nXB * tiles_y;
+    const int units = (g_S + NS - 1) / NS;
+    int u, tile;
+    {   // tiles of one unit on one XCD (see rotate_bwd_planned_kernel)
+        const int per8 = 8 * tiles, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
+        if ((octet + 1) * 8 <= units) {
+            tile = rem >> 3;
+            u = octet * 8 + (rem & 7);
+        } else {
+            u = octet * 8 + rem / tiles;
+            tile = rem - (rem / tiles) * tiles;
+        }
+    }
+    const int s = u * NS;
+    const bool has2 = NS == 2 && s + 1 < g_S;
+    const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
+    const int xb = tile % nXB, ty = tile / nXB;
+    const int xcol = xb * 64 + lane;
+    const int yq = min(ty * nwaves + wave, HQ - 1);   // a wave past the slice re-reads the last row quad, never stores
+    const bool wave_live = ty * nwaves + wave < HQ;
+    const float *gs = gsino + (size_t)s * n_sel * g.PW;
+    const unsigned *p = idx4 + (size_t)yq * Wpad + xcol;
+    const size_t astride = (size_t)HQ * Wpad;
+    vec_t acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = 0.0f;
+
+    auto load16 = [&](int kbase, unsigned (&q)[16]) {   // the taps of 16 selected angles: one dword per lane each
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int k = min(kbase + e, n_sel - 1);
+            const int a = min(max(HOSTSEL ? selh.get(k) : sel[k], 0), g.A - 1);   // a bad index cannot leave the plan
+            q[e] = p[(size_t)a * astride];
+        }
+    };
+    for (int kc = 0; kc < n_sel; kc += kChunk) {
+        const int nk = min(kChunk, n_sel - kc);
+        unsigned q0[16];
+        load16(kc, q0);   // in flight while the cotangent rows are staged
+        if (kc > 0) __syncthreads();
+        for (int t = threadIdx.x; t < nk * NS; t += blockDim.x) lds[((t / NS) * kBwdPitch + 255) * NS + (t % NS)] = 0.0f;
+        if constexpr (NS == 1) {
+            stage_rows(lds, gs + (size_t)kc * g.PW, nk, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        } else {
+            const float *srcs[2] = {gs + (size_t)kc * g.PW, gs + (has2 ? (size_t)n_sel * g.PW : 0) + (size_t)kc * g.PW};
+            stage_rows_interleaved<2>(lds, srcs, nk, g.PW, g.PW, kBwdPitch, false, lane, wave, nwaves);
+        }
+        // the taps of up to 16 selected angles at a time: scalar loads of their plan angles, then one dword per lane each
+        auto block16 = [&](auto k0_tag) {
+            constexpr int K0 = decltype(k0_tag)::value;
+            if constexpr (K0 < kChunk) {
+                if (K0 >= nk) return;   // wave-uniform
+                unsigned q[16];
+                if constexpr (K0 == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) q[e] = q0[e];
+                    __syncthreads();   // the staged rows
+                } else {
+                    load16(kc + K0, q);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (K0 + e < nk) {   // wave-uniform
+                        int b0, b1, b2, b3;
+                        unpack4<NS == 1 ? 2 : 3>(q[e], b0, b1, b2, b3);
+                        acc[0] += lds_at_vec<NS>(lds, b0 + (K0 + e) * ROW);
+                        acc[1] += lds_at_vec<NS>(lds, b1 + (K0 + e) * ROW);
+                        acc[2] += lds_at_vec<NS>(lds, b2 + (K0 + e) * ROW);
+                        acc[3] += lds_at_vec<NS>(lds, b3 + (K0 + e) * ROW);
+                    }
+                }
+            }
+        };
+        block16(std::integral_constant<int, 0>{});
+        block16(std::integral_constant<int, 16>{});
+        block16(std::integral_constant<int, 32>{});
+        block16(std::integral_constant<int, 48>{});
+    }
+    if (xcol < g.W && wave_live) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int y = 4 * yq + e;
+            if (y < g.H) {
+                if constexpr (NS == 1) {
+                    gimg[((size_t)s * g.H + y) * g.W + xcol] = k0 * acc[e];
+                } else {
+                    gimg[((size_t)s * g.H + y) * g.W + xcol] = k0 * acc[e].x;
+                    if (has2) gimg[((size_t)(s + 1) * g.H + y) * g.W + xcol] = k1 * acc[e].y;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace ctpvae
 
 using namespace ctpvae;
@@ -957,6 +1097,74 @@ int ctpvae_rotate_bwd_planned_scaled_f32(const float *gsino_dev, int S, int H, i
                                          float *gimg_dev, ctpvae_stream_t stream)
 {
     return launch_bwd_planned(gsino_dev, S, H, W, PH, PW, A, bwd_plan_dev, scale_dev, scale_stride, gimg_dev, 1, stream);
+}
+
+// ---- angle subsets of a dense backward plan ---------------------------------------------------------------------------------
+long long ctpvae_rotate_bwd4_plan_bytes(int H, int W, int PH, int PW, int A)
+{
+    if (H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_bwd4_plan_bytes: bad sizes");
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    if (!bwd_plan_fits(g) || knob(kKnobNoPlan) >= 0) return 0;   // bins do not fit a byte: keep ctpvae_rotate_bwd_sel_scaled_f32
+    return (long long)A * ceil_div(H, 4) * (ceil_div(W, 64) * 64) * 4;
+}
+
+int ctpvae_rotate_bwd4_plan_build_f32(const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py, int px,
+                                      void *plan_dev, ctpvae_stream_t stream)
+{
+    if (int rc = check_plan_geom("rotate_bwd4_plan_build", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(Tinv8_dev && plan_dev, "rotate_bwd4_plan_build: null pointer");
+    const PlanGeom g{H, W, PH, PW, py, px, A};
+    CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd4_plan_build: the plan stores bins as bytes (PW=%d > 255)", PW);
+    const int HQ = ceil_div(H, 4), nXB = ceil_div(W, 64);
+    CTPVAE_REQUIRE(HQ <= 65535 && A <= 65535, "rotate_bwd4_plan_build: at most 262140 rows and 65535 angles");
+    hipLaunchKernelGGL(rotate_bwd4_plan_kernel, dim3(nXB, HQ, A), dim3(64), 0, (hipStream_t)stream, g, Tinv8_dev, nXB * 64, HQ,
+                       (unsigned *)plan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_bwd4_plan_kernel");
+    return CTPVAE_OK;
+}
+
+int ctpvae_rotate_bwd_planned_sel_scaled_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                             const void *bwd4_plan_dev, const int *angle_idx, int n_idx, int idx_on_host,
+                                             const float *scale_dev, long long scale_stride, float *gimg_dev,
+                                             ctpvae_stream_t stream)
+{
+    const int *angle_idx_dev = angle_idx;   // (host memory when idx_on_host)
+    CTPVAE_REQUIRE(gsino_dev && bwd4_plan_dev && angle_idx_dev && gimg_dev, "rotate_bwd_planned_sel: null pointer");
+    CTPVAE_REQUIRE(!idx_on_host || n_idx <= kMaxSelAngles, "rotate_bwd_planned_sel: at most %d host-resident angles (got %d)",
+                   kMaxSelAngles, n_idx);
+    CTPVAE_REQUIRE(S > 0 && n_idx > 0, "rotate_bwd_planned_sel: need slices and angles (S=%d, subset %d)", S, n_idx);
+    if (int rc = check_plan_geom("rotate_bwd_planned_sel", H, W, PH, PW, 0, 0, A)) return rc;
+    const PlanGeom g{H, W, PH, PW, 0, 0, A};
+    CTPVAE_REQUIRE(bwd_plan_fits(g), "rotate_bwd_planned_sel: the plan stores bins as bytes (PW=%d > 255)", PW);
+    const int HQ = ceil_div(H, 4), nXB = ceil_div(W, 64);
+    int ns = S >= 2 ? 2 : 1;
+    if (knob(kKnobBns) >= 0) ns = (knob(kKnobBns) == 2 && S >= 2) ? 2 : 1;
+    const int units = ceil_div(S, ns);
+    // tile = 64 columns x 4 * waves rows.  Four waves: every workgroup stages all n cotangent rows of its unit, and fewer waves
+    // would need more than one batch of loads per lane for it (20 rows of a pair = 29 KB = 7 loads per lane of 256 threads)
+    int waves = std::min(4, HQ);
+    if (knob(kKnobBw) > 0) waves = std::min(4, std::max(1, knob(kKnobBw)));
+    const int tiles_y = ceil_div(HQ, waves);
+    const long long nblk = (long long)units * nXB * tiles_y;
+    CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned_sel: too many slices");
+    const size_t shmem = (size_t)std::min(n_idx, kBwdChunk / ns) * kBwdPitch * sizeof(float) * ns;
+    SelHost selh = {};
+    if (idx_on_host) {
+        for (int k = 0; k < n_idx; ++k) selh.set(k, std::min(std::max(angle_idx_dev[k], 0), A - 1));
+        angle_idx_dev = nullptr;
+    }
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, nXB * 64, HQ,
+                           (const unsigned *)bwd4_plan_dev, angle_idx_dev, n_idx, tiles_y, S, SliceScale{scale_dev, scale_stride},
+                           gimg_dev, selh);
+    };
+    if (idx_on_host) {
+        if (ns == 2) launch(rotate_bwd_planned_sel_kernel<2, true>); else launch(rotate_bwd_planned_sel_kernel<1, true>);
+    } else {
+        if (ns == 2) launch(rotate_bwd_planned_sel_kernel<2, false>); else launch(rotate_bwd_planned_sel_kernel<1, false>);
+    }
+    CTPVAE_LAUNCH_CHECK("rotate_bwd_planned_sel_kernel");
+    return CTPVAE_OK;
 }
 
 // ---- exact transpose through a plan (NEAREST): deterministic gather, see rotate_exact_plan_kernel ----------------------

@@ -26,6 +26,7 @@ using fwd_lik_sel_fn = decltype(&ctpvae_rotate_fwd_planned_loglik_sel_f32);
 using bwd_seg_fn = decltype(&ctpvae_rotate_bwd_scaled_f32);
 using bwd_sel_fn = decltype(&ctpvae_rotate_bwd_sel_scaled_f32);
 using fwd_compact_fn = decltype(&ctpvae_rotate_fwd_compact_f32);
+using bwd_psel_fn = decltype(&ctpvae_rotate_bwd_planned_sel_scaled_f32);
 using abi_fn = decltype(&ctpvae_abi_version);
 fwd_fn g_fwd = nullptr;
 bwd_fn g_bwd = nullptr;
@@ -35,6 +36,7 @@ fwd_lik_sel_fn g_fwd_lik_sel = nullptr;
 bwd_seg_fn g_bwd_seg = nullptr;
 bwd_sel_fn g_bwd_sel = nullptr;
 fwd_compact_fn g_fwd_compact = nullptr;
+bwd_psel_fn g_bwd_psel = nullptr;
 
 // The ABI this node was COMPILED against (the header's macro) must be the ABI of the library it binds at run time: the
 // entry points are resolved by name only, so a node left over from an older build would otherwise call them with an old
@@ -57,7 +59,8 @@ void bind(const std::string &lib_path)
     g_bwd_seg = (bwd_seg_fn)dlsym(h, "ctpvae_rotate_bwd_scaled_f32");
     g_bwd_sel = (bwd_sel_fn)dlsym(h, "ctpvae_rotate_bwd_sel_scaled_f32");
     g_fwd_compact = (fwd_compact_fn)dlsym(h, "ctpvae_rotate_fwd_compact_f32");
-    TORCH_CHECK(g_fwd && g_bwd && g_err && g_fwd_lik && g_fwd_lik_sel && g_bwd_seg && g_bwd_sel && g_fwd_compact, lib_path,
+    g_bwd_psel = (bwd_psel_fn)dlsym(h, "ctpvae_rotate_bwd_planned_sel_scaled_f32");
+    TORCH_CHECK(g_fwd && g_bwd && g_err && g_fwd_lik && g_fwd_lik_sel && g_bwd_seg && g_bwd_sel && g_fwd_compact && g_bwd_psel, lib_path,
                 " does not export the planned projector entry points");
 }
 
@@ -80,7 +83,7 @@ struct RotateVae : public torch::autograd::Function<RotateVae> {
         const int64_t S = x4.size(0);
         at::Tensor out = at::empty({S, A, PW, 1}, x4.options());
         const int rc = compact ? g_fwd_compact(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A,
-                                               fwd_plan.data_ptr(), nullptr, 0, nullptr, nullptr, 0, nullptr, 0.0f,
+                                               fwd_plan.data_ptr(), nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0.0f,
                                                out.data_ptr<float>(), nullptr, nullptr, nullptr, nullptr, (void *)stream)
                                : g_fwd(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
                                        out.data_ptr<float>(), (void *)stream);
@@ -108,8 +111,8 @@ struct RotateVae : public torch::autograd::Function<RotateVae> {
     }
 };
 
-// geo = {H, W, PH, PW, A_plan, py, px, backward_uses_plan, dense_inputs, stream, compact forward plan}; angles: int32 [n] on
-// the device or undefined
+// geo = {H, W, PH, PW, A_plan, py, px, backward plan kind (0: none -- segment kernel, 1: the dense plan, 2: the bwd4 plan of
+// an angle subset), dense_inputs, stream, compact forward plan}; angles: int32 [n] on the device or undefined
 struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
     static at::Tensor forward(torch::autograd::AutogradContext *ctx, const at::Tensor &x4, const at::Tensor &fwd_plan,
                               const at::Tensor &bwd_plan, const at::Tensor &Tinv8, const at::Tensor &mask, const at::Tensor &meas,
@@ -128,15 +131,17 @@ struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
                               mask.size(1) == n_in && meas.dim() == 3 && meas.size(0) == S && meas.size(1) == n_in && meas.size(2) == PW,
                           "need contiguous float32 mask [", S, "][", n_in, "], proj_sample [", S, "][", n_in, "][", PW,
                           "] and a one-element pnm on ", x4.device());
-        TORCH_CHECK_VALUE(!sel || (angles->is_cuda() && angles->scalar_type() == at::kInt && angles->is_contiguous() && n > 0),
-                          "angles_i must be a non-empty contiguous int32 device vector");
+        const bool host_idx = sel && !angles->is_cuda();   // host-resident subsets ride the launch arguments (compact plan only)
+        TORCH_CHECK_VALUE(!sel || (angles->scalar_type() == at::kInt && angles->is_contiguous() && n > 0 &&
+                                   (angles->is_cuda() || (compact && geo[7] == 2 && n <= 256))),
+                          "angles_i must be a non-empty contiguous int32 vector, on the device or (compact plans) in host memory");
         at::Tensor sino = at::empty({S, n, PW}, x4.options());
         at::Tensor lp = at::empty({S, n, PW, 1}, x4.options());
         at::Tensor dlp = at::empty({S, n, PW}, x4.options());
         int rc;
         if (compact)
             rc = g_fwd_compact(x4.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A, fwd_plan.data_ptr(),
-                               sel ? angles->data_ptr<int>() : nullptr, sel ? (int)n : 0, mask.data_ptr<float>(),
+                               sel ? angles->data_ptr<int>() : nullptr, sel ? (int)n : 0, host_idx ? 1 : 0, mask.data_ptr<float>(),
                                meas.data_ptr<float>(), (int)dense, pnm.data_ptr<float>(), (float)eps, sino.data_ptr<float>(),
                                lp.data_ptr<float>(), dlp.data_ptr<float>(), nullptr, nullptr, (void *)stream);
         else if (sel)
@@ -178,7 +183,13 @@ struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
         }
         at::Tensor gimg = at::empty({S, H, W, 1}, dlp.options());
         int rc;
-        if (sel) {
+        if (sel && use_plan == 2) {                    // the bwd4 plan: a planned backward that selects angles
+            const at::Tensor ai = ctx->saved_data["angles"].toTensor();
+            rc = g_bwd_psel(cot.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A,
+                            ctx->saved_data["bwd_plan"].toTensor().data_ptr(), ai.data_ptr<int>(), (int)n, ai.is_cuda() ? 0 : 1,
+                            scale, stride,
+                            gimg.data_ptr<float>(), stream);
+        } else if (sel) {
             const at::Tensor ai = ctx->saved_data["angles"].toTensor();
             rc = g_bwd_sel(cot.data_ptr<float>(), (int)S, (int)A, (int)PH, (int)PW, ctx->saved_data["Tinv8"].toTensor().data_ptr<float>(),
                            ai.data_ptr<int>(), (int)n, (int)H, (int)W, (int)py, (int)px, scale, stride, gimg.data_ptr<float>(), stream);

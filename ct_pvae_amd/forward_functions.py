@@ -142,13 +142,18 @@ def rotate_tables(theta, H, W, device):
     return tables[0], tables[1]
 
 
-def as_angle_index(angles_i, device):
-    """The per-step angle subset (ctvae/helper_functions.py:350-357) as the int32 device vector the kernels take."""
+def as_angle_index(angles_i, device, keep_host=False):
+    """The per-step angle subset (ctvae/helper_functions.py:350-357) as the int32 vector the kernels take: on `device`, or --
+    keep_host -- left in HOST memory when that is where the caller has it (a list, a numpy array, a CPU tensor: the training
+    loop draws its subset on the host, ctvae/helper_functions.py:104-107).  Kernels that accept host indices carry them in
+    their launch arguments: no upload, nothing on the stream in front of the projector."""
     t = torch.as_tensor(angles_i) if not isinstance(angles_i, torch.Tensor) else angles_i
     if t.dim() != 1 or t.numel() == 0:
         raise ValueError(f"angles_i must be a non-empty 1-D index vector (got shape {tuple(t.shape)})")
     if t.dtype.is_floating_point or t.dtype is torch.bool:
         raise TypeError(f"angles_i must hold integers (got {t.dtype})")
+    if keep_host and t.device.type == "cpu":
+        return t if (t.dtype is torch.int32 and t.is_contiguous()) else t.to(torch.int32).contiguous()
     if t.device != device or t.dtype is not torch.int32 or not t.is_contiguous():
         t = t.to(device=device, dtype=torch.int32).contiguous()
     return t
@@ -197,8 +202,11 @@ class RotatePlan:
         self._lib = _lib.load()
         # Gather plans (NEAREST): tap indices computed once for this geometry, shared by every slice of every call.
         # The forward plan is built now, the backward plan on the first backward.
-        self._fwd_plan = self._bwd_plan = self._exact_plan = None
+        self._fwd_plan = self._bwd_plan = self._exact_plan = self._bwd4_plan = None
         self._want_bwd_plan = False
+        # angle subsets of the backward (the training call): a plan whose layout lets a launch select angles, built on
+        # the first subset backward
+        self._want_bwd4 = bool(use_plan and self.interp == _lib.NEAREST and self.mode == _lib.BWD_TF_COMPAT)
         # exact transpose (nearest): a deterministic gather through an inverse plan
         self._want_exact_plan = bool(use_plan and self.mode == _lib.BWD_EXACT and self.interp == _lib.NEAREST)
         self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
@@ -246,6 +254,22 @@ class RotatePlan:
         _lib.check(over, "rotate_cplan_overflowed")
         return buf if over == 0 else None
 
+    def _get_bwd4_plan(self):
+        """The angle-selecting backward plan (one dword = the four rows a lane owns at one angle), or None when the geometry
+        does not fit byte taps -- the segment kernel (ctpvae_rotate_bwd_sel_scaled_f32) serves subsets then."""
+        if self._bwd4_plan is None and self._want_bwd4:
+            self._want_bwd4 = False
+            nbytes = self._lib.ctpvae_rotate_bwd4_plan_bytes(self.H, self.W, self.PH, self.PW, self.A)
+            _lib.check(nbytes, "rotate_bwd4_plan_bytes")
+            if nbytes > 0:
+                buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                with torch.cuda.device(self.device):
+                    _lib.check(self._lib.ctpvae_rotate_bwd4_plan_build_f32(self.Tinv8.data_ptr(), self.A, self.H, self.W, self.PH,
+                                                                           self.PW, self.py, self.px, buf.data_ptr(),
+                                                                           _stream_ptr()), "rotate_bwd4_plan_build")
+                self._bwd4_plan = buf
+        return self._bwd4_plan
+
     def _build_exact_plan(self):
         """Inverse plan of the nearest forward (<= 2 hitting bins per angle and pixel).  Falls back to the scatter kernel
         (atomics) when the geometry does not fit byte taps or the rows are not a rotation."""
@@ -279,7 +303,8 @@ class RotatePlan:
                      lp_ptr=None, dlp_ptr=None, part_ptr=None, sum_ptr=None):
         return self._lib.ctpvae_rotate_fwd_compact_f32(
             img_ptr, S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(),
-            angles_i.data_ptr() if angles_i is not None else None, n, mask.data_ptr() if mask is not None else None,
+            angles_i.data_ptr() if angles_i is not None else None, n,
+            1 if (angles_i is not None and angles_i.device.type == "cpu") else 0, mask.data_ptr() if mask is not None else None,
             meas.data_ptr() if meas is not None else None, dense, pnm.data_ptr() if pnm is not None else None,
             ctypes.c_float(eps), out_ptr, lp_ptr, dlp_ptr, part_ptr, sum_ptr, _stream_ptr(self._dev_index))
 
@@ -292,7 +317,7 @@ class RotatePlan:
         log-probabilities and reduce them with the same-order kernel."""
         if angles_i is not None and not self.sel_supported(angles_i.numel()):
             if dense_inputs:
-                idx = angles_i.long()
+                idx = self._sel_dev(angles_i).long()
                 mask, meas = mask.index_select(1, idx).contiguous(), meas.index_select(1, idx).contiguous()
             return self.subset(angles_i).forward_loglik_sums(img, mask, meas, pnm, eps, with_dlp=with_dlp)
         with torch.cuda.device(self._dev_index):
@@ -323,6 +348,10 @@ class RotatePlan:
             if rc:
                 _lib.check(rc, "rotate_fwd_compact")
             return sums, dlp
+
+    def _sel_dev(self, angles_i):
+        """The subset as a device vector (kernels without a host-index form; torch gathers)."""
+        return angles_i if angles_i.device == self._tdev else angles_i.to(self._tdev)
 
     def subset(self, angles_i):
         """A plan over rows `angles_i` of this one's tables (two small gathers, no plan kernels): the fallback for angle
@@ -364,7 +393,7 @@ class RotatePlan:
         angles (the reference's tf.gather of both, ctvae/helper_functions.py:356-357, costs no launch)."""
         if angles_i is not None and not self.sel_supported(angles_i.numel()):
             if dense_inputs:
-                idx = angles_i.long()
+                idx = self._sel_dev(angles_i).long()
                 mask, meas = mask.index_select(1, idx).contiguous(), meas.index_select(1, idx).contiguous()
             return self.subset(angles_i).forward_loglik(img, mask, meas, pnm, eps, out, out_lp, out_dlp, with_dlp)
         if _current_device() == self._dev_index:
@@ -424,10 +453,17 @@ class RotatePlan:
         return self._tile_workspace(1) is not None
 
     def _check_sel(self, angles_i):
+        host = angles_i.device.type == "cpu"
         if (angles_i.dtype is not torch.int32 or angles_i.dim() != 1 or not angles_i.is_contiguous()
-                or angles_i.device != self._tdev):
-            raise ValueError(f"angles_i must be a contiguous int32 vector on {self._tdev} (see as_angle_index; got "
-                             f"{tuple(angles_i.shape)}, {angles_i.dtype}, {angles_i.device})")
+                or not (host or angles_i.device == self._tdev)):
+            raise ValueError(f"angles_i must be a contiguous int32 vector on {self._tdev} or in host memory (see "
+                             f"as_angle_index; got {tuple(angles_i.shape)}, {angles_i.dtype}, {angles_i.device})")
+        if host and angles_i.numel():
+            # host-resident indices are checked like the reference's tf.gather would (it raises on an index outside the
+            # angle list); device-resident ones cannot be read without a sync and are clamped by the kernels
+            lo, hi = int(angles_i.min()), int(angles_i.max())
+            if lo < 0 or hi >= self.A:
+                raise ValueError(f"angles_i holds indices outside this plan's {self.A} angles (min {lo}, max {hi})")
         return angles_i.numel()
 
     def _forward(self, img, out=None, angles_i=None):
@@ -446,6 +482,7 @@ class RotatePlan:
                 _lib.check(rc, "rotate_fwd_compact")
             return out
         if angles_i is not None:
+            angles_i = self._sel_dev(angles_i)
             rc = self._lib.ctpvae_rotate_fwd_planned_sel_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                              self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
                                                              out.data_ptr(), _stream_ptr(self._dev_index))
@@ -503,6 +540,7 @@ class RotatePlan:
             rc = self._run_compact(img.data_ptr(), S, out.data_ptr(), angles_i, n if angles_i is not None else 0, mask, meas,
                                    1 if dense_inputs else 0, pnm, eps, out_lp.data_ptr(), dlp_ptr)
         elif angles_i is not None:
+            angles_i = self._sel_dev(angles_i)
             rc = self._lib.ctpvae_rotate_fwd_planned_loglik_sel_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
                 mask.data_ptr(), meas.data_ptr(), 1 if dense_inputs else 0, pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
@@ -545,8 +583,17 @@ class RotatePlan:
             self._check(out, (self.H, self.W), "out")
             if out.shape[0] != S:
                 raise ValueError(f"out holds {out.shape[0]} slices for {S} sinograms")
+        if angles_i is not None and self._get_bwd4_plan() is not None:
+            rc = self._lib.ctpvae_rotate_bwd_planned_sel_scaled_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
+                                                                    self._bwd4_plan.data_ptr(), angles_i.data_ptr(), n,
+                                                                    1 if angles_i.device.type == "cpu" else 0,
+                                                                    sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
+            if rc:
+                _lib.check(rc, "rotate_bwd_planned_sel")
+            return out
         if angles_i is not None:
             # the segment kernel reads its table rows through the index vector: nothing is gathered, no plan is built
+            angles_i = self._sel_dev(angles_i)
             rc = self._lib.ctpvae_rotate_bwd_sel_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, self.Tinv8.data_ptr(),
                                                             angles_i.data_ptr(), n, self.H, self.W, self.py, self.px,
                                                             sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
@@ -630,14 +677,20 @@ class RotatePlan:
         node = _lib.torch_node()
         if node is None or self._fwd_plan is None or not self.supports_scale:
             return None
-        use_plan = False
+        use_plan, bplan = 0, self.Tinv8
         if angles_i is None:
-            use_plan = self.backward_uses_plan(x4.shape[0])
+            use_plan = int(self.backward_uses_plan(x4.shape[0]))
             if use_plan and self._bwd_plan is None:
                 self._bwd_plan = self._build_plan(1)
+            if use_plan:
+                bplan = self._bwd_plan
         else:
             self._check_sel(angles_i)
-        return node.rotate_loglik(x4, self._fwd_plan, self._bwd_plan if use_plan else self.Tinv8, self.Tinv8, mask, meas, pnm,
+            if self._get_bwd4_plan() is not None:      # 2: the angle-selecting planned backward
+                use_plan, bplan = 2, self._bwd4_plan
+            if angles_i.device.type == "cpu" and not (self._compact and use_plan == 2):
+                angles_i = self._sel_dev(angles_i)     # the u16 / segment kernels read the subset from device memory
+        return node.rotate_loglik(x4, self._fwd_plan, bplan, self.Tinv8, mask, meas, pnm,
                                   angles_i, eps, [self.H, self.W, self.PH, self.PW, self.A, self.py, self.px, int(use_plan),
                                                   int(angles_i is not None), _stream_ptr(self._dev_index), int(self._compact)])
 

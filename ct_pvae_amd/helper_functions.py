@@ -175,7 +175,7 @@ class _ProjectLogLik(torch.autograd.Function):
         else:
             sino, lp = plan.forward_loglik(slices, mask, x, pnm, eps, angles_i=angles_i, dense_inputs=dense)
             if dense:      # the two-step backward reads compact operands
-                idx = angles_i.long()
+                idx = angles_i.to(mask.device).long()
                 mask, x = mask.index_select(1, idx).contiguous(), x.index_select(1, idx).contiguous()
             ctx.save_for_backward(sino, mask, x, pnm)
         return lp.unsqueeze(-1)
@@ -280,9 +280,9 @@ def calculate_log_prob_M_given_R(output_sample, mask, proj_sample, poisson_noise
         if plan.planned[0] or plan.tiled:
             sel = None
             if angles_i is not None:
-                sel = as_angle_index(angles_i, x.device)
+                sel = as_angle_index(angles_i, x.device, keep_host=True)   # host indices ride the launch arguments
                 if not plan.planned[0] or sel.numel() > plan.MAX_SEL:     # tiled geometry: gather here, tables in subset()
-                    idx = sel.long()
+                    idx = sel.to(x.device).long()
                     mask, proj_sample = mask.index_select(1, idx), proj_sample.index_select(1, idx)
                     plan, sel = plan.subset(sel), None
             n_in = plan.A

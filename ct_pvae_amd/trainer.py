@@ -398,7 +398,9 @@ class PVAETrainer:
         """Host side of a step: the batch, the angle subset and the two annealed scalars."""
         a = self.args
         proj_sample, mask, input_encode = self._batch()
-        angles_i = self._to_device(self.angles.next().astype(np.int32))   # the kernels' index operand is int32
+        # the step's angle subset stays in HOST memory: the projector kernels carry it in their launch arguments (no upload,
+        # nothing on the stream in front of the forward)
+        angles_i = torch.from_numpy(np.ascontiguousarray(self.angles.next().astype(np.int32)))
         pnm_factor = self.pnm_anneal ** self.iter
         self.kl_anneal = min(max(self.kl_anneal * a.klaf, 0.0), 100.0)
         return proj_sample, mask, input_encode, angles_i, pnm_factor, self.kl_anneal

@@ -186,7 +186,10 @@ int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H,
  * instead of 17 MB at the dataset's 180 angles, L2-resident on every XCD.  The plan kernel evaluates the reference
  * arithmetic exactly as the u16 plan's does; ctpvae_rotate_fwd_compact_f32 computes the SAME sums, bit for bit, as
  * ctpvae_rotate_fwd_planned{,_sel,_loglik,_loglik_sel}_f32 -- one entry point, optional operands:
- *   angle_idx_dev  NULL = all A plan angles; else the n_idx (1..256) plan angles to project, outputs [S][n_idx][PW]
+ *   angle_idx      NULL = all A plan angles; else the n_idx (1..256) plan angles to project, outputs [S][n_idx][PW];
+ *                  idx_on_host = 0: a DEVICE int32 vector; != 0: HOST memory (the training loop draws its subset on the
+ *                  host, ctvae/helper_functions.py:104-107) -- the indices then travel in the kernel arguments: no upload,
+ *                  no device copy for the kernel to wait on; the array may be reused as soon as the call returns
  *   lp_dev         NULL = ray-sums only; else the log-likelihood epilogue of ctpvae_rotate_fwd_planned_loglik_f32
  *                  (mask_dev, meas_dev, pnm_dev required; dense_inputs as in the _sel entry point; dlp_dev may be NULL)
  *   lp_sum_dev     NULL, or [S]: the PER-OBJECT log-likelihood sums the loss takes (ctvae/helper_functions.py:305-312),
@@ -204,9 +207,9 @@ int ctpvae_rotate_cplan_build_f32(const float *T8_dev, int A, int H, int W, int 
                                   ctpvae_stream_t stream);
 int ctpvae_rotate_cplan_overflowed(const void *cplan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream);
 int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *cplan_dev,
-                                  const int *angle_idx_dev, int n_idx, const float *mask_dev, const float *meas_dev,
-                                  int dense_inputs, const float *pnm_dev, float eps, float *sino_dev, float *lp_dev,
-                                  float *dlp_dev, float *lp_part_dev, float *lp_sum_dev, ctpvae_stream_t stream);
+                                  const int *angle_idx, int n_idx, int idx_on_host, const float *mask_dev,
+                                  const float *meas_dev, int dense_inputs, const float *pnm_dev, float eps, float *sino_dev,
+                                  float *lp_dev, float *dlp_dev, float *lp_part_dev, float *lp_sum_dev, ctpvae_stream_t stream);
 
 /* ... and the TF_COMPAT / NEAREST backward of such a subset: gsino_dev [S][n_idx][PW], Tinv8_dev the DENSE inverted table
  * [A_plan][8]; row k of a cotangent uses table row angle_idx_dev[k].  Same bits as ctpvae_rotate_bwd_scaled_f32 on the
@@ -215,6 +218,18 @@ int ctpvae_rotate_bwd_sel_scaled_f32(const float *gsino_dev, int S, int A_plan, 
                                      const int *angle_idx_dev, int n_idx, int H, int W, int py, int px,
                                      const float *scale_dev, long long scale_stride, float *gimg_dev,
                                      ctpvae_stream_t stream);
+
+/* ... through a plan: the "bwd4" layout stores the byte taps of the backward plan as one dword per (angle, four consecutive rows,
+ * column), so a launch can take any subset of the plan's angles (the 16-angles-per-vector layout of the plan above
+ * cannot).  Same bits as ctpvae_rotate_bwd_sel_scaled_f32 (sum over subset rows k ascending), no per-sample index
+ * arithmetic.  angle_idx / idx_on_host as in ctpvae_rotate_fwd_compact_f32 (host indices: n_idx <= 256).  _bytes: 0 if the geometry does not fit byte taps (PW > 255: keep ctpvae_rotate_bwd_sel_scaled_f32). */
+long long ctpvae_rotate_bwd4_plan_bytes(int H, int W, int PH, int PW, int A);
+int ctpvae_rotate_bwd4_plan_build_f32(const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py, int px,
+                                      void *plan_dev, ctpvae_stream_t stream);
+int ctpvae_rotate_bwd_planned_sel_scaled_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
+                                             const void *bwd4_plan_dev, const int *angle_idx, int n_idx, int idx_on_host,
+                                             const float *scale_dev, long long scale_stride, float *gimg_dev,
+                                             ctpvae_stream_t stream);
 
 /* (Which backward: both give the same bits.  The planned one wins except for large batches at few angles -- S >= 80
  * and A <= 64 -- where ctpvae_rotate_bwd_f32's segment kernel, which streams no indices, is up to 25 % faster.) */

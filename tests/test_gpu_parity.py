@@ -1714,3 +1714,79 @@ def test_calculate_log_prob_reduce_per_object(oracle, subset):
     assert torch.equal(xa.grad, xb.grad)
     with pytest.raises(ValueError, match="reduce must be"):
         cp.calculate_log_prob_M_given_R(xb, mask, meas, 1e4, 1.2e-7, theta=theta, reduce="mean")
+
+
+@pytest.mark.parametrize("shape,A,S,n", [((128, 128), 180, 10, 20), ((128, 128), 180, 1, 70), ((33, 47), 24, 5, 9),
+                                         ((128, 128), 180, 50, 180), ((6, 5), 7, 3, 40)])
+def test_angle_selecting_planned_backward(oracle, shape, A, S, n):
+    """The bwd4 plan (one dword = the four rows a lane owns at one angle): a planned backward that takes any subset of the
+    plan's angles (any order, repeats) -- the bits of the oracle on the gathered table and of the segment kernel."""
+    d = dev()
+    rng = np.random.default_rng(A + n)
+    theta = phantoms.dense_theta(A) if A == 180 else rng.uniform(-3, 3, A).astype(np.float32)
+    plan = RotatePlan(theta, shape[0], shape[1], True, d)
+    sub = rng.integers(0, A, n).astype(np.int32)
+    g = rng.standard_normal((S, n, plan.PW)).astype(np.float32)
+    gt, ai = torch.from_numpy(g).to(d), torch.from_numpy(sub).to(d)
+    scale = torch.from_numpy(rng.standard_normal(S).astype(np.float32)).to(d)
+    got = plan.backward(gt, angles_i=ai)
+    assert plan._bwd4_plan is not None
+    want = oracle.rotate_bwd_tfcompat(g, oracle.Geometry(shape[0], shape[1], True), oTinv(oracle, theta, plan)[sub], 0)
+    np.testing.assert_array_equal(to_np(got), want)
+    for ns, bw in ((1, 1), (2, 4), (1, 4), (2, 2)):
+        _lib.tune("BNS", ns), _lib.tune("BW", bw)
+        assert torch.equal(plan.backward(gt, angles_i=ai), got), (ns, bw)
+    _lib.tune("*")
+    got_s = plan.backward(gt, angles_i=ai, scale=scale)
+    plan._bwd4_plan, plan._want_bwd4 = None, False          # the segment kernel
+    assert torch.equal(plan.backward(gt, angles_i=ai), got)
+    assert torch.equal(plan.backward(gt, angles_i=ai, scale=scale), got_s)
+
+
+def test_host_resident_angle_subsets_ride_the_launch_arguments(oracle, torch_node):
+    """A subset that lives in host memory (the trainer draws it on the host) is carried in the kernel arguments of the compact
+    forward and of the angle-selecting backward: same bits as the device-index launches, no upload; an index outside the
+    angle list raises like the reference's tf.gather (device-resident indices cannot be read and are clamped)."""
+    from ct_pvae_amd.forward_functions import as_angle_index
+    import ct_pvae_amd.forward_functions as ff
+    d = dev()
+    rng = np.random.default_rng(21)
+    S, N = 5, 128
+    theta = phantoms.dense_theta(180)
+    plan = RotatePlan(theta, N, N, True, d)
+    assert plan.compact
+    x = torch.from_numpy(rng.random((S, N, N), dtype=np.float32)).to(d)
+    for n in (1, 20, 100, 256):
+        sub = rng.integers(0, 180, n).astype(np.int32)
+        host = as_angle_index(sub, d, keep_host=True)
+        assert host.device.type == "cpu"
+        on_dev = as_angle_index(sub, d)
+        f_h, f_d = plan.forward(x, angles_i=host), plan.forward(x, angles_i=on_dev)
+        assert torch.equal(f_h, f_d)
+        g = torch.from_numpy(rng.standard_normal((S, n, plan.PW)).astype(np.float32)).to(d)
+        assert torch.equal(plan.backward(g, angles_i=host), plan.backward(g, angles_i=on_dev))
+    with pytest.raises(ValueError, match="outside this plan"):
+        plan.forward(x, angles_i=as_angle_index(np.array([3, 180]), d, keep_host=True))
+    with pytest.raises(ValueError, match="outside this plan"):
+        plan.forward(x, angles_i=as_angle_index(np.array([-1, 2]), d, keep_host=True))
+    # the public call: numpy subset (host path) == device tensor subset, values and gradients, both autograd nodes
+    B = 4
+    x0 = torch.from_numpy(rng.random((B, N, N, 1), dtype=np.float32)).to(d)
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (B, 180)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((B, 180, 184), dtype=np.float32)).to(d)
+    sub = rng.permutation(180)[:20]
+    res = []
+    for use_cpp in (True, False):
+        ff.USE_CPP_NODE = use_cpp
+        try:
+            for idx in (sub, torch.from_numpy(sub).to(d)):
+                for red in (None, "per_object"):
+                    xa = x0.clone().requires_grad_(True)
+                    lp = cp.calculate_log_prob_M_given_R(xa, mask, meas, 1e4, 1.2e-7, theta=theta, angles_i=idx, pad=True, reduce=red)
+                    (lp.sum() if red is None else lp.sum()).backward()
+                    res.append((red, lp.detach().clone(), xa.grad.clone()))
+        finally:
+            ff.USE_CPP_NODE = True
+    for red, lp, gx in res:
+        ref = next(r for r in res if r[0] == red)
+        assert torch.equal(lp, ref[1]) and torch.equal(gx, ref[2])

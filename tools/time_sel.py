@@ -53,6 +53,19 @@ def bwd_sel():
     for ai in subs:
         dense.backward(dlp, out=gx, scale=w, angles_i=ai)
 
+subs_h = [ai.cpu() for ai in subs]
+def fwd_sel_host():
+    for ai in subs_h:
+        dense.forward_loglik(x, mask_d, meas_d, pnm, 1e-7, out=o, out_lp=lp, out_dlp=dlp, angles_i=ai, dense_inputs=True)
+
+def fwd_sums_host():
+    for ai in subs_h:
+        dense.forward_loglik_sums(x, mask_d, meas_d, pnm, 1e-7, angles_i=ai, dense_inputs=True)
+
+def bwd_sel_host():
+    for ai in subs_h:
+        dense.backward(dlp, out=gx, scale=w, angles_i=ai)
+
 def bwd_small():
     for _ in subs:
         small.backward(dlp, out=gx, scale=w)
@@ -62,6 +75,13 @@ for ns in (-1, 1, 2):
     print(f"NS={'auto' if ns < 0 else ns}: fwd+loglik sel (rotating subsets) {timed(fwd_sel):.2f} us, sel (one subset) {timed(fwd_sel_same):.2f} us, "
           f"own 20-angle plan {timed(fwd_small):.2f} us")
 _lib.tune("NS")
+print(f"host-resident subsets (launch arguments): fwd+loglik {timed(fwd_sel_host):.2f} us, fwd + per-object sums (2 launches) "
+      f"{timed(fwd_sums_host):.2f} us, bwd {timed(bwd_sel_host):.2f} us")
+for bns in (1, 2):
+    for bw in (1, 2, 4):
+        _lib.tune("BNS", bns); _lib.tune("BW", bw)
+        print(f"  bwd4 sel BNS={bns} BW={bw}: {timed(bwd_sel_host):.2f} us")
+_lib.tune("BNS"); _lib.tune("BW")
 for g in (1, 2, 3, 4, 6):
     _lib.tune("G", g)
     print(f"G={g}: sel rotating {timed(fwd_sel):.2f} us, own plan {timed(fwd_small):.2f} us")

@@ -5,9 +5,10 @@
 Runs `steps` (default 50) iterations of what find_loss_vae_unsup does with the projector (ctvae/helper_functions.py:336-368
 under ctvae/main_ct_vae.py:471-481): calculate_log_prob_M_given_R on ns * b = 10 objects with a fresh random 20-angle subset
 of the dataset's 180 angles per step, then backward of the per-object sums.  With ONE dense plan and the angle-index
-operand the trace must show the plan / table kernels (rotate_fwd_first_kernel, rotate_fwd_plan_kernel,
-rotate_class_list_kernel) ONCE, whatever the number of steps, and per step exactly one rotate_fwd_planned_kernel and one
-rotate_bwd_tfcompat_seg_kernel (profiles/r02_training_call_kernel_stats.csv)."""
+operand the trace must show the plan kernels (rotate_cplan_kernel, rotate_cplan_class_list_kernel, rotate_bwd4_plan_kernel) ONCE,
+whatever the number of steps, and per step exactly: one rotate_fwd_compact_kernel (projection + log-likelihood + per-task
+partial sums), one loglik_sum_partials_kernel, one rotate_bwd_planned_sel_kernel -- no at::native::reduce_kernel over the
+log-probabilities, no per-step copy of the angle subset (profiles/r03_training_call_kernel_stats.csv)."""
 import os
 import sys
 
@@ -27,11 +28,11 @@ mask = torch.from_numpy(((rng.random((B, 180)) > 0.5) / 20).astype(np.float32)).
 meas = torch.from_numpy((rng.random((B, 180, P)) * 3).astype(np.float32)).to(d)
 x = torch.rand((B, N, N, 1), device=d, requires_grad=True)
 pnm = torch.tensor(1e4, device=d)
-subsets = [torch.from_numpy(rng.permutation(180)[:20].astype(np.int32)).to(d) for _ in range(steps)]
+subsets = [rng.permutation(180)[:20].astype(np.int32) for _ in range(steps)]      # host-resident, as the trainer draws them
 torch.cuda.synchronize()
 for ai in subsets:
     x.grad = None
-    lp = cp.calculate_log_prob_M_given_R(x, mask, meas, pnm, 1e-7, theta=theta, angles_i=ai, pad=True)
+    lp = cp.calculate_log_prob_M_given_R(x, mask, meas, pnm, 1e-7, theta=theta, angles_i=ai, pad=True, reduce="per_object")
     lp.sum().backward()
 torch.cuda.synchronize()
 print("done", steps)
