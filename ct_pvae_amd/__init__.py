@@ -9,6 +9,6 @@ from .helper_functions import (calculate_log_prob_M_given_R, create_sinogram, cr
                                gaussian_poisson_log_prob)
 from .create_masks import create_all_masks  # noqa: F401
 from .fbp import iradon, iradon_all  # noqa: F401
-from .recon import crop, recon, siddon_backproject  # noqa: F401
+from .recon import crop, evaluate_sinogram, recon, siddon_backproject  # noqa: F401
 
 __version__ = "0.2.0"

@@ -84,6 +84,10 @@ SIGNATURES = {
                                                 ctypes.c_double, ctypes.c_double, _vp, _vp]),
     "ctpvae_fbp_backproject_geom_f64": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, ctypes.c_double,
                                                  ctypes.c_double, ctypes.c_double, _vp, _vp]),
+    "ctpvae_gridrec_tables_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
+    "ctpvae_gridrec_tables_host_f32": (_c_int, [_c_int, _c_int, _c_float, _vp, _c_int, _vp, _vp]),
+    "ctpvae_gridrec_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "ctpvae_gridrec_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp]),
     "ctpvae_loglik_fwd_f32": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_float, _vp, _vp]),
     "ctpvae_poisson_measure_f32": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_float, ctypes.c_ulonglong, _vp, _vp]),
     "ctpvae_philox4x32_10": (_c_int, [_vp, _vp, _vp]),

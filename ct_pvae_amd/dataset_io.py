@@ -52,7 +52,8 @@ def images_to_sinograms(x_train_imgs, save_path, theta=None, pad=True, batch=256
 
 
 def crop(img_2d, final_x, final_y, ignore_dim_0=False):
-    """ctvae/helper_functions.py:420-430"""
+    """ctvae/helper_functions.py:420-430 -- the package's one `crop` (arrays and tensors, any leading axes; ignore_dim_0 is
+    accepted for the reference's signature: the last two axes are cropped either way)."""
     x, y = img_2d.shape[-2:]
     rx, ry = final_x % 2, final_y % 2
     return img_2d[..., x // 2 - final_x // 2:x // 2 + final_x // 2 + rx, y // 2 - final_y // 2:y // 2 + final_y // 2 + ry]

@@ -139,7 +139,7 @@ def iradon_all(all_proj_samples, all_masks, num_proj_pix, theta, algorithms, sqr
     `algorithms` -- tomopy.recon(proj_sample_expand, theta, center=None, sinogram_order=True, algorithm=...) cropped to
     x_size x y_size (:503-505) -- plus the un-filtered back-projection of the dose mask (algorithm='fbp',
     filter_name='none', :514-515).  The reconstructions run on the GPU (ct_pvae_amd/recon.py: 'fbp', 'sirt' on the
-    TomoPy-style operator pair, 'gridrec' as ramp-filtered back-projection on the same grid, 'tv' as a flagged
+    TomoPy-style operator pair, 'gridrec' = libtomo's gridrec.c on csrc/gridrec.hip, 'tv' as a flagged
     Chambolle-Pock stand-in).
     Returns [n][x_size][y_size][len(algorithms) + 1] float32 on the sinograms' device and, like the reference, writes /
     reads ``all_input_encode.npy`` under `save_path`."""

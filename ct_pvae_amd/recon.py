@@ -13,10 +13,13 @@ Here `recon` takes the same arguments and runs on the hand-written kernels behin
                reference asks for the mask channel.  [3P-recalled: TomoPy 1.11.0]
     'sirt'     libtomo's sirt.c update rule on the same operator pair (ctpvae_siddon_fwd_f32 / _bwd_f32 / _rownorm_f32):
                recon += (A^T ((data - A recon) / sum_dist2)) / sum_dist, tomopy's defaults num_iter=1, init 1e-6.
-    'gridrec'  STAND-IN, flagged: gridrec is a Fourier-gridding inversion (gridrec.c: PSWF convolution kernel, 2-D FFT) of
-               which only the operator it approximates -- ramp-filtered back-projection, filter_name 'none' = plain ramp -- is
-               restated here, as the float64 FBP of csrc/fbp.hip on the same grid.  Same reconstruction up to discretisation;
-               not TomoPy's bits.
+    'gridrec'  libtomo's gridrec.c (round 3): zero-padded 1-D FFTs of the projections, filter x centre phase, convolution onto
+               a Cartesian frequency grid with the prolate-spheroidal window, 2-D FFT, window correction -- csrc/gridrec.hip
+               (hand-written LDS FFTs, the convolution as a deterministic gather), restated in oracle/gridrec_oracle.c.
+               filter_name defaults to tomopy's per-algorithm default 'parzen' (algorithm.py _get_algorithm_kwargs); 'none',
+               'shepp', 'cosine', 'hann', 'hamming', 'ramlak', 'butterworth' are built too.  [3P-recalled: TomoPy 1.11.0]
+               (The round-2 stand-in -- float64 ramp-filtered back-projection on the same grid -- stays reachable under its own
+               name: algorithm='fbp', filter_name='ramp'; it is NOT a tomopy filter name.)
     'tv'       STAND-IN, flagged: total-variation regularised reconstruction on the same operator pair by the diagonally
                preconditioned Chambolle-Pock iteration (Pock & Chambolle 2011: step sizes from the operator's own row and
                column sums -- sirt.c's sum_dist2-free weights -- so nothing has to be tuned), reg_par[0] = the TV weight.
@@ -30,21 +33,47 @@ import numpy as np
 import torch
 
 from . import _lib
+from .dataset_io import compare, crop
 from .fbp import iradon, ramp_filter
 from .forward_functions import _stream_ptr
 from .helper_functions import _siddon_tables
 
-__all__ = ["recon", "siddon_backproject", "crop", "ALGORITHMS"]
+__all__ = ["recon", "siddon_backproject", "crop", "evaluate_sinogram", "ALGORITHMS", "GRIDREC_FILTERS"]
 
 ALGORITHMS = ("fbp", "sirt", "gridrec", "tv")
+GRIDREC_FILTERS = {"none": 0, "shepp": 1, "cosine": 2, "hann": 3, "hamming": 4, "ramlak": 5, "parzen": 6, "butterworth": 7}
+# tomopy/recon/algorithm.py _get_algorithm_kwargs [3P-recalled]: the default filter_name is per algorithm
+_DEFAULT_FILTER = {"gridrec": "parzen", "fbp": "none"}
+_GRIDREC_TABLES = {}
 
 
-def crop(img, final_x, final_y, ignore_dim_0=False):
-    """ctvae/helper_functions.py:420-430 (works on tensors and arrays alike)."""
-    x, y = img.shape[-2], img.shape[-1]
-    rx, ry = final_x % 2, final_y % 2
-    sl = (slice(x // 2 - final_x // 2, x // 2 + final_x // 2 + rx), slice(y // 2 - final_y // 2, y // 2 + final_y // 2 + ry))
-    return img[(slice(None),) + sl] if ignore_dim_0 else img[sl]
+def _gridrec(data, theta, gx, gy, filter_name, filter_par):
+    """data [oy][dt][dx] float32 on the device -> [oy][gx][gy] (tomopy.recon(algorithm='gridrec'), center = dx / 2)."""
+    lib = _lib.load()
+    oy, dt, dx = data.shape
+    if filter_name not in GRIDREC_FILTERS:
+        raise ValueError(f"recon: gridrec filter_name must be one of {sorted(GRIDREC_FILTERS)} (got {filter_name!r})")
+    th = np.ascontiguousarray(np.asarray(theta, dtype=np.float32))
+    par = np.ascontiguousarray(np.asarray([0.5, 8.0] if filter_par is None else filter_par, dtype=np.float32))
+    key = (th.tobytes(), dx, filter_name, par.tobytes(), str(data.device))
+    tab = _GRIDREC_TABLES.get(key)
+    if tab is None:
+        nbytes = lib.ctpvae_gridrec_tables_bytes(dt, dx)
+        _lib.check(nbytes, "gridrec_tables_bytes")
+        host = np.empty(int(nbytes), dtype=np.uint8)
+        _lib.check(lib.ctpvae_gridrec_tables_host_f32(dt, dx, ctypes.c_float(dx / 2.0), th.ctypes.data, GRIDREC_FILTERS[filter_name],
+                                                      par.ctypes.data, host.ctypes.data), "gridrec_tables")
+        tab = torch.from_numpy(host).to(data.device)
+        if len(_GRIDREC_TABLES) >= 16:
+            _GRIDREC_TABLES.pop(next(iter(_GRIDREC_TABLES)))
+        _GRIDREC_TABLES[key] = tab
+    need = lib.ctpvae_gridrec_workspace_bytes(oy, dt, dx)
+    _lib.check(need, "gridrec_workspace_bytes")
+    ws = torch.empty(int(need), dtype=torch.uint8, device=data.device)
+    out = torch.empty((oy, gx, gy), dtype=torch.float32, device=data.device)
+    _lib.check(lib.ctpvae_gridrec_f32(data.data_ptr(), oy, dt, dx, tab.data_ptr(), gx, gy, ws.data_ptr(), out.data_ptr(),
+                                      _stream_ptr()), "gridrec")
+    return out
 
 
 def _as_device_f32(t, what):
@@ -161,11 +190,14 @@ def _tv(data, tables, gx, gy, num_iter, init, lam):
 
 
 def recon(tomo, theta, center=None, sinogram_order=False, algorithm=None, init_recon=None, num_gridx=None, num_gridy=None,
-          num_iter=1, filter_name="none", reg_par=None, **kwargs):
+          num_iter=1, filter_name=None, filter_par=None, reg_par=None, **kwargs):
     """tomopy.recon's call shape for the algorithms above.  tomo: [angles][slices][dx] (sinogram_order=False) or
-    [slices][angles][dx] (True), a float tensor on a HIP device.  Returns [slices][num_gridx][num_gridy] float32."""
+    [slices][angles][dx] (True), a float tensor on a HIP device.  Returns [slices][num_gridx][num_gridy] float32.
+    filter_name None = tomopy's default for the algorithm ('parzen' for gridrec, 'none' for fbp)."""
     if algorithm not in ALGORITHMS:
         raise ValueError(f"recon: unknown algorithm {algorithm!r}; available: {ALGORITHMS}")
+    if filter_name is None:
+        filter_name = _DEFAULT_FILTER.get(algorithm, "none")
     data = _as_device_f32(tomo, "tomo")
     if data.dim() != 3:
         raise ValueError(f"tomo must be 3-D (got {tuple(data.shape)})")
@@ -181,14 +213,17 @@ def recon(tomo, theta, center=None, sinogram_order=False, algorithm=None, init_r
         return data.new_empty((0, gx, gy))
     with torch.cuda.device(data.device):
         if algorithm == "gridrec":
-            if filter_name != "none":
-                raise NotImplementedError("recon: the gridrec stand-in has the plain ramp (filter_name='none') only")
+            return _gridrec(data, theta, gx, gy, filter_name, filter_par)
+        if algorithm == "fbp" and filter_name == "ramp":
+            # round 2's gridrec stand-in under its own name: float64 ramp-filtered back-projection on tomopy's grid (an
+            # extension: 'ramp' is not a tomopy filter name)
             return iradon(data.to(torch.float64), np.asarray(theta, dtype=np.float64), gx, gy, ramp_filter(dx),
                           tomopy_geometry=True).to(torch.float32)
         tables = _siddon_tables(theta, data.device)
         if algorithm == "fbp":
             if filter_name != "none":
-                raise NotImplementedError("recon: 'fbp' is built with filter_name='none' (the reference's only use of it)")
+                raise NotImplementedError("recon: 'fbp' is built with filter_name='none' (the reference's only use of it) and "
+                                          "the extension 'ramp'")
             out = _backproject(data, tables, gx, gy)
             return out if init_recon is None else out + init_recon
         init = torch.full((oy, gx, gy), 1e-6, dtype=torch.float32, device=data.device) if init_recon is None else \
@@ -199,3 +234,31 @@ def recon(tomo, theta, center=None, sinogram_order=False, algorithm=None, init_r
                 raise ValueError("recon: reg_par[0] (the TV weight) must be positive")
             return _tv(data, tables, gx, gy, num_iter, init, lam)
         return _sirt(data, tables, gx, gy, num_iter, init)
+
+
+def evaluate_sinogram(actual_sinogram, computed_sinogram, partial_noisy_sinogram, mask, theta, final_x, final_y,
+                      algorithm="sirt", verbose=True):
+    """ctvae/helper_functions.py:433-475: reconstruct the actual, the predicted and the masked noisy sinogram ([angles][P]
+    each) with `algorithm`, crop to final_x x final_y and compare the last two against the first -- (MSE, SSIM, PSNR) twice,
+    then the three reconstructions.  Sinograms and mask may be numpy arrays or tensors; the reconstructions run on the GPU."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def to_dev(a):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+        return t.to(device=dev, dtype=torch.float32)
+
+    theta = np.asarray(theta, dtype=np.float32)
+    mask_h = mask.detach().cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+    used = mask_h > 0
+    recon0 = recon(to_dev(actual_sinogram)[:, None, :], theta, center=None, algorithm=algorithm, sinogram_order=False)[0]
+    recon1 = recon(to_dev(computed_sinogram)[:, None, :], theta, center=None, algorithm=algorithm, sinogram_order=False)[0]
+    noisy = to_dev(partial_noisy_sinogram)[torch.from_numpy(used).to(dev)] / to_dev(mask_h[used])[:, None]
+    recon2 = recon(noisy[:, None, :], theta[used], center=None, algorithm=algorithm, sinogram_order=False)[0]
+    recon0, recon1, recon2 = (crop(r, final_x, final_y).cpu().numpy() for r in (recon0, recon1, recon2))
+    if verbose:
+        print("Predicted")
+    predicted_err = list(compare(recon0, recon1, verbose=verbose))
+    if verbose:
+        print("Noisy")
+    noisy_err = list(compare(recon0, recon2, verbose=verbose))
+    return predicted_err, noisy_err, recon0, recon1, recon2

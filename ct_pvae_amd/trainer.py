@@ -586,7 +586,7 @@ def get_args(argv=None):
     p.add_argument("--td", type=int, dest="td", default=100)
     p.add_argument("--algorithms", nargs="+", default=["gridrec"],
                    help="initial reconstructions fed to the encoder, one channel each (ctvae/main_ct_vae.py:111-112, same "
-                        "default); on the GPU: gridrec (ramp-filtered back-projection stand-in), sirt, fbp "
+                        "default); on the GPU: gridrec (csrc/gridrec.hip, tomopy's default parzen filter), sirt, fbp "
                         "(ct_pvae_amd/recon.py), tv (flagged stand-in)")
     p.add_argument("--train", action="store_true")
     # synthetic-data knobs (the reference reads these from its dataset folder)

@@ -37,6 +37,8 @@
  *                                              ctvae/helper_functions.py:33-38
  *   ctpvae_siddon_bwd_f32 / _rownorm_f32       tomopy.recon(algorithm='fbp' | 'sirt') behind iradon_all / evaluate_sinogram
  *                                              ctvae/helper_functions.py:445-457,503,514
+ *   ctpvae_gridrec_*                           tomopy.recon(algorithm='gridrec'), the default of iradon_all / evaluate_sinogram
+ *                                              ctvae/helper_functions.py:445-457,503; ctvae/main_ct_vae.py:111-112
  *   ctpvae_fbp_filter_f64 / _backproject{,_bwd}_f64   iradon  ctvae/fbp_tensorflow.py:14-75
  *   ctpvae_loglik_fwd_f32 / _bwd_f32           calculate_log_prob_M_given_R
  *                                              ctvae/helper_functions.py:360-368
@@ -301,6 +303,23 @@ int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P,
 int ctpvae_fbp_backproject_bwd_f64(const double *grecon_dev, int B, int A, int P, const double *cos_dev,
                                    const double *sin_dev, int X, int Y, double x0, double y0, double t0,
                                    double *gfilt_dev, ctpvae_stream_t stream);
+
+/* ---- f3: TomoPy's gridrec (the encoder's default input channel: tomopy.recon(..., algorithm='gridrec') at
+ * ctvae/helper_functions.py:503, defaults ctvae/main_ct_vae.py:111-112; evaluate_sinogram ctvae/helper_functions.py:445-457;
+ * bin/final_merit.py:58,81) -- TomoPy 1.11.0 libtomo/gridrec/gridrec.c [recalled, see oracle/gridrec_oracle.c]: zero-padded
+ * 1-D FFT of every projection (two slices per complex transform), filter x centre phase, convolution onto a pdim x pdim
+ * frequency grid with the separable prolate-spheroidal window, 2-D FFT, window correction.  pdim = the power of two >= dx.
+ * _tables_host_f32 fills a HOST buffer of _tables_bytes() bytes (twiddles, window, correction, trig, filter x phase; every
+ * pointer host memory; filter_name 0 none, 1 shepp, 2 cosine, 3 hann, 4 hamming, 5 ramlak, 6 parzen = tomopy's default for
+ * gridrec, 7 butterworth with filter_par = {cutoff, order}); the caller uploads it.  _f32: data_dev [dy][dt][dx] (sinogram
+ * order) -> recon_dev [dy][ngridx][ngridy]; deterministic (the convolution is a gather in gridrec.c's order, no atomics);
+ * workspace_dev: _workspace_bytes() bytes of device memory, contents undefined. */
+long long ctpvae_gridrec_tables_bytes(int dt, int dx);
+int ctpvae_gridrec_tables_host_f32(int dt, int dx, float center, const float *theta, int filter_name, const float *filter_par,
+                                   void *tables);
+long long ctpvae_gridrec_workspace_bytes(int dy, int dt, int dx);
+int ctpvae_gridrec_f32(const float *data_dev, int dy, int dt, int dx, const void *tables_dev, int ngridx, int ngridy,
+                       void *workspace_dev, float *recon_dev, ctpvae_stream_t stream);
 
 /* Per-object sums of a log-probability array lp_dev [S][A][PW] -> out_dev [S] (reduce_sum over angles and bins,
  * ctvae/helper_functions.py:305-306), in a FIXED order so that every path gives the same bits: the [A][PW] values of a slice

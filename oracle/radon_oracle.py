@@ -22,10 +22,10 @@ _i = ctypes.c_int
 
 def build(force=False):
     """Compile the restatement with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "radon_oracle.c")
+    srcs = [os.path.join(_HERE, "radon_oracle.c"), os.path.join(_HERE, "gridrec_oracle.c")]
     if "CTPVAE_ORACLE_LIB" in os.environ:
         return LIB_PATH
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-s", "-B"], check=True)
     return LIB_PATH
 
@@ -60,6 +60,13 @@ def lib():
         L.oracle_poisson_count.restype = ctypes.c_double
         L.oracle_poisson_count.argtypes = [ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64]
         L.oracle_poisson_measure.argtypes = [_f32p, _f32p, _i, _i, _i, ctypes.c_float, ctypes.c_uint64, _f32p]
+        L.oracle_gridrec_pdim.restype = _i
+        L.oracle_gridrec_pdim.argtypes = [_i]
+        L.oracle_gridrec.restype = _i
+        L.oracle_gridrec.argtypes = [_f32p, _i, _i, _i, ctypes.c_float, _f32p, _i, _i, _i, _f32p, _f32p]
+        L.oracle_gridrec_pswf_tables.argtypes = [_i, _f32p, _f32p]
+        L.oracle_gridrec_filter.restype = ctypes.c_float
+        L.oracle_gridrec_filter.argtypes = [_i, ctypes.c_float, _i, _f32p]
         for name in ("oracle_series_log_public", "oracle_series_exp_neg_public"):
             getattr(L, name).restype = ctypes.c_double
             getattr(L, name).argtypes = [ctypes.c_double]
@@ -231,6 +238,31 @@ def loglik(proj, mask, x, pnm, eps):
     out = np.empty_like(proj)
     lib().oracle_loglik(proj, mask, x, B, A, P, pnm, eps, out)
     return out
+
+
+GRIDREC_FILTERS = {"none": 0, "shepp": 1, "cosine": 2, "hann": 3, "hamming": 4, "ramlak": 5, "parzen": 6, "butterworth": 7}
+
+
+def gridrec(data, theta, filter_name="parzen", filter_par=(0.5, 8.0), ngridx=None, ngridy=None, center=None):
+    """tomopy.recon(data, theta, center=None, sinogram_order=True, algorithm='gridrec') [3P-recalled: TomoPy 1.11.0
+    gridrec.c + algorithm.py defaults: filter 'parzen', grid = detector width, center = width / 2]; data [dy][dt][dx]."""
+    data, theta = _c32(data), _c32(theta)
+    dy, dt, dx = data.shape
+    gx, gy = int(ngridx or dx), int(ngridy or dx)
+    out = np.empty((dy, gx, gy), np.float32)
+    par = _c32(np.asarray(filter_par, np.float32))
+    rc = lib().oracle_gridrec(data, dy, dt, dx, float(dx / 2.0 if center is None else center), theta, gx, gy,
+                              GRIDREC_FILTERS[filter_name], par, out)
+    if rc:
+        raise ValueError("oracle_gridrec: the grid must not exceed the padded detector width")
+    return out
+
+
+def gridrec_pswf_tables(dx):
+    pdim = lib().oracle_gridrec_pdim(dx)
+    wtbl, winv = np.empty(513, np.float32), np.empty(pdim - 1, np.float32)
+    lib().oracle_gridrec_pswf_tables(pdim // 2 - 1, wtbl, winv)
+    return wtbl, winv
 
 
 def loglik_task_bins(PW, partition=0):

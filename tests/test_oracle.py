@@ -494,3 +494,63 @@ def test_object_sum_order_covers_every_bin_once(oracle):
         want = lp.astype(np.float64).sum(axis=(1, 2))
         assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
     assert not np.array_equal(oracle.loglik_object_sums(lp, 0), lp.sum(axis=(1, 2)))   # it IS an order of its own
+
+
+def _asym_phantom(N):
+    yy, xx = np.mgrid[0:N, 0:N].astype(np.float64)
+    img = np.exp(-((yy - N * 0.4) ** 2 + (xx - N * 0.55) ** 2) / (2 * (N / 10) ** 2))
+    img += 0.5 * np.exp(-((yy - N * 0.65) ** 2 + (xx - N * 0.35) ** 2) / (2 * (N / 14) ** 2))
+    return img.astype(np.float32)[None]
+
+
+def test_gridrec_restatement_reconstructs_a_projected_phantom_in_place(oracle):
+    """What pins the recalled gridrec (oracle/gridrec_oracle.c): tomopy.project -> tomopy.recon(gridrec) must return the
+    phantom where it was.  A smooth asymmetric phantom, projected by the ray-driven oracle, comes back in place: of the eight
+    flips / transposes only the identity fits, no shift of +-1 pixel fits better, and after an affine fit (gridrec drops the
+    zero frequency -> a small negative offset; its gain is what the recalled normalisation gives: measured 1.10-1.15, stated
+    here and in DESIGN.md, not hidden) the residual is under 12 % at this 64-pixel size (5 % at 128).  The correction table is symmetric with alternating
+    sign and the window decays monotonically from 1."""
+    N = 64
+    img = _asym_phantom(N)
+    theta = np.linspace(0, np.pi, 180, endpoint=False).astype(np.float32)
+    data = np.ascontiguousarray(oracle.siddon_project(img, theta, pad=True).transpose(1, 0, 2))
+    dx = data.shape[2]
+    pad = (dx - N) // 2
+    full = np.zeros((dx, dx))
+    full[pad:pad + N, pad:pad + N] = img[0]
+
+    def fit(rec):
+        A = np.stack([full.ravel(), np.ones(full.size)], 1)
+        (a, b), *_ = np.linalg.lstsq(A, rec.ravel().astype(np.float64), rcond=None)
+        return a, b, np.linalg.norm(rec - a * full - b) / np.linalg.norm(full)
+
+    for name in ("parzen", "ramlak", "shepp", "hann", "hamming", "cosine", "butterworth"):
+        rec = oracle.gridrec(data, theta, filter_name=name)[0]
+        a, b, res = fit(rec)
+        assert 1.0 < a < 1.25 and -0.05 < b <= 0.0 and res < 0.12, (name, a, b, res)
+    rec = oracle.gridrec(data, theta)[0]          # the default: parzen
+    variants = {"id": rec, "T": rec.T, "f0": rec[::-1], "f1": rec[:, ::-1], "Tf0": rec.T[::-1], "Tf1": rec.T[:, ::-1],
+                "r180": rec[::-1, ::-1], "Tr180": rec.T[::-1, ::-1]}
+    res = {k: fit(v)[2] for k, v in variants.items()}
+    assert min(res, key=res.get) == "id" and res["id"] < 0.5 * sorted(res.values())[1]
+    # position: rows (the axis gridrec.c mirrors on the way out) sit in place; along the columns -- the detector axis at
+    # theta = 0 -- the recalled gridrec lands HALF A PIXEL off the ray-driven projector's grid (its centre dx / 2 is sample
+    # 92, the projector's axis lies between bins 91 and 92): stated, not corrected -- the restatement follows the recollection
+    w = np.clip(rec, 0, None).astype(np.float64)
+    idx = np.arange(dx)
+    drow = (w * idx[:, None]).sum() / w.sum() - (full * idx[:, None]).sum() / full.sum()
+    dcol = (w * idx[None, :]).sum() / w.sum() - (full * idx[None, :]).sum() / full.sum()
+    assert abs(drow) < 0.15 and 0.35 < dcol < 0.8, (drow, dcol)
+    shifts = {(da, db): fit(np.roll(np.roll(rec, da, 0), db, 1))[2] for da in (-1, 0, 1) for db in (-1, 0, 1)}
+    assert min(shifts, key=shifts.get) in ((0, 0), (0, -1))
+    # two slices ride one complex transform: each comes out as if reconstructed alone (to fp32 rounding); odd counts too
+    img2 = np.concatenate([img, img[:, ::-1].copy(), 0.5 * img], 0)
+    data3 = np.ascontiguousarray(oracle.siddon_project(img2, theta, pad=True).transpose(1, 0, 2))
+    rec3 = oracle.gridrec(data3, theta)
+    for k in range(3):
+        alone = oracle.gridrec(data3[k:k + 1], theta)[0]
+        assert np.abs(rec3[k] - alone).max() <= 2e-5 * np.abs(alone).max()
+    wtbl, winv = oracle.gridrec_pswf_tables(dx)
+    assert wtbl[0] == 1.0 and (np.diff(wtbl) < 0).all() and wtbl[-1] > 0
+    c = len(winv) // 2
+    assert (winv[c + 1:] == winv[:c][::-1]).all() and (np.sign(winv[c:]) == np.where(np.arange(c + 1) % 2 == 0, 1, -1)).all()
