@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="config 4 (batch=400 over 8 GPUs, 180 angles): every step also sums one flat fp32 bucket of the "
                          "P-VAE's 711,164 gradients (2.8 MB) over the ranks -- the data-parallel trainer's only collective")
+    ap.add_argument("--cold", action="store_true",
+                    help="cycle 96 distinct input batches (objects + cotangents, 385 MB at the default shape: more than the "
+                         "256 MB Infinity Cache) instead of re-projecting ONE resident batch; config.inputs says which")
     ap.add_argument("--n512-batch", type=int, default=32,
                     help="objects per GPU in --mode n512 (32: 768 tile workgroups = 3 full rounds on 256 CUs; 8: 192)")
     return ap.parse_args()
@@ -373,25 +376,42 @@ def main():
     g = torch.from_numpy(g_host).to(dev)
     sino = torch.empty((B, A, P), dtype=torch.float32, device=dev)
     gimg = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+    # Cache state of the inputs.  Default ("cache-warm"): every step re-projects the SAME resident batch -- 3.3 MB of objects
+    # and 0.7 MB of cotangents that stay in the 256 MB Infinity Cache between steps.  --cold cycles n_cold distinct batches
+    # (the first is the foam batch, the others are it rolled and rescaled: same statistics, distinct memory) whose total
+    # exceeds the Infinity Cache, so every step's inputs come from HBM.
+    n_cold = 96 if args.cold else 1
+    x_bank, g_bank = [x], [g]
+    for k in range(1, n_cold):
+        x_bank.append(torch.roll(x, shifts=(k, 3 * k), dims=(1, 2)) * (1.0 - 0.002 * k))
+        g_bank.append(torch.roll(g, shifts=k, dims=2).contiguous())
+    cursor = [0]
 
-    bucket = torch.zeros(711164, dtype=torch.float32, device=dev) if args.grad_allreduce else None
+    bucket = torch.zeros(711164, dtype=torch.float32, device=dev) if (args.grad_allreduce or world > 1) else None
+
+    def projector_step():
+        i = cursor[0]
+        cursor[0] = (i + 1) % n_cold
+        plan.forward(x_bank[i], out=sino)
+        plan.backward(g_bank[i], out=gimg)
 
     def step():
-        plan.forward(x, out=sino)
-        plan.backward(g, out=gimg)
-        if bucket is not None and world > 1:
+        projector_step()
+        if args.grad_allreduce and world > 1:
             torch.distributed.all_reduce(bucket)                 # RCCL over xGMI: the bucket is already flat
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, n_cold if args.cold else 0)):
         step()
     # The two launches of a step take 6-8 us each -- about what one Python call of them costs the host -- so the timed
     # loop replays HIP graphs of 10 steps (20 kernel nodes, the same launches in the same order) and launches only the
     # K mod 10 remaining steps from Python: the GPU runs back to back whatever the host's speed (measured: 13.97 us per
     # step replayed against 14.45 us launched on a fast host, and host-bound on a slow one).  Not with the RCCL bucket.
-    chunk = 10
+    chunk = n_cold if args.cold else 10        # (cold: one graph walks all the distinct batches once)
     graph = None
-    if not args.no_graph and bucket is None and args.steps >= chunk:
+    cursor[0] = 0
+    if not args.no_graph and not args.grad_allreduce and args.steps >= chunk:
         graph = capture_graph(lambda: [step() for _ in range(chunk)])
+        cursor[0] = 0
     n_replay, n_eager = divmod(args.steps, chunk) if graph is not None else (0, args.steps)
 
     def timed_region():
@@ -411,6 +431,41 @@ def main():
     while sum(regions) * 1e3 < args.min_ms and len(regions) < 10000:
         regions.append(timed_region())
     elapsed = float(np.median(regions))
+
+    # ---- multi-GPU: the same K steps WITH the data-parallel trainer's one collective ------------------------------------
+    # north_star: "batches of objects shard across the GPUs of one node with RCCL all-reduce of VAE gradients".  The projector
+    # itself needs no collective (value above); a data-parallel training step also sums ONE flat fp32 bucket of the P-VAE's
+    # 711,164 gradients (2.8 MB) over the ranks.  Reported beside `value`, never instead of it: every step = the projector
+    # pair (replayed from a one-step HIP graph) followed by the bucket's all-reduce on the same stream.
+    with_allreduce = None
+    if world > 1 and not args.grad_allreduce:
+        import torch.distributed as dist
+        cursor[0] = 0
+        g1 = None if (args.no_graph or args.cold) else capture_graph(projector_step)
+        cursor[0] = 0
+
+        def ar_region():
+            barrier_sync(world)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                (g1.replay if g1 is not None else projector_step)()
+                dist.all_reduce(bucket)
+            return close_timed_region(t0, world)
+
+        ar_region()
+        ar_regions = [ar_region()]
+        while sum(ar_regions) * 1e3 < args.min_ms and len(ar_regions) < 10000:
+            ar_regions.append(ar_region())
+        ev_ar = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+        barrier_sync(world)
+        for e0, e1 in ev_ar:
+            e0.record()
+            dist.all_reduce(bucket)
+            e1.record()
+        torch.cuda.synchronize()
+        with_allreduce = {"seconds": float(np.median(ar_regions)), "repeats": len(ar_regions),
+                          "allreduce_us": float(np.median([e0.elapsed_time(e1) * 1e3 for e0, e1 in ev_ar])),
+                          "backend": dist.get_backend(), "ranks": dist.get_world_size()}
 
     # ---- per-kernel durations, HIP events on the launch stream (torch's current stream) -------------------
     # One event pair brackets n_ev back-to-back launches of ONE kernel: the average duration of a launch in a stream of
@@ -442,8 +497,17 @@ def main():
             runs.append(e0.elapsed_time(e1) * 1e-3 / n_ev)
         return float(np.median(runs))
 
-    t_fwd = avg_launch_seconds(lambda: plan.forward(x, out=sino))
-    t_bwd = avg_launch_seconds(lambda: plan.backward(g, out=gimg))
+    def cycling(fn_of_index):
+        state = [0]
+
+        def fn():
+            i = state[0]
+            state[0] = (i + 1) % n_cold
+            fn_of_index(i)
+        return fn
+
+    t_fwd = avg_launch_seconds(cycling(lambda i: plan.forward(x_bank[i], out=sino)))
+    t_bwd = avg_launch_seconds(cycling(lambda i: plan.backward(g_bank[i], out=gimg)))
 
     # spread of single steps (median and p10/p90): one event pair per fwd+adj step, 200 steps; each figure
     # carries the ~1.5 us of its own event pair, so read it as a distribution, not as `ms_per_step`
@@ -530,7 +594,7 @@ def main():
     if rank != 0:
         return
     bytes_dir = 4.0 * B * (N * N + A * P)                 # one direction: read once + write once (fp32)
-    fwd_name = "rotate_fwd_planned_kernel" if plan.planned[0] else "rotate_fwd_fast_kernel"
+    fwd_name = ("rotate_fwd_compact_kernel" if plan.compact else "rotate_fwd_planned_kernel") if plan.planned[0] else "rotate_fwd_fast_kernel"
     bwd_name = "rotate_bwd_planned_kernel" if plan.backward_uses_plan(B) else "rotate_bwd_tfcompat_seg_kernel"
     dom = (fwd_name, t_fwd) if t_fwd >= t_bwd else (bwd_name, t_bwd)
     achieved = bytes_dir / dom[1] / 1e9
@@ -564,6 +628,11 @@ def main():
         "developer_knobs": {"library_knobs_set": _lib.load().ctpvae_tune_active(), "env": tune_env},
         "config": {"workload": f"batch={B}/GPU {N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
                    "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}",
+                   "inputs": (f"cold: {n_cold} distinct batches cycled, {n_cold * (x.numel() + g.numel()) * 4 / 1e6:.0f} MB > the "
+                              "256 MB Infinity Cache" if args.cold else
+                              "cache-warm: ONE resident batch re-projected every step (3.3 MB of objects + 0.7 MB of cotangents "
+                              "stay in the Infinity Cache; --cold cycles 96 distinct batches)"),
+                   "forward_plan": "compact (2 bits per row)" if plan.compact else "u16 taps",
                    "grad_allreduce_bytes_per_step": 4 * 711164 if args.grad_allreduce else 0,
                    "launch": (f"{n_replay} replays of a HIP graph of {chunk} steps + {n_eager} steps launched from Python"
                               if graph is not None else "every step launched from Python")},
@@ -579,6 +648,17 @@ def main():
                                 "p90": float(np.percentile(step_us, 90)), "n": len(step_us)},
         "api": api,
     }
+    if with_allreduce is not None:
+        out["value_with_grad_allreduce"] = world * B * A * args.steps / with_allreduce["seconds"]
+        out["ms_per_step_with_grad_allreduce"] = with_allreduce["seconds"] / args.steps * 1e3
+        out["allreduce_us"] = with_allreduce["allreduce_us"]
+        out["rccl_ranks"] = with_allreduce["ranks"]
+        out["collective_backend"] = with_allreduce["backend"] + (" (rehearsal on one GPU over gloo: not a scaling measurement)"
+                                                                 if os.environ.get("CTPVAE_REHEARSE_ONE_GPU") else " = RCCL over xGMI")
+        out["grad_allreduce"] = {"bytes_per_step": 4 * 711164, "repeats": with_allreduce["repeats"],
+                                 "what": "the same K steps, each followed by ONE all-reduce of the P-VAE's flat fp32 gradient bucket "
+                                         "(711,164 floats) over all ranks on the projector's stream -- the data-parallel trainer's "
+                                         "only collective (ct_pvae_amd/sharding.py); `value` is the projector pair alone"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(imgs, theta, g_host, args.cpu_threads)
     print(json.dumps(out))

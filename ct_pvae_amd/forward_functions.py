@@ -197,7 +197,6 @@ class RotatePlan:
         self._interp_name, self._backward_name, self._pad = interp, backward, bool(pad)
         self.T8, self.Tinv8 = _tables if _tables is not None else rotate_tables(theta, self.PH, self.PW, self.device)
         self._tdev = self.T8.device
-        self._seen = {}
         self.A = self.T8.shape[0]
         self._lib = _lib.load()
         # Gather plans (NEAREST): tap indices computed once for this geometry, shared by every slice of every call.
@@ -422,17 +421,14 @@ class RotatePlan:
 
     def _check(self, t, shape_tail, what):
         """Operand checks before a launch: the kernels index by these shapes and would read out of bounds otherwise.
-        A tensor object that passed is remembered (weakly) per role, so a loop over fixed buffers pays the checks once."""
-        seen = self._seen.get(shape_tail)          # keyed by the expected shape: a role name alone could alias
-        if seen is not None and seen() is t:
-            return
+        Every call checks -- the tests cost about a microsecond.  (Round 2 remembered tensor OBJECTS that had passed;
+        `t.data = other`, `t.resize_()` or `t.set_()` change dtype, shape or storage under an unchanged object, and a
+        kernel would then have indexed a buffer of the wrong size.)"""
         if (t.shape[1:] == shape_tail and t.dtype is torch.float32 and t.is_contiguous() and t.device == self._tdev
                 and t.shape[0] > 0):
-            self._seen[shape_tail] = weakref.ref(t)
             return
-        if True:
-            raise ValueError(f"{what} must be a contiguous float32 tensor [S]{list(shape_tail)} on {self.T8.device} "
-                             f"(got {tuple(t.shape)}, {t.dtype}, {t.device}, contiguous={t.is_contiguous()})")
+        raise ValueError(f"{what} must be a contiguous float32 tensor [S]{list(shape_tail)} on {self.T8.device} "
+                         f"(got {tuple(t.shape)}, {t.dtype}, {t.device}, contiguous={t.is_contiguous()})")
 
     def _tile_workspace(self, S):
         """Device workspace of the tiled forward for S slices, or None when this geometry is not tiled."""

@@ -1204,6 +1204,9 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 20 and d["repeats"] >= 1 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 50 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # world > 1: the projector-only value AND the same steps with the data-parallel trainer's one collective, both reported
+    assert d["value_with_grad_allreduce"] > 0 and d["allreduce_us"] > 0 and d["rccl_ranks"] == 2
+    assert d["value_with_grad_allreduce"] <= d["value"] * 1.05 and "cache-warm" in d["config"]["inputs"]
 
 
 def test_random_geometries_against_the_oracle(oracle):
@@ -1851,3 +1854,42 @@ def test_evaluate_sinogram_wrapper(oracle):
         assert np.isfinite(pe + ne).all() and pe[1] > 0.9       # a 2 % rescaled sinogram reconstructs to nearly the same image
         if alg == "gridrec":
             assert pe[0] < ne[0] and pe[2] > ne[2]              # ... closer than the 20-angle noisy one
+
+
+def test_operand_checks_see_a_tensor_whose_storage_was_swapped():
+    """the operand checks must not trust a tensor OBJECT that passed before -- `t.data = other` puts a buffer of
+    another size (or dtype) under the same object, and the kernels index by the plan's shapes."""
+    d = dev()
+    plan = RotatePlan(phantoms.dense_theta(180)[::9], 128, 128, True, d)
+    x = torch.rand((4, 128, 128), device=d)
+    out = torch.empty((4, 20, plan.PW), device=d)
+    plan.forward(x, out=out)
+    x.data = torch.rand((4, 64, 64), device=d)             # same object, a quarter of the storage
+    with pytest.raises(ValueError, match="img must be"):
+        plan.forward(x, out=out)
+    x.data = torch.rand((4, 128, 128), device=d, dtype=torch.float64)
+    with pytest.raises(ValueError, match="img must be"):
+        plan.forward(x, out=out)
+    x.data = torch.rand((4, 128, 128), device=d)
+    out.data = torch.empty((4, 10, plan.PW), device=d)     # the OUTPUT shrank: a launch would write past its end
+    with pytest.raises(ValueError, match="out must be"):
+        plan.forward(x, out=out)
+    g = torch.rand((4, 20, plan.PW), device=d)
+    gi = torch.empty((4, 128, 128), device=d)
+    plan.backward(g, out=gi)
+    gi.resize_(4, 64, 64)
+    with pytest.raises(ValueError, match="out must be"):
+        plan.backward(g, out=gi)
+
+
+def test_bench_cold_inputs():
+    """`bench.py --cold` cycles 96 distinct batches (more than the Infinity Cache) and says so in its config."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cold", "--steps", "192", "--warmup", "5", "--min-ms", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["inputs"].startswith("cold: 96 distinct batches") and d["steps"] == 192 and d["value"] > 0
