@@ -1893,3 +1893,27 @@ def test_bench_cold_inputs():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["config"]["inputs"].startswith("cold: 96 distinct batches") and d["steps"] == 192 and d["value"] > 0
+
+
+def test_hip_ray_driven_fbp_and_gridrec_against_the_scikit_image_fixture(golden_dir):
+    """The HIP kernels -- no oracle in this test -- against scikit-image 0.18.3's radon / iradon (tests/golden/
+    skimage_crosscheck.npz; bounds and what they mean: tests/test_oracle.py, same fixture)."""
+    from tests.test_oracle import _skimage_mapped
+    from ct_pvae_amd.recon import recon
+    d = dev()
+    z = np.load(os.path.join(golden_dir, "skimage_crosscheck.npz"))
+    img, theta = z["img"], np.deg2rad(z["theta_deg"])
+    sino = cp.create_sinograms(torch.from_numpy(img[None]).to(d), theta, pad=True)          # [1][A][184]
+    ours = to_np(sino)[0].astype(np.float64)
+    sk = z["sk_sino"].T.astype(np.float64)
+    m = _skimage_mapped(ours, theta)
+    l2, worst = np.linalg.norm(m - sk) / np.linalg.norm(sk), np.abs(m - sk).max() / np.abs(sk).max()
+    assert l2 < 0.008 and worst < 0.05, (l2, worst)
+    rec = to_np(cp.iradon(sino.to(torch.float64), theta, 128, 128, z["ramp184"]))[0]
+    assert np.linalg.norm(rec - img) / np.linalg.norm(img) < 0.2
+    assert np.linalg.norm(rec - z["sk_rec"]) / np.linalg.norm(z["sk_rec"]) < 0.18
+    g = to_np(recon(sino, theta, sinogram_order=True, algorithm="gridrec", filter_name="ramlak"))[0][28:156, 28:156].astype(np.float64)
+    A = np.stack([img.ravel().astype(np.float64), np.ones(img.size)], 1)
+    (a, b), *_ = np.linalg.lstsq(A, g.ravel(), rcond=None)
+    assert 1.05 < a < 1.2 and np.linalg.norm((g - b) / a - z["sk_rec"]) / np.linalg.norm(z["sk_rec"]) < 0.12
+    print(f"HIP vs scikit-image: radon L2 {l2:.4f} / worst {worst:.4f}; gridrec gain {a:.3f}")

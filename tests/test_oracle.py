@@ -554,3 +554,52 @@ def test_gridrec_restatement_reconstructs_a_projected_phantom_in_place(oracle):
     assert wtbl[0] == 1.0 and (np.diff(wtbl) < 0).all() and wtbl[-1] > 0
     c = len(winv) // 2
     assert (winv[c + 1:] == winv[:c][::-1]).all() and (np.sign(winv[c:]) == np.where(np.arange(c + 1) % 2 == 0, 1, -1)).all()
+
+
+def _skimage_mapped(ours, theta):
+    """Our ray-driven sinogram [A][184] resampled at scikit-image's 182 bin positions: skimage pads the 128 x 128 image to
+    182 x 182 and rotates about pixel 91, half a pixel off the phantom's centre (90.5, 90.5) in both axes, and its bin j is
+    our detector coordinate j + 0.5 + 0.5 cos(theta) - 0.5 sin(theta)."""
+    x184 = np.arange(184.0)
+    return np.stack([np.interp(np.arange(182) + 0.5 + 0.5 * np.cos(t) - 0.5 * np.sin(t), x184, row) for t, row in zip(theta, ours)])
+
+
+def test_ray_driven_and_fbp_restatements_against_scikit_image(oracle, golden_dir):
+    """The a6 / a7 / f3 analogue of the grid_sample cross-check: scikit-image 0.18.3's radon / iradon (fixture generated in the
+    build container by tests/golden/make_skimage_crosscheck.py) -- another discretisation by other people, so agreement is
+    loose by construction, but orientation, angle sense, centre and scale errors would read 50-100 %:
+      a7  oracle.siddon_project vs skimage.radon under the documented centre mapping: 0.4 % (L2), 3.3 % (worst bin)
+      a6  oracle.iradon (the reference's formulas) of OUR sinogram with skimage's own 184-bin ramp: the phantom in place in the
+          identity orientation (flips / transposes read 74-92 %), 13 % from skimage's reconstruction, most of it the
+          reference's integer-centred grid (x = i - X/2, t = k - P/2): a measured (+1.2, +0.5) pixel centroid offset against
+          the half-pixel-centred TomoPy geometry the sinogram was made in -- the reference's formulas, restated as they are
+      f3  oracle.gridrec(ramlak): gain 1.13, offset -0.014, 8 % from skimage's reconstruction after that affine fit."""
+    z = np.load(os.path.join(golden_dir, "skimage_crosscheck.npz"))
+    img = z["img"]
+    theta = np.deg2rad(z["theta_deg"])
+    ours = oracle.siddon_project(img[None], theta.astype(np.float32), pad=True)[:, 0, :].astype(np.float64)
+    sk = z["sk_sino"].T.astype(np.float64)
+    m = _skimage_mapped(ours, theta)
+    l2, worst = np.linalg.norm(m - sk) / np.linalg.norm(sk), np.abs(m - sk).max() / np.abs(sk).max()
+    print(f"siddon_project vs skimage.radon: L2 {l2:.4f}, worst bin {worst:.4f} at {np.unravel_index(np.abs(m - sk).argmax(), sk.shape)}")
+    assert l2 < 0.008 and worst < 0.05
+    assert np.linalg.norm(m[::-1] - sk) / np.linalg.norm(sk) > 0.3          # the reversed angle sense does not fit
+    assert np.linalg.norm(m[:, ::-1] - sk) / np.linalg.norm(sk) > 0.3       # nor the flipped detector
+
+    rec = oracle.iradon(ours[None], theta, 128, 128, z["ramp184"])[0]
+    e = {k: np.linalg.norm(v - img) / np.linalg.norm(img) for k, v in
+         {"id": rec, "T": rec.T, "f0": rec[::-1], "f1": rec[:, ::-1]}.items()}
+    w, idx = np.clip(rec, 0, None), np.arange(128)
+    drow = (w * idx[:, None]).sum() / w.sum() - (img * idx[:, None]).sum() / img.sum()
+    dcol = (w * idx[None, :]).sum() / w.sum() - (img * idx[None, :]).sum() / img.sum()
+    d_sk = np.linalg.norm(rec - z["sk_rec"]) / np.linalg.norm(z["sk_rec"])
+    print(f"iradon vs phantom {e['id']:.3f} (flips {min(e['T'], e['f0'], e['f1']):.2f}+), vs skimage.iradon {d_sk:.3f}, centroid offset ({drow:.2f}, {dcol:.2f}) px")
+    assert e["id"] < 0.2 and min(e["T"], e["f0"], e["f1"]) > 0.6 and d_sk < 0.18
+    assert 0.9 < drow < 1.5 and 0.3 < dcol < 0.8
+
+    g = oracle.gridrec(ours[None].astype(np.float32), theta.astype(np.float32), filter_name="ramlak")[0][28:156, 28:156].astype(np.float64)
+    A = np.stack([img.ravel().astype(np.float64), np.ones(img.size)], 1)
+    (a, b), *_ = np.linalg.lstsq(A, g.ravel(), rcond=None)
+    d_sk = np.linalg.norm((g - b) / a - z["sk_rec"]) / np.linalg.norm(z["sk_rec"])
+    print(f"gridrec(ramlak): gain {a:.3f}, offset {b:.4f}, vs skimage.iradon after the fit {d_sk:.3f}")
+    assert 1.05 < a < 1.2 and -0.03 < b <= 0 and d_sk < 0.12
