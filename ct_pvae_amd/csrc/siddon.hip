@@ -90,7 +90,25 @@ __device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, f
     int k_begin = 0, k_end = csize, ia0 = 0;
     if constexpr (CHUNKED) {
         const int nseg = max(csize - 1, 0);
-        const int s0 = (int)((long long)nseg * chunk / nchunks), s1 = (int)((long long)nseg * (chunk + 1) / nchunks);
+        // Runs of one ray may share a pixel only where they touch -- the back-projector's phase rule -- as long as the ray
+        // meets a pixel in consecutive segments only.  That fails for a ray that lies ON a grid line of a direction it is
+        // (numerically) parallel to: with a slope of ~1e7 the crossings with the coinciding line family land at erratic
+        // positions and libtomo's merge gives long zig-zag segments whose midpoints revisit pixels (odd grids under the even
+        // padded detector, theta = pi/2 or 0 exactly); and with fewer segments than runs, empty runs break the even / odd
+        // alternation.  Such a ray is walked whole by ITS FIRST RUN's lane: one lane, sequential adds, nothing to collide
+        // with (same-parity rays stay two detector pitches away).
+        bool whole = nseg < nchunks;
+        if (!(fabsf(slope) <= 1.0e6f)) {          // parallel to the x = gridx[n] lines
+            const float f = srcx - gx0;
+            whole = whole || fabsf(f - rintf(f)) < 1.0e-3f;
+        }
+        if (!(fabsf(islope) <= 1.0e6f)) {         // parallel to the y = gridy[n] lines
+            const float f = srcy - gy0;
+            whole = whole || fabsf(f - rintf(f)) < 1.0e-3f;
+        }
+        if (whole && chunk != 0) return;
+        const int s0 = whole ? 0 : (int)((long long)nseg * chunk / nchunks);
+        const int s1 = whole ? nseg : (int)((long long)nseg * (chunk + 1) / nchunks);
         if (s1 <= s0) return;
         k_begin = s0;
         k_end = s1 + 1;

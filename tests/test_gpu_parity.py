@@ -836,13 +836,16 @@ def test_poisson_sampler_kernel_equals_its_cpu_twin(oracle, tmp_path):
 
 
 @pytest.mark.parametrize("shape,A,S,pad", [((128, 128), 180, 4, True), ((184, 184), 60, 3, False), ((40, 57), 23, 1, True),
-                                          ((2, 2), 2, 2, False), ((300, 300), 12, 2, True), ((64, 64), 16, 600, True)])
+                                          ((2, 2), 2, 2, False), ((300, 300), 12, 2, True), ((64, 64), 16, 600, True),
+                                          ((33, 47), 8, 3, True), ((33, 33), 4, 2, True), ((5, 3), 6, 2, True)])
 def test_siddon_backprojector_is_the_transpose(oracle, shape, A, S, pad):
     """The ray-driven back-projector (libtomo fbp.c's accumulation = the transpose of project.c): against the oracle's
     restatement to 1e-5 of the largest value (the kernel adds even rays before odd rays per angle and angle groups in
     ascending order -- a fixed order, not libtomo's d-ascending one), <A x, y> = <x, A^T y> with the GPU forward, and bit-
     reproducible from run to run -- LDS-resident grids, a 300 x 300 one accumulated in global memory, one slice split over
-    many angle groups, 600 slices in one group, sparse sinograms (zero rays are skipped)."""
+    many angle groups, 600 slices in one group, sparse sinograms (zero rays are skipped); ODD grids under the even padded
+    detector with theta = 0 and pi / 2 exactly (rays that lie on grid lines, whose zig-zag segments revisit pixels --
+    walked whole by one lane) and grids with fewer segments per ray than runs."""
     from ct_pvae_amd.recon import siddon_backproject
     d = dev()
     rng = np.random.default_rng(shape[0] + A)
