@@ -313,10 +313,12 @@ def n512_mode(args, world, rank, dev):
     up = torch.full((B,), -1.0 / B, device=dev)      # upstream gradient of the per-object sums (the trainer's mean loss)
 
     def step():
-        # projection + log-likelihood + d lp / d projection in one pass; the backward applies the upstream gradient of
-        # the per-object sum in its own store (both halves): no elementwise pass, no [B][A][P] cotangent
-        plan.forward_loglik(x, mask, meas, pnm, eps, out=sino, out_lp=lp, out_dlp=dlp)
-        plan.backward(dlp, out=gx, scale=up)
+        # projection + log-likelihood, reduced to the per-object sums the loss takes inside the tiled forward's reduce pass
+        # (only d lp / d projection and one partial per object, angle and 64 bins leave it), then the backward with the
+        # upstream gradient of those sums applied in its own store (both halves): no elementwise pass, no
+        # [B][A][P] sinogram or log-probabilities in HBM
+        sums, dlp_ = plan.forward_loglik_sums(x, mask, meas, pnm, eps)
+        plan.backward(dlp_, out=gx, scale=up)
 
     steps = max(args.steps // 10, 10)
     el = _time_loop(step, steps, 3, world)
@@ -332,7 +334,8 @@ def n512_mode(args, world, rank, dev):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / n
 
-    t_fwd = ev_time(lambda: plan.forward_loglik(x, mask, meas, pnm, eps, out=sino, out_lp=lp, out_dlp=dlp))
+    t_fwd = ev_time(lambda: plan.forward_loglik_sums(x, mask, meas, pnm, eps))
+    dlp = plan.forward_loglik_sums(x, mask, meas, pnm, eps)[1]
     t_bwd = ev_time(lambda: plan.backward(dlp, out=gx, scale=up))
     if rank == 0:
         bytes_step = 8.0 * B * (N * N + A * plan.PW)
@@ -342,14 +345,15 @@ def n512_mode(args, world, rank, dev):
                           "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"batch={B}/GPU 512x512, 90 angles, P={plan.PW}, nearest fwd + "
-                                                 "fused Gaussian-Poisson log-likelihood and its derivative, tf_compat adj with the upstream per-object factor (tiled fwd, 4 slices per workgroup; segment-staged adj)"},
+                                                 "fused Gaussian-Poisson log-likelihood reduced per object in the launch + its derivative, tf_compat adj with the upstream per-object factor (tiled fwd through compact tile plans, 4 slices per workgroup; segment-staged adj)",
+                                     "forward_plan": "compact tile plans" if plan._tplan is not None else "direct tiled kernel"},
                           "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS,
-                          "roofline": {"bound": "hbm", "kernel": "rotate_fwd_fast_kernel<tiled> + rotate_tile_reduce_kernel<loglik>",
+                          "roofline": {"bound": "hbm", "kernel": "rotate_fwd_tile_compact_kernel + rotate_tile_reduce_kernel<loglik, per-object sums>",
                                        "achieved": bytes_fwd / t_fwd / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": bytes_fwd / t_fwd / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                        "algorithmic_bytes_per_launch": bytes_fwd,
                                        "kernel_us": {"tiled_fwd_plus_reduce_loglik": t_fwd * 1e6, "segment_adj_scaled": t_bwd * 1e6},
-                                       "note": "VALU-bound on the shared address arithmetic (DESIGN.md section 9), not HBM-bound"}}))
+                                       "note": "bound by the LDS gathers (ds_read_b128 of four interleaved slices, 2-way bank conflicts at oblique angles), not by HBM (DESIGN.md section 9)"}}))
 
 
 def main():

@@ -53,6 +53,11 @@ SIGNATURES = {
                                              _vp, _vp]),
     "ctpvae_rotate_fwd_tiled_loglik_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                                     _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp]),
+    "ctpvae_rotate_tplan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_rotate_tplan_build_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_rotate_tplan_overflowed": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ctpvae_rotate_fwd_tiled_compact_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp,
+                                                     _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctpvae_rotate_bwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int,
                                        _c_int, _c_int, _vp, _vp]),
     "ctpvae_rotate_bwd_scaled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int,

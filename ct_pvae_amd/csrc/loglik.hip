@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void loglik_bwd_kernel(const float *__restrict
 // Per-object sums of a stored log-probability array in the fixed order of the fused epilogues (LogLikEpilogue::part):
 // a slice's [A][PW] values are cut into 64-lane tasks -- partition 0: the planned kernels' (angle, bin block) tasks, two
 // 32-bin bands mirrored about the detector centre (lane_to_bin); partition 1: the tiled reduce pass's contiguous 64-bin
-// blocks -- each task is added by the xor butterfly (lanes without a bin add +0.0f), and the task sums are added in
-// ascending (angle, task) order.  One workgroup per slice; the task sums wait in LDS.
+// blocks -- each task is added by the xor butterfly (lanes without a bin add +0.0f), an angle's task sums are added in
+// ascending order, and the angle sums by object_sum_of_parts' rule (loglik_math.h).  One workgroup per slice; the task sums
+// wait in LDS.
 __global__ __launch_bounds__(256) void loglik_object_sums_kernel(const float *__restrict__ lp, int A, int PW, int partition,
                                                                  int tasks_per_row, float *__restrict__ out)
 {
@@ -64,10 +65,9 @@ __global__ __launch_bounds__(256) void loglik_object_sums_kernel(const float *__
         if (lane == 0) part[t] = tot;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float acc = 0.0f;
-        for (int t = 0; t < NT; ++t) acc += part[t];
-        out[s] = acc;
+    if (wave == 0) {
+        const float total = object_sum_of_parts(part, A, tasks_per_row, lane);
+        if (lane == 0) out[s] = total;
     }
 }
 

@@ -45,7 +45,7 @@ struct LogLikEpilogue {
     // per-object sums ("reduction to per-object log-lik", ctvae/helper_functions.py:305-312): when `part` is set
     // the kernel writes ONE partial sum per 64-lane task into part[(s * A_out + k) * tasks_per_row + task] (lanes added by
     // the xor butterfly 32, 16, 8, 4, 2, 1; lanes without a bin add +0.0f) and lp / the ray-sum store become optional; a
-    // second, tiny launch adds a slice's partials in ascending slot order (wave_sum / loglik.hip).
+    // second, tiny launch adds a slice's partials in the fixed order of object_sum_of_parts below.
     float *part = nullptr;
 
     // o: offset of the ray-sum in the outputs; om / sa: offsets of its measured sample and its mask entry
@@ -81,20 +81,30 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// lp_sum[s] = the NT partial sums of slice s added in ascending slot order.  One wave per slice: 64 partials per coalesced
-// load, then added one by one through readlane (every lane keeps the same running sum).
-[[maybe_unused]] static __global__ __launch_bounds__(64) void loglik_sum_partials_kernel(const float *__restrict__ part, int S, int NT,
-                                                                                       float *__restrict__ out)
+// The fixed order of the per-object sum over task sums part[a][k] (A angles x tpr tasks per angle):
+//   S_a   = ((0 + part[a][0]) + part[a][1]) + ...            one angle's tasks, ascending
+//   total = ((0 + B_0) + B_1) + ...,  B_g = wave_sum over lanes l of S_(64 g + l)  (angles past A add +0.0f)
+// -- every level is either a short sequential sum or the xor butterfly, so a wave computes it in a few hundred cycles whatever
+// A is (a plain ascending sum over all A * tpr task sums took 40 us at 90 angles x 12 tasks: 1080 dependent adds).
+__device__ __forceinline__ float object_sum_of_parts(const float *__restrict__ part, int A, int tpr, int lane)
+{
+    float total = 0.0f;
+    for (int a0 = 0; a0 < A; a0 += 64) {
+        const int a = a0 + lane;
+        float sa = 0.0f;
+        if (a < A)
+            for (int k = 0; k < tpr; ++k) sa += part[(size_t)a * tpr + k];
+        total += wave_sum(sa);
+    }
+    return total;
+}
+// lp_sum[s] of the partial sums a fused epilogue wrote (LogLikEpilogue::part): one wave per slice
+[[maybe_unused]] static __global__ __launch_bounds__(64) void loglik_sum_partials_kernel(const float *__restrict__ part, int S, int A,
+                                                                                       int tpr, float *__restrict__ out)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
-    const float *p = part + (size_t)s * NT;
-    float acc = 0.0f;
-    for (int t0 = 0; t0 < NT; t0 += 64) {
-        const float v = t0 + lane < NT ? p[t0 + lane] : 0.0f;
-        const int m = min(64, NT - t0);
-        for (int t = 0; t < m; ++t) acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
-    }
-    if (lane == 0) out[s] = acc;
+    const float total = object_sum_of_parts(part + (size_t)s * A * tpr, A, tpr, lane);
+    if (lane == 0) out[s] = total;
 }
 
 }  // namespace ctpvae

@@ -25,6 +25,8 @@
 #include "common.h"
 #include "lds_stage.h"
 #include "loglik_math.h"
+#include "rotate_plan.h"
+#include "cplan_walk.h"
 
 namespace ctpvae {
 
@@ -617,7 +619,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 // serves all the workgroup's slices -- then adds their partial sums tile by tile, the slices' loads in flight together.
 // (One slice per workgroup made this pass wave-launch bound: 34.5 k waves of a dozen loads each at B=32, 27 us.)
 constexpr int kReduceSlices = 8;
-template <bool EPI>   // EPI: also write the log-probability of the measured sample under every ray-sum (loglik_math.h)
+// EPI 1: also write the log-probability of the measured sample under every ray-sum (loglik_math.h); EPI 2: the log-probabilities
+// are REDUCED -- one partial sum per (slice, angle, 64-bin block) into epi.part (LogLikEpilogue; partition 1 of
+// ctpvae_loglik_object_sums_f32), d lp / d ray-sum stored, ray-sums and log-probabilities only where buffers were given.
+template <int EPI>
 __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
                                                                   const float *__restrict__ T8, float *__restrict__ sino,
                                                                   LogLikEpilogue epi)
@@ -669,6 +674,24 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
         }
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (EPI == 2) {
+        const int tpr = (g.PW + 63) >> 6;
+#pragma unroll
+        for (int q = 0; q < kReduceSlices; ++q) {
+            const int s = s0 + q;
+            if (s < g.S) {   // wave-uniform
+                float lpv = 0.0f;
+                if (j < g.PW) {
+                    const size_t o = ((size_t)s * g.A + a) * g.PW + j;
+                    if (sino) sino[o] = acc[q];
+                    lpv = epi.eval(o, o, (size_t)s * g.A + a, acc[q]);
+                }
+                const float tot = wave_sum(lpv);
+                if (lane == 0) epi.part[((size_t)s * g.A + a) * tpr + (j0 >> 6)] = tot;
+            }
+        }
+        return;
+    }
     if (j >= g.PW) return;
 #pragma unroll
     for (int q = 0; q < kReduceSlices; ++q) {
@@ -676,7 +699,7 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
         if (s < g.S) {
             const size_t o = ((size_t)s * g.A + a) * g.PW + j;
             sino[o] = acc[q];
-            if constexpr (EPI) epi.write(o, o, (size_t)s * g.A + a, acc[q]);
+            if constexpr (EPI == 1) epi.write(o, o, (size_t)s * g.A + a, acc[q]);
         }
     }
 }
@@ -1153,6 +1176,175 @@ static size_t tile_lds_bytes(const TileSpec &ts, int ns)
     return (size_t)(ts.th + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float) * ns;
 }
 
+
+// ---- tiled forward through COMPACT tile plans (round 3) --------------------------------------------------------------------
+// The tiled kernel above is VALU-bound on TensorFlow's index arithmetic (23 ops per two rows of four slices).
+// A tile is an ordinary slice at its own (py, px) of the canvas, so the compact plan of rotate_cplan.hip -- first tap + 2 bits
+// per row, decoded through a step table in LDS -- applies tile by tile: a plan section per (tile, angle, ray slot) written once
+// per geometry by rotate_tplan_kernel with the reference arithmetic, walked by rotate_fwd_tile_compact_kernel with
+// cplan_walk.h's cwalk.  Same taps, same row order inside a tile, same slot layout of the partial sums => the SAME partial
+// sums as the kernel above, bit for bit; rotate_tile_reduce_kernel is unchanged.
+struct TLayout {
+    int nt, nb, nbk, NQ, pitch, cells;
+    long long off_cls, off_ng, off_start, off_codes, off_flag, bytes;
+};
+static TLayout t_layout(const TileSpec &ts, int A)
+{
+    TLayout L;
+    L.nt = ts.ntx * ts.nty;
+    L.nb = ts.nb;
+    L.nbk = ts.nb >> 6;
+    L.NQ = ceil_div((int)ceilf(sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th))) + 4, kRowsPerChunk);   // rows of a ray inside a tile
+    L.pitch = pitch_mod32_is_1(ts.tw + 1);
+    L.cells = 1 + (ts.th + 2) * L.pitch + 1;
+    auto up = [](long long v) { return (v + 255) / 256 * 256; };
+    L.off_cls = 0;                                                            // [A] class words (cplan_class_word)
+    L.off_ng = up((long long)A * 4);                                          // [nt][A][nbk] row groups of a task
+    L.off_start = up(L.off_ng + (long long)L.nt * A * L.nbk * 4);             // [nt][A][nb] first cell | live << 31
+    L.off_codes = up(L.off_start + (long long)L.nt * A * L.nb * 4);           // [nt][A][NQ][nb] uint4
+    L.off_flag = L.off_codes + (long long)L.nt * A * L.NQ * L.nb * 16;
+    L.bytes = L.off_flag + 256;
+    return L;
+}
+static size_t t_lds_bytes(const TLayout &L, int A, int ns) { return (size_t)kLutBytes + (size_t)L.cells * 4 * ns + ((size_t)A + 2) * 4; }
+
+// one wave per (64-slot block, angle, tile): the mirrored 32-slot runs of the tiled kernel's tasks
+__global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpec ts, const float *__restrict__ T8, TLayout L,
+                                                          char *__restrict__ plan)
+{
+    const int blk = blockIdx.x, a = blockIdx.y, t = blockIdx.z, lane = threadIdx.x;
+    int y0, x0, h, w;
+    tile_rect(gfull, ts, t, y0, x0, h, w);
+    const PlanGeom g{h, w, gfull.PH, gfull.PW, gfull.py + y0, gfull.px + x0, gfull.A};
+    const float *t6 = T8 + 8 * a;
+    const float tile_cx = (float)g.px + 0.5f * (float)(g.W - 1), tile_cy = (float)g.py + 0.5f * (float)(g.H - 1);
+    const int slot = lane < 32 ? blk * 32 + lane : L.nb - 32 * (blk + 1) + (lane - 32);
+    const int j = tile_first_bin(t6, tile_cx, tile_cy, ts.radius) + slot;
+    const bool valid = (unsigned)j < (unsigned)g.PW;
+    int *cls = reinterpret_cast<int *>(plan + L.off_cls);
+    int *ngt = reinterpret_cast<int *>(plan + L.off_ng);
+    unsigned *start = reinterpret_cast<unsigned *>(plan + L.off_start);
+    uint4 *codes = reinterpret_cast<uint4 *>(plan + L.off_codes);
+    if (t == 0 && blk == 0 && lane == 0) cls[a] = cplan_class_word(t6);
+    const RayScan rs = cplan_scan_ray(g, t6, j, valid, L.pitch);
+    const int ng = (wave_max_i(rs.n) + kRowsPerGroup - 1) / kRowsPerGroup;
+    const size_t ta = (size_t)t * gfull.A + a;
+    if (lane == 0) ngt[ta * L.nbk + blk] = ng;
+    start[ta * L.nb + slot] = (unsigned)rs.start | (valid ? 0x80000000u : 0u);
+    bool bad = cplan_encode_ray(g, t6, j, rs, kRowsPerGroup * ng, L.pitch, L.NQ, codes + ta * L.NQ * L.nb + slot, (size_t)L.nb);
+    bad = bad || kRowsPerGroup * ng > kRowsPerChunk * L.NQ;
+    if (__any(bad) && lane == 0) atomicOr(reinterpret_cast<int *>(plan + L.off_flag), 1);
+}
+
+// Workgroup = (tile of NS slices, mirror class, task group), launched like the tiled kernel above: blockIdx.x = 2 * group +
+// class, blockIdx.y = slice group * tiles + tile.  Stages the tile with its zero border (class 0 column-mirrored), then its
+// waves take (angle, 64-slot block) tasks from an LDS counter, long ones first, each prepared while the previous one is walked.
+template <int NS>
+__global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
+                                                                       TLayout L, const char *__restrict__ plan,
+                                                                       float *__restrict__ partial)
+{
+    typedef typename SliceVec<NS>::type vec_t;
+    extern __shared__ float lds[];
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();   // see cplan_walk.h lut_issue
+    float *image = lds + kLutBytes / 4;
+    const int nt = L.nt, v = blockIdx.y, t = v % nt, s = (v / nt) * NS, A = gfull.A;
+    int y0, x0, h, w;
+    tile_rect(gfull, ts, t, y0, x0, h, w);
+    const float *im = img + ((size_t)s * gfull.H + y0) * gfull.W + x0;
+    const int cls = blockIdx.x & 1, gi = blockIdx.x >> 1, G = gridDim.x >> 1;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int *clsw = reinterpret_cast<const int *>(plan + L.off_cls);
+    const int *ngt = reinterpret_cast<const int *>(plan + L.off_ng) + (size_t)t * A * L.nbk;
+    const unsigned *start = reinterpret_cast<const unsigned *>(plan + L.off_start) + (size_t)t * A * L.nb;
+    const uint4 *codes = reinterpret_cast<const uint4 *>(plan + L.off_codes) + (size_t)t * A * L.NQ * L.nb;
+    // behind the image: the ascending list of this class's angles ([0] = their count), then the task counter
+    int *cls_list = reinterpret_cast<int *>(image + (size_t)L.cells * NS);
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int a0 = 0; a0 < A; a0 += 64) {
+            const bool in_cls = a0 + lane < A && (clsw[min(a0 + lane, A - 1)] & 1) == cls;
+            const unsigned long long m = __ballot(in_cls);
+            if (in_cls) cls_list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
+            n += __popcll(m);
+        }
+        if (lane == 0) {
+            cls_list[0] = n;
+            cls_list[1 + A] = nwaves;   // the task counter: every wave's first task is its own number
+        }
+    }
+    cplan_init_lut<NS>(lds, L.pitch);
+    cplan_zero_border<NS>(image, h, w, L.pitch);
+    float *core = image + (size_t)(1 + L.pitch) * NS;
+    if constexpr (NS == 1) {
+        stage_rows(core, im, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
+    } else {
+        const float *srcs[NS];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) srcs[n] = im + (size_t)(min(s + n, gfull.S - 1) - s) * gfull.H * gfull.W;
+        stage_rows_interleaved<NS>(core, srcs, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
+    }
+    __syncthreads();
+    const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
+    int *next_task = cls_list + 1 + A;
+    const int ntask = ncls * L.nbk;
+    const size_t st = (size_t)L.nb;
+    struct Task {
+        bool valid, neg, live;
+        int a, slot, ng, adr;
+        const uint4 *p;
+        uint4 c0, c1;
+    };
+    auto prepare = [&](int m) -> Task {
+        Task q;
+        q.valid = m < ntask;
+        q.neg = q.live = false;
+        q.a = q.slot = q.ng = 0;
+        q.adr = kLutBytes;
+        q.p = codes;
+        q.c0 = q.c1 = uint4{0u, 0u, 0u, 0u};
+        if (q.valid) {   // wave-uniform
+            // m counts 64-slot blocks from the innermost (longest rays) outwards, the class's angles within a block
+            const int bi = m / ncls, ai = m - bi * ncls, blk = L.nbk - 1 - bi;
+            q.a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
+            q.neg = (clsw[q.a] >> 1) != 0;
+            q.ng = __builtin_amdgcn_readfirstlane(ngt[q.a * L.nbk + blk]);
+            q.slot = lane < 32 ? blk * 32 + lane : L.nb - 32 * (blk + 1) + (lane - 32);
+            const unsigned sw = start[(size_t)q.a * L.nb + q.slot];
+            q.live = (sw >> 31) != 0;
+            q.adr = kLutBytes + (int)(sw & 0x7fffffffu) * (4 * NS);
+            const uint4 *p = codes + (size_t)q.a * L.NQ * L.nb + q.slot;
+            q.c0 = p[0];
+            if (L.NQ > 1) q.c1 = p[st];
+            q.p = p + 2 * st;
+        }
+        return q;
+    };
+    Task cur = prepare(wave * G + gi);
+    while (cur.valid) {
+        int m = 0;
+        if (lane == 0) m = atomicAdd(next_task, 1);
+        const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m) * G + gi);
+        vec_t acc = 0.0f;
+        const int ng = __builtin_amdgcn_readfirstlane(cur.ng);
+        const bool neg = __builtin_amdgcn_readfirstlane((int)cur.neg) != 0;
+        if (ng > 0)
+            acc = neg ? cwalk<NS, true>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ)
+                      : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
+        if (cur.live) {
+            const size_t ray = (size_t)cur.a * L.nb + cur.slot, nrays = (size_t)A * L.nb;
+            if constexpr (NS == 1) {
+                partial[((size_t)s * nt + t) * nrays + ray] = acc;
+            } else {
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    if (s + n < gfull.S) partial[((size_t)(s + n) * nt + t) * nrays + ray] = acc[n];
+            }
+        }
+        cur = nxt;
+    }
+}
+
 }  // namespace ctpvae
 
 using namespace ctpvae;
@@ -1246,35 +1438,39 @@ long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, i
 }
 
 static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
-                               int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream);
+                               int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream,
+                               const void *tplan_dev);
 
 // tile workgroups are indexed with a grid dimension too: at most 65535 / tiles slices per launch, the workspace reused by
 // the chunks (they run one after the other on the stream)
 static int launch_fwd_tiled(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
-                           int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
+                           int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream,
+                           const void *tplan_dev = nullptr)
 {
-    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0,
+    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && (sino_dev || epi.part) && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0,
                    "rotate_fwd_tiled: null pointer or empty sizes");
     const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
     const int nt = std::max(1, ts.ntx * ts.nty);
     const int chunk = std::max(4, std::min(max_slices_per_launch(), 65535 / nt) / 4 * 4);
     return for_slice_chunks(S, chunk, [&](int s0, int n) {
         LogLikEpilogue e = epi;
-        if (e.lp) {
+        if (e.lp || e.part) {
             e.mask += (size_t)s0 * A;
             e.meas += (size_t)s0 * A * PW;
-            e.lp += (size_t)s0 * A * PW;
+            if (e.lp) e.lp += (size_t)s0 * A * PW;
             if (e.dlp) e.dlp += (size_t)s0 * A * PW;
+            if (e.part) e.part += (size_t)s0 * A * ((PW + 63) >> 6);
         }
         return launch_fwd_tiled_one(img_dev + (size_t)s0 * H * W, n, H, W, PH, PW, py, px, T8_dev, A, workspace_dev,
-                                    sino_dev + (size_t)s0 * A * PW, e, stream);
+                                    sino_dev ? sino_dev + (size_t)s0 * A * PW : nullptr, e, stream, tplan_dev);
     });
 }
 
 static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
-                               int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream)
+                               int A, void *workspace_dev, float *sino_dev, const LogLikEpilogue &epi, ctpvae_stream_t stream,
+                               const void *tplan_dev)
 {
-    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev, "rotate_fwd_tiled: null pointer");
+    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && (sino_dev || epi.part), "rotate_fwd_tiled: null pointer");
     if (int rc = check_geom("rotate_fwd_tiled", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
     const RotGeom g{S, H, W, PH, PW, py, px, A};
     const bool tie_fix = (px == 0 || py == 0);
@@ -1304,8 +1500,21 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
         CTPVAE_LAUNCH_CHECK("rotate_fwd_fast_kernel (tiled)");
         return CTPVAE_OK;
     };
+    // compact tile plans (ctpvae_rotate_tplan_build_f32): the same partial sums without per-sample index arithmetic
+    auto launch_compact = [&](auto kernel) -> int {
+        static std::atomic<unsigned long long> attr_set{0};
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
+        const TLayout TL = t_layout(ts, A);
+        hipLaunchKernelGGL(kernel, dim3(2 * G, groups * nt), dim3(64 * waves), t_lds_bytes(TL, A, ns), (hipStream_t)stream, img_dev, g,
+                           ts, TL, (const char *)tplan_dev, (float *)workspace_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_tile_compact_kernel");
+        return CTPVAE_OK;
+    };
     int rc;
-    if (tie_fix)
+    if (tplan_dev && !tie_fix)
+        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4>)
+                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2>) : launch_compact(rotate_fwd_tile_compact_kernel<1>));
+    else if (tie_fix)
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, true, 1>);
     else if (ns == 4)
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 4>);
@@ -1316,11 +1525,14 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     if (rc) return rc;
     const int rwaves = std::min(16, ceil_div(PW, 64));   // waves per workgroup: 64 bins each
     const dim3 rgrid(ceil_div(PW, 64 * rwaves), A, ceil_div(S, kReduceSlices)), rblock(64 * rwaves);
-    if (epi.lp)
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream,
+    if (epi.part)
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<2>, rgrid, rblock, 0, (hipStream_t)stream,
+                           (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
+    else if (epi.lp)
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<1>, rgrid, rblock, 0, (hipStream_t)stream,
                            (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
     else
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<0>, rgrid, rblock, 0, (hipStream_t)stream,
                            (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
     CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
     return CTPVAE_OK;
@@ -1340,6 +1552,67 @@ int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W
     CTPVAE_REQUIRE(mask_dev && meas_dev && pnm_dev && lp_dev, "rotate_fwd_tiled_loglik: null pointer");
     return launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev,
                             LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev}, stream);
+}
+
+// ---- compact tile plans -----------------------------------------------------------------------------------------------------
+long long ctpvae_rotate_tplan_bytes(int H, int W, int PH, int PW, int A)
+{
+    if (H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_tplan_bytes: bad sizes");
+    const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
+    if (ts.ntx == 0 || knob(kKnobForceGeneric) >= 0 || knob(kKnobNoCompact) >= 0 || knob(kKnobNoPlan) >= 0) return 0;
+    const TLayout L = t_layout(ts, A);
+    if (t_lds_bytes(L, A, 4) > (size_t)kMaxLdsBytes || 12ll * L.pitch * 4 > 32767) return 0;
+    return L.bytes;
+}
+
+int ctpvae_rotate_tplan_build_f32(const float *T8_dev, int A, int H, int W, int PH, int PW, int py, int px, void *tplan_dev,
+                                  ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(T8_dev && tplan_dev, "rotate_tplan_build: null pointer");
+    if (int rc = check_geom("rotate_tplan_build", 1, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
+    const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
+    CTPVAE_REQUIRE(ts.ntx > 0, "rotate_tplan_build: a %dx%d slice fits LDS whole (ctpvae_rotate_cplan_build_f32)", H, W);
+    const TLayout L = t_layout(ts, A);
+    CTPVAE_REQUIRE(A <= 65535 && L.nt <= 65535, "rotate_tplan_build: at most 65535 angles and tiles");
+    const RotGeom g{1, H, W, PH, PW, py, px, A};
+    CTPVAE_HIP(hipMemsetAsync((char *)tplan_dev + L.off_flag, 0, 256, (hipStream_t)stream));
+    hipLaunchKernelGGL(rotate_tplan_kernel, dim3(L.nbk, A, L.nt), dim3(64), 0, (hipStream_t)stream, g, ts, T8_dev, L, (char *)tplan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_tplan_kernel");
+    return CTPVAE_OK;
+}
+
+// 1 if some ray's steps do not fit the code: keep ctpvae_rotate_fwd_tiled_f32.  SYNCHRONISES the stream.
+int ctpvae_rotate_tplan_overflowed(const void *tplan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(tplan_dev && H > 0 && W > 0 && A > 0 && PH >= H && PW >= W, "rotate_tplan_overflowed: bad arguments");
+    const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
+    CTPVAE_REQUIRE(ts.ntx > 0, "rotate_tplan_overflowed: not a tiled geometry");
+    const TLayout L = t_layout(ts, A);
+    int flag = 0;
+    CTPVAE_HIP(hipMemcpyAsync(&flag, (const char *)tplan_dev + L.off_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CTPVAE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return flag ? 1 : 0;
+}
+
+int ctpvae_rotate_fwd_tiled_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                        const float *T8_dev, int A, const void *tplan_dev, void *workspace_dev,
+                                        const float *mask_dev, const float *meas_dev, const float *pnm_dev, float eps,
+                                        float *sino_dev, float *lp_dev, float *dlp_dev, float *lp_part_dev, float *lp_sum_dev,
+                                        ctpvae_stream_t stream)
+{
+    const bool red = lp_sum_dev != nullptr, lik = lp_dev != nullptr || red;
+    CTPVAE_REQUIRE(!lik || (mask_dev && meas_dev && pnm_dev), "rotate_fwd_tiled_compact: the likelihood epilogue needs mask, meas and pnm");
+    CTPVAE_REQUIRE(lik || dlp_dev == nullptr, "rotate_fwd_tiled_compact: dlp without lp");
+    CTPVAE_REQUIRE(!red || lp_part_dev, "rotate_fwd_tiled_compact: per-object sums need the partial-sum workspace");
+    const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, 0, red ? lp_part_dev : nullptr}
+                                   : LogLikEpilogue{};
+    if (int rc = launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev, epi, stream, tplan_dev)) return rc;
+    if (red) {   // a slice's partials (angle, 64-bin block) in ascending order: ctpvae_loglik_object_sums_f32, partition 1
+        hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S, A, (PW + 63) >> 6,
+                           lp_sum_dev);
+        CTPVAE_LAUNCH_CHECK("loglik_sum_partials_kernel");
+    }
+    return CTPVAE_OK;
 }
 
 int ctpvae_rotate_bwd_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *T8_dev, int interp,

@@ -36,12 +36,10 @@
 #include "lds_stage.h"
 #include "loglik_math.h"
 #include "rotate_plan.h"
+#include "cplan_walk.h"
 
 namespace ctpvae {
 
-constexpr int kLutBytes = 64 * 32 * 8;   // 64 entries x 32 lane copies x (3 x i16 + pad), at LDS offset 0
-constexpr int kRowsPerChunk = 48;       // a uint4 of codes: 16 bytes x 3 rows
-constexpr int kRowsPerGroup = 6;        // rows gathered per step of the walk: two code bytes
 constexpr int kCSelRounds = 4;    // angle subsets hold <= 64 * kCSelRounds angles
 
 struct CLayout {
@@ -76,27 +74,6 @@ static bool cplan_fits(const PlanGeom &g, int ns = 1)
 }
 
 // ---- plan builder ------------------------------------------------------------------------------------------------
-struct RawTap {
-    int ix, iy;   // rounded source column / row relative to the core's origin (may lie outside the core)
-};
-// ImageProjectiveTransformV3, NEAREST: (t0*x + t1*y) + t2, std::round -- the expressions of rotate_plan.hip's fwd_tap
-__device__ __forceinline__ RawTap raw_tap(const PlanGeom &g, float xj, float yj, float t1, float t2, float t4, float t5, int i)
-{
-    const float fi = (float)i;
-    const float x = (xj + t1 * fi) + t2;
-    const float y = (yj + t4 * fi) + t5;
-    return RawTap{(int)__builtin_roundf(x) - g.px, (int)__builtin_roundf(y) - g.py};
-}
-__device__ __forceinline__ bool in_core(const PlanGeom &g, RawTap t)
-{
-    return (unsigned)t.ix < (unsigned)g.W && (unsigned)t.iy < (unsigned)g.H;
-}
-// cell of (ix, iy), ix in [-1, W], iy in [-1, H], in the bordered (and, for class 0, column-mirrored) image
-__device__ __forceinline__ int c_cell(const PlanGeom &g, const CLayout &L, bool plus, RawTap t)
-{
-    return 1 + (t.iy + 1) * L.pitch + (plus ? t.ix : g.W - 1 - t.ix);
-}
-
 // one wave per (bin block, angle)
 __global__ __launch_bounds__(64) void rotate_cplan_kernel(PlanGeom g, const float *__restrict__ T8, CLayout L,
                                                           char *__restrict__ plan)
@@ -104,59 +81,18 @@ __global__ __launch_bounds__(64) void rotate_cplan_kernel(PlanGeom g, const floa
     const int a = blockIdx.y, jb = blockIdx.x, lane = threadIdx.x;
     const int j = lane_to_bin(g.PW, jb, lane);
     const float *t = T8 + 8 * a;
-    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
-    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
-    const int sigma = t4 < 0.0f ? -1 : 1;   // the kernel's convention: a step moves the cell by sigma * (by * pitch - bx)
     int *cls = reinterpret_cast<int *>(plan + L.off_cls);
     int *ngt = reinterpret_cast<int *>(plan + L.off_ng);
     unsigned *start = reinterpret_cast<unsigned *>(plan + L.off_start);
     uint4 *codes = reinterpret_cast<uint4 *>(plan + L.off_codes);
     int *flag = reinterpret_cast<int *>(plan + L.off_flag);
-    if (jb == 0 && lane == 0) cls[a] = (plus ? 1 : 0) | (sigma < 0 ? 2 : 0);
-    const float xj = t0 * (float)j, yj = t3 * (float)j;
-    const bool valid = (unsigned)j < (unsigned)g.PW;
-
-    int first = g.PH, last = -1, cnt = 0;
-    if (valid)
-        for (int i = 0; i < g.PH; ++i)
-            if (in_core(g, raw_tap(g, xj, yj, t1, t2, t4, t5, i))) {
-                first = min(first, i);
-                last = i;
-                ++cnt;
-            }
-    bool bad = cnt > 0 && cnt != last - first + 1;   // live rows must be one interval
-    const int n = cnt;
-    const int ng = (wave_max_i(n) + kRowsPerGroup - 1) / kRowsPerGroup, R = kRowsPerGroup * ng;
+    if (jb == 0 && lane == 0) cls[a] = cplan_class_word(t);
+    const RayScan rs = cplan_scan_ray(g, t, j, (unsigned)j < (unsigned)g.PW, L.pitch);
+    const int ng = (wave_max_i(rs.n) + kRowsPerGroup - 1) / kRowsPerGroup;
     if (lane == 0) ngt[a * L.nJB + jb] = ng;
-
-    RawTap cur{0, 0};
-    int curcell = 0;   // a ray that misses the core stands on the guard cell (0.0f) with all codes 0
-    if (n > 0) {
-        cur = raw_tap(g, xj, yj, t1, t2, t4, t5, first);
-        curcell = c_cell(g, L, plus, cur);
-    }
-    start[(size_t)a * L.PWpad + jb * 64 + lane] = (unsigned)curcell;
-    for (int q = 0; q < L.NQ; ++q) {
-        unsigned w[4] = {0u, 0u, 0u, 0u};
-        for (int e = 0; e < kRowsPerChunk; ++e) {
-            const int r = kRowsPerChunk * q + e;   // the step from row first + r to row first + r + 1
-            const bool inner = r + 1 < n, leave = r + 1 == n && n < R;
-            if (inner || leave) {
-                const RawTap nxt = raw_tap(g, xj, yj, t1, t2, t4, t5, first + r + 1);   // (row PH: the same arithmetic)
-                const int bx = nxt.ix != cur.ix, by = nxt.iy != cur.iy;
-                if (leave && (in_core(g, nxt) || nxt.ix < -1 || nxt.ix > g.W || nxt.iy < -1 || nxt.iy > g.H)) {
-                    bad = true;   // the ray cannot step onto the border
-                } else {
-                    const int nc = c_cell(g, L, plus, nxt);
-                    if (nc - curcell != sigma * (by * L.pitch - bx)) bad = true;
-                    w[e / 12] |= (unsigned)(bx | (by << 1)) << (8 * ((e % 12) / 3) + 2 * (e % 3));   // byte e / 3, step e % 3
-                    cur = nxt;
-                    curcell = nc;
-                }
-            }
-        }
-        codes[((size_t)a * L.NQ + q) * L.PWpad + jb * 64 + lane] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
+    start[(size_t)a * L.PWpad + jb * 64 + lane] = (unsigned)rs.start;
+    const bool bad = cplan_encode_ray(g, t, j, rs, kRowsPerGroup * ng, L.pitch, L.NQ,
+                                      codes + (size_t)a * L.NQ * L.PWpad + jb * 64 + lane, (size_t)L.PWpad);
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
@@ -180,130 +116,6 @@ __global__ __launch_bounds__(64) void rotate_cplan_class_list_kernel(int A, CLay
 }
 
 // ---- executing a compact plan ---------------------------------------------------------------------------------------
-// table address of code byte BYTE of `w` for this lane: byte * 256 + (lane & 31) * 8.  `la` holds (lane & 31) * 8 in its
-// byte 0; one SDWA move writes the code into byte 1 and preserves the rest.
-template <int BYTE> __device__ __forceinline__ void lut_addr(int &la, unsigned w)
-{
-    if constexpr (BYTE == 0)
-        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0" : "+v"(la) : "v"(w));
-    else if constexpr (BYTE == 1)
-        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(la) : "v"(w));
-    else if constexpr (BYTE == 2)
-        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2" : "+v"(la) : "v"(w));
-    else
-        asm("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(la) : "v"(w));
-}
-// base +- the sign-extended 16-bit half HALF of `pk`: one SDWA op
-template <bool NEG, int HALF> __device__ __forceinline__ int step16(int base, unsigned pk)
-{
-    int r;
-    if constexpr (!NEG && HALF == 0)
-        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(base), "v"(pk));
-    else if constexpr (!NEG && HALF == 1)
-        asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(pk));
-    else if constexpr (NEG && HALF == 0)
-        asm("v_sub_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(base), "v"(pk));
-    else
-        asm("v_sub_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(pk));
-    return r;
-}
-// group GG (six rows = two code bytes) of the chunk pair (c0: groups 0..7, c1: groups 8..15): its code dword and byte pair
-template <int GG> __device__ __forceinline__ unsigned group_dword(const uint4 &c0, const uint4 &c1)
-{
-    constexpr int d = GG >> 1;
-    if constexpr (d == 0) return c0.x;
-    else if constexpr (d == 1) return c0.y;
-    else if constexpr (d == 2) return c0.z;
-    else if constexpr (d == 3) return c0.w;
-    else if constexpr (d == 4) return c1.x;
-    else if constexpr (d == 5) return c1.y;
-    else if constexpr (d == 6) return c1.z;
-    else return c1.w;
-}
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-struct LutPair {
-    u32x2 e0, e1;   // the table entries of a group's two code bytes: (c1 | c2 << 16, c3) each
-};
-// LDS is addressed by absolute 32-bit byte addresses here: the kernel has no static LDS, so its dynamic LDS -- the table
-// first -- starts at address 0 (checked once per workgroup), and a table address is just code byte * 8.
-typedef const __attribute__((address_space(3))) u32x2 *lds_u2_cptr;
-template <int GG> __device__ __forceinline__ LutPair lut_issue(int &la0, int &la1, const uint4 &c0, const uint4 &c1)
-{
-    const unsigned w = group_dword<GG>(c0, c1);
-    constexpr int b = (GG & 1) * 2;
-    LutPair p;
-    lut_addr<b>(la0, w);
-    p.e0 = *(lds_u2_cptr)(size_t)(unsigned)la0;
-    lut_addr<b + 1>(la1, w);
-    p.e1 = *(lds_u2_cptr)(size_t)(unsigned)la1;
-    return p;
-}
-// the six tap addresses of a group from the ray's running address and the group's two table entries
-template <bool NEG> __device__ __forceinline__ void group_addr(int &adr, const LutPair &p, int (&a)[6])
-{
-    a[0] = adr;
-    a[1] = step16<NEG, 0>(adr, p.e0.x);
-    a[2] = step16<NEG, 1>(adr, p.e0.x);
-    const int mid = step16<NEG, 0>(adr, p.e0.y);
-    a[3] = mid;
-    a[4] = step16<NEG, 0>(mid, p.e1.x);
-    a[5] = step16<NEG, 1>(mid, p.e1.x);
-    adr = step16<NEG, 0>(mid, p.e1.y);
-}
-template <int NS> __device__ __forceinline__ void group_gather(const int (&a)[6], typename SliceVec<NS>::type (&v)[6])
-{
-    typedef const __attribute__((address_space(3))) typename SliceVec<NS>::type *lds_vec_cptr;
-#pragma unroll
-    for (int e = 0; e < 6; ++e) v[e] = *(lds_vec_cptr)(size_t)(unsigned)a[e];   // a[e]: absolute LDS byte address
-}
-
-// One ray-sum per lane: walks ng groups of six rows from byte address adr0.  c0 / c1: the ray's code chunks 0 and 1 (48 rows
-// each; chunks behind the plan's NQ-th are zeros: stay); chunk q + 2 is loaded from pc (chunk 2 on) while chunk q is walked.
-// The table entries of group n + 3 and the gathers of group n + 1 are in flight while group n is added.
-template <int NS, bool NEG>
-__device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, int lane8, uint4 c0, uint4 c1, const uint4 *pc,
-                                                              size_t st, int NQ)
-{
-    typedef typename SliceVec<NS>::type vec_t;
-    vec_t acc = 0.0f;
-    vec_t va[6], vb[6];
-    int an[6];
-    int la0 = lane8, la1 = lane8;   // table address registers: byte 0 = (lane & 31) * 8, byte 1 = the code
-    LutPair l0 = lut_issue<0>(la0, la1, c0, c1), l1 = lut_issue<1>(la0, la1, c0, c1);
-    const LutPair l2 = lut_issue<2>(la0, la1, c0, c1);
-    __builtin_amdgcn_sched_barrier(0);   // all six table reads of the first three groups in flight together
-    group_addr<NEG>(adr, l0, an);
-    group_gather<NS>(an, va);
-    group_addr<NEG>(adr, l1, an);
-    l0 = l2;
-    int n = 0;   // first group of the current chunk
-    for (int q = 0;; ++q) {
-        const bool more = q + 2 < NQ && n + 8 < ng;   // wave-uniform: chunk q + 2 exists and may be walked
-        uint4 c2;
-        if (more) c2 = pc[(size_t)q * st];
-#define CTPVAE_CSTEP(G, VCUR, VNXT, LNEW, LUSE)                                                    \
-        group_gather<NS>(an, VNXT);                        /* group n + G + 1 */             \
-        LNEW = lut_issue<G + 3>(la0, la1, c0, c1);        /* table entries of group n + G + 3 */ \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* group n + G */          \
-        if (n + G + 1 >= ng) break;                                                                \
-        group_addr<NEG>(adr, LUSE, an);                          /* addresses of group n + G + 2 */
-        CTPVAE_CSTEP(0, va, vb, l1, l0)
-        CTPVAE_CSTEP(1, vb, va, l0, l1)
-        CTPVAE_CSTEP(2, va, vb, l1, l0)
-        CTPVAE_CSTEP(3, vb, va, l0, l1)
-        CTPVAE_CSTEP(4, va, vb, l1, l0)
-        CTPVAE_CSTEP(5, vb, va, l0, l1)
-        CTPVAE_CSTEP(6, va, vb, l1, l0)
-        CTPVAE_CSTEP(7, vb, va, l0, l1)
-#undef CTPVAE_CSTEP
-        n += 8;
-        c0 = c1;
-        c1 = more ? c2 : uint4{0u, 0u, 0u, 0u};
-    }
-    return acc;
-}
-
 // Forward.  Workgroup = (slice or slice pair, mirror class, task group), placed as in rotate_fwd_planned_kernel; stages the
 // unit with its zero border, builds the step table, then its waves take (angle, bin block) tasks.
 // EPI: 0 = ray-sums only; 1 = + log-probabilities (and d lp / d ray-sum) of the measured samples; 2 = the
@@ -418,29 +230,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
     int *next_task = reinterpret_cast<int *>(image + (size_t)L.cells * NS);
     if (threadIdx.x == 0) *next_task = nwaves;
 
-    // step table: entry e = the cumulative byte offsets after 1..3 of the steps coded in e (bit 2m: column, 2m+1: row), one
-    // copy per lane of a half-wave at byte e * 256 + l * 8
-    for (int t = threadIdx.x; t < 64 * 32; t += blockDim.x) {
-        const int e = t >> 5;
-        int acc = 0;
-        unsigned short cum[3];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            acc += (((e >> (2 * m + 1)) & 1) * L.pitch - ((e >> (2 * m)) & 1)) * (4 * NS);
-            cum[m] = (unsigned short)(short)acc;
-        }
-        reinterpret_cast<uint2 *>(lds)[t] = make_uint2(cum[0] | ((unsigned)cum[1] << 16), cum[2]);
-    }
-    // zero border: guard + row -1 (cells 0 .. pitch), row H + guard, and the gutter columns W .. pitch-1 of rows 0..H-1
-    {
-        const int nthreads = blockDim.x, gut = L.pitch - g.W;
-        for (int t = threadIdx.x; t < (L.pitch + 1) * NS; t += nthreads) image[t] = 0.0f;
-        for (int t = threadIdx.x; t < (L.pitch + 1) * NS; t += nthreads) image[(size_t)(1 + (g.H + 1) * L.pitch) * NS + t] = 0.0f;
-        for (int t = threadIdx.x; t < g.H * gut * NS; t += nthreads) {
-            const int row = t / (gut * NS), k = t - row * (gut * NS);
-            image[(size_t)(1 + (row + 1) * L.pitch + g.W) * NS + k] = 0.0f;
-        }
-    }
+    cplan_init_lut<NS>(lds, L.pitch);
+    cplan_zero_border<NS>(image, g.H, g.W, L.pitch);
     float *core = image + (size_t)(1 + L.pitch) * NS;   // cell of (iy = 0, column 0)
     if constexpr (NS == 1) {
         stage_rows(core, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
@@ -638,7 +429,7 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
     if (red) {
         if (int rc = by_ns(std::integral_constant<int, 2>{})) return rc;
         hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S,
-                           A_run * L.nJB, lp_sum_dev);
+                           A_run, L.nJB, lp_sum_dev);
         CTPVAE_LAUNCH_CHECK("loglik_sum_partials_kernel");
         return CTPVAE_OK;
     }

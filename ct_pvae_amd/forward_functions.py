@@ -221,6 +221,11 @@ class RotatePlan:
                 self._fwd_plan = self._build_plan(0)
             self._want_bwd_plan = bool(self.mode == _lib.BWD_TF_COMPAT and
                                        self._lib.ctpvae_rotate_plan_supported(*geo, 1))
+        # slices larger than LDS: the tiled forward walks compact TILE plans when they can be built (csrc/rotate.hip)
+        self._tplan = None
+        if (use_plan and self._fwd_plan is None and self.interp == _lib.NEAREST and plan_format != "u16"
+                and self.py > 0 and self.px > 0):
+            self._tplan = self._build_tile_plan()
         if self._want_exact_plan:
             # built here, not on the first backward: reading its overflow word synchronises the stream, which must not
             # happen inside a caller's HIP-graph capture
@@ -251,6 +256,21 @@ class RotatePlan:
             over = self._lib.ctpvae_rotate_cplan_overflowed(buf.data_ptr(), self.H, self.W, self.PH, self.PW, self.A,
                                                             _stream_ptr())
         _lib.check(over, "rotate_cplan_overflowed")
+        return buf if over == 0 else None
+
+    def _build_tile_plan(self):
+        """Compact plans of the tiles of a slice that does not fit LDS (None: not a tiled geometry, or a ray whose steps do
+        not fit the code -- the direct tiled kernel then)."""
+        nbytes = self._lib.ctpvae_rotate_tplan_bytes(self.H, self.W, self.PH, self.PW, self.A)
+        _lib.check(nbytes, "rotate_tplan_bytes")
+        if nbytes == 0:
+            return None
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctpvae_rotate_tplan_build_f32(self.T8.data_ptr(), self.A, self.H, self.W, self.PH, self.PW, self.py,
+                                                               self.px, buf.data_ptr(), _stream_ptr()), "rotate_tplan_build")
+            over = self._lib.ctpvae_rotate_tplan_overflowed(buf.data_ptr(), self.H, self.W, self.PH, self.PW, self.A, _stream_ptr())
+        _lib.check(over, "rotate_tplan_overflowed")
         return buf if over == 0 else None
 
     def _get_bwd4_plan(self):
@@ -322,6 +342,24 @@ class RotatePlan:
         with torch.cuda.device(self._dev_index):
             S = img.shape[0]
             sums = torch.empty((S,), dtype=torch.float32, device=self._tdev)
+            ws = self._tile_workspace(S) if angles_i is None else None
+            if ws is not None:      # tiled geometry: the reduce pass of the tiled forward reduces the log-probabilities too
+                self._check(img, (self.H, self.W), "img")
+                self._check(meas, (self.A, self.PW), "meas")
+                self._check(mask, (self.A,), "mask")
+                if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
+                    raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
+                dlp = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=self._tdev) if with_dlp else None
+                tpr = self._lib.ctpvae_loglik_tasks_per_row(self.PW, 1)
+                part = torch.empty((S * self.A * tpr,), dtype=torch.float32, device=self._tdev)
+                rc = self._lib.ctpvae_rotate_fwd_tiled_compact_f32(
+                    img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,
+                    self._tplan.data_ptr() if self._tplan is not None else None, ws.data_ptr(), mask.data_ptr(), meas.data_ptr(),
+                    pnm.data_ptr(), ctypes.c_float(eps), None, None, dlp.data_ptr() if dlp is not None else None,
+                    part.data_ptr(), sums.data_ptr(), _stream_ptr(self._dev_index))
+                if rc:
+                    _lib.check(rc, "rotate_fwd_tiled_compact")
+                return sums, dlp
             if not self._compact:
                 res = self._forward_loglik(img, mask, meas, pnm, eps, with_dlp=with_dlp, angles_i=angles_i,
                                            dense_inputs=dense_inputs)
@@ -489,6 +527,11 @@ class RotatePlan:
         if self._fwd_plan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                          self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+        elif ws is not None and self._tplan is not None:
+            rc = self._lib.ctpvae_rotate_fwd_tiled_compact_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
+                                                               self.px, self.T8.data_ptr(), self.A, self._tplan.data_ptr(),
+                                                               ws.data_ptr(), None, None, None, ctypes.c_float(0.0),
+                                                               out.data_ptr(), None, None, None, None, _stream_ptr(self._dev_index))
         elif ws is not None:
             rc = self._lib.ctpvae_rotate_fwd_tiled_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
                                                        self.px, self.T8.data_ptr(), self.A, ws.data_ptr(), out.data_ptr(),
@@ -546,6 +589,11 @@ class RotatePlan:
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), mask.data_ptr(),
                 meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(), out_lp.data_ptr(), dlp_ptr,
                 _stream_ptr(self._dev_index))
+        elif self._tplan is not None:
+            rc = self._lib.ctpvae_rotate_fwd_tiled_compact_f32(
+                img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,
+                self._tplan.data_ptr(), ws.data_ptr(), mask.data_ptr(), meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps),
+                out.data_ptr(), out_lp.data_ptr(), dlp_ptr, None, None, _stream_ptr(self._dev_index))
         else:
             rc = self._lib.ctpvae_rotate_fwd_tiled_loglik_f32(
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,

@@ -127,6 +127,25 @@ int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W
                                        const float *meas_dev, const float *pnm_dev, float eps, float *sino_dev,
                                        float *lp_dev, float *dlp_dev, ctpvae_stream_t stream);
 
+/* ... through COMPACT tile plans (round 3): the per-sample index arithmetic the tiled kernel is bound by, hoisted into a plan as
+ * for slices that fit LDS (ctpvae_rotate_cplan_*): a section per (tile, angle, ray slot) = the ray's first tap inside the tile +
+ * 2 bits per row.  Same taps, same order, same partial sums and reduce pass: the bits of ctpvae_rotate_fwd_tiled{,_loglik}_f32.
+ * _bytes: 0 if the slice is not tiled (or compact plans are switched off); _overflowed (SYNCHRONISES): 1 = do not use the plan.
+ * tplan_dev NULL: the direct tiled kernel (this is then ctpvae_rotate_fwd_tiled{,_loglik}_f32 with the options below).
+ * lp_dev NULL: ray-sums only; else the log-likelihood epilogue in the reduce pass (mask, meas, pnm required; dlp_dev optional).
+ * lp_sum_dev [S] (with lp_part_dev: S * A * ctpvae_loglik_tasks_per_row(PW, 1) floats): the per-object log-likelihood sums
+ * reduced in the reduce pass, as ctpvae_rotate_fwd_compact_f32 does for slices that fit LDS -- the bits of
+ * ctpvae_loglik_object_sums_f32(lp, partition 1); sino_dev and lp_dev may then be NULL. */
+long long ctpvae_rotate_tplan_bytes(int H, int W, int PH, int PW, int A);
+int ctpvae_rotate_tplan_build_f32(const float *T8_dev, int A, int H, int W, int PH, int PW, int py, int px, void *tplan_dev,
+                                  ctpvae_stream_t stream);
+int ctpvae_rotate_tplan_overflowed(const void *tplan_dev, int H, int W, int PH, int PW, int A, ctpvae_stream_t stream);
+int ctpvae_rotate_fwd_tiled_compact_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                        const float *T8_dev, int A, const void *tplan_dev, void *workspace_dev,
+                                        const float *mask_dev, const float *meas_dev, const float *pnm_dev, float eps,
+                                        float *sino_dev, float *lp_dev, float *dlp_dev, float *lp_part_dev, float *lp_sum_dev,
+                                        ctpvae_stream_t stream);
+
 /* ---- a4: backward of the above -------------------------------------------------------------
  * gsino_dev [S][A][PW] cotangent.  gimg_dev [S][H][W] (overwritten).
  * mode CTPVAE_BWD_TF_COMPAT: T8_dev must hold the INVERTED rows (Tinv8 above).
@@ -198,7 +217,7 @@ int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H,
  *                  reduced inside the launch: every (angle, 64-bin) task adds its log-probabilities by a
  *                  fixed xor butterfly and writes one partial into lp_part_dev (workspace of
  *                  S * angles * ctpvae_loglik_tasks_per_row(PW, 0) floats), a second tiny launch adds a slice's partials
- *                  in ascending order -- the bits of ctpvae_loglik_object_sums_f32(lp, partition 0).  sino_dev and lp_dev
+ *                  in the fixed order stated at ctpvae_loglik_object_sums_f32 -- its bits (partition 0).  sino_dev and lp_dev
  *                  may then be NULL (nothing but dlp [S][n][PW] and the sums leaves the kernel).
  * _supported: 1 if the slice with its one-cell zero border fits LDS (interp NEAREST).  _overflowed (SYNCHRONISES): 1 if some
  * ray's steps do not fit the code (rows that are not a rotation, a ray still inside the slice at the canvas' last row, a
@@ -326,7 +345,9 @@ int ctpvae_gridrec_f32(const float *data_dev, int dy, int dt, int dx, const void
  * are cut into 64-lane tasks (partition 0: the planned kernels' tasks -- angle a, bin block jb = the two 32-bin bands
  * [c - 32 (jb + 1), c - 32 jb) and [c + 32 jb, c + 32 (jb + 1)), c = PW / 2, lanes 0..31 and 32..63; partition 1: the tiled
  * reduce pass's contiguous 64-bin blocks), a task's values are added by the xor butterfly 32, 16, 8, 4, 2, 1 (lanes
- * without a bin add +0.0f), and the task sums are added in ascending (angle, task) order.  _tasks_per_row: tasks per angle. */
+ * without a bin add +0.0f); an angle's task sums are added in ascending order (S_a), and the object's sum is
+ * ((0 + B_0) + B_1) + ... with B_g = the same butterfly over S_(64 g) .. S_(64 g + 63) (angles past A add +0.0f).
+ * _tasks_per_row: tasks per angle. */
 int ctpvae_loglik_tasks_per_row(int PW, int partition);
 int ctpvae_loglik_object_sums_f32(const float *lp_dev, int S, int A, int PW, int partition, float *out_dev,
                                   ctpvae_stream_t stream);

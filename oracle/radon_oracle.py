@@ -277,26 +277,37 @@ def loglik_task_bins(PW, partition=0):
     return [64 * k + np.arange(64) for k in range((PW + 63) // 64)]
 
 
+def _butterfly64(v):
+    lanes = np.arange(64)
+    v = v.astype(np.float32)
+    for off in (32, 16, 8, 4, 2, 1):
+        v = (v + v[lanes ^ off]).astype(np.float32)
+    return v[0]
+
+
 def loglik_object_sums(lp, partition=0):
     """Per-object log-likelihood sums, reduce_sum over angles and bins of lp [S][A][PW] (ctvae/helper_functions.py:305-306) --
     TensorFlow does not fix the order of that sum; the build does, so that every path gives the same bits:
-    a task's 64 values (idle lanes: +0.0) are added by the xor butterfly -- for off in 32, 16, 8, 4, 2, 1: v[l] = v[l] +
-    v[l ^ off] in fp32 -- and the task sums are added one by one in ascending (angle, task) order, starting from +0.0."""
+      * a task's 64 values (idle lanes: +0.0) are added by the xor butterfly -- for off in 32, 16, 8, 4, 2, 1:
+        v[l] = v[l] + v[l ^ off] in fp32;
+      * an angle's task sums are added one by one in ascending order, starting from +0.0  ->  S_a;
+      * the object's sum is ((0 + B_0) + B_1) + ..., B_g = the same butterfly over S_(64 g) .. S_(64 g + 63) (angles past A: +0.0)."""
     lp = _c32(lp)
     S, A, PW = lp.shape
     tasks = loglik_task_bins(PW, partition)
     out = np.zeros(S, np.float32)
-    lanes = np.arange(64)
     for s in range(S):
-        acc = np.float32(0.0)
+        sa = np.zeros(((A + 63) // 64) * 64, np.float32)
         for a in range(A):
+            acc = np.float32(0.0)
             for bins in tasks:
                 ok = (bins >= 0) & (bins < PW)
-                v = np.where(ok, lp[s, a, np.clip(bins, 0, PW - 1)], np.float32(0.0)).astype(np.float32)
-                for off in (32, 16, 8, 4, 2, 1):
-                    v = (v + v[lanes ^ off]).astype(np.float32)
-                acc = np.float32(acc + v[0])
-        out[s] = acc
+                acc = np.float32(acc + _butterfly64(np.where(ok, lp[s, a, np.clip(bins, 0, PW - 1)], np.float32(0.0))))
+            sa[a] = acc
+        tot = np.float32(0.0)
+        for g0 in range(0, A, 64):
+            tot = np.float32(tot + _butterfly64(sa[g0:g0 + 64]))
+        out[s] = tot
     return out
 
 

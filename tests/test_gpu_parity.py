@@ -1920,3 +1920,60 @@ def test_hip_ray_driven_fbp_and_gridrec_against_the_scikit_image_fixture(golden_
     (a, b), *_ = np.linalg.lstsq(A, g.ravel(), rcond=None)
     assert 1.05 < a < 1.2 and np.linalg.norm((g - b) / a - z["sk_rec"]) / np.linalg.norm(z["sk_rec"]) < 0.12
     print(f"HIP vs scikit-image: radon L2 {l2:.4f} / worst {worst:.4f}; gridrec gain {a:.3f}")
+
+
+# ---- round 3: the tiled forward through compact tile plans ----------------------------------------------------------------------
+@pytest.mark.parametrize("shape,A,S", [((512, 512), 90, 5), ((300, 260), 17, 3), ((512, 512), 12, 1), ((257, 400), 9, 6)])
+def test_tiled_forward_through_compact_tile_plans(oracle, shape, A, S):
+    """Slices larger than LDS: the compact tile plans (first tap inside the tile + 2 bits per row, per tile / angle / ray slot)
+    give the partial sums of the direct tiled kernel -- the tiled oracle's bits -- for 4, 2 and 1 slices per workgroup."""
+    d = dev()
+    rng = np.random.default_rng(shape[0] + A)
+    img = rng.random((S,) + shape, dtype=np.float32)
+    theta = rng.uniform(-3.0, 6.0, A).astype(np.float32)
+    theta[:2] = [0.0, np.pi / 2]
+    plan = RotatePlan(theta, shape[0], shape[1], True, d)
+    assert plan.tiled and plan._tplan is not None
+    x = torch.from_numpy(img).to(d)
+    got = plan.forward(x)
+    want = oracle.rotate_fwd_tiled(img, oracle.Geometry(shape[0], shape[1], True), oT(oracle, theta, plan), tile=(96, 64))
+    np.testing.assert_array_equal(to_np(got), want)
+    direct = RotatePlan(theta, shape[0], shape[1], True, d, plan_format="u16")     # the direct tiled kernel
+    assert direct.tiled and direct._tplan is None
+    assert torch.equal(direct.forward(x), got)
+    for ns, G in ((1, 1), (2, 2), (4, 3), (4, 1)):
+        _lib.tune("TILED_NS", ns), _lib.tune("TILED_G", G)
+        assert torch.equal(plan.forward(x), got), (ns, G)
+    _lib.tune("*")
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32)).to(d)
+    pnm = torch.tensor([1e4], device=d)
+    a3, b3 = plan.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True), direct.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True)
+    assert all(torch.equal(u, v) for u, v in zip(a3, b3))
+
+
+@pytest.mark.parametrize("fmt", ["auto", "u16"])
+def test_per_object_loglik_sums_of_a_tiled_geometry(oracle, fmt):
+    """Config 5's geometry (512 x 512, tiled): the reduce pass of the tiled forward reduces the log-probabilities per object too
+    (partition 1 of the fixed order: contiguous 64-bin blocks) -- the ordered sum of the unreduced launch's log-probabilities, bit
+    for bit, and the same d lp / d ray-sum; through the public call with reduce='per_object' as well."""
+    d = dev()
+    rng = np.random.default_rng(2)
+    S, N, A = 5, 512, 12
+    theta = (np.pi * np.arange(A) / A).astype(np.float32)
+    plan = RotatePlan(theta, N, N, True, d, plan_format=fmt)
+    assert plan.tiled and (plan._tplan is not None) == (fmt == "auto")
+    x = torch.from_numpy(rng.random((S, N, N), dtype=np.float32)).to(d)
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32)).to(d)
+    pnm = torch.tensor([1e4], device=d)
+    sino, lp, dlp = plan.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True)
+    sums, dlp2 = plan.forward_loglik_sums(x, mask, meas, pnm, 1.2e-7)
+    np.testing.assert_array_equal(to_np(sums), oracle.loglik_object_sums(to_np(lp), 1))
+    assert torch.equal(dlp2, dlp)
+    if fmt == "auto":
+        xa = x[..., None].clone().requires_grad_(True)
+        got = cp.calculate_log_prob_M_given_R(xa, mask, meas, pnm, 1.2e-7, theta=theta, pad=True, reduce="per_object")
+        assert torch.equal(got, sums)
+        got.sum().backward()
+        assert torch.isfinite(xa.grad).all() and xa.grad.abs().max() > 0
