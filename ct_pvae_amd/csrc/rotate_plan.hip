@@ -39,7 +39,7 @@
 namespace ctpvae {
 
 struct FwdLayout {
-    int nJB, PWpad, NG, Galloc, pitch, zero;
+    int nJB, PWpad, NG, Galloc, pitch, zero, skew0;
     long long off_cls, off_clist, off_first, off_rng, off_idx, bytes;
 };
 constexpr int kBwdPitch = 257;   // dwords per staged cotangent row (== 1 mod 32; bins, then zeros up to cell 256)
@@ -56,7 +56,13 @@ static FwdLayout fwd_layout(const PlanGeom &g)
     L.PWpad = L.nJB * 64;
     L.NG = ceil_div(g.PH, 8);
     L.Galloc = L.NG + 8;  // dead groups behind the canvas: the kernel prefetches up to 7 groups past a range
-    L.pitch = pitch_mod32_is_1(g.W);
+    // EXPERIMENT (developer knob SKEW0, DESIGN.md section 9 "LDS bank conflicts"): row pitch == 0 (mod 32), no mirroring, and
+    // lane l of a half-wave delayed by round(alpha * l) rows so that consecutive lanes' taps step by one 8-byte slot --
+    // tools/sim_lds_conflicts.py's "skew k=0", which only helps angles within 45 degrees of the row direction.  The plan is
+    // then built for measurements on such angle sets; results stay exact (delayed rows read the zero cell).
+    L.skew0 = knob(kKnobSkew0) > 0 ? 1 : 0;
+    L.pitch = L.skew0 ? (g.W + 31) / 32 * 32 : pitch_mod32_is_1(g.W);
+    if (L.skew0) L.Galloc += 6;   // delayed lanes walk up to ~40 rows more
     L.zero = g.H * L.pitch;
     L.off_cls = 0;
     L.off_clist = (long long)g.A * 4;                                     // two lists of (count, angles...)
@@ -113,10 +119,10 @@ __global__ __launch_bounds__(64) void rotate_fwd_first_kernel(PlanGeom g, const 
     const int j = lane_to_bin(g.PW, jb, lane);
     const float *t = T8 + 8 * a;
     const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
-    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
+    const bool plus = L.skew0 ? true : (t0 >= 0.0f) == (t3 >= 0.0f);
     int *cls = reinterpret_cast<int *>(plan + L.off_cls);
     int *first = reinterpret_cast<int *>(plan + L.off_first);
-    if (jb == 0 && lane == 0) cls[a] = plus ? 1 : 0;
+    if (jb == 0 && lane == 0) cls[a] = L.skew0 ? (a & 1) : (plus ? 1 : 0);   // skew0: one layout, angles dealt to both "classes"
     const float xj = t0 * (float)j, yj = t3 * (float)j;
     int f = g.PH;
     if ((unsigned)j < (unsigned)g.PW)
@@ -125,6 +131,34 @@ __global__ __launch_bounds__(64) void rotate_fwd_first_kernel(PlanGeom g, const 
                 f = i;
                 break;
             }
+    if (L.skew0) {
+        // start_l = d_l + c, d_l = round(alpha * (l % 32)), c = min over the half-wave's live lanes of (first_l - d_l): every
+        // lane starts at or before its first live row; alpha makes the column step between consecutive lanes +-1
+        int best_steps = INT_MAX, best_start = f;
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            const float target = sgn ? -1.0f : 1.0f;
+            const float alpha = fabsf(t1) < 1e-3f ? 0.0f : (target - t0) / t1;
+            const int d = (int)rintf(alpha * (float)(lane & 31));
+            int cmin = f < g.PH ? f - d : INT_MAX;
+            for (int off = 16; off > 0; off >>= 1) cmin = min(cmin, __shfl_xor(cmin, off, 64));   // within the 32-lane half
+            const int start = cmin == INT_MAX ? f : d + cmin;
+            // rows this half would walk: the largest (last live row - start + 1); last live row = first + live count - 1
+            int last = -1;
+            if (f < g.PH)
+                for (int i = g.PH - 1; i >= f; --i)
+                    if (fwd_tap(g, L, plus, xj, yj, t1, t2, t4, t5, i) >= 0) {
+                        last = i;
+                        break;
+                    }
+            int steps = f < g.PH ? last - start + 1 : 0;
+            for (int off = 32; off > 0; off >>= 1) steps = max(steps, __shfl_xor(steps, off, 64));
+            if (steps < best_steps) {
+                best_steps = steps;
+                best_start = start;
+            }
+        }
+        f = f < g.PH ? max(best_start, -(1 << 20)) : f;
+    }
     first[(size_t)a * L.PWpad + jb * 64 + lane] = f;
 }
 // pass 2, one wave per (bin block, angle, row group): rng[a][jb] = {first live group, kRngBias - last live group}, both
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
     const int j = lane_to_bin(g.PW, jb, lane);
     const float *t = T8 + 8 * a;
     const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
-    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
+    const bool plus = L.skew0 ? true : (t0 >= 0.0f) == (t3 >= 0.0f);
     const int *first = reinterpret_cast<const int *>(plan + L.off_first);
     int *rng = reinterpret_cast<int *>(plan + L.off_rng);
     uint4 *idx = reinterpret_cast<uint4 *>(plan + L.off_idx);
@@ -149,7 +183,7 @@ __global__ __launch_bounds__(64) void rotate_fwd_plan_kernel(PlanGeom g, const f
     for (int e = 0; e < 8; ++e) {
         const int i = i0 + e;
         unsigned v = (unsigned)L.zero;
-        if (i < g.PH && (unsigned)j < (unsigned)g.PW) {
+        if (i >= 0 && i < g.PH && (unsigned)j < (unsigned)g.PW) {
             const int tap = fwd_tap(g, L, plus, xj, yj, t1, t2, t4, t5, i);
             if (tap >= 0) {
                 v = (unsigned)tap;
@@ -445,10 +479,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 
     // Stage the slice(s): 16-byte loads, conflict-free ds_write_b32 (see stage_rows_v4).
     if constexpr (NS == 1) {
-        stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+        stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0 && !L.skew0, lane, wave, nwaves);
     } else {   // both slices of the pair in one load round trip, written as float2
         const float *srcs[2] = {im, im + (has2 ? (size_t)g.H * g.W : 0)};
-        stage_rows_interleaved<2>(lds, srcs, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+        stage_rows_interleaved<2>(lds, srcs, g.H, g.W, g.W, L.pitch, c == 0 && !L.skew0, lane, wave, nwaves);
     }
     if (threadIdx.x < NS) lds[L.zero * NS + threadIdx.x] = 0.0f;
     CTPVAE_PSTAMP(1);

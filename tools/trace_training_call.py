@@ -29,10 +29,11 @@ meas = torch.from_numpy((rng.random((B, 180, P)) * 3).astype(np.float32)).to(d)
 x = torch.rand((B, N, N, 1), device=d, requires_grad=True)
 pnm = torch.tensor(1e4, device=d)
 subsets = [rng.permutation(180)[:20].astype(np.int32) for _ in range(steps)]      # host-resident, as the trainer draws them
+w = torch.full((B,), -1.0 / B, device=d)          # the upstream gradient of the per-object sums (the trainer's mean loss)
 torch.cuda.synchronize()
 for ai in subsets:
     x.grad = None
     lp = cp.calculate_log_prob_M_given_R(x, mask, meas, pnm, 1e-7, theta=theta, angles_i=ai, pad=True, reduce="per_object")
-    lp.sum().backward()
+    lp.backward(w)
 torch.cuda.synchronize()
 print("done", steps)
