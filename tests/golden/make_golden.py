@@ -65,8 +65,26 @@ def round2_case():
     np.savez_compressed(os.path.join(OUT, "round2_setup_path.npz"), **out)
 
 
+def round3_case():
+    """Round-3 operators: gridrec (f3; tomopy's default parzen filter and the plain ramlak, an odd slice count, a grid smaller
+    than the detector) on the ray-driven sinograms of small foams, and the per-object log-likelihood sums in the library's
+    fixed order (f1), both partitions."""
+    img = phantoms.foam_batch(3, 32, seed=4, supersample=2)
+    theta = np.linspace(0, np.pi, 24, endpoint=False)
+    data = np.ascontiguousarray(np.swapaxes(orc.siddon_project(img, theta, pad=True), 0, 1))        # [3][24][48]
+    out = dict(g_img=img, g_theta=theta, g_data=data, g_parzen=orc.gridrec(data, theta),
+               g_ramlak_40x44=orc.gridrec(data, theta, filter_name="ramlak", ngridx=40, ngridy=44))
+    rng = np.random.default_rng(33)
+    lp = (-6.0 * rng.random((4, 70, 184))).astype(np.float32)
+    out.update(s_lp=lp, s_sums_bands=orc.loglik_object_sums(lp, 0), s_sums_blocks=orc.loglik_object_sums(lp, 1))
+    np.savez_compressed(os.path.join(OUT, "round3.npz"), **out)
+
+
 def main():
     orc.build(force=True)
+    if sys.argv[1:] == ["round3"]:
+        round3_case()
+        return
     if sys.argv[1:] == ["tiled"]:
         tiled_case()
         return
@@ -74,6 +92,7 @@ def main():
         round2_case()
         return
     round2_case()
+    round3_case()
     tiled_case()
     rng = np.random.default_rng(0)
     # the reference's 2x2 toy set (scripts/create_toy_images.py:36-40), no padding

@@ -82,3 +82,16 @@ def test_round2_setup_path_golden(oracle, golden_dir):
     lhs = float((data.astype(np.float64) ** 2).sum())
     rhs = float((z["r_img"].astype(np.float64) * z["r_backproject_obj"]).sum())
     assert abs(lhs - rhs) <= 1e-5 * lhs
+
+
+def test_round3_golden(oracle, golden_dir):
+    """gridrec (f3) and the per-object log-likelihood sums' fixed order (f1) against their committed vectors."""
+    z = load(golden_dir, "round3")
+    np.testing.assert_array_equal(np.swapaxes(oracle.siddon_project(z["g_img"], z["g_theta"], pad=True), 0, 1), z["g_data"])
+    np.testing.assert_array_equal(oracle.gridrec(z["g_data"], z["g_theta"]), z["g_parzen"])
+    np.testing.assert_array_equal(oracle.gridrec(z["g_data"], z["g_theta"], filter_name="ramlak", ngridx=40, ngridy=44),
+                                  z["g_ramlak_40x44"])
+    np.testing.assert_array_equal(oracle.loglik_object_sums(z["s_lp"], 0), z["s_sums_bands"])
+    np.testing.assert_array_equal(oracle.loglik_object_sums(z["s_lp"], 1), z["s_sums_blocks"])
+    want = z["s_lp"].astype(np.float64).sum(axis=(1, 2))
+    assert np.abs(z["s_sums_bands"] - want).max() <= 2e-6 * np.abs(want).max()

@@ -1977,3 +1977,21 @@ def test_per_object_loglik_sums_of_a_tiled_geometry(oracle, fmt):
         assert torch.equal(got, sums)
         got.sum().backward()
         assert torch.isfinite(xa.grad).all() and xa.grad.abs().max() > 0
+
+
+def test_round3_operators_against_golden(golden_dir):
+    """The HIP gridrec and the same-order object sums against tests/golden/round3.npz directly (no oracle in this test)."""
+    from ct_pvae_amd.recon import recon
+    d = dev()
+    z = np.load(os.path.join(golden_dir, "round3.npz"))
+    data, theta = torch.from_numpy(z["g_data"]).to(d), z["g_theta"]
+    np.testing.assert_array_equal(to_np(cp.create_sinograms(torch.from_numpy(z["g_img"]).to(d), theta, pad=True)), z["g_data"])
+    assert rel_err(to_np(recon(data, theta, sinogram_order=True, algorithm="gridrec")), z["g_parzen"]) <= REL
+    assert rel_err(to_np(recon(data, theta, sinogram_order=True, algorithm="gridrec", filter_name="ramlak", num_gridx=40,
+                               num_gridy=44)), z["g_ramlak_40x44"]) <= REL
+    lib = _lib.load()
+    lp = torch.from_numpy(z["s_lp"]).to(d)
+    out = torch.empty(lp.shape[0], device=d)
+    for part, key in ((0, "s_sums_bands"), (1, "s_sums_blocks")):
+        assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), lp.shape[0], lp.shape[1], lp.shape[2], part, out.data_ptr(), None) == 0
+        np.testing.assert_array_equal(to_np(out), z[key])
