@@ -37,6 +37,9 @@ traffic training_call python3 "$ROOT/tools/trace_training_call.py" 50
 python3 "$ROOT/tools/time_recon.py" > "$OUT/time_recon.txt" 2>&1
 python3 "$ROOT/tools/time_sel.py" 10 > "$OUT/time_sel.txt" 2>&1
 python3 "$ROOT/tools/time_compact_shapes.py" > "$OUT/time_compact_shapes.txt" 2>&1
+python3 "$ROOT/tools/time_tplan.py" > "$OUT/time_tplan.txt" 2>&1
+python3 "$ROOT/tools/time_skew.py" > "$OUT/time_skew.txt" 2>&1
+"$ROOT/tools/probe_lut.bin" > "$OUT/probe_lut.txt" 2>&1 || true
 cd "$ROOT"
 bash tools/collect_sq.sh r03_a20 && bash tools/collect_sq.sh r03_a180 --angles 180
 CTPVAE_TUNE_NO_COMPACT=1 bash tools/collect_sq.sh r03_a180_u16 --angles 180
