@@ -11,6 +11,10 @@ namespace ctpvae {
 constexpr int kLutBytes = 64 * 32 * 8;   // 64 entries x 32 lane copies x (3 x i16 + pad), at LDS offset 0
 constexpr int kRowsPerChunk = 48;       // a uint4 of codes: 16 bytes x 3 rows
 constexpr int kRowsPerGroup = 6;        // rows gathered per step of the walk: two code bytes
+// (Round 3, built and measured: THREE bytes -- nine rows -- per step, on 12-byte chunks, to shorten a ray's chain of dependent
+// steps from 19 to 13 (the u16 plan has 14 of eight taps).  It lost everywhere -- 7.99 vs 7.61 us at the headline shape, 155 vs
+// 145 us at B = 400 x 180 angles, 152 vs 139 us for the 512 x 512 tiles, whose four-slice form then spilled: twelve LDS
+// operations per step plus the next step's leave a wave at the 15 it may have in flight, and 18 more VGPRs.  Reverted.)
 template <> struct SliceVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
 // ---- encoding ------------------------------------------------------------------------------------------------------------
