@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="config 4 (batch=400 over 8 GPUs, 180 angles): every step also sums one flat fp32 bucket of the "
                          "P-VAE's 711,164 gradients (2.8 MB) over the ranks -- the data-parallel trainer's only collective")
+    ap.add_argument("--plan-format", choices=["auto", "compact", "u16"], default="auto",
+                    help="forward gather plan of the projector mode (auto: u16 taps below 64 angles, step codes from there)")
     ap.add_argument("--cold", action="store_true",
                     help="cycle 96 distinct input batches (objects + cotangents, 385 MB at the default shape: more than the "
                          "256 MB Infinity Cache) instead of re-projecting ONE resident batch; config.inputs says which")
@@ -373,7 +375,7 @@ def main():
     theta_dense = phantoms.dense_theta(180)
     theta = theta_dense[phantoms.sparse_angle_indices(180, A)] if A < 180 else theta_dense
     imgs = phantoms.foam_batch(B, N, seed=rank, supersample=2)
-    plan = RotatePlan(theta, N, N, True, dev, interp="nearest", backward="tf_compat")
+    plan = RotatePlan(theta, N, N, True, dev, interp="nearest", backward="tf_compat", plan_format=args.plan_format)
     P = plan.PW
     g_host = np.random.default_rng(1000 + rank).standard_normal((B, A, P)).astype(np.float32)
     x = torch.from_numpy(imgs).to(dev)
@@ -606,10 +608,10 @@ def main():
     # command, tools/collect_profiles.sh -> profiles/rNN_traffic_pmc.json), not something this run can observe itself
     traffic, traffic_source = None, None
     try:
-        if (B, N, A) != (50, N_PIX, 20):
+        if (B, N, A) != (50, N_PIX, 20) or args.plan_format != "auto":
             raise LookupError("the committed counters are for the default workload only")
         import glob
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_pmc.json")))[-1]
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_pmc.json")))[-1]
         pmc = json.load(open(newest))
         # the instantiation the timed loop launches is the one with the most dispatches in that run
         traffic = max((v for k, v in pmc["kernels"].items() if dom[0] in k),

@@ -203,8 +203,8 @@ int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H,
                                              float *dlp_dev, ctpvae_stream_t stream);
 /* COMPACT forward plans (round 3): the same taps as the u16 plan above, stored as the ray's first tap + 2 bits per canvas
  * row (does the source column step? does the source row step? -- x_in and y_in of ImageProjectiveTransformV3 are monotone in
- * the row number with slope <= 1, so their rounded values stay or step by one): 0.25 B instead of 2 B per sample, 1.8 MB
- * instead of 17 MB at the dataset's 180 angles, L2-resident on every XCD.  The plan kernel evaluates the reference
+ * the row number with slope <= 1, so their rounded values stay or step by one): 1/3 B instead of 2 B per sample (three rows
+ * per code byte), 2.4 MB instead of 17 MB at the dataset's 180 angles, L2-resident on every XCD.  The plan kernel evaluates the reference
  * arithmetic exactly as the u16 plan's does; ctpvae_rotate_fwd_compact_f32 computes the SAME sums, bit for bit, as
  * ctpvae_rotate_fwd_planned{,_sel,_loglik,_loglik_sel}_f32 -- one entry point, optional operands:
  *   angle_idx      NULL = all A plan angles; else the n_idx (1..256) plan angles to project, outputs [S][n_idx][PW];

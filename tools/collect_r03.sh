@@ -33,6 +33,8 @@ stats training_call python3 "$ROOT/tools/trace_training_call.py" 50
 stats setup_path python3 "$ROOT/tools/time_recon.py"
 traffic bench python3 "$ROOT/bench.py" --steps 50 --warmup 10 --no-cpu-baseline
 traffic angles180 python3 "$ROOT/bench.py" --steps 50 --warmup 10 --no-cpu-baseline --angles 180
+traffic bench_compact python3 "$ROOT/bench.py" --steps 50 --warmup 10 --no-cpu-baseline --plan-format compact
+traffic angles180_u16 python3 "$ROOT/bench.py" --steps 50 --warmup 10 --no-cpu-baseline --angles 180 --plan-format u16
 traffic training_call python3 "$ROOT/tools/trace_training_call.py" 50
 python3 "$ROOT/tools/time_recon.py" > "$OUT/time_recon.txt" 2>&1
 python3 "$ROOT/tools/time_sel.py" 10 > "$OUT/time_sel.txt" 2>&1
