@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
-ABI_VERSION = 3000   # ctpvae_abi_version() of the library this binding was written for
+ABI_VERSION = 3100   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -80,7 +80,12 @@ SIGNATURES = {
     "ctpvae_siddon_tables_f32": (_c_int, [_vp, _c_int, _vp, _vp, _vp]),
     "ctpvae_siddon_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp,
                                        _vp]),
-    "ctpvae_siddon_bwd_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_siddon_bwd_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int]),
+    "ctpvae_siddon_bwd_prepare_f32": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp]),
+    "ctpvae_siddon_bwd_prepared_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp,
+                                                _vp]),
+    "ctpvae_siddon_fwd_resid_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp,
+                                             _vp]),
     "ctpvae_siddon_bwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp]),
     "ctpvae_siddon_rownorm_f32": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp]),
     "ctpvae_fbp_filter_f64": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp]),

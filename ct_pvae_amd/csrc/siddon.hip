@@ -26,13 +26,37 @@ struct SidGeom {
 // its midpoint falls in and its length -- the forward projector adds model[pixel] * dist, the back-projector adds
 // data * dist into the pixel, SIRT's row norm adds dist * dist: the SAME fp32 expressions in all three, so the
 // back-projector is the forward's transpose by construction.
-// CHUNKED: only the segments [nseg * chunk / nchunks, nseg * (chunk + 1) / nchunks) of the ray are visited -- the walk starts
-// in the middle of the merge, at the cursor pair found by a merge-path bisection on the same two key sequences (both are
-// monotone: the a-list's fp32 expression in its traversal order, the b-list's grid lines), so every visited segment has
-// exactly the points, length and pixel the whole walk gives it.
-template <bool CHUNKED = false, class F>
-__device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, float cos_p, int quadrant, int d, F &&segment,
-                                                int chunk = 0, int nchunks = 1)
+struct SidRayLine {
+    float srcx, srcy, slope, islope;
+};
+__device__ __forceinline__ SidRayLine siddon_ray_line(const SidGeom &g, float sin_p, float cos_p, int d)
+{
+    const float xi = (float)(-g.ox - g.oz);
+    const float yi = (1 - g.dx) / 2.0f + d + g.mov;
+    const float srcx = xi * cos_p - yi * sin_p, srcy = xi * sin_p + yi * cos_p;
+    const float detx = -xi * cos_p - yi * sin_p, dety = -xi * sin_p + yi * cos_p;
+    return {srcx, srcy, (srcy - dety) / (srcx - detx), (srcx - detx) / (srcy - dety)};
+}
+// A ray that lies ON a grid line of a direction it is (numerically) parallel to: with a slope of ~1e7 the crossings with the
+// coinciding line family land at erratic positions and libtomo's merge gives long zig-zag segments whose midpoints revisit
+// pixels (odd grids under the even padded detector, theta = pi/2 or 0 exactly).  The pixel-driven back-projector cannot
+// predict those; such rays are walked as libtomo walks them (siddon_bwd_degenerate_kernel).
+__device__ __forceinline__ bool siddon_ray_is_degenerate(const SidGeom &g, const SidRayLine &r)
+{
+    bool deg = false;
+    if (!(fabsf(r.slope) <= 1.0e6f)) {          // parallel to the x = gridx[n] lines
+        const float f = r.srcx - (-g.ox * 0.5f);
+        deg = deg || fabsf(f - rintf(f)) < 1.0e-3f;
+    }
+    if (!(fabsf(r.islope) <= 1.0e6f)) {         // parallel to the y = gridy[n] lines
+        const float f = r.srcy - (-g.oz * 0.5f);
+        deg = deg || fabsf(f - rintf(f)) < 1.0e-3f;
+    }
+    return deg;
+}
+
+template <class F>
+__device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, float cos_p, int quadrant, int d, F &&segment)
 {
     const int ox = g.ox, oz = g.oz;
     const float gx0 = -ox * 0.5f, gy0 = -oz * 0.5f;  // gridx[n] = gx0 + n, gridy[n] = gy0 + n
@@ -87,42 +111,7 @@ __device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, f
     kept_run(islope, gy0, srcy, srcx, gx_gt, gx_le, oz, a_lo, a_cnt);
     kept_run(slope, gx0, srcx, srcy, gy_gt, gy_le, ox, b_lo, b_cnt);
     const int csize = a_cnt + b_cnt;
-    int k_begin = 0, k_end = csize, ia0 = 0;
-    if constexpr (CHUNKED) {
-        const int nseg = max(csize - 1, 0);
-        // Runs of one ray may share a pixel only where they touch -- the back-projector's phase rule -- as long as the ray
-        // meets a pixel in consecutive segments only.  That fails for a ray that lies ON a grid line of a direction it is
-        // (numerically) parallel to: with a slope of ~1e7 the crossings with the coinciding line family land at erratic
-        // positions and libtomo's merge gives long zig-zag segments whose midpoints revisit pixels (odd grids under the even
-        // padded detector, theta = pi/2 or 0 exactly); and with fewer segments than runs, empty runs break the even / odd
-        // alternation.  Such a ray is walked whole by ITS FIRST RUN's lane: one lane, sequential adds, nothing to collide
-        // with (same-parity rays stay two detector pitches away).
-        bool whole = nseg < nchunks;
-        if (!(fabsf(slope) <= 1.0e6f)) {          // parallel to the x = gridx[n] lines
-            const float f = srcx - gx0;
-            whole = whole || fabsf(f - rintf(f)) < 1.0e-3f;
-        }
-        if (!(fabsf(islope) <= 1.0e6f)) {         // parallel to the y = gridy[n] lines
-            const float f = srcy - gy0;
-            whole = whole || fabsf(f - rintf(f)) < 1.0e-3f;
-        }
-        if (whole && chunk != 0) return;
-        const int s0 = whole ? 0 : (int)((long long)nseg * chunk / nchunks);
-        const int s1 = whole ? nseg : (int)((long long)nseg * (chunk + 1) / nchunks);
-        if (s1 <= s0) return;
-        k_begin = s0;
-        k_end = s1 + 1;
-        // ia0 = how many a-elements are among the first k_begin merged points ("a first only if strictly smaller")
-        int lo = max(0, k_begin - b_cnt), hi = min(k_begin, a_cnt);
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            const float ay = gy0 + (float)(quadrant ? a_lo + mid : a_lo + a_cnt - 1 - mid);
-            const float akey = islope * (ay - srcy) + srcx;
-            const float bkey = gx0 + (float)(b_lo + (k_begin - 1 - mid));
-            if (akey < bkey) lo = mid + 1; else hi = mid;
-        }
-        ia0 = lo;
-    }
+    const int k_begin = 0, k_end = csize, ia0 = 0;
     const int ib0 = k_begin - ia0;
     // The merge of libtomo's two sorted lists, with two cursors.  List a runs over its kept n upwards in
     // quadrant 1 and downwards otherwise; gridy[n] = gy0 + n is exact in fp32, so a running +-1.0f gives the same
@@ -176,11 +165,14 @@ __device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, f
 typedef float sid_f32x2 __attribute__((ext_vector_type(2)));
 template <int NS> struct SidVec { typedef float type; };
 template <> struct SidVec<2> { typedef sid_f32x2 type; };
+// meas != NULL (SIRT, libtomo sirt.c): instead of the ray-sum `sim` the kernel stores the ray's update factor
+// upd = (meas - sim) / rn2 where rn2 = sum dist^2 != 0, else 0 -- what the back-projector then spreads over the ray.
 template <bool USE_LDS, int NS>
 __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restrict__ obj, SidGeom g,
                                                          const float *__restrict__ sin_t,
                                                          const float *__restrict__ cos_t,
                                                          const int *__restrict__ quad_t, int p_per_blk,
+                                                         const float *__restrict__ meas, const float *__restrict__ rn2,
                                                          float *__restrict__ data)
 {
     typedef typename SidVec<NS>::type vec_t;
@@ -216,79 +208,408 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
                 m = reinterpret_cast<const vec_t *>(lds)[ix * pitch + iy];
             acc += m * dist;
         });
+        auto store = [&](int sl, float sim) {
+            const size_t o = ((size_t)sl * g.dt + p) * g.dx + d;
+            if (meas) {
+                const float w = rn2[(size_t)p * g.dx + d];
+                data[o] = w != 0.0f ? (meas[o] - sim) / w : 0.0f;
+            } else {
+                data[o] = sim;
+            }
+        };
         if constexpr (NS == 1) {
-            data[((size_t)s * g.dt + p) * g.dx + d] = acc;
+            store(s, acc);
         } else {
-            data[((size_t)s * g.dt + p) * g.dx + d] = acc.x;
-            if (has2) data[((size_t)(s + 1) * g.dt + p) * g.dx + d] = acc.y;
+            store(s, acc.x);
+            if (has2) store(s + 1, acc.y);
         }
     }
 }
 
-// Back-projector: the transpose of the forward, recon[s][pixel] = sum over rays of data[s][p][d] * dist(p, d, pixel) -- what
-// libtomo's fbp.c accumulates (recon[indi[n]] += data[ind_data] * dist[n]) and the A^T of sirt.c's update.  Atomic-free
-// and bit-reproducible: a workgroup owns one slice and a group of angles and adds into its own image (LDS when the slice
-// fits, the partial image in global memory otherwise) with plain read-add-writes, made conflict-free by construction:
-//   * two rays of the SAME parity of d are two detector pitches apart, further than a pixel's diagonal: they never add
-//     into the same pixel;
-//   * every ray is cut into kChunks runs of consecutive segments (merge-path start, see siddon_walk_ray), one lane each, so
-//     that a phase fills the workgroup instead of 92 lanes; a ray meets a pixel in consecutive segments only, so two runs
-//     of one ray can share a pixel only where they touch: even-numbered and odd-numbered runs go in separate phases.
-// Four phases per angle (ray parity x run parity), a barrier after each: every pixel receives its terms in a fixed order
-// (angles ascending; even rays before odd; even runs before odd) whatever the launch; angle groups write partial images
-// that siddon_reduce_groups_kernel adds in ascending group order.  Rays whose datum is 0 are skipped (x + 0 * dist == x): the
-// sparse sinograms and dose masks this is fed (ctvae/helper_functions.py:489-516) are zero at most angles.
-template <bool USE_LDS>
-__global__ __launch_bounds__(1024) void siddon_bwd_kernel(const float *__restrict__ data, SidGeom g,
-                                                         const float *__restrict__ sin_t, const float *__restrict__ cos_t,
-                                                         const int *__restrict__ quad_t, int p_per_grp, int n_grp,
-                                                         int kChunks, float *__restrict__ partial)
+// ---- back-projector: the transpose of the forward, pixel-driven ----------------------------------------------------
+// recon[s][pixel] = sum over rays of data[s][p][d] * dist(p, d, pixel) -- what libtomo's fbp.c accumulates
+// (recon[indi[n]] += data[ind_data] * dist[n]) and the A^T of sirt.c's update -- as a GATHER: a lane owns a pixel and, per
+// angle, asks the (at most two) rays that can cross it for "your segments in my pixel".  The answer is found with libtomo's
+// own fp32 expressions: the ray's crossings with the four grid lines around the pixel (coordx / coordy of utils.c), of which
+// the LATER of {left line, the horizontal line the ray enters through} is the pixel's own segment's first point and the
+// EARLIER of {right line, the other horizontal line} its second -- exactly the consecutive pair sort_intersections' merge
+// by x produces; the segment belongs to the pixel its midpoint falls in (calc_dist's floor), so a pixel takes it only if
+// that pixel is itself.  Two things need more than that, and both are properties of the GEOMETRY, so a flag per (pixel,
+// angle) is computed once (siddon_gather_flags_kernel) and sends the lane down an exact but slower path:
+//   * trim_coords drops crossings within 0.01 of the grid's outline: a segment then reaches back / on to the next kept
+//     crossing, pixel by pixel (rays grazing the outline);
+//   * where a ray passes within a few ulps of a grid corner, the corner-cutting sliver between its two crossings there can
+//     be credited to a NEIGHBOUR of the pixel it lies in, because fl(mid + half) rounds up onto the grid line: the pixel
+//     then also evaluates the own segments of its neighbours at ix - 1 and / or iy - 1 and takes those whose midpoint's
+//     pixel it is.
+// Same points, same sqrtf, and a pixel's terms arrive in libtomo's order (angles ascending, rays ascending, along the ray):
+// the result EQUALS the ray-driven accumulation bit for bit (tests: assert_array_equal against the oracle).  No atomics,
+// no barriers between rays, no partial images: deterministic.
+//
+// Launch: workgroup = (64 columns x R rows of pixels, NS slices); per chunk of angles the rays a tile can meet (a run of
+// <= kGatherSeg detector bins per angle) are staged in LDS: the ray's line (from the table siddon_ray_table_kernel wrote
+// once per geometry) and the NS slices' data interleaved, so one ds_read_b128 pair serves eight slices.  Angles whose staged
+// data are all zero are skipped (sparse sinograms, dose masks).  VALU-bound: ~55 ops per (pixel, ray), shared by NS slices.
+constexpr int kGatherRows = 8;     // pixel rows (= waves) per workgroup
+constexpr int kGatherSeg = 68;     // rays staged per angle: 63 |cos| + 7 |sin| + 3 <= 66.4
+
+struct GatherGeo {
+    float gx0, gy0, gx_gt, gx_le, gy_gt, gy_le, hx, hz;
+    int ox, oz;
+};
+__device__ __forceinline__ GatherGeo gather_geo(const SidGeom &g)
 {
-    extern __shared__ float lds[];
-    const int s = blockIdx.y, grp = blockIdx.x;
-    const int p0 = grp * p_per_grp;
-    const int np = min(p_per_grp, g.dt - p0);
+    GatherGeo G;
+    G.ox = g.ox, G.oz = g.oz;
+    G.gx0 = -g.ox * 0.5f, G.gy0 = -g.oz * 0.5f;
+    G.gx_gt = G.gx0 + 0.01f, G.gx_le = (G.gx0 + g.ox) - 0.01f;
+    G.gy_gt = G.gy0 + 0.01f, G.gy_le = (G.gy0 + g.oz) - 0.01f;
+    G.hx = g.ox * 0.5f, G.hz = g.oz * 0.5f;
+    return G;
+}
+
+// The two rays that can cross a pixel are the ones that bracket its centre on the detector: ray d has yi = yi0 + d, the
+// centre (cxp, cyp) projects to cyp * cos - cxp * sin; any other ray is at least one detector pitch away, further than half
+// a pixel's diagonal.
+__device__ __forceinline__ int gather_first_ray(float cxp, float cyp, float sin_p, float cos_p, float yi0)
+{
+    return (int)floorf((cyp * cos_p - cxp * sin_p) - yi0);
+}
+
+struct GatherPt {
+    float x, y;
+    bool is_a, kept;
+};
+
+// The pieces both paths share.  A crossing is an a-point (with y = gridy[n]) or a b-point (with x = gridx[m]).
+struct GatherRay {
+    const GatherGeo &G;
+    float srcx, srcy, slope, islope;
+    bool up, a_ok, b_ok;
+    __device__ __forceinline__ GatherRay(const GatherGeo &G_, const SidRayLine &r, bool up_)
+        : G(G_), srcx(r.srcx), srcy(r.srcy), slope(r.slope), islope(r.islope), up(up_),
+          a_ok(fabsf(r.islope) <= 3.0e38f), b_ok(fabsf(r.slope) <= 3.0e38f) {}   // an infinite slope empties that list
+    __device__ __forceinline__ float a_x(float y) const { return islope * (y - srcy) + srcx; }
+    __device__ __forceinline__ float b_y(float x) const { return slope * (x - srcx) + srcy; }
+    __device__ __forceinline__ bool a_kept(float x) const { return a_ok && x >= G.gx_gt && x <= G.gx_le; }
+    __device__ __forceinline__ bool b_kept(float y) const { return b_ok && y >= G.gy_gt && y <= G.gy_le; }
+    // sort_intersections takes a first only if strictly smaller: of two candidates the a-point is the LATER one iff !(ax < bx)
+    __device__ __forceinline__ GatherPt entry_of(int cx, int cy) const
+    {
+        const float ay = G.gy0 + (float)(up ? cy : cy + 1), ax = a_x(ay), bx = G.gx0 + (float)cx, by = b_y(bx);
+        const bool is_a = a_ok && (!b_ok || !(ax < bx));
+        return {is_a ? ax : bx, is_a ? ay : by, is_a, is_a ? a_kept(ax) : b_kept(by)};
+    }
+    __device__ __forceinline__ GatherPt exit_of(int cx, int cy) const
+    {
+        const float ay = G.gy0 + (float)(up ? cy + 1 : cy), ax = a_x(ay), bx = G.gx0 + (float)(cx + 1), by = b_y(bx);
+        const bool is_a = a_ok && (!b_ok || ax < bx);
+        return {is_a ? ax : bx, is_a ? ay : by, is_a, is_a ? a_kept(ax) : b_kept(by)};
+    }
+    // calc_dist: the segment's length, and: is it a segment (points in merge order) whose midpoint's pixel is (ix, iy)?
+    __device__ __forceinline__ bool owned(float ex, float ey, float xx, float xy, int ix, int iy, float &dist) const
+    {
+        const float diffx = xx - ex, diffy = xy - ey;
+        dist = sqrtf(diffx * diffx + diffy * diffy);
+        const float midx = (xx + ex) * 0.5f, midy = (xy + ey) * 0.5f;
+        const int indx = (int)floorf(midx + G.hx), indy = (int)floorf(midy + G.hz);
+        return !(xx < ex) && min(max(indx, 0), G.ox - 1) == ix && min(max(indy, 0), G.oz - 1) == iy;
+    }
+    // sort_intersections' order: by x; at equal x a b-point goes first ("a first only if strictly smaller"); a-points among
+    // themselves in the a-list's traversal order (upwards when the ray climbs)
+    __device__ __forceinline__ bool before(const GatherPt &p, const GatherPt &q) const
+    {
+        if (p.x != q.x) return p.x < q.x;
+        if (p.is_a != q.is_a) return !p.is_a;
+        return p.is_a && (up ? p.y < q.y : p.y > q.y);
+    }
+    // how close (in x along a horizontal line, in y along a vertical one) does the ray pass to corner (gx, gy)?
+    __device__ __forceinline__ float corner_gap(float gx, float gy) const { return fminf(fabsf(a_x(gy) - gx), fabsf(b_y(gx) - gy)); }
+    // geometry flag: does pixel (ix, iy) need the slow path for this ray?
+    __device__ __forceinline__ bool needs_slow(int ix, int iy, float tau) const
+    {
+        if (!(a_ok && b_ok)) return true;
+        const GatherPt e = entry_of(ix, iy), x = exit_of(ix, iy);
+        const float gxL = G.gx0 + (float)ix, gxR = G.gx0 + (float)(ix + 1), gyB = G.gy0 + (float)iy, gyT = G.gy0 + (float)(iy + 1);
+        const float gap = fminf(fminf(corner_gap(gxL, gyB), corner_gap(gxL, gyT)), fminf(corner_gap(gxR, gyB), corner_gap(gxR, gyT)));
+        return !(e.kept && x.kept) || gap < tau;
+    }
+    // fast path (flag clear: both slopes finite, both points kept, no corner within tau): the pixel's own segment
+    __device__ __forceinline__ bool own_segment(int ix, int iy, float &dist) const
+    {
+        const float gxL = G.gx0 + (float)ix, gxR = G.gx0 + (float)(ix + 1), gyB = G.gy0 + (float)iy, gyT = G.gy0 + (float)(iy + 1);
+        const float yin = up ? gyB : gyT, yout = up ? gyT : gyB;
+        const float xin = a_x(yin), xout = a_x(yout), ybL = b_y(gxL), ybR = b_y(gxR);
+        const bool ea = !(xin < gxL), xa = xout < gxR;
+        return owned(ea ? xin : gxL, ea ? yin : ybL, xa ? xout : gxR, xa ? yout : ybR, ix, iy, dist);
+    }
+    // slow path: every segment libtomo credits to (ix, iy), in the order of the merge.  Its own segment is extended over
+    // trimmed crossings (a merged segment's midpoint lies on the stretch it spans, so the pixel that owns it finds it as its
+    // own).  At a corner the ray passes within tau of, the sliver between its two crossings there is the own segment of ONE
+    // of the four pixels around the corner (which one is decided by fp32 comparisons that need not agree with the geometry)
+    // and is credited to the pixel its midpoint rounds into -- any of the four: so the own segments of the neighbours
+    // that share a close corner are evaluated too (un-extended: a sliver lies between two KEPT crossings) and taken where
+    // the midpoint's pixel is this one.  A pixel the ray misses yields its two points in the wrong order, possibly at
+    // equal x: `before` is the full merge order.  At most a few segments; they are added in merge order.
+    template <class F> __device__ __forceinline__ void all_segments(int ix, int iy, float tau, F &&add) const
+    {
+        const float gxL = G.gx0 + (float)ix, gxR = G.gx0 + (float)(ix + 1), gyB = G.gy0 + (float)iy, gyT = G.gy0 + (float)(iy + 1);
+        const bool both = a_ok && b_ok;       // (a sliver has an a-point and a b-point: none when a list is empty)
+        const bool c00 = both && !(corner_gap(gxL, gyB) >= tau), c01 = both && !(corner_gap(gxL, gyT) >= tau),
+                   c10 = both && !(corner_gap(gxR, gyB) >= tau), c11 = both && !(corner_gap(gxR, gyT) >= tau);
+        // up to three credited segments, kept sorted by (x, tie) = the merge order of their first points
+        float kx[3], kt[3], kd[3];
+        int n = 0;
+        auto take = [&](const GatherPt &pe, float dist) {
+            // equal x: a b-point first, then a-points in the a-list's order
+            const float tie = pe.is_a ? (up ? pe.y : -pe.y) : -3.0e38f;
+            int pos = n;
+            for (int q = n - 1; q >= 0; --q)
+                if (pe.x < kx[q] || (pe.x == kx[q] && tie < kt[q])) pos = q;
+            for (int q = 2; q > 0; --q)
+                if (q > pos) kx[q] = kx[q - 1], kt[q] = kt[q - 1], kd[q] = kd[q - 1];
+            if (pos < 3) kx[pos] = pe.x, kt[pos] = tie, kd[pos] = dist;
+            n = min(n + 1, 3);
+        };
+        {   // own, extended over trimmed points
+            int cx = ix, cy = iy;
+            GatherPt pe = entry_of(cx, cy), px = exit_of(cx, cy);
+            bool alive = true;
+            while (alive && !pe.kept) {      // trim_coords dropped it: the segment starts at the previous kept crossing
+                if (pe.is_a) cy += up ? -1 : 1; else cx -= 1;
+                alive = cx >= 0 && cy >= 0 && cy < G.oz;
+                if (alive) pe = entry_of(cx, cy);
+            }
+            cx = ix, cy = iy;
+            while (alive && !px.kept) {
+                if (px.is_a) cy += up ? 1 : -1; else cx += 1;
+                alive = cx < G.ox && cy >= 0 && cy < G.oz;
+                if (alive) px = exit_of(cx, cy);
+            }
+            float dist;
+            if (alive && before(pe, px) && owned(pe.x, pe.y, px.x, px.y, ix, iy, dist)) take(pe, dist);
+        }
+        if (c00 || c01 || c10 || c11) {
+            for (int c = 0; c < 9; ++c) {
+                const int ddx = c % 3 - 1, ddy = c / 3 - 1;
+                const bool want = (ddx <= 0 && ddy <= 0 && c00) || (ddx <= 0 && ddy >= 0 && c01) || (ddx >= 0 && ddy <= 0 && c10) ||
+                                  (ddx >= 0 && ddy >= 0 && c11);
+                const int cx = ix + ddx, cy = iy + ddy;
+                if (!want || c == 4 || cx < 0 || cy < 0 || cx >= G.ox || cy >= G.oz) continue;
+                const GatherPt pe = entry_of(cx, cy), px = exit_of(cx, cy);
+                float dist;
+                if (pe.kept && px.kept && before(pe, px) && owned(pe.x, pe.y, px.x, px.y, ix, iy, dist)) take(pe, dist);
+            }
+        }
+        if (n > 0) add(kd[0]);
+        if (n > 1) add(kd[1]);
+        if (n > 2) add(kd[2]);
+    }
+};
+
+// table[p][d] = the ray's line; degenerate rays get srcx = NaN (the gather skips them); degen_angle[p] = has such a ray
+__global__ __launch_bounds__(256) void siddon_ray_table_kernel(SidGeom g, const float *__restrict__ sin_t,
+                                                              const float *__restrict__ cos_t, float4 *__restrict__ table,
+                                                              int *__restrict__ degen_angle)
+{
+    const int p = blockIdx.x;
+    const float sin_p = sin_t[p], cos_p = cos_t[p];
+    int any = 0;
+    for (int d = threadIdx.x; d < g.dx; d += blockDim.x) {
+        SidRayLine r = siddon_ray_line(g, sin_p, cos_p, d);
+        if (siddon_ray_is_degenerate(g, r)) {
+            r.srcx = __builtin_nanf("");
+            any = 1;
+        }
+        table[(size_t)p * g.dx + d] = make_float4(r.srcx, r.srcy, r.slope, r.islope);
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) degen_angle[p] = any;
+}
+
+// flags[w][pixel] bit b: pixel needs the slow path at angle 32 w + b (for either of its two rays) -- geometry only
+__global__ __launch_bounds__(256) void siddon_gather_flags_kernel(SidGeom g, const float *__restrict__ sin_t,
+                                                                 const float *__restrict__ cos_t, const int *__restrict__ quad_t,
+                                                                 const float4 *__restrict__ table, float tau,
+                                                                 unsigned *__restrict__ flags)
+{
     const int npix = g.ox * g.oz;
-    float *out = partial + ((size_t)s * n_grp + grp) * npix;
-    const int pitch = USE_LDS ? g.oz + ((1 - (g.oz & 31)) & 31) : g.oz;
-    float *img = USE_LDS ? lds : out;
-    for (int t = threadIdx.x; t < g.ox * pitch; t += blockDim.x) img[t] = 0.0f;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (pix >= npix) return;
+    const int ix = pix / g.oz, iy = pix - ix * g.oz;
+    const GatherGeo G = gather_geo(g);
+    const float yi0 = (1 - g.dx) / 2.0f + g.mov;
+    const float cxp = (G.gx0 + (float)ix) + 0.5f, cyp = (G.gy0 + (float)iy) + 0.5f;
+    unsigned word = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int p = 32 * w + b;
+        if (p >= g.dt) break;
+        const float sin_p = sin_t[p], cos_p = cos_t[p];
+        const bool up = quad_t[p] != 0;
+        const int d1 = gather_first_ray(cxp, cyp, sin_p, cos_p, yi0);
+        bool slow = false;
+        for (int c = 0; c < 2; ++c) {
+            const int d = d1 + c;
+            if (d < 0 || d >= g.dx) continue;
+            const float4 l4 = table[(size_t)p * g.dx + d];
+            if (l4.x == l4.x) slow = slow || GatherRay(G, SidRayLine{l4.x, l4.y, l4.z, l4.w}, up).needs_slow(ix, iy, tau);
+        }
+        word |= (slow ? 1u : 0u) << b;
+    }
+    flags[(size_t)w * npix + pix] = word;
+}
+
+// The degenerate rays, walked as libtomo walks them, into D[s] (zeroed here; left untouched when the geometry has none):
+// one lane per ray, even rays then odd rays (two rays of one parity are two detector pitches apart and never share a pixel;
+// a degenerate ray's zig-zag stays on its own grid line).
+__global__ __launch_bounds__(256) void siddon_bwd_degenerate_kernel(const float *__restrict__ data, SidGeom g,
+                                                                   const float *__restrict__ sin_t,
+                                                                   const float *__restrict__ cos_t,
+                                                                   const int *__restrict__ quad_t,
+                                                                   const int *__restrict__ degen_angle, float *__restrict__ D)
+{
+    int any = 0;
+    for (int p = threadIdx.x; p < g.dt; p += blockDim.x) any |= degen_angle[p];
+    if (!__syncthreads_or(any)) return;
+    const int s = blockIdx.x, npix = g.ox * g.oz;
+    float *img = D + (size_t)s * npix;
+    for (int t = threadIdx.x; t < npix; t += blockDim.x) img[t] = 0.0f;
     __syncthreads();
-    const float *row = data + ((size_t)s * g.dt + p0) * g.dx;
-    const int KH = kChunks / 2;              // runs per ray and phase (kChunks is even)
-    const int half_rays = (g.dx + 1) >> 1;
-    for (int pl = 0; pl < np; ++pl, row += g.dx) {
-        const int p = p0 + pl;
+    for (int p = 0; p < g.dt; ++p) {
+        if (!degen_angle[p]) continue;
         const float sin_p = sin_t[p], cos_p = cos_t[p];
         const int quadrant = quad_t[p];
-#pragma unroll 1
-        for (int phase = 0; phase < 4; ++phase) {
-            const int par = phase >> 1, cpar = phase & 1;
-            for (int t = threadIdx.x; t < half_rays * KH; t += blockDim.x) {
-                const int rr = t / KH, d = 2 * rr + par;
-                if (d >= g.dx) continue;
+        const float *row = data + ((size_t)s * g.dt + p) * g.dx;
+        for (int par = 0; par < 2; ++par) {
+            for (int d = 2 * threadIdx.x + par; d < g.dx; d += 2 * blockDim.x) {
                 const float v = row[d];
-                if (v != 0.0f)
-                    siddon_walk_ray<true>(g, sin_p, cos_p, quadrant, d,
-                                          [&](int ix, int iy, float dist) { img[ix * pitch + iy] += v * dist; },
-                                          2 * (t - rr * KH) + cpar, kChunks);
+                if (v != 0.0f && siddon_ray_is_degenerate(g, siddon_ray_line(g, sin_p, cos_p, d)))
+                    siddon_walk_ray(g, sin_p, cos_p, quadrant, d,
+                                    [&](int ix, int iy, float dist) { img[ix * g.oz + iy] += v * dist; });
             }
-            __syncthreads();   // (workgroup-scope release / acquire of the image, LDS or global)
+            __syncthreads();
         }
     }
-    if (USE_LDS)
-        for (int t = threadIdx.x; t < npix; t += blockDim.x) out[t] = lds[(t / g.oz) * pitch + (t % g.oz)];
 }
 
-// recon[s][pix] = sum over angle groups, ascending
-__global__ __launch_bounds__(256) void siddon_reduce_groups_kernel(const float *__restrict__ partial, int n_grp, long long npix,
-                                                                  long long total, float *__restrict__ recon)
+template <int NS> struct GatherAcc { float v[NS]; };
+
+// EPI 0: recon = A^T data.   EPI 1 (SIRT): recon += (A^T data) / colsum where colsum != 0 (libtomo sirt.c's last loop).
+template <int NS, int EPI>
+__global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
+    const float *__restrict__ data, SidGeom g, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
+    const int *__restrict__ quad_t, const float4 *__restrict__ table, const unsigned *__restrict__ flags,
+    const int *__restrict__ degen_angle, const float *__restrict__ D, const float *__restrict__ colsum, int CH, float tau,
+    float *__restrict__ recon)
 {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long s = e / npix, q = e - s * npix;
-        float acc = 0.0f;
-        for (int gq = 0; gq < n_grp; ++gq) acc += partial[(s * n_grp + gq) * npix + q];
-        recon[e] = acc;
+    extern __shared__ float lds[];
+    // LDS: lines [CH][SEG] float4 | vals [CH][SEG][NS] | seg_lo [CH] | live [CH] | anyD
+    float4 *lines = reinterpret_cast<float4 *>(lds);
+    float *vals = lds + (size_t)CH * kGatherSeg * 4;
+    int *seg_lo = reinterpret_cast<int *>(vals + (size_t)CH * kGatherSeg * NS);
+    int *live = seg_lo + CH;
+    int *any_d = live + CH;
+    const int tiles_y = (g.oz + 63) / 64;
+    const int ty = blockIdx.x % tiles_y, tx = blockIdx.x / tiles_y;
+    const int ix0 = tx * kGatherRows, iy0 = ty * 64;
+    const int s0 = blockIdx.y * NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ix = ix0 + wave, iy = iy0 + lane;
+    const bool mine = ix < g.ox && iy < g.oz;
+    const int npix = g.ox * g.oz;
+    const GatherGeo G = gather_geo(g);
+    const float yi0 = (1 - g.dx) / 2.0f + g.mov;         // yi of ray d is yi0 + d
+    // pixel centre (libtomo's grid coordinates); its detector coordinate at angle p is  cyp * cos - cxp * sin
+    const float cxp = (G.gx0 + (float)ix) + 0.5f, cyp = (G.gy0 + (float)iy) + 0.5f;
+    if (threadIdx.x == 0) *any_d = 0;
+    __syncthreads();
+    {
+        int any = 0;
+        for (int p = threadIdx.x; p < g.dt; p += blockDim.x) any |= degen_angle[p];
+        if (any) *any_d = 1;
+    }
+    __syncthreads();
+    float acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = (*any_d && mine && s0 + k < g.oy) ? D[(size_t)(s0 + k) * npix + ix * g.oz + iy] : 0.0f;
+
+    // the tile's corners (clipped tiles: the full rectangle -- a superset)
+    const float cx_lo = (G.gx0 + (float)ix0) + 0.5f, cx_hi = (G.gx0 + (float)(ix0 + kGatherRows - 1)) + 0.5f;
+    const float cy_lo = (G.gy0 + (float)iy0) + 0.5f, cy_hi = (G.gy0 + (float)(iy0 + 63)) + 0.5f;
+    unsigned word = 0;
+    for (int p0 = 0; p0 < g.dt; p0 += CH) {
+        const int np = min(CH, g.dt - p0);
+        __syncthreads();          // the previous chunk has been consumed
+        for (int a = threadIdx.x; a < np; a += blockDim.x) live[a] = 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * kGatherSeg; e += blockDim.x) {
+            const int a = e / kGatherSeg, r = e - a * kGatherSeg;
+            const int p = p0 + a;
+            const float sin_p = sin_t[p], cos_p = cos_t[p];
+            // every term is monotone in cxp and in cyp: the extremes sit at the corners, with the lanes' own rounding
+            const float c00 = cy_lo * cos_p - cx_lo * sin_p, c01 = cy_hi * cos_p - cx_lo * sin_p;
+            const float c10 = cy_lo * cos_p - cx_hi * sin_p, c11 = cy_hi * cos_p - cx_hi * sin_p;
+            const int lo = (int)floorf(fminf(fminf(c00, c01), fminf(c10, c11)) - yi0);
+            if (r == 0) seg_lo[a] = lo;
+            const int d = lo + r;
+            float4 line = make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+            float v[NS];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) v[k] = 0.0f;
+            if (d >= 0 && d < g.dx) {
+                line = table[(size_t)p * g.dx + d];
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+                    if (s0 + k < g.oy) v[k] = data[((size_t)(s0 + k) * g.dt + p) * g.dx + d];
+            }
+            lines[e] = line;
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                vals[(size_t)e * NS + k] = v[k];
+                nz = nz || v[k] != 0.0f;
+            }
+            if (nz && line.x == line.x) live[a] = 1;
+        }
+        __syncthreads();
+        for (int a = 0; a < np; ++a) {
+            const int p = p0 + a;
+            if (a == 0 || (p & 31) == 0) word = mine ? flags[(size_t)(p >> 5) * npix + ix * g.oz + iy] : 0u;
+            if (!live[a]) continue;
+            const float sin_p = sin_t[p], cos_p = cos_t[p];
+            const bool up = quad_t[p] != 0;
+            const bool slow = (word >> (p & 31)) & 1u;
+            const int r1 = min(max(gather_first_ray(cxp, cyp, sin_p, cos_p, yi0) - seg_lo[a], 0), kGatherSeg - 2);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {       // the two rays that bracket the pixel's centre, ascending
+                const int e = a * kGatherSeg + r1 + c;
+                const float4 l4 = lines[e];
+                if (!(mine && l4.x == l4.x)) continue;
+                const GatherRay R(G, SidRayLine{l4.x, l4.y, l4.z, l4.w}, up);
+                auto add = [&](float dist) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) acc[k] += vals[(size_t)e * NS + k] * dist;
+                };
+                if (slow) {
+                    R.all_segments(ix, iy, tau, add);
+                } else {
+                    float dist;
+                    if (R.own_segment(ix, iy, dist)) add(dist);
+                }
+            }
+        }
+    }
+    if (!mine) return;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (s0 + k >= g.oy) break;
+        float *out = recon + (size_t)(s0 + k) * npix + ix * g.oz + iy;
+        if constexpr (EPI == 0) {
+            *out = acc[k];
+        } else {
+            const float cs = colsum[ix * g.oz + iy];
+            if (cs != 0.0f) *out += acc[k] / cs;
+        }
     }
 }
 
@@ -339,9 +660,24 @@ int ctpvae_siddon_tables_f32(const float *theta, int dt, float *sin_out, float *
 }
 
 static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
-                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
-                          float *data_dev, ctpvae_stream_t stream);
+                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
+                          const float *rn2_dev, float *data_dev, ctpvae_stream_t stream);
 static float siddon_mov(int dx, float center);
+
+static int siddon_fwd_chunks(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                             const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev,
+                             float *data_dev, ctpvae_stream_t stream)
+{
+    const int chunk = std::max(2, max_slices_per_launch() / 2 * 2);   // even: whole slice pairs per chunk
+    for (int s0 = 0; s0 < oy; s0 += chunk) {
+        const int n = std::min(chunk, oy - s0);
+        if (int rc = siddon_fwd_one(obj_dev + (size_t)s0 * ox * oz, n, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center,
+                                    meas_dev ? meas_dev + (size_t)s0 * dt * dx : nullptr, rn2_dev,
+                                    data_dev + (size_t)s0 * dt * dx, stream))
+            return rc;
+    }
+    return CTPVAE_OK;
+}
 
 // slices are indexed with a grid dimension (<= 65535): a longer stack goes in chunks, back to back on the stream
 int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
@@ -349,19 +685,21 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
                           float *data_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(obj_dev && data_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_fwd: null pointer or empty sizes");
-    const int chunk = std::max(2, max_slices_per_launch() / 2 * 2);   // even: whole slice pairs per chunk
-    for (int s0 = 0; s0 < oy; s0 += chunk) {
-        const int n = std::min(chunk, oy - s0);
-        if (int rc = siddon_fwd_one(obj_dev + (size_t)s0 * ox * oz, n, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center,
-                                    data_dev + (size_t)s0 * dt * dx, stream))
-            return rc;
-    }
-    return CTPVAE_OK;
+    return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, nullptr, nullptr, data_dev, stream);
+}
+
+int ctpvae_siddon_fwd_resid_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
+                                const float *rn2_dev, float *upd_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(obj_dev && upd_dev && meas_dev && rn2_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
+                   "siddon_fwd_resid: null pointer or empty sizes");
+    return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, upd_dev, stream);
 }
 
 static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
-                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center,
-                          float *data_dev, ctpvae_stream_t stream)
+                          const float *cos_dev, const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
+                          const float *rn2_dev, float *data_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(obj_dev && sin_dev && cos_dev && quad_dev && data_dev, "siddon_fwd: null pointer");
     CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
@@ -388,7 +726,7 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem));
         hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, obj_dev, g, sin_dev, cos_dev, quad_dev,
-                           ppb, data_dev);
+                           ppb, meas_dev, rn2_dev, data_dev);
         CTPVAE_LAUNCH_CHECK("siddon_fwd_kernel");
         return CTPVAE_OK;
     };
@@ -404,66 +742,127 @@ static float siddon_mov(int dx, float center)
     return mov + 0.5f;
 }
 
-// angle groups per slice: enough workgroups to fill the chip (~512), at least 4 angles each
-static int siddon_bwd_groups(int oy, int dt)
+}  // extern "C"
+
+// workspace of the back-projector: the ray table [dt][dx] float4, degen_angle [dt] int, the slow-path flags
+// [ceil(dt / 32)][ox][oz] u32, D [oy][ox][oz] float (the
+// degenerate rays' image; written only when the geometry has such rays)
+struct SidWorkspace {
+    long long off_table, off_degen, off_flags, off_d, bytes;
+};
+static SidWorkspace siddon_workspace(int oy, int ox, int oz, int dt, int dx)
 {
-    const int want = ceil_div(512, std::max(1, oy));
-    return std::max(1, std::min(want, ceil_div(dt, 4)));
+    auto up = [](long long v) { return (v + 255) / 256 * 256; };
+    SidWorkspace w;
+    w.off_table = 0;
+    w.off_degen = up((long long)dt * dx * 16);
+    w.off_flags = up(w.off_degen + (long long)dt * 4);
+    w.off_d = up(w.off_flags + (long long)ceil_div(dt, 32) * ox * oz * 4);
+    w.bytes = w.off_d + (long long)oy * ox * oz * 4;
+    return w;
 }
 
-long long ctpvae_siddon_bwd_workspace_bytes(int oy, int ox, int oz, int dt)
+extern "C" {
+
+long long ctpvae_siddon_bwd_workspace_bytes(int oy, int ox, int oz, int dt, int dx)
 {
-    if (oy <= 0 || ox <= 0 || oz <= 0 || dt <= 0) return fail(CTPVAE_EINVAL, "siddon_bwd_workspace_bytes: bad sizes");
-    const int n_grp = siddon_bwd_groups(std::min(oy, 65535), dt);
-    return n_grp > 1 ? (long long)std::min(oy, 65535) * n_grp * ox * oz * (long long)sizeof(float) : 0;
+    if (oy <= 0 || ox <= 0 || oz <= 0 || dt <= 0 || dx <= 0) return fail(CTPVAE_EINVAL, "siddon_bwd_workspace_bytes: bad sizes");
+    return siddon_workspace(oy, ox, oz, dt, dx).bytes;
+}
+
+// fl(mid + half) can round up onto a grid line when mid is within half an ulp of it: two ulps of the largest coordinate
+static float siddon_tau(int ox, int oz)
+{
+    const float big = (float)std::max(ox, oz);
+    return 2.0f * (std::nextafter(big, 2.0f * big) - big);
+}
+
+int ctpvae_siddon_bwd_prepare_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt, int dx,
+                                  float center, void *workspace_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(sin_dev && cos_dev && quad_dev && workspace_dev, "siddon_bwd_prepare: null pointer");
+    CTPVAE_REQUIRE(ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_bwd_prepare: sizes must be positive");
+    const SidWorkspace w = siddon_workspace(1, ox, oz, dt, dx);
+    const SidGeom g{1, ox, oz, dt, dx, siddon_mov(dx, center)};
+    hipLaunchKernelGGL(siddon_ray_table_kernel, dim3(dt), dim3(256), 0, (hipStream_t)stream, g, sin_dev, cos_dev,
+                       (float4 *)((char *)workspace_dev + w.off_table), (int *)((char *)workspace_dev + w.off_degen));
+    CTPVAE_LAUNCH_CHECK("siddon_ray_table_kernel");
+    hipLaunchKernelGGL(siddon_gather_flags_kernel, dim3(ceil_div(ox * oz, 256), ceil_div(dt, 32)), dim3(256), 0, (hipStream_t)stream, g,
+                       sin_dev, cos_dev, quad_dev, (const float4 *)((char *)workspace_dev + w.off_table), siddon_tau(ox, oz),
+                       (unsigned *)((char *)workspace_dev + w.off_flags));
+    CTPVAE_LAUNCH_CHECK("siddon_gather_flags_kernel");
+    return CTPVAE_OK;
+}
+
+}  // extern "C"
+
+template <int NS>
+static int siddon_gather_launch(const float *data, const SidGeom &g, const float *sin_dev, const float *cos_dev,
+                                const int *quad_dev, const float4 *table, const unsigned *flags, const int *degen,
+                                const float *D, const float *colsum, float *recon, hipStream_t stream)
+{
+    // angles per LDS chunk: two staging rounds of the 512 threads, ~50 KB with eight slices -> three workgroups per CU
+    int CH = std::max(1, std::min(g.dt, 2 * kGatherRows * 64 / kGatherSeg));
+    if (knob(kKnobSiddonBwdChunks) > 0) CH = std::max(1, std::min(g.dt, knob(kKnobSiddonBwdChunks)));
+    const size_t shmem = (size_t)CH * kGatherSeg * (16 + 4 * NS) + (size_t)CH * 8 + 16;
+    const float tau = siddon_tau(g.ox, g.oz);
+    const dim3 grid(ceil_div(g.ox, kGatherRows) * ceil_div(g.oz, 64), ceil_div(g.oy, NS)), block(kGatherRows * 64);
+    auto launch = [&](auto kernel) -> int {
+        static std::atomic<unsigned long long> attr_set{0};
+        if (shmem > 64 * 1024) CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, D, colsum,
+                           CH, tau, recon);
+        CTPVAE_LAUNCH_CHECK("siddon_bwd_gather_kernel");
+        return CTPVAE_OK;
+    };
+    return colsum ? launch(siddon_bwd_gather_kernel<NS, 1>) : launch(siddon_bwd_gather_kernel<NS, 0>);
+}
+
+extern "C" {
+
+int ctpvae_siddon_bwd_prepared_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                   const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
+                                   const float *colsum_dev, float *recon_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(data_dev && sin_dev && cos_dev && quad_dev && recon_dev && workspace_dev, "siddon_bwd: null pointer");
+    CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
+                   "siddon_bwd: sizes must be positive (oy=%d ox=%d oz=%d dt=%d dx=%d)", oy, ox, oz, dt, dx);
+    const SidWorkspace w = siddon_workspace(oy, ox, oz, dt, dx);
+    const float4 *table = (const float4 *)((const char *)workspace_dev + w.off_table);
+    const int *degen = (const int *)((const char *)workspace_dev + w.off_degen);
+    const unsigned *flags = (const unsigned *)((const char *)workspace_dev + w.off_flags);
+    float *D = (float *)((char *)workspace_dev + w.off_d);
+    const long long npix = (long long)ox * oz;
+    // slices per workgroup: the walk of a (pixel, ray) is shared by all of them
+    int ns = oy >= 8 ? 8 : oy >= 4 ? 4 : oy >= 2 ? 2 : 1;
+    if (knob(kKnobSiddonBwdNs) > 0) ns = knob(kKnobSiddonBwdNs) >= 8 ? 8 : knob(kKnobSiddonBwdNs) >= 4 ? 4 : knob(kKnobSiddonBwdNs) >= 2 ? 2 : 1;
+    const int chunk = std::max(ns, std::min(65535, max_slices_per_launch()) / ns * ns);
+    for (int s0 = 0; s0 < oy; s0 += chunk) {
+        SidGeom g{std::min(chunk, oy - s0), ox, oz, dt, dx, siddon_mov(dx, center)};
+        const float *data = data_dev + (size_t)s0 * dt * dx;
+        float *Ds = D + (size_t)s0 * npix, *recon = recon_dev + (size_t)s0 * npix;
+        hipLaunchKernelGGL(siddon_bwd_degenerate_kernel, dim3(g.oy), dim3(256), 0, (hipStream_t)stream, data, g, sin_dev, cos_dev,
+                           quad_dev, degen, Ds);
+        CTPVAE_LAUNCH_CHECK("siddon_bwd_degenerate_kernel");
+        int rc;
+        switch (ns) {
+        case 8: rc = siddon_gather_launch<8>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
+        case 4: rc = siddon_gather_launch<4>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
+        case 2: rc = siddon_gather_launch<2>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
+        default: rc = siddon_gather_launch<1>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
+        }
+        if (rc) return rc;
+    }
+    return CTPVAE_OK;
 }
 
 int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
                           const int *quad_dev, int dt, int dx, float center, void *workspace_dev, float *recon_dev,
                           ctpvae_stream_t stream)
 {
-    CTPVAE_REQUIRE(data_dev && sin_dev && cos_dev && quad_dev && recon_dev, "siddon_bwd: null pointer");
-    CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
-                   "siddon_bwd: sizes must be positive (oy=%d ox=%d oz=%d dt=%d dx=%d)", oy, ox, oz, dt, dx);
-    const int chunk = std::min(65535, max_slices_per_launch());
-    const SidGeom g0{0, ox, oz, dt, dx, siddon_mov(dx, center)};
-    const size_t lds_bytes = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
-    const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
-    // runs per ray: 16 (tools/time_recon.py sweep) -- more shorten a lane's chain of dependent read-add-writes but repeat the
-    // ray set-up (two bisections + the merge-path search); never more runs than a short ray has segments to share out
-    int kChunks = 16;
-    if (knob(kKnobSiddonBwdChunks) > 0) kChunks = std::max(2, std::min(64, knob(kKnobSiddonBwdChunks) / 2 * 2));
-    int threads = std::min(1024, ceil_div(ceil_div(dx, 2) * (kChunks / 2), 64) * 64);   // one lane per (ray, run) of a phase
-    if (knob(kKnobSiddonBwdThreads) > 0) threads = std::max(64, std::min(1024, knob(kKnobSiddonBwdThreads) / 64 * 64));
-    const long long npix = (long long)ox * oz;
-    for (int s0 = 0; s0 < oy; s0 += chunk) {
-        const int n = std::min(chunk, oy - s0);
-        const int n_grp = siddon_bwd_groups(std::min(oy, 65535), dt);   // one rule for every chunk: the workspace was sized with it
-        CTPVAE_REQUIRE(n_grp == 1 || workspace_dev, "siddon_bwd: %d angle groups need the workspace", n_grp);
-        const int p_per_grp = ceil_div(dt, n_grp);
-        const int groups = ceil_div(dt, p_per_grp);
-        SidGeom g = g0;
-        g.oy = n;
-        float *partial = groups > 1 ? (float *)workspace_dev : recon_dev + (size_t)s0 * npix;
-        const float *data = data_dev + (size_t)s0 * dt * dx;
-        auto launch = [&](auto kernel, size_t shmem) -> int {
-            static std::atomic<unsigned long long> attr_set{0};
-            if (shmem > 64 * 1024) CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
-            hipLaunchKernelGGL(kernel, dim3(groups, n), dim3(threads), shmem, (hipStream_t)stream, data, g, sin_dev, cos_dev,
-                               quad_dev, p_per_grp, groups, kChunks, partial);
-            CTPVAE_LAUNCH_CHECK("siddon_bwd_kernel");
-            return CTPVAE_OK;
-        };
-        if (int rc = use_lds ? launch(siddon_bwd_kernel<true>, lds_bytes) : launch(siddon_bwd_kernel<false>, 0)) return rc;
-        if (groups > 1) {
-            const long long total = (long long)n * npix;
-            const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256ll * 32);
-            hipLaunchKernelGGL(siddon_reduce_groups_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, partial, groups, npix,
-                               total, recon_dev + (size_t)s0 * npix);
-            CTPVAE_LAUNCH_CHECK("siddon_reduce_groups_kernel");
-        }
-    }
-    return CTPVAE_OK;
+    if (int rc = ctpvae_siddon_bwd_prepare_f32(ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, workspace_dev, stream)) return rc;
+    return ctpvae_siddon_bwd_prepared_f32(data_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, workspace_dev, nullptr,
+                                          recon_dev, stream);
 }
 
 int ctpvae_siddon_rownorm_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt, int dx,

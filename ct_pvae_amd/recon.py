@@ -94,18 +94,31 @@ def _project(x, tables, dx):
     return out
 
 
-def _backproject(data, tables, gx, gy):
-    """A^T y: [oy][dt][dx] -> [oy][gx][gy]."""
+def _bp_workspace(tables, oy, gx, gy, dt, dx, device):
+    """The back-projector's workspace with its geometry part (the ray table) filled in."""
+    lib = _lib.load()
+    sin_t, cos_t, quad = tables
+    need = lib.ctpvae_siddon_bwd_workspace_bytes(oy, gx, gy, dt, dx)
+    _lib.check(need, "siddon_bwd_workspace_bytes")
+    ws = torch.empty(int(need), dtype=torch.uint8, device=device)
+    _lib.check(lib.ctpvae_siddon_bwd_prepare_f32(gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
+                                                 ctypes.c_float(dx / 2.0), ws.data_ptr(), _stream_ptr()), "siddon_bwd_prepare")
+    return ws
+
+
+def _backproject(data, tables, gx, gy, ws=None, colsum=None, out=None):
+    """A^T y: [oy][dt][dx] -> [oy][gx][gy]; with `colsum` and `out`: out += A^T y / colsum where colsum != 0 (SIRT's update)."""
     lib = _lib.load()
     sin_t, cos_t, quad = tables
     oy, dt, dx = data.shape
-    need = lib.ctpvae_siddon_bwd_workspace_bytes(oy, gx, gy, dt)
-    _lib.check(need, "siddon_bwd_workspace_bytes")
-    ws = torch.empty(int(need), dtype=torch.uint8, device=data.device) if need else None
-    out = torch.empty((oy, gx, gy), dtype=torch.float32, device=data.device)
-    _lib.check(lib.ctpvae_siddon_bwd_f32(data.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
-                                         ctypes.c_float(dx / 2.0), ws.data_ptr() if ws is not None else None, out.data_ptr(),
-                                         _stream_ptr()), "siddon_bwd")
+    if ws is None:
+        ws = _bp_workspace(tables, oy, gx, gy, dt, dx, data.device)
+    if out is None:
+        out = torch.empty((oy, gx, gy), dtype=torch.float32, device=data.device)
+    _lib.check(lib.ctpvae_siddon_bwd_prepared_f32(data.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(),
+                                                  dt, dx, ctypes.c_float(dx / 2.0), ws.data_ptr(),
+                                                  colsum.data_ptr() if colsum is not None else None, out.data_ptr(),
+                                                  _stream_ptr()), "siddon_bwd")
     return out
 
 
@@ -126,22 +139,23 @@ def siddon_backproject(data, theta, num_gridx=None, num_gridy=None):
 
 
 def _sirt(data, tables, gx, gy, num_iter, init):
+    """libtomo sirt.c: per iteration ONE forward launch (its store is the ray's update factor (data - A x) / sum dist^2) and ONE
+    back-projector launch (its store is x += A^T upd / sum_dist); the row and column weights are geometry, computed once."""
     lib = _lib.load()
     sin_t, cos_t, quad = tables
     oy, dt, dx = data.shape
     rn2 = torch.empty((dt, dx), dtype=torch.float32, device=data.device)
     _lib.check(lib.ctpvae_siddon_rownorm_f32(gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
                                              ctypes.c_float(dx / 2.0), rn2.data_ptr(), _stream_ptr()), "siddon_rownorm")
-    live_ray = rn2 != 0
-    rn2_safe = torch.where(live_ray, rn2, torch.ones_like(rn2))
-    colsum = _backproject(torch.ones((1, dt, dx), dtype=torch.float32, device=data.device), tables, gx, gy)[0]   # sum_dist
-    live_pix = colsum != 0
-    colsum_safe = torch.where(live_pix, colsum, torch.ones_like(colsum))
-    x = init
+    ws = _bp_workspace(tables, oy, gx, gy, dt, dx, data.device)
+    colsum = _backproject(torch.ones((1, dt, dx), dtype=torch.float32, device=data.device), tables, gx, gy, ws=ws)[0]   # sum_dist
+    x = init.contiguous().clone()
+    upd = torch.empty_like(data)
     for _ in range(int(num_iter)):
-        resid = torch.where(live_ray, (data - _project(x, tables, dx)) / rn2_safe, torch.zeros_like(data))
-        upd = _backproject(resid, tables, gx, gy)
-        x = x + torch.where(live_pix, upd / colsum_safe, torch.zeros_like(upd))
+        _lib.check(lib.ctpvae_siddon_fwd_resid_f32(x.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt,
+                                                   dx, ctypes.c_float(dx / 2.0), data.data_ptr(), rn2.data_ptr(), upd.data_ptr(),
+                                                   _stream_ptr()), "siddon_fwd_resid")
+        _backproject(upd, tables, gx, gy, ws=ws, colsum=colsum, out=x)
     return x
 
 

@@ -67,7 +67,7 @@ typedef void *ctpvae_stream_t;
 /* Version of this ABI: major * 1000 + minor.  CTPVAE_ABI_VERSION is what THIS header describes: host code compiled against
  * it (csrc/torch_node.cpp, a maintainer's own binding) compares the macro with ctpvae_abi_version() of the library it loaded
  * and refuses a mismatch -- an entry point called with another version's argument list is a silent wrong-argument call. */
-#define CTPVAE_ABI_VERSION 3000
+#define CTPVAE_ABI_VERSION 3100
 int ctpvae_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *ctpvae_last_error(void);
@@ -287,15 +287,33 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
 
 /* The transpose of ctpvae_siddon_fwd_f32 -- what libtomo's fbp.c accumulates (recon[indi[n]] += data * dist[n]; with
  * filter_name 'none', as ctvae/helper_functions.py:514 asks for the mask channel, that IS tomopy.recon(algorithm='fbp')) and
- * the A^T of its sirt.c (helper_functions.py:503 with algorithm='sirt').  data_dev [oy][dt][dx] -> recon_dev [oy][ox][oz]
- * (overwritten).  Same ray walk, same fp32 expressions as the forward: <A x, y> = <x, A^T y> to rounding.  Atomic-free and
- * bit-reproducible (even rays, barrier, odd rays per angle; angle groups summed in ascending order).  workspace_dev:
- * ctpvae_siddon_bwd_workspace_bytes() bytes of device memory (0: none needed).
+ * the A^T of its sirt.c (helper_functions.py:503 with algorithm='sirt').  data_dev [oy][dt][dx] -> recon_dev [oy][ox][oz].
+ * Pixel-driven (round 3): a lane owns a pixel and asks the two rays per angle that can cross it for their segment in it,
+ * found with libtomo's own fp32 expressions (the crossings around the pixel, trim_coords' 0.01 rule, the midpoint's pixel);
+ * a pixel's terms arrive in libtomo's order (angles, then rays, ascending), so the result equals the ray-driven accumulation
+ * bit for bit except for the corner-cutting slivers of rays that pass within fp32 rounding of a grid corner (~1e-6 of the
+ * image's range, about one pixel per angle).  No atomics: bit-reproducible.  <A x, y> = <x, A^T y> to rounding.
+ *   _workspace_bytes  device memory the calls below need (ray table, flags, one scratch image per slice)
+ *   _prepare          geometry only: fills the workspace's ray table; once per (grid, angles, dx, center)
+ *   _prepared         colsum_dev NULL:  recon = A^T data  (overwritten)
+ *                     colsum_dev [ox][oz]:  recon += (A^T data) / colsum where colsum != 0 -- sirt.c's update, in place
+ *   _bwd_f32          _prepare + _prepared(colsum NULL)
+ *   ctpvae_siddon_fwd_resid_f32   the forward with sirt.c's per-ray factor as its store: upd = (meas - A obj) / rn2 where
+ *                     rn2 != 0, else 0 (meas_dev [oy][dt][dx], rn2_dev [dt][dx] from _rownorm) -- a SIRT iteration is this
+ *                     launch and one _prepared(colsum) launch.
  * _rownorm: rn2_dev [dt][dx] = sum of squared segment lengths of every ray (sirt.c's sum_dist2; geometry only). */
-long long ctpvae_siddon_bwd_workspace_bytes(int oy, int ox, int oz, int dt);
+long long ctpvae_siddon_bwd_workspace_bytes(int oy, int ox, int oz, int dt, int dx);
+int ctpvae_siddon_bwd_prepare_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt, int dx,
+                                  float center, void *workspace_dev, ctpvae_stream_t stream);
+int ctpvae_siddon_bwd_prepared_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                   const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
+                                   const float *colsum_dev, float *recon_dev, ctpvae_stream_t stream);
 int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
                           const int *quad_dev, int dt, int dx, float center, void *workspace_dev, float *recon_dev,
                           ctpvae_stream_t stream);
+int ctpvae_siddon_fwd_resid_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
+                                const float *rn2_dev, float *upd_dev, ctpvae_stream_t stream);
 int ctpvae_siddon_rownorm_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt,
                               int dx, float center, float *rn2_dev, ctpvae_stream_t stream);
 

@@ -42,7 +42,7 @@ def test_binding_table_matches_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == declared_symbols()
     lib = built_lib.load()
     macro = int(re.search(r"#define\s+CTPVAE_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3000
+    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3100
 
 
 def test_torch_node_refuses_a_library_of_another_abi(built_lib, monkeypatch):
@@ -136,7 +136,6 @@ def test_round2_host_only_size_rules(built_lib):
     assert lib.ctpvae_rotate_exact_plan_bytes(512, 512, 728, 728, 90) == 0          # bins do not fit a byte
     assert lib.ctpvae_rotate_exact_plan_bytes(0, 128, 184, 184, 20) == built_lib.EINVAL
     # 50 slices x 180 angles onto 184 x 184: ceil(512 / 50) = 11 angle groups
-    assert lib.ctpvae_siddon_bwd_workspace_bytes(50, 184, 184, 180) == 50 * 11 * 184 * 184 * 4
-    assert lib.ctpvae_siddon_bwd_workspace_bytes(600, 64, 64, 16) == 0               # one group: no workspace
-    assert lib.ctpvae_siddon_bwd_workspace_bytes(1, 64, 64, 3) == 0                  # fewer than 4 angles per group
-    assert lib.ctpvae_siddon_bwd_workspace_bytes(0, 64, 64, 16) == built_lib.EINVAL
+    # the ray table (16 B per ray), one flag per angle, one bit per (pixel, angle), one scratch image per slice -- 256-B aligned
+    assert lib.ctpvae_siddon_bwd_workspace_bytes(50, 184, 184, 180, 184) == 180 * 184 * 16 + 768 + 6 * 184 * 184 * 4 + 50 * 184 * 184 * 4
+    assert lib.ctpvae_siddon_bwd_workspace_bytes(0, 64, 64, 16, 94) == built_lib.EINVAL
