@@ -226,6 +226,64 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
     }
 }
 
+// Many slices per walk, from global memory: a grid too large for a PAIR of slices in LDS (184 x 184: the reconstruction grid of
+// the training set, SIRT's forward) walks every ray once per slice with the kernel above.  Here NS = 4 or 8 slices are first
+// interleaved per pixel ([group][pixel][NS], siddon_pack_kernel) and a lane fetches all of a pixel's values with one or two
+// 16-byte loads from L2 / L1; the product of a segment is accumulated one step late, so the load has a whole step of the walk
+// (~60 VALU ops) to arrive.  Same walk, same order of the sum: the same bits.
+template <int NS>
+__global__ __launch_bounds__(256) void siddon_pack_kernel(const float *__restrict__ obj, int oy, int npix, float *__restrict__ packed)
+{
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x, grp = blockIdx.y;
+    if (pix >= npix) return;
+    float v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = grp * NS + k < oy ? obj[(size_t)(grp * NS + k) * npix + pix] : 0.0f;
+    float4 *out = reinterpret_cast<float4 *>(packed + ((size_t)grp * npix + pix) * NS);
+#pragma unroll
+    for (int k = 0; k < NS / 4; ++k) out[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void siddon_fwd_packed_kernel(const float *__restrict__ packed, SidGeom g,
+                                                               const float *__restrict__ sin_t, const float *__restrict__ cos_t,
+                                                               const int *__restrict__ quad_t, const float *__restrict__ meas,
+                                                               const float *__restrict__ rn2, float *__restrict__ data)
+{
+    const int grp = blockIdx.y, s0 = grp * NS;
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= g.dt * g.dx) return;
+    const int p = ray / g.dx, d = ray - p * g.dx;
+    const int oz = g.oz;
+    const float4 *img = reinterpret_cast<const float4 *>(packed + (size_t)grp * g.ox * g.oz * NS);
+    float acc[NS], pm[NS], pd = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0f, pm[k] = 0.0f;
+    siddon_walk_ray(g, sin_t[p], cos_t[p], quad_t[p], d, [&](int ix, int iy, float dist) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) acc[k] += pm[k] * pd;       // the previous segment (0 + 0 * 0 the first time)
+        const float4 *q = img + (size_t)(ix * oz + iy) * (NS / 4);
+#pragma unroll
+        for (int k = 0; k < NS / 4; ++k) {
+            const float4 v = q[k];
+            pm[4 * k] = v.x, pm[4 * k + 1] = v.y, pm[4 * k + 2] = v.z, pm[4 * k + 3] = v.w;
+        }
+        pd = dist;
+    });
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float sim = acc[k] + pm[k] * pd;
+        if (s0 + k >= g.oy) break;
+        const size_t o = ((size_t)(s0 + k) * g.dt + p) * g.dx + d;
+        if (meas) {
+            const float w = rn2[(size_t)p * g.dx + d];
+            data[o] = w != 0.0f ? (meas[o] - sim) / w : 0.0f;
+        } else {
+            data[o] = sim;
+        }
+    }
+}
+
 // ---- back-projector: the transpose of the forward, pixel-driven ----------------------------------------------------
 // recon[s][pixel] = sum over rays of data[s][p][d] * dist(p, d, pixel) -- what libtomo's fbp.c accumulates
 // (recon[indi[n]] += data[ind_data] * dist[n]) and the A^T of sirt.c's update -- as a GATHER: a lane owns a pixel and, per
@@ -325,22 +383,35 @@ struct GatherRay {
     }
     // how close (in x along a horizontal line, in y along a vertical one) does the ray pass to corner (gx, gy)?
     __device__ __forceinline__ float corner_gap(float gx, float gy) const { return fminf(fabsf(a_x(gy) - gx), fabsf(b_y(gx) - gy)); }
-    // geometry flag: does pixel (ix, iy) need the slow path for this ray?
-    __device__ __forceinline__ bool needs_slow(int ix, int iy, float tau) const
+    // cheap superset of "the fast path may be wrong for pixel (ix, iy)": a trimmed point, or a corner within tau
+    __device__ __forceinline__ bool maybe_slow(int ix, int iy, float tau) const
     {
-        if (!(a_ok && b_ok)) return true;
         const GatherPt e = entry_of(ix, iy), x = exit_of(ix, iy);
         const float gxL = G.gx0 + (float)ix, gxR = G.gx0 + (float)(ix + 1), gyB = G.gy0 + (float)iy, gyT = G.gy0 + (float)(iy + 1);
         const float gap = fminf(fminf(corner_gap(gxL, gyB), corner_gap(gxL, gyT)), fminf(corner_gap(gxR, gyB), corner_gap(gxR, gyT)));
         return !(e.kept && x.kept) || gap < tau;
     }
-    // fast path (flag clear: both slopes finite, both points kept, no corner within tau): the pixel's own segment
+    // geometry flag: does the slow path credit pixel (ix, iy) with anything but what the fast path gives it?
+    __device__ __forceinline__ bool needs_slow(int ix, int iy, float tau) const
+    {
+        if (!maybe_slow(ix, iy, tau)) return false;
+        float fd = -1.0f, sd = -1.0f;
+        const bool f = own_segment(ix, iy, fd);
+        int n = 0;
+        all_segments(ix, iy, tau, [&](float dist) {
+            if (n == 0) sd = dist;
+            ++n;
+        });
+        return n != (f ? 1 : 0) || (f && sd != fd);
+    }
+    // fast path (flag clear): the pixel's own segment, no trimming, no neighbours.  (A ray along the rows -- sin = 0 exactly --
+    // has an infinite islope and no a-points: its segments run from one vertical line to the next.)
     __device__ __forceinline__ bool own_segment(int ix, int iy, float &dist) const
     {
         const float gxL = G.gx0 + (float)ix, gxR = G.gx0 + (float)(ix + 1), gyB = G.gy0 + (float)iy, gyT = G.gy0 + (float)(iy + 1);
         const float yin = up ? gyB : gyT, yout = up ? gyT : gyB;
         const float xin = a_x(yin), xout = a_x(yout), ybL = b_y(gxL), ybR = b_y(gxR);
-        const bool ea = !(xin < gxL), xa = xout < gxR;
+        const bool ea = a_ok && !(xin < gxL), xa = a_ok && xout < gxR;
         return owned(ea ? xin : gxL, ea ? yin : ybL, xa ? xout : gxR, xa ? yout : ybR, ix, iy, dist);
     }
     // slow path: every segment libtomo credits to (ix, iy), in the order of the merge.  Its own segment is extended over
@@ -578,7 +649,11 @@ __global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
             if (!live[a]) continue;
             const float sin_p = sin_t[p], cos_p = cos_t[p];
             const bool up = quad_t[p] != 0;
+#ifdef CTPVAE_TUNE_GATHER_NOSLOW
+            const bool slow = false;
+#else
             const bool slow = (word >> (p & 31)) & 1u;
+#endif
             const int r1 = min(max(gather_first_ray(cxp, cyp, sin_p, cos_p, yi0) - seg_lo[a], 0), kGatherSeg - 2);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {       // the two rays that bracket the pixel's centre, ascending
@@ -686,6 +761,58 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
 {
     CTPVAE_REQUIRE(obj_dev && data_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_fwd: null pointer or empty sizes");
     return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, nullptr, nullptr, data_dev, stream);
+}
+
+// slices per walk of the packed forward: 0 = keep the LDS kernels (few slices, or a grid whose PAIRS fit LDS and ... see below)
+static int siddon_packed_ns(int oy, int ox, int oz)
+{
+    if (knob(kKnobSiddonNs) == 1 || knob(kKnobSiddonNs) == 2) return 0;       // the knob asks for an LDS kernel
+    if (knob(kKnobSiddonNs) == 4 || knob(kKnobSiddonNs) == 8) return knob(kKnobSiddonNs);
+    return oy >= 6 ? 8 : oy >= 3 ? 4 : 0;
+}
+
+long long ctpvae_siddon_fwd_workspace_bytes(int oy, int ox, int oz)
+{
+    if (oy <= 0 || ox <= 0 || oz <= 0) return fail(CTPVAE_EINVAL, "siddon_fwd_workspace_bytes: bad sizes");
+    const int ns = siddon_packed_ns(oy, ox, oz);
+    return ns ? (long long)ceil_div(oy, ns) * ns * ox * oz * (long long)sizeof(float) : 0;
+}
+
+}  // extern "C"
+
+template <int NS>
+static int siddon_fwd_packed(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                             const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev,
+                             float *packed, float *data_dev, hipStream_t stream)
+{
+    const int npix = ox * oz, groups = ceil_div(oy, NS);
+    CTPVAE_REQUIRE(groups <= 65535, "siddon_fwd: at most %d slices per call with a workspace (got %d)", 65535 * NS, oy);
+    hipLaunchKernelGGL(siddon_pack_kernel<NS>, dim3(ceil_div(npix, 256), groups), dim3(256), 0, stream, obj_dev, oy, npix, packed);
+    CTPVAE_LAUNCH_CHECK("siddon_pack_kernel");
+    const SidGeom g{oy, ox, oz, dt, dx, siddon_mov(dx, center)};
+    hipLaunchKernelGGL(siddon_fwd_packed_kernel<NS>, dim3(ceil_div(dt * dx, 256), groups), dim3(256), 0, stream, packed, g, sin_dev,
+                       cos_dev, quad_dev, meas_dev, rn2_dev, data_dev);
+    CTPVAE_LAUNCH_CHECK("siddon_fwd_packed_kernel");
+    return CTPVAE_OK;
+}
+
+extern "C" {
+
+int ctpvae_siddon_fwd_ws_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                             const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev,
+                             void *workspace_dev, float *data_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(obj_dev && data_dev && sin_dev && cos_dev && quad_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
+                   "siddon_fwd: null pointer or empty sizes");
+    CTPVAE_REQUIRE((meas_dev == nullptr) == (rn2_dev == nullptr), "siddon_fwd: meas and rn2 go together");
+    const int ns = siddon_packed_ns(oy, ox, oz);
+    if (ns == 0)
+        return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, data_dev, stream);
+    CTPVAE_REQUIRE(workspace_dev, "siddon_fwd: %d slices need the workspace", oy);
+    return ns == 8 ? siddon_fwd_packed<8>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev,
+                                          (float *)workspace_dev, data_dev, (hipStream_t)stream)
+                   : siddon_fwd_packed<4>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev,
+                                          (float *)workspace_dev, data_dev, (hipStream_t)stream);
 }
 
 int ctpvae_siddon_fwd_resid_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,

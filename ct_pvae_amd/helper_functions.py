@@ -48,6 +48,27 @@ def _siddon_tables(theta, device):
     return tables
 
 
+def _siddon_forward(obj, tables, dx, meas=None, rn2=None, out=None):
+    """A obj: [oy][ox][oz] -> [oy][dt][dx] through ctpvae_siddon_fwd_ws_f32 (>= 3 slices: one walk of a ray serves 4 or 8 slices
+    interleaved in a workspace; fewer: the LDS kernels).  With meas [oy][dt][dx] and rn2 [dt][dx]: SIRT's update factor
+    (meas - A obj) / rn2 instead of the ray-sums."""
+    lib = _lib.load()
+    sin_t, cos_t, quad = tables
+    oy, ox, oz = obj.shape
+    dt = sin_t.numel()
+    if out is None:
+        out = torch.empty((oy, dt, dx), dtype=torch.float32, device=obj.device)
+    need = lib.ctpvae_siddon_fwd_workspace_bytes(oy, ox, oz)
+    _lib.check(need, "siddon_fwd_workspace_bytes")
+    ws = torch.empty(int(need), dtype=torch.uint8, device=obj.device) if need else None
+    # center=None -> dx / 2 (tomopy.sim.project.get_center)
+    _lib.check(lib.ctpvae_siddon_fwd_ws_f32(obj.data_ptr(), oy, ox, oz, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
+                                            ctypes.c_float(dx / 2.0), meas.data_ptr() if meas is not None else None,
+                                            rn2.data_ptr() if rn2 is not None else None, ws.data_ptr() if ws is not None else None,
+                                            out.data_ptr(), _stream_ptr()), "siddon_fwd")
+    return out
+
+
 def create_sinograms(imgs, theta, pad=True, device=None):
     """Batched create_sinogram: imgs [S][X][Y] -> [S][angles][dx] (fp32), TomoPy's ray-driven projector."""
     lib = _lib.load()
@@ -64,14 +85,11 @@ def create_sinograms(imgs, theta, pad=True, device=None):
     t = t.to(torch.float32).contiguous()
     oy, ox, oz = t.shape
     dx = lib.ctpvae_siddon_dx(ox, oz, 1 if pad else 0)
-    sin_t, cos_t, quad = _siddon_tables(theta, t.device)
-    dt = sin_t.numel()
-    data = torch.empty((oy, dt, dx), dtype=torch.float32, device=t.device)
+    tables = _siddon_tables(theta, t.device)
+    if oy == 0:
+        return np.empty((0, tables[0].numel(), dx), np.float32) if as_numpy else t.new_empty((0, tables[0].numel(), dx))
     with torch.cuda.device(t.device):
-        # center=None -> dx / 2 (tomopy.sim.project.get_center)
-        _lib.check(lib.ctpvae_siddon_fwd_f32(t.data_ptr(), oy, ox, oz, sin_t.data_ptr(), cos_t.data_ptr(),
-                                             quad.data_ptr(), dt, dx, ctypes.c_float(dx / 2.0), data.data_ptr(),
-                                             _stream_ptr()), "siddon_fwd")
+        data = _siddon_forward(t, tables, dx)
     return data.cpu().numpy() if as_numpy else data
 
 

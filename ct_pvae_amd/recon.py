@@ -36,7 +36,7 @@ from . import _lib
 from .dataset_io import compare, crop
 from .fbp import iradon, ramp_filter
 from .forward_functions import _stream_ptr
-from .helper_functions import _siddon_tables
+from .helper_functions import _siddon_forward, _siddon_tables
 
 __all__ = ["recon", "siddon_backproject", "crop", "evaluate_sinogram", "ALGORITHMS", "GRIDREC_FILTERS"]
 
@@ -84,25 +84,30 @@ def _as_device_f32(t, what):
 
 def _project(x, tables, dx):
     """A x: [oy][gx][gy] -> [oy][dt][dx] (tomopy.project on the reconstruction grid, center = dx / 2)."""
-    lib = _lib.load()
-    sin_t, cos_t, quad = tables
-    oy, gx, gy = x.shape
-    out = torch.empty((oy, sin_t.numel(), dx), dtype=torch.float32, device=x.device)
-    _lib.check(lib.ctpvae_siddon_fwd_f32(x.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(),
-                                         sin_t.numel(), dx, ctypes.c_float(dx / 2.0), out.data_ptr(), _stream_ptr()),
-               "siddon_fwd")
-    return out
+    return _siddon_forward(x, tables, dx)
+
+
+_BP_WORKSPACES = {}          # (tables' device pointer, grid, angles, dx, slices) -> (tables, workspace); a few entries
 
 
 def _bp_workspace(tables, oy, gx, gy, dt, dx, device):
-    """The back-projector's workspace with its geometry part (the ray table) filled in."""
+    """The back-projector's workspace with its geometry part (ray table, slow-path flags) filled in.  Kept per geometry --
+    iradon_all reconstructs the same stack with several algorithms (ctvae/helper_functions.py:489-516) --; calls that share an
+    entry must be on one stream (the workspace also holds the call's scratch image)."""
     lib = _lib.load()
     sin_t, cos_t, quad = tables
+    key = (sin_t.data_ptr(), int(gx), int(gy), int(dt), int(dx), int(oy), str(device))
+    hit = _BP_WORKSPACES.get(key)
+    if hit is not None and hit[0] is tables:
+        return hit[1]
     need = lib.ctpvae_siddon_bwd_workspace_bytes(oy, gx, gy, dt, dx)
     _lib.check(need, "siddon_bwd_workspace_bytes")
     ws = torch.empty(int(need), dtype=torch.uint8, device=device)
     _lib.check(lib.ctpvae_siddon_bwd_prepare_f32(gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
                                                  ctypes.c_float(dx / 2.0), ws.data_ptr(), _stream_ptr()), "siddon_bwd_prepare")
+    if len(_BP_WORKSPACES) >= 4:
+        _BP_WORKSPACES.pop(next(iter(_BP_WORKSPACES)))
+    _BP_WORKSPACES[key] = (tables, ws)
     return ws
 
 
@@ -152,9 +157,7 @@ def _sirt(data, tables, gx, gy, num_iter, init):
     x = init.contiguous().clone()
     upd = torch.empty_like(data)
     for _ in range(int(num_iter)):
-        _lib.check(lib.ctpvae_siddon_fwd_resid_f32(x.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt,
-                                                   dx, ctypes.c_float(dx / 2.0), data.data_ptr(), rn2.data_ptr(), upd.data_ptr(),
-                                                   _stream_ptr()), "siddon_fwd_resid")
+        _siddon_forward(x, tables, dx, meas=data, rn2=rn2, out=upd)
         _backproject(upd, tables, gx, gy, ws=ws, colsum=colsum, out=x)
     return x
 
