@@ -455,6 +455,37 @@ def test_paired_siddon_equals_single():
     np.testing.assert_array_equal(one[4], cp.create_sinogram(foam[4], theta, pad=True))
 
 
+@pytest.mark.parametrize("S,shape", [(3, (128, 128)), (5, (40, 57)), (8, (64, 64)), (9, (184, 184)), (17, (33, 47))])
+def test_many_slices_per_walk_equal_the_lds_kernels(oracle, S, shape):
+    """Round 3: with >= 3 slices create_sinograms interleaves 4 or 8 slices per pixel in a workspace and one walk of a ray
+    serves them all from L2 (ctpvae_siddon_fwd_ws_f32) -- the same bits as one slice per workgroup in LDS and as the oracle,
+    whatever the group size (ragged last groups, grids whose slice pairs do not fit LDS, odd rectangles); and its SIRT store
+    (meas - A x) / rn2 equals that expression on the ray-sums."""
+    from ct_pvae_amd.helper_functions import _siddon_forward, _siddon_tables
+    d = dev()
+    rng = np.random.default_rng(S)
+    img = rng.random((S,) + shape, dtype=np.float32)
+    theta = rng.uniform(0.0, np.pi, 11)
+    theta[:2] = [0.0, np.pi / 2]
+    res = {}
+    for ns in (1, 4, 8, None):
+        _lib.tune("SIDDON_NS", *([ns] if ns else []))
+        res[ns] = cp.create_sinograms(img, theta, pad=True)
+    _lib.tune("SIDDON_NS")
+    for ns in (4, 8, None):
+        np.testing.assert_array_equal(res[1], res[ns])
+    np.testing.assert_array_equal(res[None], np.swapaxes(oracle.siddon_project(img, theta, pad=True), 0, 1))
+    t = torch.from_numpy(img).to(d)
+    tables = _siddon_tables(theta, d)
+    sino = torch.from_numpy(res[None]).to(d)
+    meas = torch.from_numpy(rng.random(res[None].shape, dtype=np.float32)).to(d)
+    rn2 = torch.from_numpy(rng.random(res[None].shape[1:], dtype=np.float32)).to(d)
+    rn2[::3, ::5] = 0.0
+    upd = _siddon_forward(t, tables, sino.shape[2], meas=meas, rn2=rn2)
+    want = torch.where(rn2 != 0, (meas - sino) / torch.where(rn2 != 0, rn2, torch.ones_like(rn2)), torch.zeros_like(sino))
+    assert torch.equal(upd, want)
+
+
 def test_iradon_against_oracle_and_golden(oracle, golden_dir):
     z = np.load(os.path.join(golden_dir, "iradon.npz"))
     d = dev()
@@ -877,8 +908,9 @@ def test_siddon_backprojector_is_the_transpose(oracle, shape, A, S, pad):
 def test_sirt_and_the_encoder_channels(oracle, tmp_path):
     """tomopy.recon's algorithms behind iradon_all (ctvae/helper_functions.py:477-529): 'sirt' against the oracle's
     restatement of libtomo's sirt.c (1 iteration = tomopy's default, and 5), 'fbp' / filter 'none' against fbp.c's, the
-    'gridrec' stand-in (ramp-filtered back-projection on tomopy's grid) reconstructing the phantom in the same
-    orientation, and iradon_all stacking [algorithms..., mask channel] with the reference's crop."""
+    gridrec reconstructing the phantom in the same orientation, and iradon_all stacking [algorithms..., mask channel] with the
+    reference's crop.  (Round 3: a SIRT iteration is two launches -- the forward's store is the ray's update factor, the
+    pixel-driven back-projector's store is the update -- and equals the oracle's sirt.c restatement BIT FOR BIT at 1 iteration.)"""
     from ct_pvae_amd.recon import crop, recon
     d = dev()
     N, A = 64, 45
@@ -892,6 +924,8 @@ def test_sirt_and_the_encoder_channels(oracle, tmp_path):
         want = oracle.sirt(host, theta, num_iter=it)
         assert got.shape == want.shape == (3, P, P)
         assert rel_err(got, want) <= (1e-5 if it == 1 else 5e-5), it
+        if it == 1:
+            np.testing.assert_array_equal(got, want)
     bp = to_np(recon(sino, theta, sinogram_order=True, algorithm="fbp", filter_name="none"))
     assert rel_err(bp, oracle.siddon_backproject(host, theta)) <= REL
     # projection order (sinogram_order=False: [angles][slices][dx]) is the same reconstruction
