@@ -288,7 +288,7 @@ def siddon_mode(args, world, rank, dev):
                       "value": world * 50 * 180 / t50, "unit": "projections/s", "n_gpus": world, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": t50 * 1e3, "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                      "config": {"workload": "create_sinograms: 50 slices x 180 angles x 184 bins per call (siddon_fwd_kernel)"},
+                      "config": {"workload": "create_sinograms: 50 slices x 180 angles x 184 bins per call (siddon_fwd_packed_kernel: 8 slices per ray walk)"},
                       "single_slice_call_us": t1 * 1e6, "single_slice_projections_per_s": 180 / t1,
                       "ray_sums_per_s_per_gpu": 50 * 180 * P / t50,
                       "cpu_baseline": {"value": n * 180 / tc, "unit": "projections/s", "cores": 1, "kind": "port",
