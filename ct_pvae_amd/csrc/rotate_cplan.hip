@@ -2,7 +2,7 @@
 //
 // rotate_plan.hip stores every tap of a geometry as a u16 LDS index: 2 B per sample, 1.9 MB at 20 angles and 17 MB at the
 // dataset's 180 -- more than an XCD's 4 MB L2, so at many angles the per-slice kernel is bound by the index stream it
-// pulls through L2 (about six times its algorithmic bytes at A = 180, profiles/r02_traffic_pmc.json).  But along a ray the tap
+// pulls through L2 (nine times its algorithmic bytes at A = 180, profiles/r03_angles180_u16_traffic_pmc.json).  But along a ray the tap
 // moves, from one canvas row to the next, by one of FOUR cell deltas: x_in and y_in (ctvae/forward_functions.py:113 ->
 // tfa.image.rotate -> ImageProjectiveTransformV3) are monotone in the row number with slope |t1|, |t4| <= 1,
 // so round(x_in) and round(y_in) each stay or step by one, always the same way for an angle.  A ray is therefore
