@@ -1344,6 +1344,37 @@ def test_random_siddon_and_tiled_geometries(oracle):
         np.testing.assert_array_equal(to_np(plan.backward(torch.from_numpy(g).to(d))),
                                       oracle.rotate_bwd_tfcompat(g, geom, oTinv(oracle, theta, plan), 0),
                                       err_msg=f"segment bwd case {case}: {H}x{W} pad={pad} A={A} S={S}")
+    # the pixel-driven transpose on random grids (rectangular, tiny, larger than a workgroup's tile, detector wider or
+    # narrower than the grid), random angles plus the special ones and their fp32 neighbours, signed and sparse data:
+    # bit-equal to the oracle's ray-driven accumulation on even grids; odd grids (rays ON grid lines at 0 / pi / 2: a second
+    # kernel, another order) to 1e-5; and SIRT, two fused launches per iteration, against the oracle's sirt.c restatement
+    from ct_pvae_amd.recon import recon, siddon_backproject
+    for case in range(n_cases):
+        even = case % 3 != 2
+        gx, gy = (int(rng.integers(1, 80)) * 2, int(rng.integers(1, 80)) * 2) if even else (int(rng.integers(2, 120)), int(rng.integers(2, 120)))
+        dx, A, S = int(rng.integers(2, 200)), int(rng.integers(1, 40)), int(rng.integers(1, 12))
+        theta = rng.uniform(-7.0, 7.0, A)
+        special = np.array([0.0, np.pi / 2, np.pi / 4, 3 * np.pi / 4, np.pi, np.nextafter(np.float32(np.pi / 4), np.float32(1)),
+                            np.arctan(0.5), np.arctan(2.0), -np.pi / 2])
+        theta[: min(A, special.size)] = rng.permutation(special)[: min(A, special.size)]
+        y = rng.standard_normal((S, A, dx)).astype(np.float32)
+        y[:, rng.random(A) < 0.3] = 0.0
+        got = to_np(siddon_backproject(torch.from_numpy(y).to(d), theta, gx, gy))
+        want = np.zeros((S, gx, gy), np.float32)
+        oracle.lib().oracle_siddon_backproject(y, S, A, dx, theta.astype(np.float32), dx / 2.0, gx, gy, want)
+        msg = f"back-projector case {case}: grid {gx}x{gy} dx={dx} A={A} S={S}"
+        if even and dx % 2 == 0:     # (an odd detector over an even grid also puts its rays on grid lines)
+            np.testing.assert_array_equal(got, want, err_msg=msg)
+        else:
+            assert rel_err(got, want) <= REL, msg
+    for case in range(max(3, n_cases // 4)):
+        n, A, S = int(rng.integers(4, 40)) * 2, int(rng.integers(2, 30)), int(rng.integers(1, 10))
+        theta = np.sort(rng.uniform(0.0, np.pi, A))
+        sino = cp.create_sinograms(rng.random((S, n, n), dtype=np.float32), theta, pad=True)
+        for it in (1, 3):
+            got = to_np(recon(torch.from_numpy(sino).to(d), theta, sinogram_order=True, algorithm="sirt", num_iter=it))
+            want = oracle.sirt(sino, theta, num_iter=it)
+            assert rel_err(got, want) <= (1e-5 if it == 1 else 5e-5), (case, n, A, S, it)
 
 
 def test_launches_are_graph_capturable():
