@@ -135,7 +135,6 @@ def test_round2_host_only_size_rules(built_lib):
     assert lib.ctpvae_rotate_exact_plan_bytes(128, 128, 184, 184, 180) == 23 * 128 * 128 * 16 + 256
     assert lib.ctpvae_rotate_exact_plan_bytes(512, 512, 728, 728, 90) == 0          # bins do not fit a byte
     assert lib.ctpvae_rotate_exact_plan_bytes(0, 128, 184, 184, 20) == built_lib.EINVAL
-    # 50 slices x 180 angles onto 184 x 184: ceil(512 / 50) = 11 angle groups
     # the ray table (16 B per ray), one flag per angle, one bit per (pixel, angle), one scratch image per slice -- 256-B aligned
     assert lib.ctpvae_siddon_bwd_workspace_bytes(50, 184, 184, 180, 184) == 180 * 184 * 16 + 768 + 6 * 184 * 184 * 4 + 50 * 184 * 184 * 4
     assert lib.ctpvae_siddon_bwd_workspace_bytes(0, 64, 64, 16, 94) == built_lib.EINVAL
