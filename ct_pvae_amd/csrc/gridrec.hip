@@ -176,7 +176,9 @@ __global__ __launch_bounds__(1024) void gridrec_fft_rows_kernel(const float *__r
 // (clipped to 1 .. pdim - 1), U = j cos + M2, V = j sin + M2.  A thread owns one cell X = (iu, iv) and performs exactly the
 // additions that reach it, in that order: per angle only the samples near the projection of X (direct) or of pdim - X
 // (mirrored) onto the angle's direction can; where one sample reaches X both ways the loop order of gridrec.c decides.
-__global__ __launch_bounds__(256) void gridrec_grid_kernel(int dt, GrLayout L, const char *__restrict__ tab, char *__restrict__ ws)
+// NQ slice pairs per thread: which samples reach a cell, and with what weights, is geometry -- the same for every pair.
+template <int NQ>
+__global__ __launch_bounds__(256) void gridrec_grid_kernel(int dt, int nq, GrLayout L, const char *__restrict__ tab, char *__restrict__ ws)
 {
     extern __shared__ float lds_raw[];
     float *wtbl_s = lds_raw;                                   // kGrLtbl + 1
@@ -186,21 +188,29 @@ __global__ __launch_bounds__(256) void gridrec_grid_kernel(int dt, GrLayout L, c
     for (int i = threadIdx.x; i <= kGrLtbl; i += blockDim.x) wtbl_s[i] = wtbl[i];
     for (int i = threadIdx.x; i < dt; i += blockDim.x) trig_s[i] = trig[i];
     __syncthreads();
-    const int n = L.pdim, M2 = n / 2, q = blockIdx.y;
+    const int n = L.pdim, M2 = n / 2, q = blockIdx.y * NQ;
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= n * n) return;
     const int iu = cell / n, iv = cell - iu * n;
     cpx *H = reinterpret_cast<cpx *>(ws + L.off_h) + (size_t)q * n * n;
+    const size_t hstride = (size_t)n * n, cstride = (size_t)dt * L.pdim2 * 2;
     if (iu < 1 || iv < 1) {                                    // the aliasing row / column stays zero
-        H[cell] = cpx{0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+            if (q + k < nq) H[k * hstride + cell] = cpx{0.0f, 0.0f};
         return;
     }
-    const cpx *C = reinterpret_cast<const cpx *>(ws + L.off_c) + (size_t)q * dt * L.pdim2 * 2;
+    const cpx *C = reinterpret_cast<const cpx *>(ws + L.off_c) + (size_t)q * cstride;
+    const cpx *Ck[NQ];                                         // a ragged last group re-reads its first pair (never stored)
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) Ck[k] = C + (q + k < nq ? k : 0) * cstride;
     const float L2 = 2.0f, tblspcg = 2 * kGrLtbl / 4.0f;
     const float fu = (float)iu, fv = (float)iv, fum = (float)(n - iu), fvm = (float)(n - iv);
     const bool mirror_first = (n - iu < iu) || (n - iu == iu && n - iv < iv);   // pdim - X before X in gridrec.c's loop order
     const float u = (float)(iu - M2), v = (float)(iv - M2);
-    float hre = 0.0f, him = 0.0f;
+    float hre[NQ], him[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) hre[k] = him[k] = 0.0f;
     for (int p = 0; p < dt; ++p) {
         const float cs = trig_s[p].x, sn = trig_s[p].y;
         const float tproj = u * cs + v * sn;                   // where X projects onto the angle's direction (samples: j)
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void gridrec_grid_kernel(int dt, GrLayout L, c
         }
         jlo = max(jlo, 1);
         jhi = min(jhi, L.pdim2 - 1);
-        const cpx *Cp = C + (size_t)p * L.pdim2 * 2;
+        const size_t prow = (size_t)p * L.pdim2 * 2;
         for (int j = jlo; j <= jhi; ++j) {
             const float U = j * cs + M2, V = j * sn + M2;
             const float ulo = U - L2, uhi = U + L2, vlo = V - L2, vhi = V + L2;
@@ -224,22 +234,27 @@ __global__ __launch_bounds__(256) void gridrec_grid_kernel(int dt, GrLayout L, c
             float wd = 0.0f, wm = 0.0f;
             if (direct) wd = wtbl_s[(int)roundf(fabsf(U - fu) * tblspcg)] * wtbl_s[(int)roundf(fabsf(V - fv) * tblspcg)];
             if (mirror) wm = wtbl_s[(int)roundf(fabsf(U - fum) * tblspcg)] * wtbl_s[(int)roundf(fabsf(V - fvm) * tblspcg)];
-            const cpx c1 = Cp[2 * j], c2 = Cp[2 * j + 1];
-            if (mirror && mirror_first) {
-                hre += wm * c2.re;
-                him += wm * c2.im;
-            }
-            if (direct) {
-                hre += wd * c1.re;
-                him += wd * c1.im;
-            }
-            if (mirror && !mirror_first) {
-                hre += wm * c2.re;
-                him += wm * c2.im;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const cpx c1 = Ck[k][prow + 2 * j], c2 = Ck[k][prow + 2 * j + 1];
+                if (mirror && mirror_first) {
+                    hre[k] += wm * c2.re;
+                    him[k] += wm * c2.im;
+                }
+                if (direct) {
+                    hre[k] += wd * c1.re;
+                    him[k] += wd * c1.im;
+                }
+                if (mirror && !mirror_first) {
+                    hre[k] += wm * c2.re;
+                    him[k] += wm * c2.im;
+                }
             }
         }
     }
-    H[cell] = cpx{hre, him};
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+        if (q + k < nq) H[k * hstride + cell] = cpx{hre[k], him[k]};
 }
 
 // ---- copy-out: the central ngridx x ngridy region (wrap-around order: the image centre sits at H[0][0]) times the window's
@@ -360,8 +375,20 @@ int ctpvae_gridrec_f32(const float *data_dev, int dy, int dt, int dx, const void
         hipLaunchKernelGGL(gridrec_fft_rows_kernel<0>, dim3(dt, nq), dim3(fft_threads), fft_lds, (hipStream_t)stream, dq, dyq, dt, dx,
                            Lq, tab, ws, log2n);
         CTPVAE_LAUNCH_CHECK("gridrec_fft_rows_kernel<0>");
-        hipLaunchKernelGGL(gridrec_grid_kernel, dim3(ceil_div(pdim * pdim, 256), nq), dim3(256),
-                           (size_t)(kGrLtbl + 4) * 4 + (size_t)dt * 8, (hipStream_t)stream, dt, Lq, tab, ws);
+        {   // pairs per thread: 5 divides the training set's 25 pairs; enough workgroups must remain to fill the chip
+            const size_t shm = (size_t)(kGrLtbl + 4) * 4 + (size_t)dt * 8;
+            const int cells = ceil_div(pdim * pdim, 256);
+            const int npt = nq % 5 == 0 || nq > 20 ? 5 : nq >= 4 ? 4 : nq >= 2 ? 2 : 1;
+            const dim3 grid(cells, ceil_div(nq, npt));
+            if (npt == 5)
+                hipLaunchKernelGGL(gridrec_grid_kernel<5>, grid, dim3(256), shm, (hipStream_t)stream, dt, nq, Lq, tab, ws);
+            else if (npt == 4)
+                hipLaunchKernelGGL(gridrec_grid_kernel<4>, grid, dim3(256), shm, (hipStream_t)stream, dt, nq, Lq, tab, ws);
+            else if (npt == 2)
+                hipLaunchKernelGGL(gridrec_grid_kernel<2>, grid, dim3(256), shm, (hipStream_t)stream, dt, nq, Lq, tab, ws);
+            else
+                hipLaunchKernelGGL(gridrec_grid_kernel<1>, grid, dim3(256), shm, (hipStream_t)stream, dt, nq, Lq, tab, ws);
+        }
         CTPVAE_LAUNCH_CHECK("gridrec_grid_kernel");
         hipLaunchKernelGGL(gridrec_fft_rows_kernel<1>, dim3(pdim, nq), dim3(fft_threads), fft_lds, (hipStream_t)stream, nullptr, dyq, dt,
                            dx, Lq, tab, ws, log2n);
