@@ -31,28 +31,16 @@ __global__ __launch_bounds__(256) void fbp_filter_kernel(const double *__restric
     }
 }
 
-// tfp.math.interp_regular_1d_grid, fill_value='constant_extension' (tensorflow-probability 0.14.0)
-__device__ __forceinline__ double interp_regular_1d(const double *__restrict__ y_ref, int ny, double x,
-                                                    double x_min, double x_max)
-{
-    const double top = (double)(ny - 1);
-    // tfp: (x - x_min) / (x_max - x_min) * (ny - 1).  iradon's grid spans exactly ny - 1 (x_max - x_min == top, both
-    // exact in fp64), so the scale factor is one fp64 constant (1.0 here) instead of an fp64 division per tap; the
-    // result moves by at most 1 ulp of idx, i.e. ~1e-16 of the interpolated value (the interpolant is continuous).
-    const double idx_unclipped = (x - x_min) * (top / (x_max - x_min));
-    double idx = idx_unclipped;
-    idx = idx < 0.0 ? 0.0 : idx;
-    idx = idx > top ? top : idx;
-    double below = floor(idx);
-    const double above = fmin(below + 1.0, top);
-    below = fmax(above - 1.0, 0.0);
-    const double t = idx - below;
-    double y = t * y_ref[(int)above] + (1.0 - t) * y_ref[(int)below];
-    if (idx_unclipped < 0.0) y = y_ref[0];
-    if (idx_unclipped > top) y = y_ref[ny - 1];
-    return y;
-}
-
+// Back-projection by tfp.math.interp_regular_1d_grid, fill_value='constant_extension' (tensorflow-probability 0.14.0):
+//   idx = (x - x_min) / (x_max - x_min) * (ny - 1), clipped to [0, ny - 1]; above = min(floor(idx) + 1, ny - 1), below = max(above - 1, 0);
+//   y = t * y_ref[above] + (1 - t) * y_ref[below] with t = idx - below; y_ref[0] / y_ref[ny - 1] beyond the grid.
+// iradon's grid spans exactly ny - 1 (x_max - x_min == top, both exact in fp64), so the scale factor is one fp64 constant
+// (1.0 here) instead of an fp64 division per tap; the result moves by at most 1 ulp of idx, i.e. ~1e-16 of the
+// interpolated value (the interpolant is continuous).
+// NB sinograms per thread: where a pixel falls on the detector at an angle, and with what weights it interpolates, is
+// geometry -- the fp64 index arithmetic (the kernel's cost) is done once for all of them; every sinogram's sum is the
+// same expression in the same order as with one sinogram per thread.
+template <int NB>
 __global__ __launch_bounds__(256) void fbp_backproject_kernel(const double *__restrict__ filt, int B, int A,
                                                               int P, const double *__restrict__ cos_t,
                                                               const double *__restrict__ sin_t, int X, int Y,
@@ -61,19 +49,44 @@ __global__ __launch_bounds__(256) void fbp_backproject_kernel(const double *__re
 {
     // pixel (i, j) sits at (i - x0, j - y0); detector sample k at k - t0.  The reference's iradon
     // (ctvae/fbp_tensorflow.py:52-70): x0 = X / 2, y0 = Y / 2, t0 = P / 2.
-    const int b = blockIdx.y;
+    const int b0 = blockIdx.y * NB;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= X * Y) return;
     const int i = p / Y, j = p - i * Y;
     const double xpr = (double)i - x0, ypr = (double)j - y0;
-    const double x_min = 0.0 - t0, x_max = (double)(P - 1) - t0;
-    const double *f = filt + (size_t)b * A * P;
-    double acc = 0.0;
+    const double x_min = 0.0 - t0, x_max = (double)(P - 1) - t0, top = (double)(P - 1);
+    const double scale = top / (x_max - x_min);
+    const size_t bstride = (size_t)A * P;
+    const double *f[NB];                                   // a ragged last group re-reads its first sinogram (never stored)
+#pragma unroll
+    for (int n = 0; n < NB; ++n) f[n] = filt + (size_t)(b0 + (b0 + n < B ? n : 0)) * bstride;
+    double acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = 0.0;
     for (int a = 0; a < A; ++a) {
         const double t = ypr * cos_t[a] - xpr * sin_t[a];
-        acc += interp_regular_1d(f + (size_t)a * P, P, t, x_min, x_max);
+        const double idx_unclipped = (t - x_min) * scale;
+        double idx = idx_unclipped;
+        idx = idx < 0.0 ? 0.0 : idx;
+        idx = idx > top ? top : idx;
+        double below = floor(idx);
+        const double above = fmin(below + 1.0, top);
+        below = fmax(above - 1.0, 0.0);
+        const double tt = idx - below;
+        const int ka = (int)above, kb = (int)below;
+        const bool lo = idx_unclipped < 0.0, hi = idx_unclipped > top;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const double *row = f[n] + (size_t)a * P;
+            double y = tt * row[ka] + (1.0 - tt) * row[kb];
+            if (lo) y = row[0];
+            if (hi) y = row[P - 1];
+            acc[n] += y;
+        }
     }
-    recon[(size_t)b * X * Y + p] = acc * 3.14159265358979323846 / (2.0 * A);
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+        if (b0 + n < B) recon[(size_t)(b0 + n) * X * Y + p] = acc[n] * 3.14159265358979323846 / (2.0 * A);
 }
 
 // The transpose of fbp_backproject_kernel (the gradient of iradon with respect to the filtered sinogram):
@@ -161,9 +174,19 @@ int ctpvae_fbp_backproject_geom_f64(const double *filt_dev, int B, int A, int P,
     const int chunk = max_slices_per_launch();
     for (int b0 = 0; b0 < B; b0 += chunk) {   // sinograms are indexed with a grid dimension: longer batches go in chunks
         const int n = B - b0 < chunk ? B - b0 : chunk;
-        hipLaunchKernelGGL(fbp_backproject_kernel, dim3(ceil_div(X * Y, 256), n), dim3(256), 0, (hipStream_t)stream,
-                           filt_dev + (size_t)b0 * A * P, n, A, P, cos_dev, sin_dev, X, Y, x0, y0, t0,
-                           recon_dev + (size_t)b0 * X * Y);
+        // two sinograms per thread (measured at 50 x 180 x 184 -> 128 x 128: one 264 us per iradon call, two 233 us, five
+        // 360 us -- the per-lane fp64 gathers from L2, not the index arithmetic, bound the kernel, and fewer, fatter threads hide them worse)
+        const int cells = ceil_div(X * Y, 256);
+        const int nb = n >= 2 && (long long)cells * ceil_div(n, 2) >= 512 ? 2 : 1;
+        const dim3 grid(cells, ceil_div(n, nb));
+        const double *f0 = filt_dev + (size_t)b0 * A * P;
+        double *r0 = recon_dev + (size_t)b0 * X * Y;
+        if (nb == 2)
+            hipLaunchKernelGGL(fbp_backproject_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, f0, n, A, P, cos_dev, sin_dev, X, Y,
+                               x0, y0, t0, r0);
+        else
+            hipLaunchKernelGGL(fbp_backproject_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, f0, n, A, P, cos_dev, sin_dev, X, Y,
+                               x0, y0, t0, r0);
         CTPVAE_LAUNCH_CHECK("fbp_backproject_kernel");
     }
     return CTPVAE_OK;
