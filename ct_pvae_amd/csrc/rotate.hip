@@ -1048,6 +1048,216 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
     }
 }
 
+// ---- the segment backward over a STEP PLAN (round 3) ---------------------------------------------------------------------
+// The kernel above spends five index operations per tap (multiply, two adds, round, shift-add) on x_in = (t0 x + t1 y) + t2.
+// Down a column of pixels x_in moves by t1 per row, |t1| <= 1, so the rounded tap stays or steps by one, always the same way
+// for an angle: a lane that owns EIGHT CONSECUTIVE rows of a column needs its first row's tap and seven bits.  The plan holds,
+// per (angle, row octet, column), one u16: bits 0..6 the first row's tap relative to the segment the tile stages for that
+// angle (the same `first` the kernel computes), bits 7..13 "the tap steps" for rows 1..7 -- written by a kernel that evaluates
+// the reference arithmetic exactly as the kernel above does, so the taps, their order and the sums are the same bits.  Per
+// tap: one bit-field extract and one multiply-add onto the running LDS address.  Geometries the code cannot hold (a pixel
+// that samples outside the canvas at some angle -- unpadded canvases --, a row that is not a rotation) raise the plan's
+// overflow word and the caller keeps the kernel above.  5.9 MB for 512 x 512 x 90 angles, read once per slice pair.
+constexpr int kStepRows = 8;           // rows per lane = rows per plan word
+constexpr int kStepTileRows = 32;      // four waves of eight rows: the tile whose segment `first` the plan is relative to
+
+struct StepLayout {
+    int H8, Wpad;
+    long long off_flag, bytes;
+};
+static StepLayout step_layout(int H, int W, int A)
+{
+    StepLayout L;
+    L.H8 = ceil_div(H, kStepTileRows) * (kStepTileRows / kStepRows);
+    L.Wpad = ceil_div(W, 64) * 64;
+    L.off_flag = (long long)A * L.H8 * L.Wpad * 2;
+    L.off_flag = (L.off_flag + 255) / 256 * 256;
+    L.bytes = L.off_flag + 256;
+    return L;
+}
+
+// the segment a 64 x 32 tile stages for an angle: its first bin, or "cannot" (the tile spans more bins than a segment
+// holds) -- ONE definition for the plan builder and the kernel.  (The whole rectangle counts, also where a ragged tile hangs
+// over the image: those pixels are never stored, but their taps must not decide the segment differently in the two places.)
+__device__ __forceinline__ bool step_segment_first(const float *__restrict__ t, float X0, float Y0, int &first)
+{
+    const float X1 = X0 + 63.0f, Y1 = Y0 + (float)(kStepTileRows - 1);
+    const float t0 = t[0], t1 = t[1], t2 = t[2];
+    const float xa = (t0 * X0 + t1 * Y0) + t2, xb = (t0 * X1 + t1 * Y0) + t2;
+    const float xc = (t0 * X0 + t1 * Y1) + t2, xd = (t0 * X1 + t1 * Y1) + t2;
+    const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+    first = 0;
+    if (!(xmax - xmin <= (float)(kSegBins - 6)) || !(fabsf(xmin) < 1.0e6f)) return false;
+    first = (int)floorf(xmin) - 2;
+    return true;
+}
+
+// one lane per (column, row octet, angle)
+__global__ __launch_bounds__(64) void rotate_bwd_step_plan_kernel(RotGeom g, const float *__restrict__ Tinv8, StepLayout L,
+                                                                 char *__restrict__ plan)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x, rg = blockIdx.y, a = blockIdx.z;
+    const float *t = Tinv8 + 8 * (size_t)a;
+    int first;
+    const bool ok_tile = step_segment_first(t, (float)(blockIdx.x * 64 + g.px),
+                                            (float)((rg / (kStepTileRows / kStepRows)) * kStepTileRows + g.py), first);
+    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+    const int sigma = t1 > 0.0f ? 1 : t1 < 0.0f ? -1 : 0;
+    const float fx = (float)(c + g.px);
+    const float xa = t0 * fx, ya = t3 * fx;
+    const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
+    bool ok = true;
+    unsigned word = 0;
+    int prev = 0;
+    for (int k = 0; k < kStepRows; ++k) {
+        const int r = rg * kStepRows + k;
+        const float fy = (float)(r + g.py);
+        const float x = (xa + t1 * fy) + t2, y = (ya + t4 * fy) + t5;
+        const int tap = cvt_rpi(x);
+        const bool live = c < g.W && r < g.H;      // pixels a ragged tile hangs over the image with are never stored
+        // a live pixel must sample INSIDE the canvas (else the reference's zero fill applies: the direct kernel's business),
+        // away from the one tie where v_cvt_rpi and std::round part, inside its tile's segment
+        if (live) ok = ok && ok_tile && x > 0.5f && x < x_hi - 1.0f && y > 0.5f && y < y_hi - 1.0f;
+        if (k == 0) {
+            const int rel = tap - first;
+            if (live) ok = ok && rel >= 0 && rel < kSegBins;
+            word = (unsigned)rel & 127u;
+        } else {
+            const int dlt = tap - prev;
+            if (live) ok = ok && (dlt == 0 || dlt == sigma) && tap - first >= 0 && tap - first < kSegBins;
+            word |= (dlt != 0 ? 1u : 0u) << (6 + k);
+        }
+        prev = tap;
+    }
+    reinterpret_cast<unsigned short *>(plan)[((size_t)a * L.H8 + rg) * L.Wpad + c] = (unsigned short)word;
+    if (!ok) *reinterpret_cast<int *>(plan + L.off_flag) = 1;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__restrict__ gsino, RotGeom g,
+                                                                 const float *__restrict__ Tinv8, int chunk_a, StepLayout L,
+                                                                 const char *__restrict__ plan, SliceScale scale,
+                                                                 float *__restrict__ gimg)
+{
+    typedef typename PixVec<NS>::type vec_t;
+    constexpr int SHIFT = NS == 1 ? 2 : 3, PPT = kStepRows;
+    // [chunk_a][kSegPitch] segment cells (NS floats each), then per angle (first bin) and (segment byte base, step in bytes)
+    extern __shared__ float lds[];
+    int *first_s = reinterpret_cast<int *>(lds + chunk_a * kSegPitch * NS);
+    int2 *meta2 = reinterpret_cast<int2 *>(lds + ((chunk_a * (kSegPitch * NS + 1) + 1) & ~1));
+    const int s = blockIdx.z * NS;
+    const bool has2 = NS == 2 && s + 1 < g.S;
+    const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int rg = blockIdx.y * (kStepTileRows / kStepRows) + wave;     // this lane's rows: rg * 8 .. rg * 8 + 7
+    const float X0 = (float)(blockIdx.x * 64 + g.px), Y0 = (float)(blockIdx.y * kStepTileRows + g.py);
+    const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
+    const unsigned short *pl = reinterpret_cast<const unsigned short *>(plan) + (size_t)rg * L.Wpad + c;
+    const size_t astride = (size_t)L.H8 * L.Wpad;
+
+    vec_t acc[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) acc[k] = 0.0f;
+
+    for (int ac = 0; ac < g.A; ac += chunk_a) {
+        const int na = min(chunk_a, g.A - ac);
+        if (ac > 0) __syncthreads();
+        for (int al = threadIdx.x; al < na; al += blockDim.x) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);
+            int first;
+            step_segment_first(t, X0, Y0, first);
+            first_s[al] = first;
+            const float t1 = t[1];
+            meta2[al] = make_int2(al * kSegPitch * 4 * NS + lds_base, (t1 > 0.0f ? 4 * NS : t1 < 0.0f ? -4 * NS : 0));
+        }
+        __syncthreads();
+        const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
+        const size_t src2 = has2 ? (size_t)g.A * g.PW : 0;
+        {
+            constexpr int U = 8 / NS;
+            const int ncell = na * kSegPitch;
+            for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
+                vec_t v[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = min(p0 + u * (int)blockDim.x, ncell - 1);
+                    const int al = p / kSegPitch, q = p - al * kSegPitch;
+                    const int j = first_s[al] + q;
+                    ok[u] = q < kSegBins && (unsigned)j < (unsigned)g.PW;
+                    const float *cell = src + al * g.PW + min(max(j, 0), g.PW - 1);
+                    if constexpr (NS == 1) {
+                        v[u] = cell[0];
+                    } else {
+                        v[u].x = cell[0];
+                        v[u].y = cell[src2];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * (int)blockDim.x;
+                    if (p < ncell) reinterpret_cast<vec_t *>(lds)[p] = ok[u] ? v[u] : vec_t(0.0f);
+                }
+            }
+        }
+        __syncthreads();
+
+        // per angle: the plan word (fetched two angles ahead), the segment base and step (one broadcast ds_read_b64), eight
+        // gathers whose addresses are a bit-field extract and a multiply-add apart; the adds of an angle run under the next
+        // angle's gathers
+        auto taps = [&](unsigned w, const int2 m, vec_t (&v)[PPT]) {
+            int addr = m.x + (int)((w & 127u) << SHIFT);
+            v[0] = lds_abs_vec<NS>(addr);
+#pragma unroll
+            for (int k = 1; k < PPT; ++k) {
+                addr += (int)((w >> (6 + k)) & 1u) * m.y;
+                v[k] = lds_abs_vec<NS>(addr);
+            }
+        };
+        const unsigned short *pa = pl + (size_t)ac * astride;
+        vec_t va[PPT], vb[PPT];
+        unsigned w0 = pa[0], w1 = pa[(size_t)min(1, na - 1) * astride];
+        taps(w0, meta2[0], va);
+        for (int al = 1; al + 1 < na; al += 2) {      // angles al (-> vb) and al + 1 (-> va)
+            w0 = pa[(size_t)(al + 1) * astride];
+            taps(w1, meta2[al], vb);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+            w1 = pa[(size_t)min(al + 2, na - 1) * astride];
+            taps(w0, meta2[al + 1], va);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+        }
+        if ((na & 1) == 0) {                           // even count: angle na - 1 is still to be gathered
+            taps(w1, meta2[na - 1], vb);
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+        }
+    }
+    if (c < g.W) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int r = rg * kStepRows + k;
+            if (r < g.H) {
+                if constexpr (NS == 1) {
+                    gimg[((size_t)s * g.H + r) * g.W + c] = k0 * acc[k];
+                } else {
+                    gimg[((size_t)s * g.H + r) * g.W + c] = k0 * acc[k].x;
+                    if (has2) gimg[((size_t)(s + 1) * g.H + r) * g.W + c] = k1 * acc[k].y;
+                }
+            }
+        }
+    }
+}
+
 // ---- backward, exact transpose (scatter) -------------------------------------------------------
 // Mirrors the forward's decomposition; every ray adds its cotangent into an LDS copy of the slice
 // (ds_add_f32), and the workgroup then adds its tile into gimg (global_atomic_add_f32; gimg is zeroed
@@ -1634,6 +1844,73 @@ int ctpvae_rotate_bwd_scaled_f32(const float *gsino_dev, int S, int A, int PH, i
         return rotate_bwd_one(gsino_dev + (size_t)s0 * A * PW, n, A, PH, PW, T8_dev, interp, mode, H, W, py, px,
                               scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr, scale_stride,
                               gimg_dev + (size_t)s0 * H * W, stream);
+    });
+}
+
+// ---- step plan of the segment backward (slices too large for the planned backward) ----
+long long ctpvae_rotate_bwd_step_plan_bytes(int H, int W, int A)
+{
+    if (H <= 0 || W <= 0 || A <= 0) return fail(CTPVAE_EINVAL, "rotate_bwd_step_plan_bytes: bad sizes");
+    return step_layout(H, W, A).bytes;
+}
+
+int ctpvae_rotate_bwd_step_plan_build_f32(const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py, int px, void *plan_dev,
+                                          ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(Tinv8_dev && plan_dev, "rotate_bwd_step_plan_build: null pointer");
+    if (int rc = check_geom("rotate_bwd_step_plan_build", 1, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
+    CTPVAE_REQUIRE(A <= 65535, "rotate_bwd_step_plan_build: at most 65535 angles (got %d)", A);
+    const StepLayout L = step_layout(H, W, A);
+    const RotGeom g{1, H, W, PH, PW, py, px, A};
+    CTPVAE_HIP(hipMemsetAsync((char *)plan_dev + L.off_flag, 0, 256, (hipStream_t)stream));
+    hipLaunchKernelGGL(rotate_bwd_step_plan_kernel, dim3(L.Wpad / 64, L.H8, A), dim3(64), 0, (hipStream_t)stream, g, Tinv8_dev, L,
+                       (char *)plan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_bwd_step_plan_kernel");
+    return CTPVAE_OK;
+}
+
+int ctpvae_rotate_bwd_step_plan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(plan_dev && H > 0 && W > 0 && A > 0, "rotate_bwd_step_plan_overflowed: bad arguments");
+    int flag = 0;
+    CTPVAE_HIP(hipMemcpyAsync(&flag, (const char *)plan_dev + step_layout(H, W, A).off_flag, sizeof(int), hipMemcpyDeviceToHost,
+                              (hipStream_t)stream));
+    CTPVAE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return flag != 0;
+}
+
+int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H, int W,
+                                         int py, int px, const void *step_plan_dev, const float *scale_dev, long long scale_stride,
+                                         float *gimg_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(gsino_dev && Tinv8_dev && gimg_dev && step_plan_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0,
+                   "rotate_bwd_stepped: null pointer or empty sizes");
+    if (int rc = check_geom("rotate_bwd_stepped", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
+    const StepLayout L = step_layout(H, W, A);
+    return for_slice_chunks(S, std::min(65534, max_slices_per_launch() / 2 * 2), [&](int s0, int n) {
+        const float *gs = gsino_dev + (size_t)s0 * A * PW;
+        const float *sc = scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr;
+        float *gi = gimg_dev + (size_t)s0 * H * W;
+        // the same rule as the direct kernel's: pairs once the launch can spare the workgroups; the plan is for 64 x 32 tiles,
+        // which small launches trade for 64 x 16 ones -- those keep the direct kernel
+        const int ns = (n >= 16 || (n >= 2 && (long long)ceil_div(n, 2) * ceil_div(W, 64) * ceil_div(H, 16) >= 256)) ? 2 : 1;
+        const int units = ceil_div(n, ns);
+        if (knob(kKnobForceGeneric) >= 0 || knob(kKnobNoPlan) >= 0 ||
+            (long long)units * ceil_div(W, 64) * ceil_div(H, kStepTileRows) < 512)
+            return rotate_bwd_one(gs, n, A, PH, PW, Tinv8_dev, CTPVAE_NEAREST, CTPVAE_BWD_TF_COMPAT, H, W, py, px, sc, scale_stride, gi,
+                                  stream);
+        const RotGeom g{n, H, W, PH, PW, py, px, A};
+        const int chunk_a = std::min(A, ns == 2 ? 48 : 96);
+        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * ns + sizeof(int) + 2 * sizeof(int)) + 16;
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, kStepTileRows), units), block(256);
+        if (ns == 2)
+            hipLaunchKernelGGL(rotate_bwd_stepped_kernel<2>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
+                               (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
+        else
+            hipLaunchKernelGGL(rotate_bwd_stepped_kernel<1>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
+                               (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
+        CTPVAE_LAUNCH_CHECK("rotate_bwd_stepped_kernel");
+        return CTPVAE_OK;
     });
 }
 

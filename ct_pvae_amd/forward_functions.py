@@ -226,6 +226,11 @@ class RotatePlan:
         if (use_plan and self._fwd_plan is None and self.interp == _lib.NEAREST and plan_format != "u16"
                 and self.py > 0 and self.px > 0):
             self._tplan = self._build_tile_plan()
+        # ... and their backward takes two index operations per tap from a step plan instead of five (csrc/rotate.hip)
+        self._step_plan = None
+        if (use_plan and self.interp == _lib.NEAREST and self.mode == _lib.BWD_TF_COMPAT and not self._want_bwd_plan
+                and self.py > 0 and self.px > 0 and self.A <= 65535 and self.H * self.W >= 128 * 128):
+            self._step_plan = self._build_step_plan()
         if self._want_exact_plan:
             # built here, not on the first backward: reading its overflow word synchronises the stream, which must not
             # happen inside a caller's HIP-graph capture
@@ -603,6 +608,20 @@ class RotatePlan:
             _lib.check(rc, "rotate_fwd_planned_loglik")
         return (out, out_lp, out_dlp) if out_dlp is not None else (out, out_lp)
 
+    def _build_step_plan(self):
+        """Step plan of the segment backward (slices too large for the planned one: 512 x 512), or None when the geometry does not
+        fit the code (the build says so).  Reading the overflow word synchronises -- at construction, never inside a capture."""
+        nbytes = self._lib.ctpvae_rotate_bwd_step_plan_bytes(self.H, self.W, self.A)
+        _lib.check(nbytes, "rotate_bwd_step_plan_bytes")
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.ctpvae_rotate_bwd_step_plan_build_f32(self.Tinv8.data_ptr(), self.A, self.H, self.W, self.PH, self.PW,
+                                                                       self.py, self.px, buf.data_ptr(), _stream_ptr()),
+                       "rotate_bwd_step_plan_build")
+            over = self._lib.ctpvae_rotate_bwd_step_plan_overflowed(buf.data_ptr(), self.H, self.W, self.A, _stream_ptr())
+        _lib.check(over, "rotate_bwd_step_plan_overflowed")
+        return buf if over == 0 else None
+
     def backward_uses_plan(self, S):
         """Large batches at few angles: the direct segment kernel (no index stream) is the faster of the two
         bit-identical backward paths -- measured 21 vs 28 us at B=400 A=20, 24 vs 26 us at B=200 A=45, 7.7 vs 8.8 us at B=80 A=20; the plan wins
@@ -656,6 +675,10 @@ class RotatePlan:
             rc = self._lib.ctpvae_rotate_bwd_planned_scaled_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                                 self._bwd_plan.data_ptr(), sc_ptr, sc_stride, out.data_ptr(),
                                                                 _stream_ptr(self._dev_index))
+        elif self._step_plan is not None:
+            rc = self._lib.ctpvae_rotate_bwd_stepped_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, self.Tinv8.data_ptr(),
+                                                                self.H, self.W, self.py, self.px, self._step_plan.data_ptr(),
+                                                                sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
         else:
             tab = self.Tinv8 if self.mode == _lib.BWD_TF_COMPAT else self.T8
             rc = self._lib.ctpvae_rotate_bwd_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, tab.data_ptr(),

@@ -252,6 +252,22 @@ int ctpvae_rotate_bwd_planned_sel_scaled_f32(const float *gsino_dev, int S, int 
                                              const float *scale_dev, long long scale_stride, float *gimg_dev,
                                              ctpvae_stream_t stream);
 
+/* STEP PLAN of the direct (segment) backward, for slices too large for the planned backward above (512 x 512; round 3):
+ * down a column of pixels the tap of an angle stays or steps by one per row (|t1| <= 1), always the same way, so a lane that
+ * owns eight consecutive rows needs its first row's tap (7 bits, relative to the 80-bin segment its 64 x 32 tile stages for
+ * the angle) and seven bits: one u16 per (angle, row octet, column), written by a kernel that evaluates the reference
+ * arithmetic exactly as ctpvae_rotate_bwd_f32's kernel does.  Same taps, same order: the same bits as ctpvae_rotate_bwd_scaled_f32
+ * (mode TF_COMPAT, NEAREST), with two index operations per tap instead of five.  _overflowed (SYNCHRONISES): 1 if the geometry
+ * does not fit the code (a tile that leaves the canvas at some angle -- unpadded canvases --, rows that are not a rotation):
+ * the plan must then not be used.  Small launches (fewer than 512 tiles of 64 x 32) run ctpvae_rotate_bwd_scaled_f32's kernel. */
+long long ctpvae_rotate_bwd_step_plan_bytes(int H, int W, int A);
+int ctpvae_rotate_bwd_step_plan_build_f32(const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py, int px, void *plan_dev,
+                                          ctpvae_stream_t stream);
+int ctpvae_rotate_bwd_step_plan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream);
+int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H, int W,
+                                         int py, int px, const void *step_plan_dev, const float *scale_dev, long long scale_stride,
+                                         float *gimg_dev, ctpvae_stream_t stream);
+
 /* (Which backward: both give the same bits.  The planned one wins except for large batches at few angles -- S >= 80
  * and A <= 64 -- where ctpvae_rotate_bwd_f32's segment kernel, which streams no indices, is up to 25 % faster.) */
 int ctpvae_rotate_bwd_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,

@@ -1377,6 +1377,31 @@ def test_random_siddon_and_tiled_geometries(oracle):
             assert rel_err(got, want) <= (1e-5 if it == 1 else 5e-5), (case, n, A, S, it)
 
 
+@pytest.mark.parametrize("shape,A,S", [((512, 512), 23, 32), ((300, 330), 9, 21), ((260, 257), 64, 17)])
+def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
+    """Round 3: the backward of slices too large for the planned kernels reads a STEP PLAN -- per (angle, row octet, column) the
+    first row's tap relative to the tile's segment and seven "the tap steps" bits -- instead of computing five index operations per
+    tap.  Same taps, same order: bit-equal to the direct segment kernel (NO_PLAN) and to the oracle, with the per-slice factor of
+    the fused likelihood backward, ragged shapes, odd batches; an unpadded canvas has no step plan and runs the direct kernel."""
+    d = dev()
+    rng = np.random.default_rng(shape[0] + A)
+    theta = rng.uniform(-np.pi, np.pi, A)
+    plan = RotatePlan(theta, shape[0], shape[1], True, d)
+    assert plan._step_plan is not None and not plan.backward_uses_plan(S)
+    g = rng.standard_normal((S, A, plan.PW)).astype(np.float32)
+    gt = torch.from_numpy(g).to(d)
+    scale = torch.from_numpy(rng.uniform(0.5, 2.0, S).astype(np.float32)).to(d)
+    got, got_s = plan.backward(gt), plan.backward(gt, scale=scale)
+    _lib.tune("NO_PLAN", 1)
+    direct, direct_s = plan.backward(gt), plan.backward(gt, scale=scale)
+    _lib.tune("NO_PLAN")
+    assert torch.equal(got, direct) and torch.equal(got_s, direct_s)
+    n_chk = 3
+    geom = oracle.Geometry(shape[0], shape[1], True)
+    np.testing.assert_array_equal(to_np(got[:n_chk]), oracle.rotate_bwd_tfcompat(g[:n_chk], geom, oTinv(oracle, theta, plan), 0))
+    assert RotatePlan(theta, shape[0], shape[1], False, d)._step_plan is None
+
+
 def test_launches_are_graph_capturable():
     """The library allocates nothing and never synchronises, so a caller can capture its launches into a HIP graph
     (torch.cuda.graph) and replay them: same results as eager launches."""
