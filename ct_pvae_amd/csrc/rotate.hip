@@ -1215,29 +1215,34 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
                 v[k] = lds_abs_vec<NS>(addr);
             }
         };
+        // plan words are fetched kAhead angles ahead of their use (an L2 round trip is several angles long)
+        constexpr int kAhead = 6;
         const unsigned short *pa = pl + (size_t)ac * astride;
+        unsigned wq[kAhead];
+#pragma unroll
+        for (int q = 0; q < kAhead; ++q) wq[q] = pa[(size_t)min(q, na - 1) * astride];
         vec_t va[PPT], vb[PPT];
-        unsigned w0 = pa[0], w1 = pa[(size_t)min(1, na - 1) * astride];
-        taps(w0, meta2[0], va);
-        for (int al = 1; al + 1 < na; al += 2) {      // angles al (-> vb) and al + 1 (-> va)
-            w0 = pa[(size_t)(al + 1) * astride];
-            taps(w1, meta2[al], vb);
-            __builtin_amdgcn_sched_barrier(0);
+        int al = 0;
+        for (; al + kAhead <= na; al += kAhead) {      // kAhead angles per trip, two register sets of gathers in flight
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) acc[k] += va[k];
-            w1 = pa[(size_t)min(al + 2, na - 1) * astride];
-            taps(w0, meta2[al + 1], va);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < kAhead; q += 2) {
+                const unsigned w0 = wq[q], w1 = wq[q + 1];
+                wq[q] = pa[(size_t)min(al + kAhead + q, na - 1) * astride];
+                wq[q + 1] = pa[(size_t)min(al + kAhead + q + 1, na - 1) * astride];
+                taps(w0, meta2[al + q], va);
+                taps(w1, meta2[al + q + 1], vb);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+                for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+            }
         }
-        if ((na & 1) == 0) {                           // even count: angle na - 1 is still to be gathered
-            taps(w1, meta2[na - 1], vb);
+        for (int q = 0; al < na; ++al, ++q) {          // the chunk's last angles (wq holds their words in order)
+            unsigned w = wq[0];
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) acc[k] += va[k];
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
-        } else {
+            for (int j = 1; j < kAhead; ++j) w = q == j ? wq[j] : w;
+            taps(w, meta2[al], va);
 #pragma unroll
             for (int k = 0; k < PPT; ++k) acc[k] += va[k];
         }
