@@ -809,6 +809,7 @@ int ctpvae_siddon_fwd_ws_f32(const float *obj_dev, int oy, int ox, int oz, const
     if (ns == 0)
         return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, data_dev, stream);
     CTPVAE_REQUIRE(workspace_dev, "siddon_fwd: %d slices need the workspace", oy);
+    CTPVAE_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, "siddon_fwd: the workspace must be 16-byte aligned");
     return ns == 8 ? siddon_fwd_packed<8>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev,
                                           (float *)workspace_dev, data_dev, (hipStream_t)stream)
                    : siddon_fwd_packed<4>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev,
@@ -909,6 +910,7 @@ int ctpvae_siddon_bwd_prepare_f32(int ox, int oz, const float *sin_dev, const fl
 {
     CTPVAE_REQUIRE(sin_dev && cos_dev && quad_dev && workspace_dev, "siddon_bwd_prepare: null pointer");
     CTPVAE_REQUIRE(ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_bwd_prepare: sizes must be positive");
+    CTPVAE_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, "siddon_bwd_prepare: the workspace must be 256-byte aligned");
     const SidWorkspace w = siddon_workspace(1, ox, oz, dt, dx);
     const SidGeom g{1, ox, oz, dt, dx, siddon_mov(dx, center)};
     hipLaunchKernelGGL(siddon_ray_table_kernel, dim3(dt), dim3(256), 0, (hipStream_t)stream, g, sin_dev, cos_dev,
@@ -954,6 +956,7 @@ int ctpvae_siddon_bwd_prepared_f32(const float *data_dev, int oy, int ox, int oz
     CTPVAE_REQUIRE(data_dev && sin_dev && cos_dev && quad_dev && recon_dev && workspace_dev, "siddon_bwd: null pointer");
     CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
                    "siddon_bwd: sizes must be positive (oy=%d ox=%d oz=%d dt=%d dx=%d)", oy, ox, oz, dt, dx);
+    CTPVAE_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, "siddon_bwd: the workspace must be 256-byte aligned");
     const SidWorkspace w = siddon_workspace(oy, ox, oz, dt, dx);
     const float4 *table = (const float4 *)((const char *)workspace_dev + w.off_table);
     const int *degen = (const int *)((const char *)workspace_dev + w.off_degen);

@@ -309,7 +309,7 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
  * a pixel's terms arrive in libtomo's order (angles, then rays, ascending), so the result equals the ray-driven accumulation
  * bit for bit except for the corner-cutting slivers of rays that pass within fp32 rounding of a grid corner (~1e-6 of the
  * image's range, about one pixel per angle).  No atomics: bit-reproducible.  <A x, y> = <x, A^T y> to rounding.
- *   _workspace_bytes  device memory the calls below need (ray table, flags, one scratch image per slice)
+ *   _workspace_bytes  device memory the calls below need (ray table, flags, one scratch image per slice); 256-byte aligned
  *   _prepare          geometry only: fills the workspace's ray table; once per (grid, angles, dx, center)
  *   _prepared         colsum_dev NULL:  recon = A^T data  (overwritten)
  *                     colsum_dev [ox][oz]:  recon += (A^T data) / colsum where colsum != 0 -- sirt.c's update, in place
@@ -331,7 +331,7 @@ int ctpvae_siddon_fwd_resid_f32(const float *obj_dev, int oy, int ox, int oz, co
                                 const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
                                 const float *rn2_dev, float *upd_dev, ctpvae_stream_t stream);
 /* The forward with a workspace (round 3): with >= 3 slices the slices are interleaved per pixel in workspace_dev
- * (_fwd_workspace_bytes() bytes) and one walk of a ray serves 4 or 8 of them from L2 -- the same bits as ctpvae_siddon_fwd_f32,
+ * (_fwd_workspace_bytes() bytes, 16-byte aligned) and one walk of a ray serves 4 or 8 of them from L2 -- the same bits as ctpvae_siddon_fwd_f32,
  * 2-5x faster on grids whose slice pairs do not fit LDS.  meas_dev / rn2_dev both NULL: ray-sums; both given: the store of
  * ctpvae_siddon_fwd_resid_f32.  _fwd_workspace_bytes() == 0: no workspace needed (the LDS kernels are taken). */
 long long ctpvae_siddon_fwd_workspace_bytes(int oy, int ox, int oz);
