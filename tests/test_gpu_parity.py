@@ -1402,6 +1402,44 @@ def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
     assert RotatePlan(theta, shape[0], shape[1], False, d)._step_plan is None
 
 
+@pytest.mark.parametrize("shift", [0.3, -1.25, 2.0])
+def test_ray_driven_pair_with_a_shifted_rotation_centre(oracle, shift):
+    """The C ABI takes tomopy's `center`; the reference only ever passes None (dx / 2), which is all the Python wrappers do --
+    so the shifted centre (libtomo's `mov`, incl. its +0.01 nudge off whole pixels) is checked through the entry points
+    themselves: forward (8 slices per walk) and the pixel-driven back-projector against the oracle, bit for bit."""
+    import ctypes
+    from ct_pvae_amd.helper_functions import _siddon_tables
+    d = dev()
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    S, n, dx, A = 9, 64, 94, 17
+    theta = np.sort(rng.uniform(0.0, np.pi, A)).astype(np.float32)
+    center = dx / 2.0 + shift
+    obj = rng.random((S, n, n), dtype=np.float32)
+    sin_t, cos_t, quad = _siddon_tables(theta, d)
+    sp = torch.cuda.current_stream().cuda_stream
+    t = torch.from_numpy(obj).to(d)
+    sino = torch.empty((S, A, dx), device=d)
+    fws = torch.empty(int(lib.ctpvae_siddon_fwd_workspace_bytes(S, n, n)), dtype=torch.uint8, device=d)
+    _lib.check(lib.ctpvae_siddon_fwd_ws_f32(t.data_ptr(), S, n, n, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), A, dx,
+                                            ctypes.c_float(center), None, None, fws.data_ptr(), sino.data_ptr(), sp), "siddon_fwd_ws")
+    want = np.empty((S, A, dx), np.float32)
+    oracle.lib().oracle_siddon_project(obj, S, n, n, theta, A, dx, center, want)
+    np.testing.assert_array_equal(to_np(sino), want)
+    y = rng.standard_normal((S, A, dx)).astype(np.float32)
+    yt = torch.from_numpy(y).to(d)
+    ws = torch.empty(int(lib.ctpvae_siddon_bwd_workspace_bytes(S, n, n, A, dx)), dtype=torch.uint8, device=d)
+    rec = torch.empty((S, n, n), device=d)
+    _lib.check(lib.ctpvae_siddon_bwd_f32(yt.data_ptr(), S, n, n, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), A, dx,
+                                         ctypes.c_float(center), ws.data_ptr(), rec.data_ptr(), sp), "siddon_bwd")
+    want_r = np.zeros((S, n, n), np.float32)
+    oracle.lib().oracle_siddon_backproject(y, S, A, dx, theta, center, n, n, want_r)
+    if float(shift).is_integer():      # whole-pixel shifts put the half-pixel rays back on the grid's lines only through mov's nudge
+        assert rel_err(to_np(rec), want_r) <= REL
+    else:
+        np.testing.assert_array_equal(to_np(rec), want_r)
+
+
 def test_launches_are_graph_capturable():
     """The library allocates nothing and never synchronises, so a caller can capture its launches into a HIP graph
     (torch.cuda.graph) and replay them: same results as eager launches."""
