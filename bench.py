@@ -601,7 +601,7 @@ def main():
         return
     bytes_dir = 4.0 * B * (N * N + A * P)                 # one direction: read once + write once (fp32)
     fwd_name = ("rotate_fwd_compact_kernel" if plan.compact else "rotate_fwd_planned_kernel") if plan.planned[0] else "rotate_fwd_fast_kernel"
-    bwd_name = "rotate_bwd_planned_kernel" if plan.backward_uses_plan(B) else "rotate_bwd_tfcompat_seg_kernel"
+    bwd_name = plan.backward_kernel_name(B)
     dom = (fwd_name, t_fwd) if t_fwd >= t_bwd else (bwd_name, t_bwd)
     achieved = bytes_dir / dom[1] / 1e9
     # HBM-side bytes per launch of the dominant kernel: a COMMITTED measurement (separate rocprofv3 --pmc passes of this

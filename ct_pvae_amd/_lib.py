@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
-ABI_VERSION = 3100   # ctpvae_abi_version() of the library this binding was written for
+ABI_VERSION = 3200   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)

@@ -1900,8 +1900,10 @@ int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, i
         // which small launches trade for 64 x 16 ones -- those keep the direct kernel
         const int ns = (n >= 16 || (n >= 2 && (long long)ceil_div(n, 2) * ceil_div(W, 64) * ceil_div(H, 16) >= 256)) ? 2 : 1;
         const int units = ceil_div(n, ns);
-        if (knob(kKnobForceGeneric) >= 0 || knob(kKnobNoPlan) >= 0 ||
-            (long long)units * ceil_div(W, 64) * ceil_div(H, kStepTileRows) < 512)
+        // (SEG_PPT = 8 / 4: a developer's way to force the 64 x 32 stepped tiles / the direct kernel whatever the launch size)
+        const bool big = knob(kKnobSegPpt) >= 0 ? knob(kKnobSegPpt) == 8
+                                                : (long long)units * ceil_div(W, 64) * ceil_div(H, kStepTileRows) >= 512;
+        if (knob(kKnobForceGeneric) >= 0 || knob(kKnobNoPlan) >= 0 || !big)
             return rotate_bwd_one(gs, n, A, PH, PW, Tinv8_dev, CTPVAE_NEAREST, CTPVAE_BWD_TF_COMPAT, H, W, py, px, sc, scale_stride, gi,
                                   stream);
         const RotGeom g{n, H, W, PH, PW, py, px, A};

@@ -27,6 +27,7 @@ using bwd_seg_fn = decltype(&ctpvae_rotate_bwd_scaled_f32);
 using bwd_sel_fn = decltype(&ctpvae_rotate_bwd_sel_scaled_f32);
 using fwd_compact_fn = decltype(&ctpvae_rotate_fwd_compact_f32);
 using bwd_psel_fn = decltype(&ctpvae_rotate_bwd_planned_sel_scaled_f32);
+using bwd_step_fn = decltype(&ctpvae_rotate_bwd_stepped_scaled_f32);
 using abi_fn = decltype(&ctpvae_abi_version);
 fwd_fn g_fwd = nullptr;
 bwd_fn g_bwd = nullptr;
@@ -37,6 +38,7 @@ bwd_seg_fn g_bwd_seg = nullptr;
 bwd_sel_fn g_bwd_sel = nullptr;
 fwd_compact_fn g_fwd_compact = nullptr;
 bwd_psel_fn g_bwd_psel = nullptr;
+bwd_step_fn g_bwd_step = nullptr;
 
 // The ABI this node was COMPILED against (the header's macro) must be the ABI of the library it binds at run time: the
 // entry points are resolved by name only, so a node left over from an older build would otherwise call them with an old
@@ -60,7 +62,9 @@ void bind(const std::string &lib_path)
     g_bwd_sel = (bwd_sel_fn)dlsym(h, "ctpvae_rotate_bwd_sel_scaled_f32");
     g_fwd_compact = (fwd_compact_fn)dlsym(h, "ctpvae_rotate_fwd_compact_f32");
     g_bwd_psel = (bwd_psel_fn)dlsym(h, "ctpvae_rotate_bwd_planned_sel_scaled_f32");
-    TORCH_CHECK(g_fwd && g_bwd && g_err && g_fwd_lik && g_fwd_lik_sel && g_bwd_seg && g_bwd_sel && g_fwd_compact && g_bwd_psel, lib_path,
+    g_bwd_step = (bwd_step_fn)dlsym(h, "ctpvae_rotate_bwd_stepped_scaled_f32");
+    TORCH_CHECK(g_fwd && g_bwd && g_err && g_fwd_lik && g_fwd_lik_sel && g_bwd_seg && g_bwd_sel && g_fwd_compact && g_bwd_psel && g_bwd_step,
+                lib_path,
                 " does not export the planned projector entry points");
 }
 
@@ -193,6 +197,10 @@ struct RotateLogLik : public torch::autograd::Function<RotateLogLik> {
             const at::Tensor ai = ctx->saved_data["angles"].toTensor();
             rc = g_bwd_sel(cot.data_ptr<float>(), (int)S, (int)A, (int)PH, (int)PW, ctx->saved_data["Tinv8"].toTensor().data_ptr<float>(),
                            ai.data_ptr<int>(), (int)n, (int)H, (int)W, (int)py, (int)px, scale, stride, gimg.data_ptr<float>(), stream);
+        } else if (use_plan == 3) {                    // the step plan: large batches (the entry point picks its kernel)
+            rc = g_bwd_step(cot.data_ptr<float>(), (int)S, (int)A, (int)PH, (int)PW, ctx->saved_data["Tinv8"].toTensor().data_ptr<float>(),
+                            (int)H, (int)W, (int)py, (int)px, ctx->saved_data["bwd_plan"].toTensor().data_ptr(), scale, stride,
+                            gimg.data_ptr<float>(), stream);
         } else if (use_plan) {
             rc = g_bwd(cot.data_ptr<float>(), (int)S, (int)H, (int)W, (int)PH, (int)PW, (int)A,
                        ctx->saved_data["bwd_plan"].toTensor().data_ptr(), scale, stride, gimg.data_ptr<float>(), stream);

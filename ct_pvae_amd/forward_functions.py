@@ -226,10 +226,11 @@ class RotatePlan:
         if (use_plan and self._fwd_plan is None and self.interp == _lib.NEAREST and plan_format != "u16"
                 and self.py > 0 and self.px > 0):
             self._tplan = self._build_tile_plan()
-        # ... and their backward takes two index operations per tap from a step plan instead of five (csrc/rotate.hip)
+        # ... and their backward takes three index operations per tap from a step plan instead of five (csrc/rotate.hip); so do
+        # large batches of slices that fit LDS, where it beats the planned backward (backward_uses_step_plan)
         self._step_plan = None
-        if (use_plan and self.interp == _lib.NEAREST and self.mode == _lib.BWD_TF_COMPAT and not self._want_bwd_plan
-                and self.py > 0 and self.px > 0 and self.A <= 65535 and self.H * self.W >= 128 * 128):
+        if (use_plan and self.interp == _lib.NEAREST and self.mode == _lib.BWD_TF_COMPAT and self.py > 0 and self.px > 0
+                and self.A <= 65535 and self.H * self.W >= 128 * 128):
             self._step_plan = self._build_step_plan()
         if self._want_exact_plan:
             # built here, not on the first backward: reading its overflow word synchronises the stream, which must not
@@ -622,11 +623,25 @@ class RotatePlan:
         _lib.check(over, "rotate_bwd_step_plan_overflowed")
         return buf if over == 0 else None
 
+    def backward_uses_step_plan(self, S):
+        """The segment backward over the step plan (ctpvae_rotate_bwd_stepped_scaled_f32; below 512 tiles of 64 x 32 that entry
+        point runs the direct segment kernel itself): always for slices too large for the planned backward; for slices that fit
+        LDS from 160 slices on, and from 80 slices at <= 64 angles -- round 3, 128 x 128, planned vs this entry point:
+        B=400 A=180 142.7 vs 111.9 us, B=400 A=20 30.0 vs 20.0, B=200 A=90 47.0 vs 39.4, B=160 A=180 62.4 vs 58.9; the planned
+        kernel keeps B=128 A=180 (42.5 vs 49.7) and everything smaller at many angles.  The three paths give the same bits."""
+        if self._step_plan is None:
+            return False
+        return (not self._want_bwd_plan) or S >= 160 or (S >= 80 and self.A <= 64)
+
     def backward_uses_plan(self, S):
-        """Large batches at few angles: the direct segment kernel (no index stream) is the faster of the two
-        bit-identical backward paths -- measured 21 vs 28 us at B=400 A=20, 24 vs 26 us at B=200 A=45, 7.7 vs 8.8 us at B=80 A=20; the plan wins
-        everywhere else."""
-        return self._want_bwd_plan and not (S >= 80 and self.A <= 64)
+        """The planned gather backward: slices that fit LDS, except where the segment kernels are faster (see above; without a
+        step plan -- unpadded canvases -- the direct segment kernel still takes S >= 80 at <= 64 angles)."""
+        return self._want_bwd_plan and not self.backward_uses_step_plan(S) and not (S >= 80 and self.A <= 64)
+
+    def backward_kernel_name(self, S):
+        if self.backward_uses_step_plan(S):
+            return "rotate_bwd_stepped_kernel"
+        return "rotate_bwd_planned_kernel" if self.backward_uses_plan(S) else "rotate_bwd_tfcompat_seg_kernel"
 
     def _backward(self, gsino, out=None, scale=None, angles_i=None):
         n = self.A if angles_i is None else self._check_sel(angles_i)
@@ -675,7 +690,7 @@ class RotatePlan:
             rc = self._lib.ctpvae_rotate_bwd_planned_scaled_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                                 self._bwd_plan.data_ptr(), sc_ptr, sc_stride, out.data_ptr(),
                                                                 _stream_ptr(self._dev_index))
-        elif self._step_plan is not None:
+        elif self.backward_uses_step_plan(S):
             rc = self._lib.ctpvae_rotate_bwd_stepped_scaled_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW, self.Tinv8.data_ptr(),
                                                                 self.H, self.W, self.py, self.px, self._step_plan.data_ptr(),
                                                                 sc_ptr, sc_stride, out.data_ptr(), _stream_ptr(self._dev_index))
@@ -747,6 +762,8 @@ class RotatePlan:
         use_plan, bplan = 0, self.Tinv8
         if angles_i is None:
             use_plan = int(self.backward_uses_plan(x4.shape[0]))
+            if self.backward_uses_step_plan(x4.shape[0]):
+                use_plan, bplan = 3, self._step_plan   # 3: the segment backward over the step plan
             if use_plan and self._bwd_plan is None:
                 self._bwd_plan = self._build_plan(1)
             if use_plan:

@@ -67,7 +67,7 @@ typedef void *ctpvae_stream_t;
 /* Version of this ABI: major * 1000 + minor.  CTPVAE_ABI_VERSION is what THIS header describes: host code compiled against
  * it (csrc/torch_node.cpp, a maintainer's own binding) compares the macro with ctpvae_abi_version() of the library it loaded
  * and refuses a mismatch -- an entry point called with another version's argument list is a silent wrong-argument call. */
-#define CTPVAE_ABI_VERSION 3100
+#define CTPVAE_ABI_VERSION 3200
 int ctpvae_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *ctpvae_last_error(void);

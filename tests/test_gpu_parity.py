@@ -1402,6 +1402,30 @@ def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
     assert RotatePlan(theta, shape[0], shape[1], False, d)._step_plan is None
 
 
+def test_large_batches_of_small_slices_take_the_step_plan_too():
+    """From 160 slices on (80 at <= 64 angles) the backward of 128 x 128 slices runs the stepped segment kernel instead of the
+    planned gather (B=400 x 180 angles: 143 -> 112 us); the three kernels give the same bits, through the raw call and through
+    the autograd API with the fused likelihood's per-slice factor."""
+    d = dev()
+    theta = phantoms.dense_theta(180)[::2]
+    plan = RotatePlan(theta, 128, 128, True, d)
+    assert plan.backward_kernel_name(50) == "rotate_bwd_planned_kernel" and plan.backward_kernel_name(200) == "rotate_bwd_stepped_kernel"
+    rng = np.random.default_rng(3)
+    g = torch.from_numpy(rng.standard_normal((200, 90, plan.PW)).astype(np.float32)).to(d)
+    scale = torch.from_numpy(rng.uniform(0.5, 2.0, 200).astype(np.float32)).to(d)
+    stepped, stepped_s = plan.backward(g), plan.backward(g, scale=scale)
+    forced = RotatePlan(theta, 128, 128, True, d)
+    forced.backward_uses_step_plan = lambda S: False
+    forced.backward_uses_plan = lambda S: True
+    assert torch.equal(stepped, forced.backward(g)) and torch.equal(stepped_s, forced.backward(g, scale=scale))
+    _lib.tune("SEG_PPT", 4)                  # the direct segment kernel through the same entry point
+    assert torch.equal(stepped, plan.backward(g))
+    _lib.tune("SEG_PPT")
+    x = torch.from_numpy(rng.random((200, 128, 128, 1), dtype=np.float32)).to(d).requires_grad_(True)
+    cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True).backward(g[..., None])
+    assert torch.equal(x.grad[..., 0], stepped)
+
+
 @pytest.mark.parametrize("shift", [0.3, -1.25, 2.0])
 def test_ray_driven_pair_with_a_shifted_rotation_centre(oracle, shift):
     """The C ABI takes tomopy's `center`; the reference only ever passes None (dx / 2), which is all the Python wrappers do --
