@@ -761,13 +761,12 @@ class RotatePlan:
             return None
         use_plan, bplan = 0, self.Tinv8
         if angles_i is None:
-            use_plan = int(self.backward_uses_plan(x4.shape[0]))
             if self.backward_uses_step_plan(x4.shape[0]):
                 use_plan, bplan = 3, self._step_plan   # 3: the segment backward over the step plan
-            if use_plan and self._bwd_plan is None:
-                self._bwd_plan = self._build_plan(1)
-            if use_plan:
-                bplan = self._bwd_plan
+            elif self.backward_uses_plan(x4.shape[0]):
+                if self._bwd_plan is None:
+                    self._bwd_plan = self._build_plan(1)
+                use_plan, bplan = 1, self._bwd_plan
         else:
             self._check_sel(angles_i)
             if self._get_bwd4_plan() is not None:      # 2: the angle-selecting planned backward

@@ -1606,11 +1606,12 @@ def test_cpp_autograd_node_and_python_node_are_the_same_calls(oracle, torch_node
 
 
 @pytest.mark.parametrize("B,subset,upstream", [(5, False, "sum"), (5, True, "sum"), (6, True, "full"), (4, False, "full"),
-                                               (5, False, "scalar"), (80, False, "sum")])
+                                               (5, False, "scalar"), (80, False, "sum"), (168, False, "sum"), (168, False, "scalar")])
 def test_cpp_loglik_node_matches_the_python_node(oracle, torch_node, B, subset, upstream):
     """calculate_log_prob_M_given_R through csrc/torch_node.cpp's RotateLogLik against _ProjectLogLik (same C-ABI calls):
     value and gradient bit-equal -- dense plan + angle subset or compact, the three upstream-gradient kinds (per-object sum:
-    the scaled backward; arbitrary; fully expanded scalar), and the large batch whose backward is the segment kernel."""
+    the scaled backward; arbitrary; fully expanded scalar), the large batch whose backward is the segment kernel, and the larger
+    one (168 slices: 672 tiles) whose backward is the STEPPED kernel over the step plan -- the node's mode 3."""
     from ct_pvae_amd import forward_functions as ff
     d = dev()
     rng = np.random.default_rng(B * 7 + subset)
