@@ -1402,6 +1402,30 @@ def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
     assert RotatePlan(theta, shape[0], shape[1], False, d)._step_plan is None
 
 
+def test_random_step_plan_geometries():
+    """Seeded random shapes (ragged in both directions), angle sets of every quadrant incl. axis-aligned ones, batch sizes just
+    large enough for the stepped kernel: the step-plan backward against the direct segment kernel, bit for bit
+    (CTPVAE_FUZZ_SEED / _CASES: more)."""
+    d = dev()
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 909)))
+    for case in range(int(os.environ.get("CTPVAE_FUZZ_CASES", 6))):
+        H, W, A = int(rng.integers(128, 300)), int(rng.integers(128, 300)), int(rng.integers(1, 50))
+        tiles = -(-W // 64) * -(-H // 32)
+        S = 2 * (-(-512 // tiles)) + int(rng.integers(0, 4))          # >= 512 workgroups of slice pairs (odd batches too)
+        theta = rng.uniform(-7.0, 7.0, A)
+        theta[: min(A, 4)] = [0.0, np.pi / 2, np.pi, -np.pi / 2][: min(A, 4)]
+        plan = RotatePlan(theta, H, W, True, d)
+        g = torch.from_numpy(rng.standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
+        tag = f"case {case}: {H}x{W} A={A} S={S}"
+        assert plan._step_plan is not None, tag
+        plan.backward_uses_step_plan = lambda S: True          # (shapes the planned backward serves would take it at this S)
+        got = plan.backward(g)
+        _lib.tune("NO_PLAN", 1)
+        ref = plan.backward(g)
+        _lib.tune("NO_PLAN")
+        assert torch.equal(got, ref), tag
+
+
 def test_large_batches_of_small_slices_take_the_step_plan_too():
     """From 160 slices on (80 at <= 64 angles) the backward of 128 x 128 slices runs the stepped segment kernel instead of the
     planned gather (B=400 x 180 angles: 143 -> 112 us); the three kernels give the same bits, through the raw call and through
