@@ -501,6 +501,12 @@ def test_iradon_against_oracle_and_golden(oracle, golden_dir):
     filt = np.abs(np.fft.fftfreq(184)) * 2
     got = cp.iradon(torch.from_numpy(sino).to(d), theta, 128, 128, filt)
     assert rel_err(to_np(got), oracle.iradon(sino, theta, 128, 128, filt)) <= 1e-10
+    # 17 sinograms: two per thread in the back-projection (the last thread group ragged), same sums
+    sino17 = rng.random((17, 24, 184))
+    theta24 = np.sort(rng.uniform(0.0, np.pi, 24))
+    got = cp.iradon(torch.from_numpy(sino17).to(d), theta24, 128, 128, filt)
+    assert rel_err(to_np(got), oracle.iradon(sino17, theta24, 128, 128, filt)) <= 1e-10
+    np.testing.assert_array_equal(to_np(got[16]), to_np(cp.iradon(torch.from_numpy(sino17[16:]).to(d), theta24, 128, 128, filt)[0]))
 
 
 def test_loglik_against_oracle_golden_and_autograd(oracle, golden_dir):
