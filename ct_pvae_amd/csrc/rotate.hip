@@ -1454,6 +1454,10 @@ __global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpe
 // Workgroup = (tile of NS slices, mirror class, task group), launched like the tiled kernel above: blockIdx.x = 2 * group +
 // class, blockIdx.y = slice group * tiles + tile.  Stages the tile with its zero border (class 0 column-mirrored), then its
 // waves take (angle, 64-slot block) tasks from an LDS counter, long ones first, each prepared while the previous one is walked.
+#ifndef CTPVAE_TILE_PERMUTE
+#define CTPVAE_TILE_PERMUTE 1
+#endif
+constexpr bool kTilePermuteLanes = CTPVAE_TILE_PERMUTE != 0;
 template <int NS>
 __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                        TLayout L, const char *__restrict__ plan,
@@ -1524,7 +1528,14 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
             q.a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
             q.neg = (clsw[q.a] >> 1) != 0;
             q.ng = __builtin_amdgcn_readfirstlane(ngt[q.a * L.nbk + blk]);
-            q.slot = lane < 32 ? blk * 32 + lane : L.nb - 32 * (blk + 1) + (lane - 32);
+            // which slot of its 32-slot band a lane walks: a ds_read_b128 is served in four groups of 16 lanes that are NOT
+            // runs of consecutive lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32), and only lanes of one
+            // group conflict: giving a group 16 CONSECUTIVE rays keeps its taps within 15 (|cos| + |sin|) <= 21 sixteen-byte
+            // slots (a 2-way wrap at worst) instead of the 38 that lanes 0..27 of a linear assignment span (3-way)
+            int li = lane & 31;
+            if constexpr (NS == 4 && kTilePermuteLanes)
+                li = li < 4 ? li : li < 12 ? li + 12 : li < 16 ? li - 8 : li < 20 ? li + 8 : li < 28 ? li - 12 : li;
+            q.slot = lane < 32 ? blk * 32 + li : L.nb - 32 * (blk + 1) + li;
             const unsigned sw = start[(size_t)q.a * L.nb + q.slot];
             q.live = (sw >> 31) != 0;
             q.adr = kLutBytes + (int)(sw & 0x7fffffffu) * (4 * NS);
