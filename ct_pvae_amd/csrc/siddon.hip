@@ -310,6 +310,11 @@ __global__ __launch_bounds__(256) void siddon_fwd_packed_kernel(const float *__r
 // data are all zero are skipped (sparse sinograms, dose masks).  VALU-bound: ~55 ops per (pixel, ray), shared by NS slices.
 constexpr int kGatherRows = 8;     // pixel rows (= waves) per workgroup
 constexpr int kGatherSeg = 68;     // rays staged per angle: 63 |cos| + 7 |sin| + 3 <= 66.4
+constexpr int kGatherMaxCh = 15;   // angles per LDS chunk (two staging rounds of the 512 threads)
+// the staged data of slice k sit in their own PLANE of kGatherPlane floats: the 64 lanes of a wave read neighbouring (or the
+// same) rays, i.e. neighbouring words of one plane -- conflict-free -- where an interleaved [ray][slice] layout put them 32 bytes
+// apart (8-way conflicts: SQ_LDS_BANK_CONFLICT was 72 % of the kernel's LDS cycles)
+constexpr int kGatherPlane = kGatherMaxCh * kGatherSeg;
 
 struct GatherGeo {
     float gx0, gy0, gx_gt, gx_le, gy_gt, gy_le, hx, hz;
@@ -574,10 +579,10 @@ __global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
     float *__restrict__ recon)
 {
     extern __shared__ float lds[];
-    // LDS: lines [CH][SEG] float4 | vals [CH][SEG][NS] | seg_lo [CH] | live [CH] | anyD
+    // LDS: lines [CH][SEG] float4 | vals [NS][kGatherPlane] | seg_lo [CH] | live [CH] | anyD
     float4 *lines = reinterpret_cast<float4 *>(lds);
     float *vals = lds + (size_t)CH * kGatherSeg * 4;
-    int *seg_lo = reinterpret_cast<int *>(vals + (size_t)CH * kGatherSeg * NS);
+    int *seg_lo = reinterpret_cast<int *>(vals + (size_t)NS * kGatherPlane);
     int *live = seg_lo + CH;
     int *any_d = live + CH;
     const int tiles_y = (g.oz + 63) / 64;
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
             bool nz = false;
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                vals[(size_t)e * NS + k] = v[k];
+                vals[k * kGatherPlane + e] = v[k];
                 nz = nz || v[k] != 0.0f;
             }
             if (nz && line.x == line.x) live[a] = 1;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
                 const GatherRay R(G, SidRayLine{l4.x, l4.y, l4.z, l4.w}, up);
                 auto add = [&](float dist) {
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) acc[k] += vals[(size_t)e * NS + k] * dist;
+                    for (int k = 0; k < NS; ++k) acc[k] += vals[k * kGatherPlane + e] * dist;
                 };
                 if (slow) {
                     R.all_segments(ix, iy, tau, add);
@@ -931,9 +936,9 @@ static int siddon_gather_launch(const float *data, const SidGeom &g, const float
                                 const float *D, const float *colsum, float *recon, hipStream_t stream)
 {
     // angles per LDS chunk: two staging rounds of the 512 threads, ~50 KB with eight slices -> three workgroups per CU
-    int CH = std::max(1, std::min(g.dt, 2 * kGatherRows * 64 / kGatherSeg));
-    if (knob(kKnobSiddonBwdChunks) > 0) CH = std::max(1, std::min(g.dt, knob(kKnobSiddonBwdChunks)));
-    const size_t shmem = (size_t)CH * kGatherSeg * (16 + 4 * NS) + (size_t)CH * 8 + 16;
+    int CH = std::max(1, std::min(g.dt, kGatherMaxCh));
+    if (knob(kKnobSiddonBwdChunks) > 0) CH = std::max(1, std::min(CH, knob(kKnobSiddonBwdChunks)));
+    const size_t shmem = (size_t)CH * kGatherSeg * 16 + (size_t)NS * kGatherPlane * 4 + (size_t)CH * 8 + 16;
     const float tau = siddon_tau(g.ox, g.oz);
     const dim3 grid(ceil_div(g.ox, kGatherRows) * ceil_div(g.oz, 64), ceil_div(g.oy, NS)), block(kGatherRows * 64);
     auto launch = [&](auto kernel) -> int {
