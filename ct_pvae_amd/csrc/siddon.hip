@@ -7,6 +7,16 @@
 // the fly with two cursors, evaluating exactly the same fp32 expressions, so no per-ray arrays exist
 // and the slice is read from LDS.  Compiled with -ffp-contract=off; '/' and sqrtf are correctly
 // rounded (hipcc default), so the result equals the CPU restatement bit for bit.
+//
+// In this file (tomopy.project / tomopy.recon(algorithm = 'fbp' | 'sirt') behind create_sinogram and iradon_all,
+// ctvae/helper_functions.py:33-38,489-516):
+//   siddon_fwd_kernel            the walk, one or two slices per workgroup in LDS (one- and two-slice calls)
+//   siddon_fwd_packed_kernel     the same walk for 4 / 8 slices interleaved per pixel in global memory (batches); optional
+//                                SIRT store (meas - A x) / sum dist^2
+//   siddon_bwd_gather_kernel     the transpose as a pixel-driven gather with libtomo's arithmetic and order: bit-equal to the
+//                                ray-driven accumulation (+ ray table, slow-path flags, the degenerate rays' ray-driven pass);
+//                                optional SIRT store x += A^T upd / sum dist
+//   siddon_rownorm_kernel        sum dist^2 of every ray
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
