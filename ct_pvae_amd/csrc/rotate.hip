@@ -1400,8 +1400,8 @@ static size_t tile_lds_bytes(const TileSpec &ts, int ns)
 // cplan_walk.h's cwalk.  Same taps, same row order inside a tile, same slot layout of the partial sums => the SAME partial
 // sums as the kernel above, bit for bit; rotate_tile_reduce_kernel is unchanged.
 struct TLayout {
-    int nt, nb, nbk, NQ, pitch, cells;
-    long long off_cls, off_ng, off_start, off_codes, off_flag, bytes;
+    int nt, nb, nbk, nq16, NQ, pitch, cells, maxT;
+    long long off_cls, off_ng, off_ng16, off_tcount, off_tasks, off_start, off_codes, off_flag, bytes;
 };
 static TLayout t_layout(const TileSpec &ts, int A)
 {
@@ -1409,13 +1409,18 @@ static TLayout t_layout(const TileSpec &ts, int A)
     L.nt = ts.ntx * ts.nty;
     L.nb = ts.nb;
     L.nbk = ts.nb >> 6;
+    L.nq16 = ts.nb >> 4;
     L.NQ = ceil_div((int)ceilf(sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th))) + 4, kRowsPerChunk);   // rows of a ray inside a tile
     L.pitch = pitch_mod32_is_1(ts.tw + 1);
     L.cells = 1 + (ts.th + 2) * L.pitch + 1;
+    L.maxT = (A * L.nq16 + 3) / 4 + 2;                                        // sorted tasks per (tile, class): two sign groups
     auto up = [](long long v) { return (v + 255) / 256 * 256; };
     L.off_cls = 0;                                                            // [A] class words (cplan_class_word)
-    L.off_ng = up((long long)A * 4);                                          // [nt][A][nbk] row groups of a task
-    L.off_start = up(L.off_ng + (long long)L.nt * A * L.nbk * 4);             // [nt][A][nb] first cell | live << 31
+    L.off_ng = up((long long)A * 4);                                          // [nt][A][nbk] row groups of a 64-slot block
+    L.off_ng16 = up(L.off_ng + (long long)L.nt * A * L.nbk * 4);              // [nt][A][nq16] row groups of a 16-slot band
+    L.off_tcount = up(L.off_ng16 + (long long)L.nt * A * L.nq16 * 4);         // [nt][2] sorted tasks of a (tile, class)
+    L.off_tasks = up(L.off_tcount + (long long)L.nt * 2 * 4);                 // [nt][2][maxT] uint4: four band words
+    L.off_start = up(L.off_tasks + (long long)L.nt * 2 * L.maxT * 16);        // [nt][A][nb] first cell | live << 31
     L.off_codes = up(L.off_start + (long long)L.nt * A * L.nb * 4);           // [nt][A][NQ][nb] uint4
     L.off_flag = L.off_codes + (long long)L.nt * A * L.NQ * L.nb * 16;
     L.bytes = L.off_flag + 256;
@@ -1423,7 +1428,9 @@ static TLayout t_layout(const TileSpec &ts, int A)
 }
 static size_t t_lds_bytes(const TLayout &L, int A, int ns) { return (size_t)kLutBytes + (size_t)L.cells * 4 * ns + ((size_t)A + 2) * 4; }
 
-// one wave per (64-slot block, angle, tile): the mirrored 32-slot runs of the tiled kernel's tasks
+// one wave per (64-slot block, angle, tile): the mirrored 32-slot runs of the tiled kernel's tasks.  Every ray's codes end with
+// its step onto the zero border (then "stay"), whatever the rows its task walks: a ray may ride in a task longer than its own
+// block's (the sorted tasks below).
 __global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpec ts, const float *__restrict__ T8, TLayout L,
                                                           char *__restrict__ plan)
 {
@@ -1438,27 +1445,103 @@ __global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpe
     const bool valid = (unsigned)j < (unsigned)g.PW;
     int *cls = reinterpret_cast<int *>(plan + L.off_cls);
     int *ngt = reinterpret_cast<int *>(plan + L.off_ng);
+    int *ng16 = reinterpret_cast<int *>(plan + L.off_ng16);
     unsigned *start = reinterpret_cast<unsigned *>(plan + L.off_start);
     uint4 *codes = reinterpret_cast<uint4 *>(plan + L.off_codes);
     if (t == 0 && blk == 0 && lane == 0) cls[a] = cplan_class_word(t6);
     const RayScan rs = cplan_scan_ray(g, t6, j, valid, L.pitch);
+    int n16 = rs.n;   // the longest ray of this lane's 16-slot band (a quarter of the wave holds one band)
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) n16 = max(n16, __shfl_xor(n16, off, 64));
     const int ng = (wave_max_i(rs.n) + kRowsPerGroup - 1) / kRowsPerGroup;
     const size_t ta = (size_t)t * gfull.A + a;
     if (lane == 0) ngt[ta * L.nbk + blk] = ng;
+    if ((lane & 15) == 0) ng16[ta * L.nq16 + (slot >> 4)] = (n16 + kRowsPerGroup - 1) / kRowsPerGroup;
     start[ta * L.nb + slot] = (unsigned)rs.start | (valid ? 0x80000000u : 0u);
-    bool bad = cplan_encode_ray(g, t6, j, rs, kRowsPerGroup * ng, L.pitch, L.NQ, codes + ta * L.NQ * L.nb + slot, (size_t)L.nb);
-    bad = bad || kRowsPerGroup * ng > kRowsPerChunk * L.NQ;
+    bool bad = cplan_encode_ray(g, t6, j, rs, kRowsPerChunk * L.NQ, L.pitch, L.NQ, codes + ta * L.NQ * L.nb + slot, (size_t)L.nb);
+    bad = bad || kRowsPerGroup * ng > kRowsPerChunk * L.NQ || ng > 127;
     if (__any(bad) && lane == 0) atomicOr(reinterpret_cast<int *>(plan + L.off_flag), 1);
+}
+
+// SORTED TASKS (round 3).  A wave walks its 64 ray slots for as many rows as its longest ray; with (angle, 64-slot block) tasks
+// the rays of a 64 x 96 tile cut obliquely have triangular length profiles and a third of the gathers add zeros (1.54 x the
+// rows of the rays themselves, counted from the geometry at 512 x 512, 90 angles).  A ds_read_b128 is served in four hardware
+// groups of 16 lanes, and a group wants 16 consecutive rays (see the kernel below) -- but nothing ties the four groups of a
+// wave to one angle.  So the unit becomes a 16-slot BAND of one angle, the bands of a (tile, mirror class) are sorted by their
+// length in row groups (descending, the sign of the step first: a wave's walk adds or subtracts its table offsets), and a
+// task is four consecutive bands of that order: 1.24 x.  Which rays ride together changes nothing in any ray's sum.
+// Task word: angle | band << 16 | the band's row groups << 20 | sigma < 0 << 28 | 1 << 31 (0: an empty quarter).
+// One wave per (tile, class); the sort is a stable counting sort over keys (sign, 127 - groups).
+__global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L, char *__restrict__ plan)
+{
+    const int t = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
+    const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
+    const int *ng16 = reinterpret_cast<const int *>(plan + L.off_ng16) + (size_t)t * A * L.nq16;
+    unsigned *tasks = reinterpret_cast<unsigned *>(plan + L.off_tasks) + ((size_t)t * 2 + c) * L.maxT * 4;
+    int *tcount = reinterpret_cast<int *>(plan + L.off_tcount) + t * 2 + c;
+    __shared__ int hist[256], base[256];
+    for (int k = lane; k < 256; k += 64) hist[k] = 0;
+    __syncthreads();
+    const int U = A * L.nq16;
+    auto key_of = [&](int u, bool &in) -> int {
+        in = false;
+        if (u >= U) return 0;
+        const int a = u / L.nq16, w = cls[a];
+        in = (w & 1) == c;
+        return ((w >> 1) & 1) * 128 + (127 - min(ng16[u], 127));
+    };
+    for (int u0 = 0; u0 < U; u0 += 64) {
+        bool in;
+        const int k = key_of(u0 + lane, in);
+        if (in) atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    if (lane == 0) {   // positions: each sign group padded to whole tasks
+        int pos = 0;
+        for (int sg = 0; sg < 2; ++sg) {
+            for (int k = 0; k < 128; ++k) {
+                base[sg * 128 + k] = pos;
+                pos += hist[sg * 128 + k];
+            }
+            pos = (pos + 3) & ~3;
+        }
+        *tcount = pos >> 2;
+    }
+    __syncthreads();
+    for (int u0 = 0; u0 < U; u0 += 64) {   // stable: units in ascending order, lanes of one key ranked by lane
+        bool in;
+        const int u = u0 + lane, k = key_of(u, in);
+        unsigned long long todo = __ballot(in);
+        int pos = -1;
+        while (todo) {
+            const int l0 = __ffsll((long long)todo) - 1;
+            const int k0 = __shfl(k, l0, 64);
+            const unsigned long long same = __ballot(in && k == k0) & todo;
+            const int b = base[k0];
+            if (in && k == k0) pos = b + (int)__popcll(same & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (lane == l0) base[k0] = b + (int)__popcll(same);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~same;
+        }
+        if (in) {   // (a task's row groups are read from its first, longest band's word)
+            const int a = u / L.nq16, band = u - a * L.nq16;
+            tasks[pos] = (unsigned)a | ((unsigned)band << 16) | ((unsigned)(127 - (k & 127)) << 20) | ((unsigned)(k >> 7) << 28) |
+                         0x80000000u;
+        }
+    }
 }
 
 // Workgroup = (tile of NS slices, mirror class, task group), launched like the tiled kernel above: blockIdx.x = 2 * group +
 // class, blockIdx.y = slice group * tiles + tile.  Stages the tile with its zero border (class 0 column-mirrored), then its
-// waves take (angle, 64-slot block) tasks from an LDS counter, long ones first, each prepared while the previous one is walked.
+// waves take tasks from an LDS counter, long ones first, each prepared while the previous one is walked.  SORTED: a task is
+// four 16-slot bands of the plan's sorted list (rotate_tplan_tasks_kernel), one per quarter of the wave; otherwise (knob
+// TILED_SORT = 0, kept for measurement) an (angle, 64-slot block) pair.
 #ifndef CTPVAE_TILE_PERMUTE
 #define CTPVAE_TILE_PERMUTE 1
 #endif
 constexpr bool kTilePermuteLanes = CTPVAE_TILE_PERMUTE != 0;
-template <int NS>
+template <int NS, bool SORTED>
 __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                        TLayout L, const char *__restrict__ plan,
                                                                        float *__restrict__ partial)
@@ -1475,23 +1558,34 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int *clsw = reinterpret_cast<const int *>(plan + L.off_cls);
     const int *ngt = reinterpret_cast<const int *>(plan + L.off_ng) + (size_t)t * A * L.nbk;
+    const uint4 *tasks = reinterpret_cast<const uint4 *>(plan + L.off_tasks) + ((size_t)t * 2 + cls) * L.maxT;
     const unsigned *start = reinterpret_cast<const unsigned *>(plan + L.off_start) + (size_t)t * A * L.nb;
     const uint4 *codes = reinterpret_cast<const uint4 *>(plan + L.off_codes) + (size_t)t * A * L.NQ * L.nb;
-    // behind the image: the ascending list of this class's angles ([0] = their count), then the task counter
+    // behind the image: the ascending list of this class's angles ([0] = their count; unsorted tasks only), then the task counter
     int *cls_list = reinterpret_cast<int *>(image + (size_t)L.cells * NS);
     if (threadIdx.x < 64) {
         int n = 0;
-        for (int a0 = 0; a0 < A; a0 += 64) {
-            const bool in_cls = a0 + lane < A && (clsw[min(a0 + lane, A - 1)] & 1) == cls;
-            const unsigned long long m = __ballot(in_cls);
-            if (in_cls) cls_list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
-            n += __popcll(m);
-        }
+        if constexpr (!SORTED)
+            for (int a0 = 0; a0 < A; a0 += 64) {
+                const bool in_cls = a0 + lane < A && (clsw[min(a0 + lane, A - 1)] & 1) == cls;
+                const unsigned long long m = __ballot(in_cls);
+                if (in_cls) cls_list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
+                n += __popcll(m);
+            }
         if (lane == 0) {
             cls_list[0] = n;
             cls_list[1 + A] = nwaves;   // the task counter: every wave's first task is its own number
         }
     }
+    // which slot of a 32-slot run a lane walks: a ds_read_b128 is served in four groups of 16 lanes that are NOT runs of
+    // consecutive lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32), and only lanes of one group conflict:
+    // giving a group 16 CONSECUTIVE rays keeps its taps within 15 (|cos| + |sin|) <= 21 sixteen-byte slots (a 2-way wrap at
+    // worst) instead of the 38 that lanes 0..27 of a linear assignment span (3-way)
+    int li = lane & 31;
+    if constexpr (NS == 4 && kTilePermuteLanes)
+        li = li < 4 ? li : li < 12 ? li + 12 : li < 16 ? li - 8 : li < 20 ? li + 8 : li < 28 ? li - 12 : li;
+    const int quarter = (lane >> 5) * 2 + (li >> 4);   // SORTED: the hardware group = the task's band this lane rides in
+    const int ntask_sorted = SORTED ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(plan + L.off_tcount)[t * 2 + cls]) : 0;
     cplan_init_lut<NS>(lds, L.pitch);
     cplan_zero_border<NS>(image, h, w, L.pitch);
     float *core = image + (size_t)(1 + L.pitch) * NS;
@@ -1506,11 +1600,11 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     __syncthreads();
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
     int *next_task = cls_list + 1 + A;
-    const int ntask = ncls * L.nbk;
+    const int ntask = SORTED ? ntask_sorted : ncls * L.nbk;
     const size_t st = (size_t)L.nb;
     struct Task {
         bool valid, neg, live;
-        int a, slot, ng, adr;
+        int ray, ng, adr;   // ray = angle * nb + slot (per lane)
         const uint4 *p;
         uint4 c0, c1;
     };
@@ -1518,31 +1612,39 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
         Task q;
         q.valid = m < ntask;
         q.neg = q.live = false;
-        q.a = q.slot = q.ng = 0;
+        q.ray = q.ng = 0;
         q.adr = kLutBytes;
         q.p = codes;
         q.c0 = q.c1 = uint4{0u, 0u, 0u, 0u};
         if (q.valid) {   // wave-uniform
-            // m counts 64-slot blocks from the innermost (longest rays) outwards, the class's angles within a block
-            const int bi = m / ncls, ai = m - bi * ncls, blk = L.nbk - 1 - bi;
-            q.a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
-            q.neg = (clsw[q.a] >> 1) != 0;
-            q.ng = __builtin_amdgcn_readfirstlane(ngt[q.a * L.nbk + blk]);
-            // which slot of its 32-slot band a lane walks: a ds_read_b128 is served in four groups of 16 lanes that are NOT
-            // runs of consecutive lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, and the same + 32), and only lanes of one
-            // group conflict: giving a group 16 CONSECUTIVE rays keeps its taps within 15 (|cos| + |sin|) <= 21 sixteen-byte
-            // slots (a 2-way wrap at worst) instead of the 38 that lanes 0..27 of a linear assignment span (3-way)
-            int li = lane & 31;
-            if constexpr (NS == 4 && kTilePermuteLanes)
-                li = li < 4 ? li : li < 12 ? li + 12 : li < 16 ? li - 8 : li < 20 ? li + 8 : li < 28 ? li - 12 : li;
-            q.slot = lane < 32 ? blk * 32 + li : L.nb - 32 * (blk + 1) + li;
-            const unsigned sw = start[(size_t)q.a * L.nb + q.slot];
-            q.live = (sw >> 31) != 0;
-            q.adr = kLutBytes + (int)(sw & 0x7fffffffu) * (4 * NS);
-            const uint4 *p = codes + (size_t)q.a * L.NQ * L.nb + q.slot;
-            q.c0 = p[0];
-            if (L.NQ > 1) q.c1 = p[st];
-            q.p = p + 2 * st;
+            int a, slot;
+            bool mine = true;
+            if constexpr (SORTED) {
+                const uint4 d = tasks[m];   // sorted longest first
+                const unsigned wq = quarter == 0 ? d.x : quarter == 1 ? d.y : quarter == 2 ? d.z : d.w;
+                mine = (wq >> 31) != 0;   // the last task of a sign group may have empty quarters
+                a = wq & 0xffffu;
+                slot = (int)((wq >> 16) & 15u) * 16 + (li & 15);
+                q.ng = __builtin_amdgcn_readfirstlane((d.x >> 20) & 127u);
+                q.neg = __builtin_amdgcn_readfirstlane((d.x >> 28) & 1u) != 0;
+            } else {
+                // m counts 64-slot blocks from the innermost (longest rays) outwards, the class's angles within a block
+                const int bi = m / ncls, ai = m - bi * ncls, blk = L.nbk - 1 - bi;
+                a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
+                q.neg = (clsw[a] >> 1) != 0;
+                q.ng = __builtin_amdgcn_readfirstlane(ngt[a * L.nbk + blk]);
+                slot = lane < 32 ? blk * 32 + li : L.nb - 32 * (blk + 1) + li;
+            }
+            if (mine) {
+                q.ray = a * L.nb + slot;
+                const unsigned sw = start[q.ray];
+                q.live = (sw >> 31) != 0;
+                q.adr = kLutBytes + (int)(sw & 0x7fffffffu) * (4 * NS);
+                const uint4 *p = codes + (size_t)a * L.NQ * L.nb + slot;
+                q.c0 = p[0];
+                if (L.NQ > 1) q.c1 = p[st];
+                q.p = p + 2 * st;
+            }
         }
         return q;
     };
@@ -1558,7 +1660,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
             acc = neg ? cwalk<NS, true>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ)
                       : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
         if (cur.live) {
-            const size_t ray = (size_t)cur.a * L.nb + cur.slot, nrays = (size_t)A * L.nb;
+            const size_t ray = (size_t)cur.ray, nrays = (size_t)A * L.nb;
             if constexpr (NS == 1) {
                 partial[((size_t)s * nt + t) * nrays + ray] = acc;
             } else {
@@ -1737,9 +1839,14 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
         return CTPVAE_OK;
     };
     int rc;
-    if (tplan_dev && !tie_fix)
-        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4>)
-                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2>) : launch_compact(rotate_fwd_tile_compact_kernel<1>));
+    if (tplan_dev && !tie_fix && knob(kKnobTiledSort) != 0)   // tasks = four sorted 16-slot bands (rotate_tplan_tasks_kernel)
+        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, true>)
+                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, true>)
+                                : launch_compact(rotate_fwd_tile_compact_kernel<1, true>));
+    else if (tplan_dev && !tie_fix)
+        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, false>)
+                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, false>)
+                                : launch_compact(rotate_fwd_tile_compact_kernel<1, false>));
     else if (tie_fix)
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, true, 1>);
     else if (ns == 4)
@@ -1802,8 +1909,11 @@ int ctpvae_rotate_tplan_build_f32(const float *T8_dev, int A, int H, int W, int 
     CTPVAE_REQUIRE(A <= 65535 && L.nt <= 65535, "rotate_tplan_build: at most 65535 angles and tiles");
     const RotGeom g{1, H, W, PH, PW, py, px, A};
     CTPVAE_HIP(hipMemsetAsync((char *)tplan_dev + L.off_flag, 0, 256, (hipStream_t)stream));
+    CTPVAE_HIP(hipMemsetAsync((char *)tplan_dev + L.off_tasks, 0, (size_t)L.nt * 2 * L.maxT * 16, (hipStream_t)stream));   // empty quarters
     hipLaunchKernelGGL(rotate_tplan_kernel, dim3(L.nbk, A, L.nt), dim3(64), 0, (hipStream_t)stream, g, ts, T8_dev, L, (char *)tplan_dev);
     CTPVAE_LAUNCH_CHECK("rotate_tplan_kernel");
+    hipLaunchKernelGGL(rotate_tplan_tasks_kernel, dim3(L.nt, 2), dim3(64), 0, (hipStream_t)stream, A, L, (char *)tplan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_tplan_tasks_kernel");
     return CTPVAE_OK;
 }
 

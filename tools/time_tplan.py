@@ -17,7 +17,10 @@ print("tile plan bytes", pc._tplan.numel())
 for B in (4, 8, 16, 32, 64):
     x = torch.rand((B, 512, 512), device=dev); out = torch.empty((B, 90, pc.PW), device=dev); o2 = torch.empty_like(out)
     tc, td = timeit(lambda: pc.forward(x, out=out)), timeit(lambda: pd.forward(x, out=o2))
-    print(f"B={B}: compact tile plans {tc:.0f} us, direct tiled {td:.0f} us, equal={torch.equal(out, o2)}", flush=True)
+    _lib.tune("TILED_SORT", 0); o3 = torch.empty_like(out)
+    tu = timeit(lambda: pc.forward(x, out=o3)); _lib.tune("TILED_SORT")
+    print(f"B={B}: compact tile plans, sorted 16-slot bands {tc:.0f} us, (angle, block) tasks {tu:.0f} us, direct tiled {td:.0f} us, "
+          f"equal={torch.equal(out, o2) and torch.equal(out, o3)}", flush=True)
     if len(sys.argv) > 1:
         for G in (1, 2, 3, 4):
             _lib.tune("TILED_G", G)
