@@ -51,7 +51,10 @@ struct LogLikEpilogue {
     // o: offset of the ray-sum in the outputs; om / sa: offsets of its measured sample and its mask entry
     __device__ __forceinline__ void write(size_t o, size_t om, size_t sa, float raysum) const
     {
-        const float m = mask[sa], x = meas[om], pnm_v = *pnm;
+        write_loaded(o, mask[sa], meas[om], *pnm, raysum);
+    }
+    __device__ __forceinline__ void write_loaded(size_t o, float m, float x, float pnm_v, float raysum) const
+    {
         lp[o] = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
         if (dlp) {
             float unused;
@@ -61,7 +64,13 @@ struct LogLikEpilogue {
     // the same, returning the log-probability; lp (and dlp) are stored only where a buffer was given
     __device__ __forceinline__ float eval(size_t o, size_t om, size_t sa, float raysum) const
     {
-        const float m = mask[sa], x = meas[om], pnm_v = *pnm;
+        return eval_loaded(o, mask[sa], meas[om], *pnm, raysum);
+    }
+    // ... with the operands already in registers: a kernel requests them BEFORE its long phase (the walk, the sum over tiles)
+    // so that their round trip to memory is not paid after it -- the stores below keep the compiler from moving the loads up
+    // by itself (nothing tells it that the buffers are distinct)
+    __device__ __forceinline__ float eval_loaded(size_t o, float m, float x, float pnm_v, float raysum) const
+    {
         const float v = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
         if (lp) lp[o] = v;
         if (dlp) {

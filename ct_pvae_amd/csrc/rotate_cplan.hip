@@ -188,7 +188,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
         int a, k, j, jb, ng, adr;   // plan angle, output row, bin, bin block, row groups, first tap's LDS byte address
         const uint4 *p;         // the ray's chunk 2
         uint4 c0, c1;
+        float em[NS], ex[NS];   // EPI: mask entry and measured sample of the task's outputs, requested with the task
     };
+    [[maybe_unused]] float epnm = 0.0f;
+    if constexpr (EPI != 0) epnm = *epi.pnm;
     auto prepare = [&](int m) -> Task {
         Task t;
         t.valid = m < ntask;
@@ -197,6 +200,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
         t.adr = kLutBytes;
         t.p = codes;
         t.c0 = t.c1 = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int n = 0; n < NS; ++n) t.em[n] = t.ex[n] = 0.0f;
         if (t.valid) {   // wave-uniform
             const int jb = m / ncls, ai = m - jb * ncls;
             t.jb = jb;
@@ -223,6 +228,17 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
             t.c0 = p[0];
             if (L.NQ > 1) t.c1 = p[st];
             t.p = p + 2 * st;
+            if constexpr (EPI != 0) {   // (loaded in the epilogue these cost the wave a round trip behind its walk)
+                const int jc = min(max(t.j, 0), g.PW - 1);   // dead lanes (bins off the detector) read a live one's sample
+#pragma unroll
+                for (int n = 0; n < NS; ++n) {
+                    const int sl = min(s + n, g_S - 1);
+                    // measured samples and masks: compact like the outputs, or the dense arrays read at the plan angle
+                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + t.a : (size_t)sl * A_out + t.k;
+                    t.em[n] = epi.mask[sa];
+                    t.ex[n] = epi.meas[sa * g.PW + jc];
+                }
+            }
         }
         return t;
     };
@@ -254,38 +270,34 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
                       : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
         if constexpr (EPI == 2) {
             const bool live = (unsigned)cur.j < (unsigned)g.PW;
-            auto reduce = [&](int sl, float v) {
+            auto reduce = [&](int n, float v) {
+                const int sl = s + n;
                 float lpv = 0.0f;
                 if (live) {
                     const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
                     if (sino) sino[o] = v;
-                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + cur.a : (size_t)sl * A_out + cur.k;
-                    lpv = epi.eval(o, sa * g.PW + cur.j, sa, v);
+                    lpv = epi.eval_loaded(o, cur.em[n], cur.ex[n], epnm, v);
                 }
                 const float tot = wave_sum(lpv);
                 if (lane == 0) epi.part[((size_t)sl * A_out + cur.k) * L.nJB + cur.jb] = tot;
             };
             if constexpr (NS == 1) {
-                reduce(s, acc);
+                reduce(0, acc);
             } else {
-                reduce(s, acc.x);
-                if (has2) reduce(s + 1, acc.y);
+                reduce(0, acc.x);
+                if (has2) reduce(1, acc.y);
             }
         } else if ((unsigned)cur.j < (unsigned)g.PW) {
-            auto store = [&](int sl, float v) {
-                const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
+            auto store = [&](int n, float v) {
+                const size_t o = ((size_t)(s + n) * A_out + cur.k) * g.PW + cur.j;
                 sino[o] = v;
-                if constexpr (EPI == 1) {
-                    // measured samples and masks: compact like the outputs, or the dense arrays read at the plan angle
-                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + cur.a : (size_t)sl * A_out + cur.k;
-                    epi.write(o, sa * g.PW + cur.j, sa, v);
-                }
+                if constexpr (EPI == 1) epi.write_loaded(o, cur.em[n], cur.ex[n], epnm, v);
             };
             if constexpr (NS == 1) {
-                store(s, acc);
+                store(0, acc);
             } else {
-                store(s, acc.x);
-                if (has2) store(s + 1, acc.y);
+                store(0, acc.x);
+                if (has2) store(1, acc.y);
             }
         }
         cur = nxt;

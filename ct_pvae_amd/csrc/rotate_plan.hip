@@ -438,13 +438,18 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
         int a, k, j, ng;   // plan angle, output row
         const uint4 *p;
         uint4 q0, q1, q2, q3;
+        float em[NS], ex[NS];   // EPI: mask entry and measured sample of the task's outputs, requested with the task
     };
+    [[maybe_unused]] float epnm = 0.0f;
+    if constexpr (EPI) epnm = *epi.pnm;
     auto prepare = [&](int m) -> Task {
         Task t;
         t.valid = m < ntask;
         t.a = t.k = t.j = t.ng = 0;
         t.p = idx;
         t.q0 = t.q1 = t.q2 = t.q3 = uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < NS; ++n) t.em[n] = t.ex[n] = 0.0f;
         if (t.valid) {   // wave-uniform
             const int jb = m / ncls, ai = m - jb * ncls;
             if constexpr (SEL) {
@@ -470,6 +475,17 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
             t.q2 = t.p[2 * st];
             t.q3 = t.p[3 * st];
             t.p += 4 * st;
+            if constexpr (EPI) {   // (loaded in the epilogue these cost the wave a round trip behind its gathers)
+                const int jc = min(max(t.j, 0), g.PW - 1);   // dead lanes (bins off the detector) read a live one's sample
+#pragma unroll
+                for (int n = 0; n < NS; ++n) {
+                    const int sl = min(s + n, g_S - 1);
+                    // measured samples and masks: compact like the outputs, or the dense arrays read at the plan angle
+                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + t.a : (size_t)sl * A_out + t.k;
+                    t.em[n] = epi.mask[sa];
+                    t.ex[n] = epi.meas[sa * g.PW + jc];
+                }
+            }
         }
         return t;
     };
@@ -532,20 +548,16 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
             }
         }
         if ((unsigned)cur.j < (unsigned)g.PW) {
-            auto store = [&](int sl, float v) {
-                const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
+            auto store = [&](int n, float v) {
+                const size_t o = ((size_t)(s + n) * A_out + cur.k) * g.PW + cur.j;
                 sino[o] = v;
-                if constexpr (EPI) {
-                    // measured samples and masks: compact like the outputs, or the dense arrays read at the plan angle
-                    const size_t sa = SEL && epi.dense ? (size_t)sl * g.A + cur.a : (size_t)sl * A_out + cur.k;
-                    epi.write(o, sa * g.PW + cur.j, sa, v);
-                }
+                if constexpr (EPI) epi.write_loaded(o, cur.em[n], cur.ex[n], epnm, v);
             };
             if constexpr (NS == 1) {
-                store(s, acc);
+                store(0, acc);
             } else {
-                store(s, acc.x);
-                if (has2) store(s + 1, acc.y);
+                store(0, acc.x);
+                if (has2) store(1, acc.y);
             }
         }
         cur = nxt;
