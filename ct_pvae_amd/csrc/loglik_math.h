@@ -102,7 +102,15 @@ __device__ __forceinline__ float object_sum_of_parts(const float *__restrict__ p
         const int a = a0 + lane;
         float sa = 0.0f;
         if (a < A)
-            for (int k = 0; k < tpr; ++k) sa += part[(size_t)a * tpr + k];
+            for (int k = 0; k < tpr; k += 4) {   // four loads in flight, added in order (one at a time: tpr round trips)
+                const float *p = part + (size_t)a * tpr + k;
+                const int n = tpr - k;
+                const float v0 = p[0], v1 = p[n > 1 ? 1 : 0], v2 = p[n > 2 ? 2 : 0], v3 = p[n > 3 ? 3 : 0];
+                sa += v0;
+                if (n > 1) sa += v1;
+                if (n > 2) sa += v2;
+                if (n > 3) sa += v3;
+            }
         total += wave_sum(sa);
     }
     return total;

@@ -674,15 +674,29 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
             list_first[wave][pos] = fb;
         }
         __builtin_amdgcn_wave_barrier();              // the list is this wave's own: LDS writes are in order
-        for (int i = 0; i < n; ++i) {                 // tiles in ascending order; loads unconditional (slot clamped)
+        // tiles in ascending order; loads unconditional (slot clamped).  The loads of tile i + 2 are requested before tile i is
+        // added: one tile at a time the pass was a chain of ~12 dependent round trips to memory per wave.
+        constexpr int D = 3;
+        float v[D][kReduceSlices];
+        bool ok[D];
+        auto issue = [&](int i, float (&dst)[kReduceSlices], bool &okd) {
             const int slot = j - list_first[wave][i];
-            const bool ok = j < g.PW && (unsigned)slot < (unsigned)ts.nb;
-            const size_t off = (size_t)list_tile[wave][i] * tstride + (ok ? slot : 0);
-            float v[kReduceSlices];
+            okd = j < g.PW && (unsigned)slot < (unsigned)ts.nb;
+            const size_t off = (size_t)list_tile[wave][i] * tstride + (okd ? slot : 0);
 #pragma unroll
-            for (int q = 0; q < kReduceSlices; ++q) v[q] = pa[q][off];
+            for (int q = 0; q < kReduceSlices; ++q) dst[q] = pa[q][off];
+        };
 #pragma unroll
-            for (int q = 0; q < kReduceSlices; ++q) acc[q] += ok ? v[q] : 0.0f;   // + 0.0f leaves the sum unchanged
+        for (int d = 0; d < D - 1; ++d)
+            if (d < n) issue(d, v[d], ok[d]);
+        for (int i = 0; i < n; i += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (i + d < n) {   // wave-uniform
+                    if (i + d + D - 1 < n) issue(i + d + D - 1, v[(d + D - 1) % D], ok[(d + D - 1) % D]);
+#pragma unroll
+                    for (int q = 0; q < kReduceSlices; ++q) acc[q] += ok[d] ? v[d][q] : 0.0f;   // + 0.0f leaves the sum unchanged
+                }
         }
         __builtin_amdgcn_wave_barrier();
     }
