@@ -1237,7 +1237,10 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             v[0] = lds_abs_vec<NS>(addr);
 #pragma unroll
             for (int k = 1; k < PPT; ++k) {
-                addr += (int)((w >> (6 + k)) & 1u) * m.y;
+                // bit-field extract + one signed 24-bit multiply-add (the compiler's own choice for bit * step was three
+                // operations: sign-extending extract, and, add)
+                const int bit = (int)__builtin_amdgcn_ubfe(w, 6 + k, 1);
+                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(addr) : "v"(bit), "v"(m.y));
                 v[k] = lds_abs_vec<NS>(addr);
             }
         };
