@@ -278,10 +278,15 @@ __device__ __forceinline__ void unpack2(unsigned pk, int &lo4, int &hi4)
         : "=v"(hi4)
         : "v"(pk));
 }
-__device__ __forceinline__ float lds_at(const float *lds, int byte_off)
+// The gathers below address LDS by ABSOLUTE byte addresses: these kernels have no static LDS, so their dynamic LDS starts at
+// address 0 (checked once per workgroup, lds_starts_at_zero) and an unpacked tap is the ds_read's address as it stands.  Through
+// the `lds` pointer every tap paid a v_add_u32 of the array's link-time base -- zero -- that the compiler cannot fold: one of
+// the three vector operations per tap of a slice pair.
+__device__ __forceinline__ void lds_starts_at_zero(const float *lds)
 {
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(lds) + byte_off);
+    if ((unsigned)(size_t)(lds_cptr)lds != 0u) __builtin_trap();
 }
+__device__ __forceinline__ float lds_at(const float *, int byte_off) { return *(lds_cptr)(size_t)(unsigned)byte_off; }
 __device__ __forceinline__ void unpack2x8(unsigned pk, int &lo8, int &hi8)
 {
     asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
@@ -299,7 +304,7 @@ __device__ __forceinline__ void gather8(const float *lds, const uint4 q, f32x2 (
     unpack2x8(q.z, a[4], a[5]);
     unpack2x8(q.w, a[6], a[7]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(lds) + a[e]);
+    for (int e = 0; e < 8; ++e) v[e] = *(const __attribute__((address_space(3))) f32x2 *)(size_t)(unsigned)a[e];
 }
 __device__ __forceinline__ void gather8(const float *lds, const uint4 q, float (&v)[8])
 {
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
+    lds_starts_at_zero(lds);
     // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only).  Slices (slice pairs) are dealt to the 8
     // XCDs so that all workgroups of one slice read it through the same L2: block = (u / 8) * 8 * wgs + wg * 8 + u % 8.
     const int units = (g_S + NS - 1) / NS;
@@ -575,9 +581,9 @@ __device__ __forceinline__ void unpack4(unsigned pk, int &b0, int &b1, int &b2, 
     asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(b2) : "v"(pk), "i"(SHIFT));
     asm("v_lshlrev_b32_sdwa %0, %2, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(b3) : "v"(pk), "i"(SHIFT));
 }
-template <int NS> __device__ __forceinline__ typename SliceVec<NS>::type lds_at_vec(const float *lds, int byte_off)
+template <int NS> __device__ __forceinline__ typename SliceVec<NS>::type lds_at_vec(const float *, int byte_off)
 {
-    return *reinterpret_cast<const typename SliceVec<NS>::type *>(reinterpret_cast<const char *>(lds) + byte_off);
+    return *(const __attribute__((address_space(3))) typename SliceVec<NS>::type *)(size_t)(unsigned)byte_off;   // see lds_at
 }
 // the 16 taps of `q` are staged rows AL0 .. AL0+15: the row offset is a compile-time ds_read immediate, the address
 // VGPR is just the SDWA-extracted bin * cell size -- no address arithmetic per tap
@@ -619,6 +625,7 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     typedef typename SliceVec<NS>::type vec_t;
     constexpr int kChunk = kBwdChunk / NS;
     extern __shared__ float lds[];
+    lds_starts_at_zero(lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int tiles = L.nXB * tiles_y;
     const int units = (g_S + NS - 1) / NS;
@@ -794,6 +801,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_planned_sel_kernel(const float
     constexpr int kChunk = kBwdChunk / NS;          // staged rows per pass: row offsets stay ds_read immediates
     constexpr int ROW = kBwdPitch * 4 * NS;         // bytes per staged row
     extern __shared__ float lds[];
+    lds_starts_at_zero(lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int nXB = Wpad >> 6, tiles = nXB * tiles_y;
     const int units = (g_S + NS - 1) / NS;
