@@ -516,7 +516,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
         if (lane == 0) m = atomicAdd(next_task, 1);
         const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m) * G + gi);
 
-        const int ng = cur.ng;
+        const int ng = __builtin_amdgcn_readfirstlane(cur.ng);   // wave-uniform: the loop's exits are scalar branches
         const uint4 *p = cur.p;
         vec_t acc = 0.0f;
         if (ng > 0) {
