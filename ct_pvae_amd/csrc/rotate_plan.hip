@@ -617,7 +617,10 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
 // the row offsets immediates).
 // DUP = 2: the exact-transpose plan (two taps per angle and pixel, as virtual angles 2a, 2a + 1 reading staged row a): the same
 // kernel with twice the index vectors per staged row; sums are added in virtual-angle order = the scatter's order.
-template <int PPT, int MAXT, int NS, int DUP = 1>
+// SHORT (at most 32 angles, DUP = 1: one staged chunk, two groups of sixteen): the second group's index vectors are requested at
+// the start with the first's -- loaded after the first group's gathers they put an L2 round trip behind the barrier of a launch
+// that is a few microseconds long -- and the chunk pipeline's registers make room for them.
+template <int PPT, int MAXT, int NS, int DUP = 1, bool SHORT = false>
 __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y, int g_S,
                                                                  SliceScale scale, float *__restrict__ gimg)
@@ -665,13 +668,19 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
         }
     };
     load_group(0);       // index loads fly while the cotangent rows land
+    [[maybe_unused]] uint4 q2nd[PPT];
+    if constexpr (SHORT) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            q2nd[k] = p[((size_t)min(1, L.NA16 - 1) * g.H + min(y0 + k * nwaves, g.H - 1)) * L.Wpad];
+    }
 
     const int VA = g.A * DUP;                            // virtual angles (= angles unless DUP = 2)
     const int chunk = min(L.NA16 * 16, kChunk * DUP);    // virtual angles per staged chunk (a multiple of 16)
     // Pairs in 16-wave workgroups (many angles, several chunks): the cotangent rows of chunk c + 1 are requested into
     // registers (two units per lane) before the gathers of chunk c and written to LDS after them -- each chunk's load
     // round trip hides behind the previous chunk's gather phase instead of standing between two barriers.
-    constexpr bool kPipe = NS == 2;                 // (the single-slice form has no registers to spare: 143 VGPRs with it)
+    constexpr bool kPipe = NS == 2 && !SHORT;       // (the single-slice form has no registers to spare: 143 VGPRs with it)
     constexpr int kAheadUnits = 2;                  // 32 rows of a pair over 16 waves
     StagedRows<NS, kPipe ? kAheadUnits : 1> ahead;
     bool ahead_valid = false;
@@ -723,7 +732,12 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
                 for (int k = 0; k < PPT; ++k) gather16<AL, NS, DUP>(lds, q[k], n_live, v[k]);
 #endif
                 const int next = (acv + AL) / 16 + 1;        // all index vectors of this group consumed: prefetch the next
-                if (next < L.NA16) load_group(next);
+                if constexpr (SHORT) {
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k) q[k] = q2nd[k];
+                } else if (next < L.NA16) {
+                    load_group(next);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int k = 0; k < PPT; ++k)
@@ -1136,6 +1150,11 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
             rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<2, 256, 2, 2>) : launch(rotate_bwd_planned_kernel<2, 1024, 2, 2>);
         else
             rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<4, 256, 1, 2>) : launch(rotate_bwd_planned_kernel<4, 1024, 1, 2>);
+    } else if (A <= 32) {   // two index groups at most: both requested up front
+        if (ns == 2)
+            rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<2, 256, 2, 1, true>) : launch(rotate_bwd_planned_kernel<2, 1024, 2, 1, true>);
+        else
+            rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<4, 256, 1, 1, true>) : launch(rotate_bwd_planned_kernel<4, 1024, 1, 1, true>);
     } else if (ns == 2) {
         rc = waves <= 4 ? launch(rotate_bwd_planned_kernel<2, 256, 2>) : launch(rotate_bwd_planned_kernel<2, 1024, 2>);
     } else {
