@@ -49,8 +49,10 @@ def parse():
                     help="projector: the headline fwd+adj metric, BASELINE config 2 (default; --angles 180 = config 4's "
                          "per-GPU share); train: config 3, P-VAE steps/s; siddon: config 1, TomoPy-style forward; "
                          "n512: config 5, 512x512 x 90 angles fwd + log-likelihood + adj")
+    ap.add_argument("--graph-steps", type=int, default=100,
+                    help="steps captured per HIP graph in the timed loop (projector mode; the K mod this remaining steps are launched from Python)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="launch every step from Python instead of replaying HIP graphs of 10 steps (projector mode)")
+                    help="launch every step from Python instead of replaying HIP graphs of --graph-steps steps (projector mode)")
     ap.add_argument("--grad-allreduce", action="store_true",
                     help="config 4 (batch=400 over 8 GPUs, 180 angles): every step also sums one flat fp32 bucket of the "
                          "P-VAE's 711,164 gradients (2.8 MB) over the ranks -- the data-parallel trainer's only collective")
@@ -408,11 +410,12 @@ def main():
 
     for _ in range(max(args.warmup, n_cold if args.cold else 0)):
         step()
-    # The two launches of a step take 6-8 us each -- about what one Python call of them costs the host -- so the timed
-    # loop replays HIP graphs of 10 steps (20 kernel nodes, the same launches in the same order) and launches only the
-    # K mod 10 remaining steps from Python: the GPU runs back to back whatever the host's speed (measured: 13.97 us per
-    # step replayed against 14.45 us launched on a fast host, and host-bound on a slow one).  Not with the RCCL bucket.
-    chunk = n_cold if args.cold else 10        # (cold: one graph walks all the distinct batches once)
+    # The two launches of a step take ~6 us each -- about what one Python call of them costs the host -- so the timed
+    # loop replays HIP graphs of up to --graph-steps steps (two kernel nodes per step: the same launches in the same order) and
+    # launches only the remaining steps from Python: the GPU runs back to back whatever the host's speed.  A replay itself
+    # costs ~4 us of stream time (measured, round 3: 12.76 us per step with graphs of 10 steps, 12.37 us with 50 or 100,
+    # 12.28 us with 250).  Not with the RCCL bucket.
+    chunk = n_cold if args.cold else max(1, min(args.graph_steps, args.steps))   # (cold: one graph walks all the distinct batches once)
     graph = None
     cursor[0] = 0
     if not args.no_graph and not args.grad_allreduce and args.steps >= chunk:
