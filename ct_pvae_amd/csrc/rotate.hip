@@ -2057,7 +2057,10 @@ int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, i
             return rotate_bwd_one(gs, n, A, PH, PW, Tinv8_dev, CTPVAE_NEAREST, CTPVAE_BWD_TF_COMPAT, H, W, py, px, sc, scale_stride, gi,
                                   stream);
         const RotGeom g{n, H, W, PH, PW, py, px, A};
-        const int chunk_a = std::min(A, ns == 2 ? 48 : 96);
+        // angles per staged chunk (knob SEG_CHUNK; measured with warm clocks at 32 x 512 x 512 x 90 angles, tools/sweep_step_chunk.py:
+        // 48 + 42 angles 56.5-57.0 us, 45 + 45 56.8, 3 x 30 57.6, 4 x 23 57.4, 5 x 18 62.3 -- flat down to chunks of 23)
+        const int max_chunk = knob(kKnobSegChunk) > 0 ? knob(kKnobSegChunk) : (ns == 2 ? 48 : 96);
+        const int chunk_a = std::min(A, max_chunk);
         const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * ns + sizeof(int) + 2 * sizeof(int)) + 16;
         const dim3 grid(ceil_div(W, 64), ceil_div(H, kStepTileRows), units), block(256);
         if (ns == 2)
