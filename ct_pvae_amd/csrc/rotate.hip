@@ -276,6 +276,14 @@ __device__ __forceinline__ int tile_first_bin(const float *t, float cx, float cy
     const float jc = t[0] * (cx - t[2]) + t[3] * (cy - t[5]);
     return (int)floorf(jc - radius);
 }
+// The workspace of partial sums: [slice / 4][tile][angle][slot][slice % 4] -- the four slices a tile workgroup walks together
+// leave it as ONE 16-byte store per ray and reach the reduce pass as one 16-byte load (per-slice planes cost four 4-byte
+// accesses each way).  Sized for a whole number of slice quads (ctpvae_rotate_fwd_tiled_workspace_bytes).
+constexpr int kPartialQuad = 4;
+__device__ __forceinline__ size_t partial_index(int s, int nt, int t, size_t nrays, size_t ray)
+{
+    return ((((size_t)(s >> 2) * nt + t) * nrays + ray) << 2) + (size_t)(s & 3);
+}
 
 template <int INTERP, bool TIE_FIX, bool TILED, int NS = 1>
 __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
@@ -544,13 +552,18 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
         if ((threadIdx.x & 63) == 0) g_stamps[8 * ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 6] = kmax;
 #endif
         if constexpr (NS == 1) {
-            if (live) sino[(size_t)blockIdx.y * nrays + ray] = acc;
+            if (live) {
+                if constexpr (TILED) {
+                    const int nt = ts.ntx * ts.nty;
+                    sino[partial_index(blockIdx.y / nt, nt, blockIdx.y % nt, nrays, ray)] = acc;
+                } else {
+                    sino[(size_t)blockIdx.y * nrays + ray] = acc;
+                }
+            }
         } else if (live) {
-            // partial sums of slice s + n, tile t: workspace row (s + n) * nt + t
+            // partial sums of slices s .. s + NS - 1, tile t (partial_index; slices past the batch hold copies of the last one)
             const int nt = ts.ntx * ts.nty, t = blockIdx.y % nt;
-#pragma unroll
-            for (int n = 0; n < NS; ++n)
-                if (s + n < gfull.S) sino[((size_t)(s + n) * nt + t) * nrays + ray] = acc[n];
+            *reinterpret_cast<typename PixVec<NS>::type *>(sino + partial_index(s, nt, t, nrays, ray)) = acc;
         }
     };
 
@@ -634,12 +647,15 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
     if (j0 >= g.PW) return;                         // (whole waves only: no barrier below)
     const float *t = T8 + 8 * a;
     const int nt = ts.ntx * ts.nty;
-    const size_t tstride = (size_t)g.A * ts.nb;     // tile stride
-    const size_t sstride = (size_t)nt * tstride;    // slice stride
-    const float *pa[kReduceSlices];
+    const size_t tstride = (size_t)g.A * ts.nb;     // tile stride, in rays (a ray = the four partial sums of a slice quad)
+    const size_t qstride = (size_t)nt * tstride;    // slice-quad stride
+    constexpr int kQuads = kReduceSlices / kPartialQuad;
+    static_assert(kReduceSlices % kPartialQuad == 0, "the reduce pass takes whole slice quads");
+    const f32x4 *pa[kQuads];
 #pragma unroll
-    for (int q = 0; q < kReduceSlices; ++q)        // slices past the batch re-read the last one, never stored
-        pa[q] = partial + (size_t)min(s0 + q, g.S - 1) * sstride + (size_t)a * ts.nb;
+    for (int q = 0; q < kQuads; ++q)               // quads past the batch re-read the last one, never stored
+        pa[q] = reinterpret_cast<const f32x4 *>(partial) + (size_t)min(s0 / kPartialQuad + q, (g.S - 1) / kPartialQuad) * qstride +
+                (size_t)a * ts.nb;
     float acc[kReduceSlices];
 #pragma unroll
     for (int q = 0; q < kReduceSlices; ++q) acc[q] = 0.0f;
@@ -677,14 +693,14 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
         // tiles in ascending order; loads unconditional (slot clamped).  The loads of tile i + 2 are requested before tile i is
         // added: one tile at a time the pass was a chain of ~12 dependent round trips to memory per wave.
         constexpr int D = 3;
-        float v[D][kReduceSlices];
+        f32x4 v[D][kQuads];
         bool ok[D];
-        auto issue = [&](int i, float (&dst)[kReduceSlices], bool &okd) {
+        auto issue = [&](int i, f32x4 (&dst)[kQuads], bool &okd) {
             const int slot = j - list_first[wave][i];
             okd = j < g.PW && (unsigned)slot < (unsigned)ts.nb;
             const size_t off = (size_t)list_tile[wave][i] * tstride + (okd ? slot : 0);
 #pragma unroll
-            for (int q = 0; q < kReduceSlices; ++q) dst[q] = pa[q][off];
+            for (int q = 0; q < kQuads; ++q) dst[q] = pa[q][off];
         };
 #pragma unroll
         for (int d = 0; d < D - 1; ++d)
@@ -695,7 +711,8 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
                 if (i + d < n) {   // wave-uniform
                     if (i + d + D - 1 < n) issue(i + d + D - 1, v[(d + D - 1) % D], ok[(d + D - 1) % D]);
 #pragma unroll
-                    for (int q = 0; q < kReduceSlices; ++q) acc[q] += ok[d] ? v[d][q] : 0.0f;   // + 0.0f leaves the sum unchanged
+                    for (int q = 0; q < kReduceSlices; ++q)   // + 0.0f leaves the sum unchanged
+                        acc[q] += ok[d] ? v[d][q / kPartialQuad][q % kPartialQuad] : 0.0f;
                 }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1690,13 +1707,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
                       : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
         if (cur.live) {
             const size_t ray = (size_t)cur.ray, nrays = (size_t)A * L.nb;
-            if constexpr (NS == 1) {
-                partial[((size_t)s * nt + t) * nrays + ray] = acc;
-            } else {
-#pragma unroll
-                for (int n = 0; n < NS; ++n)
-                    if (s + n < gfull.S) partial[((size_t)(s + n) * nt + t) * nrays + ray] = acc[n];
-            }
+            // (partial_index: one NS-wide store; slices past the batch hold copies of the last one, the workspace has room)
+            *reinterpret_cast<vec_t *>(partial + partial_index(s, nt, t, nrays, ray)) = acc;
         }
         cur = nxt;
     }
@@ -1791,7 +1803,8 @@ long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, i
     if (S <= 0 || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_fwd_tiled_workspace_bytes: bad sizes");
     const TileSpec ts = pick_tiles(H, W, interp);
     if (ts.ntx == 0 || knob(kKnobForceGeneric) >= 0) return 0;
-    return (long long)S * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
+    const long long quads = (S + kPartialQuad - 1) / kPartialQuad;   // partial_index: whole slice quads
+    return quads * kPartialQuad * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
 }
 
 static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,

@@ -42,6 +42,10 @@ python3 "$ROOT/tools/time_compact_shapes.py" > "$OUT/time_compact_shapes.txt" 2>
 python3 "$ROOT/tools/time_tplan.py" > "$OUT/time_tplan.txt" 2>&1
 python3 "$ROOT/tools/time_skew.py" > "$OUT/time_skew.txt" 2>&1
 "$ROOT/tools/probe_lut.bin" > "$OUT/probe_lut.txt" 2>&1 || true
+"$ROOT/tools/probe_lds_exec.bin" > "$OUT/probe_lds_exec.txt" 2>&1 || true
+python3 "$ROOT/tools/sweep_bwd_paths.py" > "$OUT/sweep_bwd_paths.txt" 2>&1
+python3 "$ROOT/tools/sweep_step_chunk.py" > "$OUT/sweep_step_chunk.txt" 2>&1
+python3 "$ROOT/tools/ab_compare.py" > "$OUT/ab_current.txt" 2>&1
 cd "$ROOT"
 bash tools/collect_sq.sh r03_a20 && bash tools/collect_sq.sh r03_a180 --angles 180
 CTPVAE_TUNE_NO_COMPACT=1 bash tools/collect_sq.sh r03_a180_u16 --angles 180
