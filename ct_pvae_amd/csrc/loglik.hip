@@ -28,12 +28,12 @@ __global__ __launch_bounds__(256) void loglik_bwd_kernel(const float *__restrict
                                                          float *__restrict__ gproj, float *__restrict__ gpnm)
 {
     __shared__ float red[4];
-    const float pnm = *pnm_p;
+    const float pnm = *pnm_p, inv_pnm = 1.0f / pnm;
     float gp_local = 0.0f;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
         float dpnm;
         const float g = gout[k];
-        gproj[k] = g * gaussian_poisson_dlogp(proj[k], mask[k / P], x[k], pnm, eps, dpnm);
+        gproj[k] = g * gaussian_poisson_dlogp(gaussian_poisson_terms(proj[k], mask[k / P], pnm, eps), mask[k / P], x[k], inv_pnm, dpnm);
         gp_local += g * dpnm;
     }
     if (gpnm) {

@@ -10,26 +10,49 @@ constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 
 // tfd.Normal(loc = proj * mask, scale = eps + sqrt(loc / pnm + eps)).log_prob(x), in tfp's form
 //   -0.5 * (x / scale - loc / scale)^2 - (0.5 * log(2 pi) + log(scale))
+// -- with its three IEEE divisions as they stand: where x and loc nearly cancel, the value IS the rounding of those two large
+// quotients (x / scale ~ 1e2 .. 1e4, so ~1e-5 absolute), and only the same operations on the same bits reproduce it (taken as
+// products with 1 / scale the golden log-probabilities moved by 6e-6 of their largest value, 2e-5 in single samples: reverted).
+struct GaussPoisson {
+    float loc, root, scale;
+};
+__device__ __forceinline__ GaussPoisson gaussian_poisson_terms(float proj, float m, float pnm, float eps)
+{
+    GaussPoisson t;
+    t.loc = proj * m;
+    t.root = sqrtf(t.loc / pnm + eps);
+    t.scale = eps + t.root;
+    return t;
+}
+__device__ __forceinline__ float gaussian_poisson_logp(const GaussPoisson &t, float x)
+{
+    const float z = x / t.scale - t.loc / t.scale;
+    return -0.5f * (z * z) - (kHalfLog2Pi + logf(t.scale));
+}
 __device__ __forceinline__ float gaussian_poisson_logp(float proj, float m, float x, float pnm, float eps)
 {
-    const float loc = proj * m;
-    const float scale = eps + sqrtf(loc / pnm + eps);
-    const float z = x / scale - loc / scale;
-    return -0.5f * (z * z) - (kHalfLog2Pi + logf(scale));
+    return gaussian_poisson_logp(gaussian_poisson_terms(proj, m, pnm, eps), x);
 }
 
 // d logp / d proj (the mask factor included) and d logp / d pnm of the same sample: what the backward multiplies the
-// upstream gradient by.  One expression for loglik_bwd_kernel and for the projector epilogue that stores dlp.
+// upstream gradient by.  One expression for loglik_bwd_kernel and for the projector epilogue that stores dlp.  Nothing pins
+// its bits (the tests hold it to float64 autograd at 1e-4), so its quotients are products with TWO reciprocals, 1 / scale and
+// 1 / root, and with the caller's 1 / pnm (once per kernel) -- written with a division per quotient (round 2) the derivative
+// was six divisions and a second root, ~110 of the ~180 vector instructions a sample cost.  (Measured on one box: config 5's
+// forward + likelihood + sums 122.4 -> 122.2 us, the training call 9.9 -> 9.85 us -- the epilogues' arithmetic hides under
+// their memory traffic; kept because it is less code, not because it is faster.)
+__device__ __forceinline__ float gaussian_poisson_dlogp(const GaussPoisson &t, float m, float x, float inv_pnm, float &dpnm)
+{
+    const float rs = 1.0f / t.scale;
+    const float z = (x - t.loc) * rs;
+    const float dscale = (z * z - 1.0f) * rs;            // d logp / d scale
+    const float dscale_du = 0.5f * (1.0f / t.root);      // d scale / d (loc/pnm + eps)
+    dpnm = dscale * dscale_du * (-t.loc * (inv_pnm * inv_pnm));
+    return (z * rs + dscale * dscale_du * inv_pnm) * m;
+}
 __device__ __forceinline__ float gaussian_poisson_dlogp(float proj, float m, float x, float pnm, float eps, float &dpnm)
 {
-    const float loc = proj * m;
-    const float root = sqrtf(loc / pnm + eps);
-    const float scale = eps + root;
-    const float z = (x - loc) / scale;
-    const float dscale = (z * z - 1.0f) / scale;       // d logp / d scale
-    const float dscale_du = 0.5f / root;                // d scale / d (loc/pnm + eps)
-    dpnm = dscale * dscale_du * (-loc / (pnm * pnm));
-    return (z / scale + dscale * dscale_du / pnm) * m;
+    return gaussian_poisson_dlogp(gaussian_poisson_terms(proj, m, pnm, eps), m, x, 1.0f / pnm, dpnm);
 }
 
 // what a projector kernel needs to write log-probabilities next to its ray-sums (lp == nullptr: no epilogue)
@@ -51,31 +74,30 @@ struct LogLikEpilogue {
     // o: offset of the ray-sum in the outputs; om / sa: offsets of its measured sample and its mask entry
     __device__ __forceinline__ void write(size_t o, size_t om, size_t sa, float raysum) const
     {
-        write_loaded(o, mask[sa], meas[om], *pnm, raysum);
+        const float pnm_v = *pnm;
+        write_loaded(o, mask[sa], meas[om], pnm_v, 1.0f / pnm_v, raysum);
     }
-    __device__ __forceinline__ void write_loaded(size_t o, float m, float x, float pnm_v, float raysum) const
+    // ... with the operands already in registers (pnm_v = *pnm and its reciprocal, taken once per kernel): a kernel requests them
+    // BEFORE its long phase (the walk, the sum over tiles) so that their round trip to memory is not paid after it -- the
+    // stores below keep the compiler from moving the loads up by itself (nothing tells it that the buffers are distinct)
+    __device__ __forceinline__ void write_loaded(size_t o, float m, float x, float pnm_v, float inv_pnm, float raysum) const
     {
-        lp[o] = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
-        if (dlp) {
-            float unused;
-            dlp[o] = gaussian_poisson_dlogp(raysum, m, x, pnm_v, eps, unused);
-        }
+        (void)eval_loaded(o, m, x, pnm_v, inv_pnm, raysum);
     }
     // the same, returning the log-probability; lp (and dlp) are stored only where a buffer was given
     __device__ __forceinline__ float eval(size_t o, size_t om, size_t sa, float raysum) const
     {
-        return eval_loaded(o, mask[sa], meas[om], *pnm, raysum);
+        const float pnm_v = *pnm;
+        return eval_loaded(o, mask[sa], meas[om], pnm_v, 1.0f / pnm_v, raysum);
     }
-    // ... with the operands already in registers: a kernel requests them BEFORE its long phase (the walk, the sum over tiles)
-    // so that their round trip to memory is not paid after it -- the stores below keep the compiler from moving the loads up
-    // by itself (nothing tells it that the buffers are distinct)
-    __device__ __forceinline__ float eval_loaded(size_t o, float m, float x, float pnm_v, float raysum) const
+    __device__ __forceinline__ float eval_loaded(size_t o, float m, float x, float pnm_v, float inv_pnm, float raysum) const
     {
-        const float v = gaussian_poisson_logp(raysum, m, x, pnm_v, eps);
+        const GaussPoisson t = gaussian_poisson_terms(raysum, m, pnm_v, eps);
+        const float v = gaussian_poisson_logp(t, x);
         if (lp) lp[o] = v;
         if (dlp) {
             float unused;
-            dlp[o] = gaussian_poisson_dlogp(raysum, m, x, pnm_v, eps, unused);
+            dlp[o] = gaussian_poisson_dlogp(t, m, x, inv_pnm, unused);
         }
         return v;
     }

@@ -661,9 +661,9 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
     for (int q = 0; q < kReduceSlices; ++q) acc[q] = 0.0f;
     // the epilogue's operands are requested now and arrive under the sum over tiles (loaded in the epilogue they cost each
     // slice a round trip of its own behind the previous slice's stores: 27.5 us per launch against 17.7 us without epilogue)
-    [[maybe_unused]] float ex[kReduceSlices], em[kReduceSlices], epnm = 0.0f;
+    [[maybe_unused]] float ex[kReduceSlices], em[kReduceSlices], epnm = 0.0f, einv = 0.0f;
     if constexpr (EPI != 0) {
-        epnm = *epi.pnm;
+        epnm = *epi.pnm, einv = 1.0f / epnm;   // the derivative multiplies by the reciprocal (loglik_math.h)
 #pragma unroll
         for (int q = 0; q < kReduceSlices; ++q) {
             const size_t sa = (size_t)min(s0 + q, g.S - 1) * g.A + a;
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
                 if (j < g.PW) {
                     const size_t o = ((size_t)s * g.A + a) * g.PW + j;
                     if (sino) sino[o] = acc[q];
-                    lpv = epi.eval_loaded(o, em[q], ex[q], epnm, acc[q]);
+                    lpv = epi.eval_loaded(o, em[q], ex[q], epnm, einv, acc[q]);
                 }
                 const float tot = wave_sum(lpv);
                 if (lane == 0) epi.part[((size_t)s * g.A + a) * tpr + (j0 >> 6)] = tot;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
         if (s < g.S) {
             const size_t o = ((size_t)s * g.A + a) * g.PW + j;
             sino[o] = acc[q];
-            if constexpr (EPI == 1) epi.write_loaded(o, em[q], ex[q], epnm, acc[q]);
+            if constexpr (EPI == 1) epi.write_loaded(o, em[q], ex[q], epnm, einv, acc[q]);
         }
     }
 }

@@ -190,8 +190,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
         uint4 c0, c1;
         float em[NS], ex[NS];   // EPI: mask entry and measured sample of the task's outputs, requested with the task
     };
-    [[maybe_unused]] float epnm = 0.0f;
-    if constexpr (EPI != 0) epnm = *epi.pnm;
+    [[maybe_unused]] float epnm = 0.0f, einv = 0.0f;
+    if constexpr (EPI != 0) epnm = *epi.pnm, einv = 1.0f / epnm;   // the derivative multiplies by the reciprocal (loglik_math.h)
     auto prepare = [&](int m) -> Task {
         Task t;
         t.valid = m < ntask;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
                 if (live) {
                     const size_t o = ((size_t)sl * A_out + cur.k) * g.PW + cur.j;
                     if (sino) sino[o] = v;
-                    lpv = epi.eval_loaded(o, cur.em[n], cur.ex[n], epnm, v);
+                    lpv = epi.eval_loaded(o, cur.em[n], cur.ex[n], epnm, einv, v);
                 }
                 const float tot = wave_sum(lpv);
                 if (lane == 0) epi.part[((size_t)sl * A_out + cur.k) * L.nJB + cur.jb] = tot;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
             auto store = [&](int n, float v) {
                 const size_t o = ((size_t)(s + n) * A_out + cur.k) * g.PW + cur.j;
                 sino[o] = v;
-                if constexpr (EPI == 1) epi.write_loaded(o, cur.em[n], cur.ex[n], epnm, v);
+                if constexpr (EPI == 1) epi.write_loaded(o, cur.em[n], cur.ex[n], epnm, einv, v);
             };
             if constexpr (NS == 1) {
                 store(0, acc);

@@ -446,8 +446,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
         uint4 q0, q1, q2, q3;
         float em[NS], ex[NS];   // EPI: mask entry and measured sample of the task's outputs, requested with the task
     };
-    [[maybe_unused]] float epnm = 0.0f;
-    if constexpr (EPI) epnm = *epi.pnm;
+    [[maybe_unused]] float epnm = 0.0f, einv = 0.0f;
+    if constexpr (EPI) epnm = *epi.pnm, einv = 1.0f / epnm;   // the derivative multiplies by the reciprocal (loglik_math.h)
     auto prepare = [&](int m) -> Task {
         Task t;
         t.valid = m < ntask;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
             auto store = [&](int n, float v) {
                 const size_t o = ((size_t)(s + n) * A_out + cur.k) * g.PW + cur.j;
                 sino[o] = v;
-                if constexpr (EPI) epi.write_loaded(o, cur.em[n], cur.ex[n], epnm, v);
+                if constexpr (EPI) epi.write_loaded(o, cur.em[n], cur.ex[n], epnm, einv, v);
             };
             if constexpr (NS == 1) {
                 store(0, acc);
