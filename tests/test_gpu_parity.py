@@ -300,10 +300,12 @@ def test_paired_slices_equal_single_slices(oracle, shape, pad, A, S):
 
 
 @pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 5), ((128, 128), True, 180, 7), ((40, 100), True, 33, 3),
-                                          ((65, 31), False, 9, 1), ((2, 2), False, 2, 2), ((128, 128), True, 70, 40)])
+                                          ((65, 31), False, 9, 1), ((2, 2), False, 2, 2), ((128, 128), True, 70, 40),
+                                          ((128, 128), True, 16, 50), ((128, 128), True, 17, 9), ((64, 72), True, 32, 4)])
 def test_paired_backward_equals_single(oracle, shape, pad, A, S):
     """The planned backward runs one or two slices per workgroup (two: cotangent rows fetched together and interleaved
-    as float2 behind one index stream, 32-angle chunks); both forms are the same operator bit for bit."""
+    as float2 behind one index stream, 32-angle chunks); both forms are the same operator bit for bit.  (A <= 32: the
+    instantiation that requests both index groups up front -- 16, 17 and 32 angles are its edges, 33 the other kernel's.)"""
     d = dev()
     rng = np.random.default_rng(A * 7 + S)
     theta = rng.uniform(-1.0, 4.0, A)
@@ -2131,6 +2133,11 @@ def test_tiled_forward_through_compact_tile_plans(oracle, shape, A, S):
     for ns, G in ((1, 1), (2, 2), (4, 3), (4, 1)):
         _lib.tune("TILED_NS", ns), _lib.tune("TILED_G", G)
         assert torch.equal(plan.forward(x), got), (ns, G)
+        # tasks = four 16-slot bands of the plan's sorted list (the default) against (angle, 64-slot block) tasks: which rays
+        # ride in one wave changes no ray's sum
+        _lib.tune("TILED_SORT", 0)
+        assert torch.equal(plan.forward(x), got), (ns, G, "unsorted tasks")
+        _lib.tune("TILED_SORT")
     _lib.tune("*")
     mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
     meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32)).to(d)
