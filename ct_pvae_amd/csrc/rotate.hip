@@ -1100,9 +1100,17 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
 // the reference arithmetic exactly as the kernel above does, so the taps, their order and the sums are the same bits.  Per
 // tap: one bit-field extract and one multiply-add onto the running LDS address.  Geometries the code cannot hold (a pixel
 // that samples outside the canvas at some angle -- unpadded canvases --, a row that is not a rotation) raise the plan's
-// overflow word and the caller keeps the kernel above.  5.9 MB for 512 x 512 x 90 angles, read once per slice pair.
+// overflow word and the caller keeps the kernel above.
+// (Round 3, second half) The word became EIGHT BYTES: byte 0 the first row's tap, bytes 1..7 the byte offsets of rows 1..7's
+// taps from a per-angle base (8 B cells: offset = 8 x steps so far for an angle whose taps step up the bins; 8 x (7 - steps) from
+// a base 56 B lower for one that steps down, so that every offset is added), and a tap's address is ONE SDWA add of a byte
+// onto that base: 163 -> 120 vector instructions per six angles.  Measured on one box: 101 -> 96 us at 400 x 128 x 128 x 180
+// angles, 59.9 -> 57.6 us at 32 x 512 x 512 x 90 -- a quarter fewer instructions bought 3-5 %: the kernel now waits on its LDS
+// gathers and staging as much as on issue.  23.6 MB for 512 x 512 x 90 angles (5.9 MB as u16 words); the workgroups of one tile
+// column run on one XCD (blockIdx.x == XCD), whose L2 holds that column's 3 MB of the plan.
 constexpr int kStepRows = 8;           // rows per lane = rows per plan word
 constexpr int kStepTileRows = 32;      // four waves of eight rows: the tile whose segment `first` the plan is relative to
+constexpr int kStepCell = 8;           // bytes of an LDS cell the plan's offsets are in: a float2 (slice pairs only)
 
 struct StepLayout {
     int H8, Wpad;
@@ -1113,7 +1121,7 @@ static StepLayout step_layout(int H, int W, int A)
     StepLayout L;
     L.H8 = ceil_div(H, kStepTileRows) * (kStepTileRows / kStepRows);
     L.Wpad = ceil_div(W, 64) * 64;
-    L.off_flag = (long long)A * L.H8 * L.Wpad * 2;
+    L.off_flag = (long long)A * L.H8 * L.Wpad * 8;
     L.off_flag = (L.off_flag + 255) / 256 * 256;
     L.bytes = L.off_flag + 256;
     return L;
@@ -1150,8 +1158,8 @@ __global__ __launch_bounds__(64) void rotate_bwd_step_plan_kernel(RotGeom g, con
     const float xa = t0 * fx, ya = t3 * fx;
     const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
     bool ok = true;
-    unsigned word = 0;
-    int prev = 0;
+    unsigned long long word = 0;
+    int prev = 0, steps = 0;
     for (int k = 0; k < kStepRows; ++k) {
         const int r = rg * kStepRows + k;
         const float fy = (float)(r + g.py);
@@ -1164,15 +1172,19 @@ __global__ __launch_bounds__(64) void rotate_bwd_step_plan_kernel(RotGeom g, con
         if (k == 0) {
             const int rel = tap - first;
             if (live) ok = ok && rel >= 0 && rel < kSegBins;
-            word = (unsigned)rel & 127u;
+            word = (unsigned long long)((unsigned)rel & 127u);
         } else {
             const int dlt = tap - prev;
             if (live) ok = ok && (dlt == 0 || dlt == sigma) && tap - first >= 0 && tap - first < kSegBins;
-            word |= (dlt != 0 ? 1u : 0u) << (6 + k);
+            steps += dlt != 0 ? 1 : 0;
+            // byte offset of row k's tap from the angle's base (see rotate_bwd_stepped_kernel: 56 B below the first tap for a
+            // down-stepping angle)
+            const int off = kStepCell * (sigma < 0 ? (kStepRows - 1) - steps : steps);
+            word |= (unsigned long long)(unsigned)off << (8 * k);
         }
         prev = tap;
     }
-    reinterpret_cast<unsigned short *>(plan)[((size_t)a * L.H8 + rg) * L.Wpad + c] = (unsigned short)word;
+    reinterpret_cast<unsigned long long *>(plan)[((size_t)a * L.H8 + rg) * L.Wpad + c] = word;
     if (!ok) *reinterpret_cast<int *>(plan + L.off_flag) = 1;
 }
 
@@ -1183,8 +1195,9 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
                                                                  float *__restrict__ gimg)
 {
     typedef typename PixVec<NS>::type vec_t;
-    constexpr int SHIFT = NS == 1 ? 2 : 3, PPT = kStepRows;
-    // [chunk_a][kSegPitch] segment cells (NS floats each), then per angle (first bin) and (segment byte base, step in bytes)
+    constexpr int PPT = kStepRows;
+    // [chunk_a][kSegPitch] segment cells (NS floats each), then per angle (first bin) and (segment byte base as the plan's
+    // offsets count from it, the first row's distance above it)
     extern __shared__ float lds[];
     int *first_s = reinterpret_cast<int *>(lds + chunk_a * kSegPitch * NS);
     int2 *meta2 = reinterpret_cast<int2 *>(lds + ((chunk_a * (kSegPitch * NS + 1) + 1) & ~1));
@@ -1196,7 +1209,8 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
     const int rg = blockIdx.y * (kStepTileRows / kStepRows) + wave;     // this lane's rows: rg * 8 .. rg * 8 + 7
     const float X0 = (float)(blockIdx.x * 64 + g.px), Y0 = (float)(blockIdx.y * kStepTileRows + g.py);
     const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
-    const unsigned short *pl = reinterpret_cast<const unsigned short *>(plan) + (size_t)rg * L.Wpad + c;
+    static_assert(NS == 2, "the step plan's offsets are in float2 cells: single slices ride as half-empty pairs");
+    const uint2 *pl = reinterpret_cast<const uint2 *>(plan) + (size_t)rg * L.Wpad + c;
     const size_t astride = (size_t)L.H8 * L.Wpad;
 
     vec_t acc[PPT];
@@ -1212,7 +1226,9 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             step_segment_first(t, X0, Y0, first);
             first_s[al] = first;
             const float t1 = t[1];
-            meta2[al] = make_int2(al * kSegPitch * 4 * NS + lds_base, (t1 > 0.0f ? 4 * NS : t1 < 0.0f ? -4 * NS : 0));
+            // (segment base as the plan's offsets count from it, what the first row's tap lies above it)
+            const int drop = t1 < 0.0f ? kStepCell * (kStepRows - 1) : 0;
+            meta2[al] = make_int2(al * kSegPitch * kStepCell + lds_base - drop, drop);
         }
         __syncthreads();
         const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
@@ -1246,25 +1262,34 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
         }
         __syncthreads();
 
-        // per angle: the plan word (fetched two angles ahead), the segment base and step (one broadcast ds_read_b64), eight
-        // gathers whose addresses are a bit-field extract and a multiply-add apart; the adds of an angle run under the next
-        // angle's gathers
-        auto taps = [&](unsigned w, const int2 m, vec_t (&v)[PPT]) {
-            int addr = m.x + (int)((w & 127u) << SHIFT);
-            v[0] = lds_abs_vec<NS>(addr);
-#pragma unroll
-            for (int k = 1; k < PPT; ++k) {
-                // bit-field extract + one signed 24-bit multiply-add (the compiler's own choice for bit * step was three
-                // operations: sign-extending extract, and, add)
-                const int bit = (int)__builtin_amdgcn_ubfe(w, 6 + k, 1);
-                asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(addr) : "v"(bit), "v"(m.y));
-                v[k] = lds_abs_vec<NS>(addr);
-            }
+        // per angle: the plan word (fetched kAhead angles ahead), the segment base (one broadcast ds_read_b64), eight gathers
+        // whose addresses are one SDWA add of a plan byte apart from the base; the adds of an angle run under the next angle's
+        // gathers
+        auto taps = [&](const uint2 w, const int2 m, vec_t (&v)[PPT]) {
+            static_assert(PPT == 8, "eight rows per plan word");
+            int t, base, a1, a2, a3, a4, a5, a6, a7;
+            asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(t) : "v"(w.x));
+            base = t + m.x;
+            v[0] = lds_abs_vec<NS>(base + m.y);
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a1) : "v"(base), "v"(w.x));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a2) : "v"(base), "v"(w.x));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a3) : "v"(base), "v"(w.x));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a4) : "v"(base), "v"(w.y));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a5) : "v"(base), "v"(w.y));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a6) : "v"(base), "v"(w.y));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a7) : "v"(base), "v"(w.y));
+            v[1] = lds_abs_vec<NS>(a1);
+            v[2] = lds_abs_vec<NS>(a2);
+            v[3] = lds_abs_vec<NS>(a3);
+            v[4] = lds_abs_vec<NS>(a4);
+            v[5] = lds_abs_vec<NS>(a5);
+            v[6] = lds_abs_vec<NS>(a6);
+            v[7] = lds_abs_vec<NS>(a7);
         };
         // plan words are fetched kAhead angles ahead of their use (an L2 round trip is several angles long)
         constexpr int kAhead = 6;
-        const unsigned short *pa = pl + (size_t)ac * astride;
-        unsigned wq[kAhead];
+        const uint2 *pa = pl + (size_t)ac * astride;
+        uint2 wq[kAhead];
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) wq[q] = pa[(size_t)min(q, na - 1) * astride];
         vec_t va[PPT], vb[PPT];
@@ -1272,7 +1297,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
         for (; al + kAhead <= na; al += kAhead) {      // kAhead angles per trip, two register sets of gathers in flight
 #pragma unroll
             for (int q = 0; q < kAhead; q += 2) {
-                const unsigned w0 = wq[q], w1 = wq[q + 1];
+                const uint2 w0 = wq[q], w1 = wq[q + 1];
                 wq[q] = pa[(size_t)min(al + kAhead + q, na - 1) * astride];
                 wq[q + 1] = pa[(size_t)min(al + kAhead + q + 1, na - 1) * astride];
                 taps(w0, meta2[al + q], va);
@@ -1285,7 +1310,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             }
         }
         for (int q = 0; al < na; ++al, ++q) {          // the chunk's last angles (wq holds their words in order)
-            unsigned w = wq[0];
+            uint2 w = wq[0];
 #pragma unroll
             for (int j = 1; j < kAhead; ++j) w = q == j ? wq[j] : w;
             taps(w, meta2[al], va);
@@ -2059,10 +2084,9 @@ int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, i
         const float *gs = gsino_dev + (size_t)s0 * A * PW;
         const float *sc = scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr;
         float *gi = gimg_dev + (size_t)s0 * H * W;
-        // the same rule as the direct kernel's: pairs once the launch can spare the workgroups; the plan is for 64 x 32 tiles,
-        // which small launches trade for 64 x 16 ones -- those keep the direct kernel
-        const int ns = (n >= 16 || (n >= 2 && (long long)ceil_div(n, 2) * ceil_div(W, 64) * ceil_div(H, 16) >= 256)) ? 2 : 1;
-        const int units = ceil_div(n, ns);
+        // the plan is for slice PAIRS (a lone or last odd slice rides as a half-empty pair) in 64 x 32 tiles, which small launches
+        // trade for 64 x 16 ones -- those keep the direct kernel
+        const int units = ceil_div(n, 2);
         // (SEG_PPT = 8 / 4: a developer's way to force the 64 x 32 stepped tiles / the direct kernel whatever the launch size)
         const bool big = knob(kKnobSegPpt) >= 0 ? knob(kKnobSegPpt) == 8
                                                 : (long long)units * ceil_div(W, 64) * ceil_div(H, kStepTileRows) >= 512;
@@ -2072,16 +2096,12 @@ int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, i
         const RotGeom g{n, H, W, PH, PW, py, px, A};
         // angles per staged chunk (knob SEG_CHUNK; measured with warm clocks at 32 x 512 x 512 x 90 angles, tools/sweep_step_chunk.py:
         // 48 + 42 angles 56.5-57.0 us, 45 + 45 56.8, 3 x 30 57.6, 4 x 23 57.4, 5 x 18 62.3 -- flat down to chunks of 23)
-        const int max_chunk = knob(kKnobSegChunk) > 0 ? knob(kKnobSegChunk) : (ns == 2 ? 48 : 96);
+        const int max_chunk = knob(kKnobSegChunk) > 0 ? knob(kKnobSegChunk) : 48;
         const int chunk_a = std::min(A, max_chunk);
-        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * ns + sizeof(int) + 2 * sizeof(int)) + 16;
+        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * 2 + sizeof(int) + 2 * sizeof(int)) + 16;
         const dim3 grid(ceil_div(W, 64), ceil_div(H, kStepTileRows), units), block(256);
-        if (ns == 2)
-            hipLaunchKernelGGL(rotate_bwd_stepped_kernel<2>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
-                               (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
-        else
-            hipLaunchKernelGGL(rotate_bwd_stepped_kernel<1>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
-                               (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
+        hipLaunchKernelGGL(rotate_bwd_stepped_kernel<2>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
+                           (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
         CTPVAE_LAUNCH_CHECK("rotate_bwd_stepped_kernel");
         return CTPVAE_OK;
     });
