@@ -1416,7 +1416,8 @@ def test_random_step_plan_geometries():
     (CTPVAE_FUZZ_SEED / _CASES: more)."""
     d = dev()
     rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 909)))
-    for case in range(int(os.environ.get("CTPVAE_FUZZ_CASES", 6))):
+    n_cases, no_plan = int(os.environ.get("CTPVAE_FUZZ_CASES", 6)), 0
+    for case in range(n_cases):
         H, W, A = int(rng.integers(128, 300)), int(rng.integers(128, 300)), int(rng.integers(1, 50))
         tiles = -(-W // 64) * -(-H // 32)
         S = 2 * (-(-512 // tiles)) + int(rng.integers(0, 4))          # >= 512 workgroups of slice pairs (odd batches too)
@@ -1425,13 +1426,19 @@ def test_random_step_plan_geometries():
         plan = RotatePlan(theta, H, W, True, d)
         g = torch.from_numpy(rng.standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
         tag = f"case {case}: {H}x{W} A={A} S={S}"
-        assert plan._step_plan is not None, tag
+        if plan._step_plan is None:
+            # the plan's overflow word: within a few 1e-3 rad of 90 / 270 degrees |t1| is 1 - 1e-5 and fp32 rounding can move a
+            # tap by TWO bins between two rows (found by seed 32: 264 x 278, -4.71696 rad); the direct kernel then serves the
+            # geometry -- legitimately, but it must stay the exception
+            no_plan += 1
+            continue
         plan.backward_uses_step_plan = lambda S: True          # (shapes the planned backward serves would take it at this S)
         got = plan.backward(g)
         _lib.tune("NO_PLAN", 1)
         ref = plan.backward(g)
         _lib.tune("NO_PLAN")
         assert torch.equal(got, ref), tag
+    assert no_plan <= max(1, n_cases // 20), f"{no_plan} of {n_cases} random geometries did not fit the step plan"
 
 
 def test_large_batches_of_small_slices_take_the_step_plan_too():
