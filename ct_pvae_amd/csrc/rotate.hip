@@ -1102,8 +1102,8 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
 // that samples outside the canvas at some angle -- unpadded canvases --, a row that is not a rotation) raise the plan's
 // overflow word and the caller keeps the kernel above.
 // (Round 3, second half) The word became EIGHT BYTES: byte 0 the first row's tap, bytes 1..7 the byte offsets of rows 1..7's
-// taps from a per-angle base (8 B cells: offset = 8 x steps so far for an angle whose taps step up the bins; 8 x (7 - steps) from
-// a base 56 B lower for one that steps down, so that every offset is added), and a tap's address is ONE SDWA add of a byte
+// taps from a per-angle base (8 B cells: offset = 8 x steps so far for an angle whose taps step up the bins; 8 x (14 - steps) from
+// a base 112 B lower for one that steps down, so that every offset is added; a row may step twice), and a tap's address is ONE SDWA add of a byte
 // onto that base: 163 -> 120 vector instructions per six angles.  Measured on one box: 101 -> 96 us at 400 x 128 x 128 x 180
 // angles, 59.9 -> 57.6 us at 32 x 512 x 512 x 90 -- a quarter fewer instructions bought 3-5 %: the kernel now waits on its LDS
 // gathers and staging as much as on issue.  23.6 MB for 512 x 512 x 90 angles (5.9 MB as u16 words); the workgroups of one tile
@@ -1111,6 +1111,10 @@ __global__ __launch_bounds__(256) void rotate_bwd_tfcompat_seg_kernel(const floa
 constexpr int kStepRows = 8;           // rows per lane = rows per plan word
 constexpr int kStepTileRows = 32;      // four waves of eight rows: the tile whose segment `first` the plan is relative to
 constexpr int kStepCell = 8;           // bytes of an LDS cell the plan's offsets are in: a float2 (slice pairs only)
+constexpr int kStepMax = 2 * (kStepRows - 1);   // steps a column's tap may take over a word's eight rows: up to TWO per row --
+                                                // |t1| <= 1 moves it by one, but within ~1e-3 rad of 90 / 270 degrees |t1| = 1 - 1e-5
+                                                // and fp32 rounding makes it two now and then (a seeded soak found 264 x 278 at
+                                                // -4.71696 rad; a plan of one-step words overflowed there for ALL its angles)
 
 struct StepLayout {
     int H8, Wpad;
@@ -1175,11 +1179,12 @@ __global__ __launch_bounds__(64) void rotate_bwd_step_plan_kernel(RotGeom g, con
             word = (unsigned long long)((unsigned)rel & 127u);
         } else {
             const int dlt = tap - prev;
-            if (live) ok = ok && (dlt == 0 || dlt == sigma) && tap - first >= 0 && tap - first < kSegBins;
-            steps += dlt != 0 ? 1 : 0;
-            // byte offset of row k's tap from the angle's base (see rotate_bwd_stepped_kernel: 56 B below the first tap for a
-            // down-stepping angle)
-            const int off = kStepCell * (sigma < 0 ? (kStepRows - 1) - steps : steps);
+            const int ds = dlt * sigma;     // steps of this row: 0, 1 or (rarely) 2, the angle's way
+            if (live) ok = ok && (dlt == 0 || ds == 1 || ds == 2) && tap - first >= 0 && tap - first < kSegBins;
+            steps += min(max(ds, 0), 2);
+            // byte offset of row k's tap from the angle's base (see rotate_bwd_stepped_kernel: kStepMax cells below the first
+            // tap for a down-stepping angle)
+            const int off = kStepCell * (sigma < 0 ? kStepMax - steps : steps);
             word |= (unsigned long long)(unsigned)off << (8 * k);
         }
         prev = tap;
@@ -1227,7 +1232,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             first_s[al] = first;
             const float t1 = t[1];
             // (segment base as the plan's offsets count from it, what the first row's tap lies above it)
-            const int drop = t1 < 0.0f ? kStepCell * (kStepRows - 1) : 0;
+            const int drop = t1 < 0.0f ? kStepCell * kStepMax : 0;
             meta2[al] = make_int2(al * kSegPitch * kStepCell + lds_base - drop, drop);
         }
         __syncthreads();

@@ -1441,6 +1441,23 @@ def test_random_step_plan_geometries():
     assert no_plan <= max(1, n_cases // 20), f"{no_plan} of {n_cases} random geometries did not fit the step plan"
 
 
+def test_step_plan_holds_two_bin_steps_near_a_right_angle():
+    """Within ~1e-3 rad of 90 / 270 degrees |t1| = 1 - 1e-5 and fp32 rounding moves a column's tap by TWO bins between two rows
+    now and then (seeded soak, round 3: 264 x 278 at -4.71696 rad).  The eight-byte plan words hold such steps; a plan of
+    one-step words overflowed there -- for all of its angles."""
+    d = dev()
+    theta = np.array([-4.716961354375347, 0.3, np.pi / 2 + 2.0e-3, 3 * np.pi / 2 - 1.5e-3, 1.2])
+    plan = RotatePlan(theta, 264, 278, True, d)
+    assert plan._step_plan is not None
+    g = torch.from_numpy(np.random.default_rng(1).standard_normal((25, len(theta), plan.PW)).astype(np.float32)).to(d)
+    plan.backward_uses_step_plan = lambda S: True
+    got = plan.backward(g)
+    _lib.tune("NO_PLAN", 1)
+    ref = plan.backward(g)
+    _lib.tune("NO_PLAN")
+    assert torch.equal(got, ref)
+
+
 def test_large_batches_of_small_slices_take_the_step_plan_too():
     """From 160 slices on (80 at <= 64 angles) the backward of 128 x 128 slices runs the stepped segment kernel instead of the
     planned gather (B=400 x 180 angles: 143 -> 112 us); the three kernels give the same bits, through the raw call and through
