@@ -269,8 +269,10 @@ __global__ __launch_bounds__(256) void gridrec_copy_kernel(int dy, int ngridx, i
     const float *winv = reinterpret_cast<const float *>(tab + L.off_winv);
     const cpx *H = reinterpret_cast<const cpx *>(ws + L.off_h) + (size_t)q * n * n;
     const int iu = (j - ngridy / 2 + n) % n, iv = (k - ngridx / 2 + n) % n;
-    const float corrn_u = winv[M02 + j - ngridy / 2];
-    const float corrn = corrn_u * winv[M02 + k - ngridx / 2];
+    // a grid as wide as the padded row (any power-of-two detector width) has a pixel at -n / 2, one step outside the table's
+    // 2 M02 + 1 entries: it takes the outermost entry (oracle/gridrec_oracle.c GR_WINV)
+    const float corrn_u = winv[min(max(M02 + j - ngridy / 2, 0), 2 * M02)];
+    const float corrn = corrn_u * winv[min(max(M02 + k - ngridx / 2, 0), 2 * M02)];
     const cpx h = H[(size_t)iu * n + iv];
     const int s = 2 * q;
     recon[((size_t)s * ngridx + (ngridx - 1 - k)) * ngridy + j] = corrn * h.re;

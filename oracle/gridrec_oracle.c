@@ -206,18 +206,22 @@ int oracle_gridrec(const float *data, int dy, int dt, int dx, float center, cons
         }
         /* copy the central ngridx x ngridy region (wrap-around order: the image centre sits at H[0][0]) with the window
          * correction; output pixel (k, j): row index k counts x, column index j counts y */
+        /* (a grid as wide as the padded row -- any power-of-two detector -- has a pixel at -pdim / 2, one step outside the
+         * correction table's 2 M02 + 1 entries: it takes the table's outermost entry, GR_WINV()) */
+#define GR_WINV(i) winv[(i) < 0 ? 0 : ((i) > 2 * M02 ? 2 * M02 : (i))]
         for (int j = 0; j < ngridy; ++j) {
             const int iu = (j - ngridy / 2 + pdim) % pdim;
-            const float corrn_u = winv[M02 + j - ngridy / 2];
+            const float corrn_u = GR_WINV(M02 + j - ngridy / 2);
             for (int k = 0; k < ngridx; ++k) {
                 const int iv = (k - ngridx / 2 + pdim) % pdim;
-                const float corrn = corrn_u * winv[M02 + k - ngridx / 2];
+                const float corrn = corrn_u * GR_WINV(M02 + k - ngridx / 2);
                 const cpx h = H[(size_t)iu * pdim + iv];
                 recon[((size_t)s * ngridx + (ngridx - 1 - k)) * ngridy + j] = corrn * h.re;
                 if (s + 1 < dy) recon[((size_t)(s + 1) * ngridx + (ngridx - 1 - k)) * ngridy + j] = corrn * h.im;
             }
         }
     }
+#undef GR_WINV
     free(wtbl), free(winv), free(sine), free(cose), free(sino), free(filphase), free(H), free(col);
     return 0;
 }

@@ -2013,7 +2013,8 @@ def test_host_resident_angle_subsets_ride_the_launch_arguments(oracle, torch_nod
 # ---- round 3: gridrec, csrc/gridrec.hip against oracle/gridrec_oracle.c -----------------------------------------
 @pytest.mark.parametrize("dy,dt,dx,grid,filt", [(50, 180, 184, None, "parzen"), (3, 20, 184, None, "ramlak"), (1, 7, 30, (24, 30), "shepp"),
                                                 (4, 33, 94, None, "butterworth"), (2, 12, 16, None, "none"), (5, 45, 300, (256, 200), "hann"),
-                                                (17, 12, 30, None, "cosine"), (43, 9, 16, None, "hamming")])   # 4 / 5 slice pairs per thread, ragged
+                                                (17, 12, 30, None, "cosine"), (43, 9, 16, None, "hamming"),      # 4 / 5 slice pairs per thread, ragged
+                                                (3, 30, 128, None, "parzen"), (2, 11, 64, (64, 40), "shepp")])     # grid == padded row (round-3 ADVICE)
 def test_gridrec_against_the_oracle(oracle, dy, dt, dx, grid, filt):
     """tomopy.recon(algorithm='gridrec') on the GPU: same tables (built on the host), same butterflies, the convolution gathered
     in gridrec.c's order -> the oracle's reconstruction to fp32 rounding (<= 1e-5 of its largest value; in practice the bits)."""

@@ -556,6 +556,33 @@ def test_gridrec_restatement_reconstructs_a_projected_phantom_in_place(oracle):
     assert (winv[c + 1:] == winv[:c][::-1]).all() and (np.sign(winv[c:]) == np.where(np.arange(c + 1) % 2 == 0, 1, -1)).all()
 
 
+def test_gridrec_grid_as_wide_as_the_padded_row(oracle):
+    """A power-of-two detector width (pad=False 128 x 128: dx = 128; the small tests' dx = 16) makes the grid as wide as the
+    padded row, and the pixel at -pdim / 2 falls one step outside the correction table's 2 M02 + 1 entries (round-3 ADVICE: the
+    restatement read one float before the array).  It takes the table's outermost entry: the border row / column of such a
+    reconstruction is defined -- it fits the same gain as the interior instead of reading zero or heap garbage -- and the
+    result does not depend on what precedes the table in memory (two calls agree; the ASan build runs this test clean)."""
+    N = 64
+    img = _asym_phantom(N)
+    img = np.maximum(img, 0.2).astype(np.float32)                  # positive up to the edge: a zeroed border would show
+    theta = np.linspace(0, np.pi, 90, endpoint=False).astype(np.float32)
+    data = np.ascontiguousarray(oracle.siddon_project(img, theta, pad=False).transpose(1, 0, 2))   # dx = 64 = pdim
+    assert data.shape[2] == 64 and oracle.lib().oracle_gridrec_pdim(64) == 64
+    rec = oracle.gridrec(data, theta, filter_name="ramlak")[0].astype(np.float64)
+    assert np.array_equal(rec, oracle.gridrec(data, theta, filter_name="ramlak")[0])
+    # the window correction of pixel -pdim / 2 (output row ngridx - 1, output column 0) is the table's edge value, i.e. the
+    # same one its mirror pixel +pdim / 2 - 1 gets: undoing it leaves the raw transform; check against the neighbours'
+    wtbl, winv = oracle.gridrec_pswf_tables(64)
+    assert winv[0] == winv[-1] and winv[0] != 0.0
+    inner = rec[8:-8, 8:-8]
+    assert np.abs(rec[-1]).max() > 0 and np.abs(rec[:, 0]).max() > 0          # not zeroed
+    assert np.abs(rec[-1]).max() < 20 * np.abs(inner).max() and np.abs(rec[:, 0]).max() < 20 * np.abs(inner).max()   # not garbage
+    # interior unaffected by the fix: the same grid cut out of a wider padded row (dx = 64 data in a 128-wide row is another
+    # geometry, so compare with a smaller grid of the SAME row instead: its pixels are a subset of this grid's)
+    sub = oracle.gridrec(data, theta, filter_name="ramlak", ngridx=48, ngridy=48)[0]
+    assert np.abs(sub - rec[8:56, 8:56]).max() <= 1e-6 * np.abs(rec).max()
+
+
 def _skimage_mapped(ours, theta):
     """Our ray-driven sinogram [A][184] resampled at scikit-image's 182 bin positions: skimage pads the 128 x 128 image to
     182 x 182 and rotates about pixel 91, half a pixel off the phantom's centre (90.5, 90.5) in both axes, and its bin j is
