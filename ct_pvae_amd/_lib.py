@@ -145,22 +145,44 @@ _node = False
 
 
 def build_torch_node(verbose=False):
-    """Compile csrc/torch_node.cpp (host C++, no HIP) in-tree with torch's extension builder; __graft_entry__.build() calls this."""
+    """Compile csrc/torch_node.cpp (host C++, no HIP) with torch's extension builder and put the module in-tree;
+    __graft_entry__.build() calls this.
+
+    The compile runs in a build directory of THIS process (a temporary sibling of NODE_DIR) and the finished .so is moved
+    into NODE_DIR with os.replace(): no lock file is ever shared, so a build that was killed cannot leave a baton that a
+    later build waits on forever (torch's FileBaton.wait() has no timeout), and two processes building at once each link
+    their own file and the last rename wins -- both are the same module."""
+    import importlib.util
+    import shutil
+    import tempfile
     from torch.utils.cpp_extension import load
     os.makedirs(NODE_DIR, exist_ok=True)
-    # An interrupted earlier build leaves its baton behind and load() would wait on it forever -- but a LIVE lock belongs to
-    # another process that is compiling into this directory right now (two pytest sessions, a build beside a test run):
-    # removing that one makes both link the same .so.  Only a stale baton (older than any build takes) is removed.
-    lock = os.path.join(NODE_DIR, "lock")
+    src = os.path.join(_HERE, "csrc", "torch_node.cpp")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "ctpvae_radon.h")
+    if os.path.exists(NODE_PATH) and os.path.getmtime(NODE_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        try:                                    # up to date (and loadable with this libtorch): nothing to compile
+            spec = importlib.util.spec_from_file_location(NODE_NAME, NODE_PATH)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+        except (ImportError, OSError):
+            pass
+    tmp = tempfile.mkdtemp(prefix=".build-", dir=os.path.dirname(NODE_DIR))
     try:
-        import time
-        if time.time() - os.path.getmtime(lock) > 600:
-            os.remove(lock)
-    except OSError:
-        pass
-    return load(name=NODE_NAME, sources=[os.path.join(_HERE, "csrc", "torch_node.cpp")], build_directory=NODE_DIR,
-                extra_include_paths=[os.path.join(os.path.dirname(_HERE), "include")], extra_cflags=["-O2"],
-                extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose)
+        load(name=NODE_NAME, sources=[src], build_directory=tmp, extra_include_paths=[os.path.dirname(hdr)],
+             extra_cflags=["-O2"], extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose, is_python_module=False)
+        os.replace(os.path.join(tmp, NODE_NAME + ".so"), NODE_PATH)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for stale in ("lock", "build.ninja", ".ninja_log", ".ninja_deps"):   # leftovers of the round-2/3 in-place builds
+        try:
+            os.remove(os.path.join(NODE_DIR, stale))
+        except OSError:
+            pass
+    spec = importlib.util.spec_from_file_location(NODE_NAME, NODE_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def torch_node():
@@ -197,6 +219,21 @@ def torch_node():
 def tune(name, value=-1):
     """Developer knob of the library (see ctpvae_tune_set in include/ctpvae_radon.h); value < 0 unsets, name "*" unsets all."""
     check(load().ctpvae_tune_set(name.encode(), int(value)), "tune_set")
+
+
+class tuned:
+    """`with tuned("NO_PLAN", 1): ...` -- a developer knob set for a block and unset in a finally clause, whatever the block raises."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        tune(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        tune(self.name)
+        return False
 
 
 def last_error():

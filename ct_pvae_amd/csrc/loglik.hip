@@ -53,22 +53,24 @@ __global__ __launch_bounds__(256) void loglik_bwd_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void loglik_object_sums_kernel(const float *__restrict__ lp, int A, int PW, int partition,
                                                                  int tasks_per_row, float *__restrict__ out)
 {
-    extern __shared__ float part[];
+    extern __shared__ float part[];   // the task sums of 64 angles: object_sum_of_parts' rule adds the angles in groups of 64
     const int s = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int NT = A * tasks_per_row;
     const float *row0 = lp + (size_t)s * A * PW;
-    for (int t = wave; t < NT; t += nwaves) {
-        const int a = t / tasks_per_row, jb = t - a * tasks_per_row;
-        const int j = partition == 0 ? lane_to_bin(PW, jb, lane) : 64 * jb + lane;
-        const float v = (unsigned)j < (unsigned)PW ? row0[(size_t)a * PW + j] : 0.0f;
-        const float tot = wave_sum(v);
-        if (lane == 0) part[t] = tot;
+    float total = 0.0f;
+    for (int a0 = 0; a0 < A; a0 += 64) {
+        const int na = min(64, A - a0), NT = na * tasks_per_row;
+        for (int t = wave; t < NT; t += nwaves) {
+            const int a = t / tasks_per_row, jb = t - a * tasks_per_row;
+            const int j = partition == 0 ? lane_to_bin(PW, jb, lane) : 64 * jb + lane;
+            const float v = (unsigned)j < (unsigned)PW ? row0[(size_t)(a0 + a) * PW + j] : 0.0f;
+            const float tot = wave_sum(v);
+            if (lane == 0) part[t] = tot;
+        }
+        __syncthreads();
+        if (wave == 0) total += object_sum_of_parts(part, na, tasks_per_row, lane);   // (one group: 0 + B_g)
+        __syncthreads();
     }
-    __syncthreads();
-    if (wave == 0) {
-        const float total = object_sum_of_parts(part, A, tasks_per_row, lane);
-        if (lane == 0) out[s] = total;
-    }
+    if (threadIdx.x == 0) out[s] = total;
 }
 
 }  // namespace ctpvae
@@ -118,8 +120,8 @@ int ctpvae_loglik_object_sums_f32(const float *lp_dev, int S, int A, int PW, int
     CTPVAE_REQUIRE(S > 0 && A > 0 && PW > 0 && (partition == 0 || partition == 1),
                    "loglik_object_sums: bad arguments (S=%d A=%d PW=%d partition=%d)", S, A, PW, partition);
     const int tpr = partition == 0 ? num_bin_blocks(PW) : ceil_div(PW, 64);
-    const long long NT = (long long)A * tpr;
-    CTPVAE_REQUIRE(NT * 4 <= 64 * 1024, "loglik_object_sums: %lld task sums per slice do not fit LDS", NT);
+    const long long NT = 64ll * tpr;                       // task sums of one group of 64 angles (any number of angles)
+    CTPVAE_REQUIRE(NT * 4 <= 64 * 1024, "loglik_object_sums: rows of at most 16384 bins (got %d)", PW);
     for (int s0 = 0; s0 < S; s0 += 65535) {
         const int n = std::min(65535, S - s0);
         hipLaunchKernelGGL(loglik_object_sums_kernel, dim3(n), dim3(256), (size_t)NT * 4, (hipStream_t)stream,

@@ -662,6 +662,8 @@ class RotatePlan:
             if out.shape[0] != S:
                 raise ValueError(f"out holds {out.shape[0]} slices for {S} sinograms")
         if angles_i is not None and self._get_bwd4_plan() is not None:
+            if angles_i.device.type == "cpu" and n > self.MAX_SEL:
+                angles_i = self._sel_dev(angles_i)     # host indices ride the launch arguments: at most MAX_SEL of them
             rc = self._lib.ctpvae_rotate_bwd_planned_sel_scaled_f32(gsino.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                                     self._bwd4_plan.data_ptr(), angles_i.data_ptr(), n,
                                                                     1 if angles_i.device.type == "cpu" else 0,

@@ -288,11 +288,10 @@ def test_paired_slices_equal_single_slices(oracle, shape, pad, A, S):
     x = torch.from_numpy(rng.standard_normal((S,) + shape).astype(np.float32)).to(d)
     plan = RotatePlan(theta, shape[0], shape[1], pad, d)
     assert plan.planned[0]
-    _lib.tune("NS", 1)
-    one = plan.forward(x)
-    _lib.tune("NS", 2)
-    two = plan.forward(x)
-    _lib.tune("NS")
+    with _lib.tuned("NS", 1):
+        one = plan.forward(x)
+        _lib.tune("NS", 2)
+        two = plan.forward(x)
     auto = plan.forward(x)
     assert torch.equal(one, two) and torch.equal(one, auto)
     geom = oracle.Geometry(shape[0], shape[1], pad)
@@ -312,11 +311,10 @@ def test_paired_backward_equals_single(oracle, shape, pad, A, S):
     plan = RotatePlan(theta, shape[0], shape[1], pad, d)
     assert plan.planned[1]
     g = torch.from_numpy(rng.standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
-    _lib.tune("BNS", 1)
-    one = plan.backward(g)
-    _lib.tune("BNS", 2)
-    two = plan.backward(g)
-    _lib.tune("BNS")
+    with _lib.tuned("BNS", 1):
+        one = plan.backward(g)
+        _lib.tune("BNS", 2)
+        two = plan.backward(g)
     auto = plan.backward(g)
     assert torch.equal(one, two) and torch.equal(one, auto)
     geom = oracle.Geometry(shape[0], shape[1], pad)
@@ -334,11 +332,10 @@ def test_paired_segment_backward_equals_single(oracle, shape, pad, A, S):
     theta = rng.uniform(-1.0, 4.0, A)
     plan = RotatePlan(theta, shape[0], shape[1], pad, d, use_plan=False)
     g = torch.from_numpy(rng.standard_normal((S, A, plan.PW)).astype(np.float32)).to(d)
-    _lib.tune("SEG_NS", 1)
-    one = plan.backward(g)
-    _lib.tune("SEG_NS", 2)
-    two = plan.backward(g)
-    _lib.tune("SEG_NS")
+    with _lib.tuned("SEG_NS", 1):
+        one = plan.backward(g)
+        _lib.tune("SEG_NS", 2)
+        two = plan.backward(g)
     auto = plan.backward(g)
     assert torch.equal(one, two) and torch.equal(one, auto)
     geom = oracle.Geometry(shape[0], shape[1], pad)
@@ -446,11 +443,10 @@ def test_paired_siddon_equals_single():
     numbers as one slice per workgroup, bit for bit, odd batches included."""
     foam = phantoms.foam_batch(5, 128, seed=2, supersample=2)
     theta = phantoms.dense_theta(180)[::7]
-    _lib.tune("SIDDON_NS", 1)
-    one = cp.create_sinograms(foam, theta, pad=True)
-    _lib.tune("SIDDON_NS", 2)
-    two = cp.create_sinograms(foam, theta, pad=True)
-    _lib.tune("SIDDON_NS")
+    with _lib.tuned("SIDDON_NS", 1):
+        one = cp.create_sinograms(foam, theta, pad=True)
+        _lib.tune("SIDDON_NS", 2)
+        two = cp.create_sinograms(foam, theta, pad=True)
     auto = cp.create_sinograms(foam, theta, pad=True)
     np.testing.assert_array_equal(one, two)
     np.testing.assert_array_equal(one, auto)
@@ -1162,10 +1158,9 @@ def test_long_batches_are_launched_in_chunks():
 
     torch.manual_seed(0)
     whole = run_all()
-    _lib.tune("MAX_SLICES", 5)
-    torch.manual_seed(0)
-    chunked = run_all()
-    _lib.tune("MAX_SLICES")
+    with _lib.tuned("MAX_SLICES", 5):
+        torch.manual_seed(0)
+        chunked = run_all()
     assert len(whole) == len(chunked) >= 14
     for k, (a, b) in enumerate(zip(whole, chunked)):
         if k == 12:      # the exact-transpose backward adds with float atomics: equal up to the order of the adds
@@ -1400,9 +1395,8 @@ def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
     gt = torch.from_numpy(g).to(d)
     scale = torch.from_numpy(rng.uniform(0.5, 2.0, S).astype(np.float32)).to(d)
     got, got_s = plan.backward(gt), plan.backward(gt, scale=scale)
-    _lib.tune("NO_PLAN", 1)
-    direct, direct_s = plan.backward(gt), plan.backward(gt, scale=scale)
-    _lib.tune("NO_PLAN")
+    with _lib.tuned("NO_PLAN", 1):
+        direct, direct_s = plan.backward(gt), plan.backward(gt, scale=scale)
     assert torch.equal(got, direct) and torch.equal(got_s, direct_s)
     n_chk = 3
     geom = oracle.Geometry(shape[0], shape[1], True)
@@ -1410,11 +1404,11 @@ def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
     assert RotatePlan(theta, shape[0], shape[1], False, d)._step_plan is None
 
 
-def test_random_step_plan_geometries():
+def test_random_step_plan_geometries(oracle):
     """Seeded random shapes (ragged in both directions), angle sets of every quadrant incl. axis-aligned ones, batch sizes just
     large enough for the stepped kernel: the step-plan backward against the direct segment kernel, bit for bit
     (CTPVAE_FUZZ_SEED / _CASES: more)."""
-    d = dev()
+    d, orc = dev(), oracle
     rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 909)))
     n_cases, no_plan = int(os.environ.get("CTPVAE_FUZZ_CASES", 6)), 0
     for case in range(n_cases):
@@ -1430,13 +1424,16 @@ def test_random_step_plan_geometries():
             # the plan's overflow word: within a few 1e-3 rad of 90 / 270 degrees |t1| is 1 - 1e-5 and fp32 rounding can move a
             # tap by TWO bins between two rows (found by seed 32: 264 x 278, -4.71696 rad); the direct kernel then serves the
             # geometry -- legitimately, but it must stay the exception
+            # and its result is still checked: the fallback against the oracle (two slices are enough)
             no_plan += 1
+            geom = orc.Geometry(H, W, True)
+            np.testing.assert_array_equal(to_np(plan.backward(g[:2])),
+                                          orc.rotate_bwd_tfcompat(to_np(g[:2]), geom, oTinv(orc, theta, plan), 0), err_msg=tag)
             continue
         plan.backward_uses_step_plan = lambda S: True          # (shapes the planned backward serves would take it at this S)
         got = plan.backward(g)
-        _lib.tune("NO_PLAN", 1)
-        ref = plan.backward(g)
-        _lib.tune("NO_PLAN")
+        with _lib.tuned("NO_PLAN", 1):
+            ref = plan.backward(g)
         assert torch.equal(got, ref), tag
     assert no_plan <= max(1, n_cases // 20), f"{no_plan} of {n_cases} random geometries did not fit the step plan"
 
@@ -1452,9 +1449,8 @@ def test_step_plan_holds_two_bin_steps_near_a_right_angle():
     g = torch.from_numpy(np.random.default_rng(1).standard_normal((25, len(theta), plan.PW)).astype(np.float32)).to(d)
     plan.backward_uses_step_plan = lambda S: True
     got = plan.backward(g)
-    _lib.tune("NO_PLAN", 1)
-    ref = plan.backward(g)
-    _lib.tune("NO_PLAN")
+    with _lib.tuned("NO_PLAN", 1):
+        ref = plan.backward(g)
     assert torch.equal(got, ref)
 
 
@@ -1474,9 +1470,8 @@ def test_large_batches_of_small_slices_take_the_step_plan_too():
     forced.backward_uses_step_plan = lambda S: False
     forced.backward_uses_plan = lambda S: True
     assert torch.equal(stepped, forced.backward(g)) and torch.equal(stepped_s, forced.backward(g, scale=scale))
-    _lib.tune("SEG_PPT", 4)                  # the direct segment kernel through the same entry point
-    assert torch.equal(stepped, plan.backward(g))
-    _lib.tune("SEG_PPT")
+    with _lib.tuned("SEG_PPT", 4):                  # the direct segment kernel through the same entry point
+        assert torch.equal(stepped, plan.backward(g))
     x = torch.from_numpy(rng.random((200, 128, 128, 1), dtype=np.float32)).to(d).requires_grad_(True)
     cp.project_tf_fast(x, theta, pad=True, dim=2, integrate_vae=True).backward(g[..., None])
     assert torch.equal(x.grad[..., 0], stepped)
@@ -1908,6 +1903,30 @@ def test_per_object_loglik_sums_are_the_ordered_sum_of_the_two_step_path(oracle,
     np.testing.assert_array_equal(to_np(out), oracle.loglik_object_sums(to_np(lp), 1))
 
 
+def test_object_sums_of_many_angles_and_host_subsets_past_the_argument_list(oracle):
+    """Round-3 ADVICE: (i) the same-order reduction of a stored [S][A][P] array takes any number of angles (it used to refuse
+    A x tasks-per-row > 16384: a many-angle tiled geometry that trained through lp.sum() then failed) -- the order adds angles
+    in groups of 64, so the kernel keeps one group's task sums in LDS at a time; (ii) a HOST-resident angle subset longer than
+    the 256 indices a launch's arguments hold is uploaded and runs on the device-index form of the planned backward."""
+    d = dev()
+    rng = np.random.default_rng(21)
+    lib = _lib.load()
+    lp = torch.from_numpy(rng.standard_normal((2, 600, 2048)).astype(np.float32)).to(d)       # 600 x 32 tasks = 19200
+    out = torch.empty(2, device=d)
+    for part in (0, 1):
+        assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), 2, 600, 2048, part, out.data_ptr(), None) == 0
+        np.testing.assert_array_equal(to_np(out), oracle.loglik_object_sums(to_np(lp), part))
+    theta = phantoms.dense_theta(180)
+    plan = RotatePlan(theta, 128, 128, True, d)
+    sub = rng.integers(0, 180, 300).astype(np.int32)                                        # repeats allowed
+    g = torch.from_numpy(rng.standard_normal((3, 300, plan.PW)).astype(np.float32)).to(d)
+    host, devi = plan.backward(g, angles_i=torch.from_numpy(sub)), plan.backward(g, angles_i=torch.from_numpy(sub).to(d))
+    assert torch.equal(host, devi)
+    geom = oracle.Geometry(128, 128, True)
+    want = oracle.rotate_bwd_tfcompat(to_np(g), geom, oTinv(oracle, theta, plan)[sub], 0)
+    assert rel_err(to_np(host), want) <= REL       # (300 angles incl. repeats: the gather adds them in index order, as the oracle does)
+
+
 @pytest.mark.parametrize("subset", [True, False])
 def test_calculate_log_prob_reduce_per_object(oracle, subset):
     """The drop-in call with reduce='per_object': values = the ordered sum of the unreduced call's log-probabilities, and its
@@ -2160,9 +2179,8 @@ def test_tiled_forward_through_compact_tile_plans(oracle, shape, A, S):
         assert torch.equal(plan.forward(x), got), (ns, G)
         # tasks = four 16-slot bands of the plan's sorted list (the default) against (angle, 64-slot block) tasks: which rays
         # ride in one wave changes no ray's sum
-        _lib.tune("TILED_SORT", 0)
-        assert torch.equal(plan.forward(x), got), (ns, G, "unsorted tasks")
-        _lib.tune("TILED_SORT")
+        with _lib.tuned("TILED_SORT", 0):
+            assert torch.equal(plan.forward(x), got), (ns, G, "unsorted tasks")
     _lib.tune("*")
     mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
     meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32)).to(d)
