@@ -245,11 +245,14 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
         uint4 c2;
         if (more) c2 = pc[(size_t)q * st];
 #define CTPVAE_CSTEP(G, VCUR, VNXT, LNEW, LUSE)                                                    \
+        if (n + G + 1 >= ng) {   /* the task's last group: nothing more to issue (round 4: the gathers of a group */ \
+            _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* behind the last were a tenth of */ \
+            break;                                                          /* the tile kernel's LDS cycles)   */ \
+        }                                                                                          \
         group_gather<NS>(an, VNXT);                        /* group n + G + 1 */             \
         LNEW = lut_issue<G + 3>(la0, la1, c0, c1);        /* table entries of group n + G + 3 */ \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* group n + G */          \
-        if (n + G + 1 >= ng) break;                                                                \
         group_addr<NEG>(adr, LUSE, an);                          /* addresses of group n + G + 2 */
         CTPVAE_CSTEP(0, va, vb, l1, l0)
         CTPVAE_CSTEP(1, vb, va, l0, l1)

@@ -7,7 +7,9 @@ from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 B, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 50), (int(sys.argv[2]) if len(sys.argv) > 2 else 20)
 theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, A)] if A < 180 else phantoms.dense_theta(180)
-plan = RotatePlan(theta, 128, 128, True, dev)
+FMT = sys.argv[3] if len(sys.argv) > 3 else "auto"     # u16 | compact | auto
+plan = RotatePlan(theta, 128, 128, True, dev, plan_format=FMT)
+print("B", B, "A", A, "plan format", FMT, "->", "compact" if plan._compact else "u16")
 x = torch.rand((B, 128, 128), device=dev); out = torch.empty((B, A, plan.PW), device=dev)
 def t_us():
     plan.forward(x, out=out); torch.cuda.synchronize()
