@@ -113,6 +113,43 @@ __device__ __forceinline__ bool cplan_encode_ray(const PlanGeom &g, const float 
     return bad;
 }
 
+// The same codes as BYTES, for plans whose lanes walk more than one ray (round 4, paired tile tasks): code byte b of the ray --
+// its steps 3 b .. 3 b + 2 -- goes to put(b, value).  All n codes of the ray are written: n - 1 steps inside the core and the
+// step onto the zero border (the ray may ride in any task, before or behind another ray).  Returns true if a step does not fit.
+template <class Put>
+__device__ __forceinline__ bool cplan_encode_ray_bytes(const PlanGeom &g, const float *t, int j, const RayScan &rs, int pitch, Put put)
+{
+    const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+    const bool plus = (t0 >= 0.0f) == (t3 >= 0.0f);
+    const int sigma = t4 < 0.0f ? -1 : 1;
+    const float xj = t0 * (float)j, yj = t3 * (float)j;
+    const int n = rs.n, first = rs.first;
+    bool bad = rs.bad;
+    if (n <= 0) return bad;
+    RawTap cur = raw_tap(g, xj, yj, t1, t2, t4, t5, first);
+    int curcell = rs.start;
+    unsigned byte = 0;
+    for (int r = 0; r < n; ++r) {   // the step from row first + r to row first + r + 1
+        const RawTap nxt = raw_tap(g, xj, yj, t1, t2, t4, t5, first + r + 1);
+        const int bx = nxt.ix != cur.ix, by = nxt.iy != cur.iy;
+        const bool leave = r + 1 == n;
+        if (leave && (in_core(g, nxt) || nxt.ix < -1 || nxt.ix > g.W || nxt.iy < -1 || nxt.iy > g.H)) {
+            bad = true;   // the ray cannot step onto the border
+        } else {
+            const int nc = c_cell(g, pitch, plus, nxt);
+            if (nc - curcell != sigma * (by * pitch - bx)) bad = true;
+            byte |= (unsigned)(bx | (by << 1)) << (2 * (r % 3));
+            cur = nxt;
+            curcell = nc;
+        }
+        if (r % 3 == 2 || leave) {
+            put(r / 3, byte);
+            byte = 0;
+        }
+    }
+    return bad;
+}
+
 // In-kernel set-up shared by the kernels that walk compact plans: the replicated step table at LDS offset 0 (entry e = the
 // cumulative byte offsets after 1..3 of the steps coded in e -- bit 2m: column, 2m + 1: row --, one copy per lane of a
 // half-wave at byte e * 256 + l * 8) and the zero border of an H x W image of NS interleaved slices (guard + row -1, row H +
@@ -223,9 +260,16 @@ template <int NS> __device__ __forceinline__ void group_gather(const int (&a)[6]
 // One ray-sum per lane: walks ng groups of six rows from byte address adr0.  c0 / c1: the ray's code chunks 0 and 1 (48 rows
 // each; chunks behind the plan's NQ-th are zeros: stay); chunk q + 2 is loaded from pc (chunk 2 on) while chunk q is walked.
 // The table entries of group n + 3 and the gathers of group n + 1 are in flight while group n is added.
-template <int NS, bool NEG>
+//
+// PAIRED (round 4): a lane walks TWO rays back to back -- ray A for its own gsw groups, then ray B, whose first tap sits at
+// byte address adrB and whose codes follow A's in the lane's stream (from code byte 2 gsw on).  At group gsw the running
+// sum becomes *accA and restarts from zero; lanes switch at their own group, so the per-lane tests sit behind a wave-uniform
+// "does any lane switch here" (one compare and a scalar branch per group when none does).  gsw = 0: the lane starts with B
+// (the caller passes adr = adrB); gsw >= ng: the lane never switches and the returned sum is ray A's.
+template <int NS, bool NEG, bool PAIRED = false>
 __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, int lane8, uint4 c0, uint4 c1, const uint4 *pc,
-                                                              size_t st, int NQ)
+                                                              size_t st, int NQ, int gsw = 0, int adrB = 0,
+                                                              typename SliceVec<NS>::type *accA = nullptr)
 {
     typedef typename SliceVec<NS>::type vec_t;
     vec_t acc = 0.0f;
@@ -237,22 +281,38 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
     __builtin_amdgcn_sched_barrier(0);   // all six table reads of the first three groups in flight together
     group_addr<NEG>(adr, l0, an);
     group_gather<NS>(an, va);
+    if constexpr (PAIRED)
+        if (gsw == 1) adr = adrB;
     group_addr<NEG>(adr, l1, an);
     l0 = l2;
     int n = 0;   // first group of the current chunk
+#define CTPVAE_CSWITCH_ACC(M)   /* ray A ends before group M: its sum leaves the accumulator */                 \
+        if constexpr (PAIRED)                                                                                  \
+            if (__builtin_amdgcn_ballot_w64(gsw == (M)) != 0ull)                                               \
+                if (gsw == (M)) {                                                                              \
+                    *accA = acc;                                                                               \
+                    acc = 0.0f;                                                                                \
+                }
+#define CTPVAE_CSWITCH_ADR(M)   /* group M is ray B's first: its addresses start from adrB */                    \
+        if constexpr (PAIRED)                                                                                  \
+            if (__builtin_amdgcn_ballot_w64(gsw == (M)) != 0ull)                                               \
+                if (gsw == (M)) adr = adrB;
     for (int q = 0;; ++q) {
         const bool more = q + 2 < NQ && n + 8 < ng;   // wave-uniform: chunk q + 2 exists and may be walked
         uint4 c2;
         if (more) c2 = pc[(size_t)q * st];
 #define CTPVAE_CSTEP(G, VCUR, VNXT, LNEW, LUSE)                                                    \
         if (n + G + 1 >= ng) {   /* the task's last group: nothing more to issue (round 4: the gathers of a group */ \
+            CTPVAE_CSWITCH_ACC(n + G)                                                              \
             _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* behind the last were a tenth of */ \
             break;                                                          /* the tile kernel's LDS cycles)   */ \
         }                                                                                          \
         group_gather<NS>(an, VNXT);                        /* group n + G + 1 */             \
         LNEW = lut_issue<G + 3>(la0, la1, c0, c1);        /* table entries of group n + G + 3 */ \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        CTPVAE_CSWITCH_ACC(n + G)                                                                  \
         _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* group n + G */          \
+        CTPVAE_CSWITCH_ADR(n + G + 2)                                                              \
         group_addr<NEG>(adr, LUSE, an);                          /* addresses of group n + G + 2 */
         CTPVAE_CSTEP(0, va, vb, l1, l0)
         CTPVAE_CSTEP(1, vb, va, l0, l1)
@@ -267,6 +327,8 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
         c0 = c1;
         c1 = more ? c2 : uint4{0u, 0u, 0u, 0u};
     }
+#undef CTPVAE_CSWITCH_ACC
+#undef CTPVAE_CSWITCH_ADR
     return acc;
 }
 

@@ -1477,7 +1477,9 @@ static size_t tile_lds_bytes(const TileSpec &ts, int ns)
 // sums as the kernel above, bit for bit; rotate_tile_reduce_kernel is unchanged.
 struct TLayout {
     int nt, nb, nbk, nq16, NQ, pitch, cells, maxT;
+    int nu, NQP, maxTP;   // paired tasks (round 4): band pairs per (tile, angle), code chunks of a lane's two rays, tasks per (tile, class)
     long long off_cls, off_ng, off_ng16, off_tcount, off_tasks, off_start, off_codes, off_flag, bytes;
+    long long off_ngu, off_ptcount, off_ptasks, off_pstart, off_pcodes;
 };
 static TLayout t_layout(const TileSpec &ts, int A)
 {
@@ -1499,7 +1501,21 @@ static TLayout t_layout(const TileSpec &ts, int A)
     L.off_start = up(L.off_tasks + (long long)L.nt * 2 * L.maxT * 16);        // [nt][A][nb] first cell | live << 31
     L.off_codes = up(L.off_start + (long long)L.nt * A * L.nb * 4);           // [nt][A][NQ][nb] uint4
     L.off_flag = L.off_codes + (long long)L.nt * A * L.NQ * L.nb * 16;
-    L.bytes = L.off_flag + 256;
+    // paired tasks: unit u of an angle = band u and band nq16 - 1 - u, walked back to back by the same 16 lanes
+    L.nu = L.nq16 / 2;
+    L.NQP = 2 * L.NQ;                                                         // both rays' whole groups: <= 2 x 8 NQ groups
+    L.maxTP = (A * L.nu + 3) / 4 + 2;
+    L.off_ngu = up(L.off_flag + 256);                                         // [nt][A][nu] row groups of a unit's longest lane
+    L.off_ptcount = up(L.off_ngu + (long long)L.nt * A * L.nu * 4);           // [nt][2]
+    L.off_ptasks = up(L.off_ptcount + (long long)L.nt * 2 * 4);               // [nt][2][maxTP] uint4: four unit words
+    L.off_pstart = up(L.off_ptasks + (long long)L.nt * 2 * L.maxTP * 16);     // [nt][A][nu][16] uint2: ray A's / ray B's first cell
+    L.off_pcodes = up(L.off_pstart + (long long)L.nt * A * L.nu * 16 * 8);    // [nt][A][nu][NQP][16] uint4
+    L.bytes = L.off_pcodes + (long long)L.nt * A * L.nu * L.NQP * 16 * 16;
+    // Built and measured (round 4, profiles/r04_tile_pairs.txt): the pairs cut the kernel's LDS instructions by 12 % and its
+    // LDS-array cycles by 6 % (a hardware group whose lanes sit in two rays conflicts more) for 12 % more vector instructions
+    // and 128 registers -- and the launch takes the same 88 us.  The sections above exist only while the knob TILED_PAIR = 1
+    // is set (when the plan is built AND when it is used); the default plan ends behind its flag word.
+    if (knob(kKnobTiledPair) != 1) L.bytes = L.off_flag + 256;
     return L;
 }
 static size_t t_lds_bytes(const TLayout &L, int A, int ns) { return (size_t)kLutBytes + (size_t)L.cells * 4 * ns + ((size_t)A + 2) * 4; }
@@ -1539,6 +1555,57 @@ __global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpe
     if (__any(bad) && lane == 0) atomicOr(reinterpret_cast<int *>(plan + L.off_flag), 1);
 }
 
+// PAIRED TASKS (round 4).  Even with sorted bands a third of the gathered rows add zeros (1.30 x the rays' own rows,
+// tools/sim_tile_tasks.py): the 16 rays of a band on a trapezoid's flank differ by up to 22 rows and the hardware group walks
+// the longest.  The flank on the other side of the tile falls as this one rises, so a lane walks slot s of band u and THEN slot
+// s of band nq16 - 1 - u (the mirror image of slot 15 - s): the two lengths add up to about the same for all 16 lanes (1.16 x).
+// Per lane: ray A's first cell and whole groups gA, ray B's first cell; a code stream = A's codes (2 gA bytes), then B's.
+// One wave per (64-slot block, angle, tile) as rotate_tplan_kernel: lanes 0..31 hold the A rays of two units, lanes 32..63
+// their B rays (lane ^ 48 is the partner).
+__global__ __launch_bounds__(64) void rotate_tplan_pairs_kernel(RotGeom gfull, TileSpec ts, const float *__restrict__ T8, TLayout L,
+                                                                char *__restrict__ plan)
+{
+    const int blk = blockIdx.x, a = blockIdx.y, t = blockIdx.z, lane = threadIdx.x;
+    int y0, x0, h, w;
+    tile_rect(gfull, ts, t, y0, x0, h, w);
+    const PlanGeom g{h, w, gfull.PH, gfull.PW, gfull.py + y0, gfull.px + x0, gfull.A};
+    const float *t6 = T8 + 8 * a;
+    const float tile_cx = (float)g.px + 0.5f * (float)(g.W - 1), tile_cy = (float)g.py + 0.5f * (float)(g.H - 1);
+    const int slot = lane < 32 ? blk * 32 + lane : L.nb - 32 * (blk + 1) + (lane - 32);
+    const int j = tile_first_bin(t6, tile_cx, tile_cy, ts.radius) + slot;
+    const bool valid = (unsigned)j < (unsigned)g.PW;
+    const RayScan rs = cplan_scan_ray(g, t6, j, valid, L.pitch);
+    const bool isA = lane < 32;
+    const int ul = isA ? lane : (lane ^ 48), u = 2 * blk + (ul >> 4), k = ul & 15;
+    const int gown = (rs.n + kRowsPerGroup - 1) / kRowsPerGroup, gother = __shfl_xor(gown, 48, 64);
+    const int gA = isA ? gown : gother, gB = isA ? gother : gown;
+    extern __shared__ unsigned char stream[];   // [32 unit lanes][NQP * 16] code bytes
+    const int sbytes = L.NQP * 16;
+    for (int b = lane; b < 32 * sbytes / 4; b += 64) reinterpret_cast<unsigned *>(stream)[b] = 0u;
+    __syncthreads();
+    bool bad = 2 * (gA + gB) > sbytes || gA + gB > 127;
+    if (!bad) {
+        unsigned char *mine = stream + ul * sbytes + (isA ? 0 : 2 * gA);
+        bad = cplan_encode_ray_bytes(g, t6, j, rs, L.pitch, [&](int b, unsigned v) { mine[b] = (unsigned char)v; });
+    }
+    __syncthreads();
+    const size_t unit = ((size_t)t * gfull.A + a) * L.nu + u;
+    unsigned *pstart = reinterpret_cast<unsigned *>(plan + L.off_pstart) + (unit * 16 + k) * 2;
+    if (isA)
+        pstart[0] = (unsigned)rs.start | ((unsigned)gA << 16) | (valid ? 0x80000000u : 0u);
+    else
+        pstart[1] = (unsigned)rs.start | (valid ? 0x80000000u : 0u);
+    int tot = gA + gB;   // the same on both partner lanes
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) tot = max(tot, __shfl_xor(tot, off, 64));
+    if (isA && k == 0) reinterpret_cast<int *>(plan + L.off_ngu)[unit] = tot;
+    if (isA) {
+        uint4 *out = reinterpret_cast<uint4 *>(plan + L.off_pcodes) + unit * L.NQP * 16 + k;
+        for (int q = 0; q < L.NQP; ++q) out[(size_t)q * 16] = *reinterpret_cast<const uint4 *>(stream + ul * sbytes + 16 * q);
+    }
+    if (__any(bad) && lane == 0) atomicOr(reinterpret_cast<int *>(plan + L.off_flag), 1);   // (exactly when rotate_tplan_kernel flags)
+}
+
 // SORTED TASKS (round 3).  A wave walks its 64 ray slots for as many rows as its longest ray; with (angle, 64-slot block) tasks
 // the rays of a 64 x 96 tile cut obliquely have triangular length profiles and a third of the gathers add zeros (1.54 x the
 // rows of the rays themselves, counted from the geometry at 512 x 512, 90 angles).  A ds_read_b128 is served in four hardware
@@ -1548,21 +1615,23 @@ __global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpe
 // task is four consecutive bands of that order: 1.24 x.  Which rays ride together changes nothing in any ray's sum.
 // Task word: angle | band << 16 | the band's row groups << 20 | sigma < 0 << 28 | 1 << 31 (0: an empty quarter).
 // One wave per (tile, class); the sort is a stable counting sort over keys (sign, 127 - groups).
-__global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L, char *__restrict__ plan)
+// (round 4: the same sort over the PAIRED units -- nq units per angle, lengths at off_len, lists at off_tcount / off_tasks)
+__global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L, char *__restrict__ plan, int nq, long long off_len,
+                                                                long long off_tcount, long long off_tasks, int maxT)
 {
     const int t = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
     const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
-    const int *ng16 = reinterpret_cast<const int *>(plan + L.off_ng16) + (size_t)t * A * L.nq16;
-    unsigned *tasks = reinterpret_cast<unsigned *>(plan + L.off_tasks) + ((size_t)t * 2 + c) * L.maxT * 4;
-    int *tcount = reinterpret_cast<int *>(plan + L.off_tcount) + t * 2 + c;
+    const int *ng16 = reinterpret_cast<const int *>(plan + off_len) + (size_t)t * A * nq;
+    unsigned *tasks = reinterpret_cast<unsigned *>(plan + off_tasks) + ((size_t)t * 2 + c) * maxT * 4;
+    int *tcount = reinterpret_cast<int *>(plan + off_tcount) + t * 2 + c;
     __shared__ int hist[256], base[256];
     for (int k = lane; k < 256; k += 64) hist[k] = 0;
     __syncthreads();
-    const int U = A * L.nq16;
+    const int U = A * nq;
     auto key_of = [&](int u, bool &in) -> int {
         in = false;
         if (u >= U) return 0;
-        const int a = u / L.nq16, w = cls[a];
+        const int a = u / nq, w = cls[a];
         in = (w & 1) == c;
         return ((w >> 1) & 1) * 128 + (127 - min(ng16[u], 127));
     };
@@ -1601,7 +1670,7 @@ __global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L
             todo &= ~same;
         }
         if (in) {   // (a task's row groups are read from its first, longest band's word)
-            const int a = u / L.nq16, band = u - a * L.nq16;
+            const int a = u / nq, band = u - a * nq;
             tasks[pos] = (unsigned)a | ((unsigned)band << 16) | ((unsigned)(127 - (k & 127)) << 20) | ((unsigned)(k >> 7) << 28) |
                          0x80000000u;
         }
@@ -1617,11 +1686,15 @@ __global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L
 #define CTPVAE_TILE_PERMUTE 1
 #endif
 constexpr bool kTilePermuteLanes = CTPVAE_TILE_PERMUTE != 0;
-template <int NS, bool SORTED>
+// MODE: 0 = (angle, 64-slot block) tasks (knob TILED_SORT = 0, kept for measurement); 1 = four sorted 16-slot bands
+// (round 3, the default); 2 = four sorted band PAIRS, every lane walking two rays back to back (round 4; knob TILED_PAIR = 1,
+// set while the plan is built and used: measured equal in time, see t_layout).
+template <int NS, int MODE>
 __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                        TLayout L, const char *__restrict__ plan,
                                                                        float *__restrict__ partial)
 {
+    constexpr bool SORTED = MODE != 0, PAIRED = MODE == 2;
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
     if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();   // see cplan_walk.h lut_issue
@@ -1634,9 +1707,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int *clsw = reinterpret_cast<const int *>(plan + L.off_cls);
     const int *ngt = reinterpret_cast<const int *>(plan + L.off_ng) + (size_t)t * A * L.nbk;
-    const uint4 *tasks = reinterpret_cast<const uint4 *>(plan + L.off_tasks) + ((size_t)t * 2 + cls) * L.maxT;
+    const uint4 *tasks = PAIRED ? reinterpret_cast<const uint4 *>(plan + L.off_ptasks) + ((size_t)t * 2 + cls) * L.maxTP
+                                : reinterpret_cast<const uint4 *>(plan + L.off_tasks) + ((size_t)t * 2 + cls) * L.maxT;
     const unsigned *start = reinterpret_cast<const unsigned *>(plan + L.off_start) + (size_t)t * A * L.nb;
     const uint4 *codes = reinterpret_cast<const uint4 *>(plan + L.off_codes) + (size_t)t * A * L.NQ * L.nb;
+    const uint2 *pstart = reinterpret_cast<const uint2 *>(plan + L.off_pstart) + (size_t)t * A * L.nu * 16;
+    const uint4 *pcodes = reinterpret_cast<const uint4 *>(plan + L.off_pcodes) + (size_t)t * A * L.nu * L.NQP * 16;
     // behind the image: the ascending list of this class's angles ([0] = their count; unsorted tasks only), then the task counter
     int *cls_list = reinterpret_cast<int *>(image + (size_t)L.cells * NS);
     if (threadIdx.x < 64) {
@@ -1661,10 +1737,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     if constexpr (NS == 4 && kTilePermuteLanes)
         li = li < 4 ? li : li < 12 ? li + 12 : li < 16 ? li - 8 : li < 20 ? li + 8 : li < 28 ? li - 12 : li;
     const int quarter = (lane >> 5) * 2 + (li >> 4);   // SORTED: the hardware group = the task's band this lane rides in
-    const int ntask_sorted = SORTED ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(plan + L.off_tcount)[t * 2 + cls]) : 0;
+    const int ntask_sorted =
+        SORTED ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(plan + (PAIRED ? L.off_ptcount : L.off_tcount))[t * 2 + cls]) : 0;
     cplan_init_lut<NS>(lds, L.pitch);
     cplan_zero_border<NS>(image, h, w, L.pitch);
     float *core = image + (size_t)(1 + L.pitch) * NS;
+#ifndef CTPVAE_TUNE_TILE_NOFILL   // (timing builds only: the walks over whatever LDS holds)
     if constexpr (NS == 1) {
         stage_rows(core, im, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
     } else {
@@ -1673,25 +1751,31 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
         for (int n = 0; n < NS; ++n) srcs[n] = im + (size_t)(min(s + n, gfull.S - 1) - s) * gfull.H * gfull.W;
         stage_rows_interleaved<NS>(core, srcs, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
     }
+#endif
     __syncthreads();
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
     int *next_task = cls_list + 1 + A;
     const int ntask = SORTED ? ntask_sorted : ncls * L.nbk;
-    const size_t st = (size_t)L.nb;
+    const size_t st = PAIRED ? (size_t)16 : (size_t)L.nb;
+    const int NQW = PAIRED ? L.NQP : L.NQ;   // code chunks of a lane's stream
     struct Task {
         bool valid, neg, live;
         int ray, ng, adr;   // ray = angle * nb + slot (per lane)
-        const uint4 *p;
-        uint4 c0, c1;
+        const uint4 *p;   // the lane's code chunk 2 (chunk 1 = p[-st] is fetched when the walk starts: four registers less per waiting task)
+        uint4 c0;
+        // PAIRED: `adr` holds both rays' first cells (A | B << 16) until the walk starts; pk = (groups of ray A) | (slot distance
+        // to ray B) << 8 | ray B live << 31 -- packed: a prepared task waits in registers while the current one is walked
+        unsigned pk;
     };
     auto prepare = [&](int m) -> Task {
         Task q;
         q.valid = m < ntask;
         q.neg = q.live = false;
         q.ray = q.ng = 0;
-        q.adr = kLutBytes;
-        q.p = codes;
-        q.c0 = q.c1 = uint4{0u, 0u, 0u, 0u};
+        q.adr = PAIRED ? 0 : kLutBytes;   // (PAIRED: cell 0 = the guard cell, a zero)
+        q.pk = 127u;                      // never switches
+        q.p = (PAIRED ? pcodes : codes) + 2 * st;   // (idle lanes read some ray's chunks; their codes stay zero)
+        q.c0 = uint4{0u, 0u, 0u, 0u};
         if (q.valid) {   // wave-uniform
             int a, slot;
             bool mine = true;
@@ -1700,7 +1784,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
                 const unsigned wq = quarter == 0 ? d.x : quarter == 1 ? d.y : quarter == 2 ? d.z : d.w;
                 mine = (wq >> 31) != 0;   // the last task of a sign group may have empty quarters
                 a = wq & 0xffffu;
-                slot = (int)((wq >> 16) & 15u) * 16 + (li & 15);
+                slot = (int)((wq >> 16) & 15u) * 16 + (li & 15);   // (PAIRED: unit * 16 + lane of the unit = ray A's slot)
                 q.ng = __builtin_amdgcn_readfirstlane((d.x >> 20) & 127u);
                 q.neg = __builtin_amdgcn_readfirstlane((d.x >> 28) & 1u) != 0;
             } else {
@@ -1713,13 +1797,25 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
             }
             if (mine) {
                 q.ray = a * L.nb + slot;
-                const unsigned sw = start[q.ray];
-                q.live = (sw >> 31) != 0;
-                q.adr = kLutBytes + (int)(sw & 0x7fffffffu) * (4 * NS);
-                const uint4 *p = codes + (size_t)a * L.NQ * L.nb + slot;
-                q.c0 = p[0];
-                if (L.NQ > 1) q.c1 = p[st];
-                q.p = p + 2 * st;
+                q.pk |= 0x40000000u;   // this lane holds a ray: its code chunk 1 exists
+                if constexpr (PAIRED) {
+                    const int u = slot >> 4, ul = (a * L.nu + u) * 16 + (slot & 15);
+                    const uint2 sw = pstart[ul];
+                    const unsigned gA = (sw.x >> 16) & 127u;
+                    q.live = (sw.x >> 31) != 0;
+                    q.adr = (int)((sw.x & 0xffffu) | (sw.y << 16));
+                    q.pk = gA | ((unsigned)(16 * (L.nq16 - 1 - 2 * u)) << 8) | (sw.y & 0x80000000u) | 0x40000000u;
+                    const uint4 *p = pcodes + (size_t)(a * L.nu + u) * L.NQP * 16 + (slot & 15);
+                    q.c0 = p[0];
+                    q.p = p + 2 * st;
+                } else {
+                    const unsigned sw = start[q.ray];
+                    q.live = (sw >> 31) != 0;
+                    q.adr = kLutBytes + (int)(sw & 0x7fffffffu) * (4 * NS);
+                    const uint4 *p = codes + (size_t)a * L.NQ * L.nb + slot;
+                    q.c0 = p[0];
+                    q.p = p + 2 * st;
+                }
             }
         }
         return q;
@@ -1730,15 +1826,37 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
         if (lane == 0) m = atomicAdd(next_task, 1);
         const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m) * G + gi);
         vec_t acc = 0.0f;
+        [[maybe_unused]] vec_t accA = 0.0f;
+#ifdef CTPVAE_TUNE_TILE_NOWALK   // timing builds only (tools/): what the kernel costs without its walks
+        const int ng = 0;
+#else
         const int ng = __builtin_amdgcn_readfirstlane(cur.ng);
+#endif
         const bool neg = __builtin_amdgcn_readfirstlane((int)cur.neg) != 0;
-        if (ng > 0)
-            acc = neg ? cwalk<NS, true>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ)
-                      : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, cur.c1, cur.p, st, L.NQ);
-        if (cur.live) {
-            const size_t ray = (size_t)cur.ray, nrays = (size_t)A * L.nb;
+        [[maybe_unused]] const int gsw = (int)(cur.pk & 127u);
+        uint4 c1 = uint4{0u, 0u, 0u, 0u};
+        if (NQW > 1 && ng > 5 && (cur.pk & 0x40000000u)) c1 = cur.p[-(ptrdiff_t)st];   // wanted from the walk's sixth group on
+        if (ng > 0) {
+            if constexpr (PAIRED) {
+                const int adrB = kLutBytes + (int)((unsigned)cur.adr >> 16) * (4 * NS);
+                const int adrA = gsw ? kLutBytes + (int)((unsigned)cur.adr & 0xffffu) * (4 * NS) : adrB;   // no groups of its own: ray B first
+                acc = neg ? cwalk<NS, true, true>(adrA, ng, (lane & 31) << 3, cur.c0, c1, cur.p, st, NQW, gsw, adrB, &accA)
+                          : cwalk<NS, false, true>(adrA, ng, (lane & 31) << 3, cur.c0, c1, cur.p, st, NQW, gsw, adrB, &accA);
+            } else
+                acc = neg ? cwalk<NS, true>(cur.adr, ng, (lane & 31) << 3, cur.c0, c1, cur.p, st, NQW)
+                          : cwalk<NS, false>(cur.adr, ng, (lane & 31) << 3, cur.c0, c1, cur.p, st, NQW);
+        }
+        const size_t nrays = (size_t)A * L.nb;
+        if constexpr (PAIRED) {
+            const bool switched = gsw < ng;          // (gsw = 0: ray A holds no rows, its sum is the zero accA starts from)
+            const vec_t zero = 0.0f;
+            if (cur.live) *reinterpret_cast<vec_t *>(partial + partial_index(s, nt, t, nrays, (size_t)cur.ray)) = switched ? accA : acc;
+            if ((cur.pk >> 31) != 0)
+                *reinterpret_cast<vec_t *>(partial + partial_index(s, nt, t, nrays, (size_t)cur.ray + ((cur.pk >> 8) & 0xffffu))) =
+                    switched ? acc : zero;
+        } else if (cur.live) {
             // (partial_index: one NS-wide store; slices past the batch hold copies of the last one, the workspace has room)
-            *reinterpret_cast<vec_t *>(partial + partial_index(s, nt, t, nrays, ray)) = acc;
+            *reinterpret_cast<vec_t *>(partial + partial_index(s, nt, t, nrays, (size_t)cur.ray)) = acc;
         }
         cur = nxt;
     }
@@ -1911,14 +2029,18 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
         return CTPVAE_OK;
     };
     int rc;
-    if (tplan_dev && !tie_fix && knob(kKnobTiledSort) != 0)   // tasks = four sorted 16-slot bands (rotate_tplan_tasks_kernel)
-        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, true>)
-                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, true>)
-                                : launch_compact(rotate_fwd_tile_compact_kernel<1, true>));
+    if (tplan_dev && !tie_fix && knob(kKnobTiledSort) != 0 && knob(kKnobTiledPair) == 1)   // tasks = four sorted band pairs
+        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, 2>)
+                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, 2>)
+                                : launch_compact(rotate_fwd_tile_compact_kernel<1, 2>));
+    else if (tplan_dev && !tie_fix && knob(kKnobTiledSort) != 0)   // tasks = four sorted 16-slot bands (rotate_tplan_tasks_kernel)
+        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, 1>)
+                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, 1>)
+                                : launch_compact(rotate_fwd_tile_compact_kernel<1, 1>));
     else if (tplan_dev && !tie_fix)
-        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, false>)
-                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, false>)
-                                : launch_compact(rotate_fwd_tile_compact_kernel<1, false>));
+        rc = ns == 4 ? launch_compact(rotate_fwd_tile_compact_kernel<4, 0>)
+                     : (ns == 2 ? launch_compact(rotate_fwd_tile_compact_kernel<2, 0>)
+                                : launch_compact(rotate_fwd_tile_compact_kernel<1, 0>));
     else if (tie_fix)
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, true, true, 1>);
     else if (ns == 4)
@@ -1984,8 +2106,17 @@ int ctpvae_rotate_tplan_build_f32(const float *T8_dev, int A, int H, int W, int 
     CTPVAE_HIP(hipMemsetAsync((char *)tplan_dev + L.off_tasks, 0, (size_t)L.nt * 2 * L.maxT * 16, (hipStream_t)stream));   // empty quarters
     hipLaunchKernelGGL(rotate_tplan_kernel, dim3(L.nbk, A, L.nt), dim3(64), 0, (hipStream_t)stream, g, ts, T8_dev, L, (char *)tplan_dev);
     CTPVAE_LAUNCH_CHECK("rotate_tplan_kernel");
-    hipLaunchKernelGGL(rotate_tplan_tasks_kernel, dim3(L.nt, 2), dim3(64), 0, (hipStream_t)stream, A, L, (char *)tplan_dev);
+    hipLaunchKernelGGL(rotate_tplan_tasks_kernel, dim3(L.nt, 2), dim3(64), 0, (hipStream_t)stream, A, L, (char *)tplan_dev, L.nq16,
+                       L.off_ng16, L.off_tcount, L.off_tasks, L.maxT);
     CTPVAE_LAUNCH_CHECK("rotate_tplan_tasks_kernel");
+    if (knob(kKnobTiledPair) != 1) return CTPVAE_OK;
+    // paired units (round 4, knob TILED_PAIR = 1): lane streams, then the same sort over them
+    CTPVAE_HIP(hipMemsetAsync((char *)tplan_dev + L.off_ptasks, 0, (size_t)L.nt * 2 * L.maxTP * 16, (hipStream_t)stream));
+    hipLaunchKernelGGL(rotate_tplan_pairs_kernel, dim3(L.nbk, A, L.nt), dim3(64), (size_t)32 * L.NQP * 16, (hipStream_t)stream, g, ts, T8_dev, L, (char *)tplan_dev);
+    CTPVAE_LAUNCH_CHECK("rotate_tplan_pairs_kernel");
+    hipLaunchKernelGGL(rotate_tplan_tasks_kernel, dim3(L.nt, 2), dim3(64), 0, (hipStream_t)stream, A, L, (char *)tplan_dev, L.nu,
+                       L.off_ngu, L.off_ptcount, L.off_ptasks, L.maxTP);
+    CTPVAE_LAUNCH_CHECK("rotate_tplan_tasks_kernel (pairs)");
     return CTPVAE_OK;
 }
 

@@ -2182,6 +2182,15 @@ def test_tiled_forward_through_compact_tile_plans(oracle, shape, A, S):
         with _lib.tuned("TILED_SORT", 0):
             assert torch.equal(plan.forward(x), got), (ns, G, "unsorted tasks")
     _lib.tune("*")
+    # round 4 (built, measured equal in time, kept behind a knob): lanes that walk TWO rays back to back -- band u, then band
+    # nq - 1 - u of the same angle -- through their own plan sections
+    with _lib.tuned("TILED_PAIR", 1):
+        pairs = RotatePlan(theta, shape[0], shape[1], True, d)
+        assert pairs._tplan is not None and pairs._tplan.numel() > plan._tplan.numel()
+        for ns in (4, 2, 1):
+            _lib.tune("TILED_NS", ns)
+            assert torch.equal(pairs.forward(x), got), (ns, "paired bands")
+    _lib.tune("*")
     mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
     meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32)).to(d)
     pnm = torch.tensor([1e4], device=d)
