@@ -603,7 +603,7 @@ def main():
     if rank != 0:
         return
     bytes_dir = 4.0 * B * (N * N + A * P)                 # one direction: read once + write once (fp32)
-    fwd_name = ("rotate_fwd_compact_kernel" if plan.compact else "rotate_fwd_planned_kernel") if plan.planned[0] else "rotate_fwd_fast_kernel"
+    fwd_name = plan.forward_kernel_name(B)
     bwd_name = plan.backward_kernel_name(B)
     dom = (fwd_name, t_fwd) if t_fwd >= t_bwd else (bwd_name, t_bwd)
     achieved = bytes_dir / dom[1] / 1e9
@@ -641,7 +641,7 @@ def main():
                               "256 MB Infinity Cache" if args.cold else
                               "cache-warm: ONE resident batch re-projected every step (3.3 MB of objects + 0.7 MB of cotangents "
                               "stay in the Infinity Cache; --cold cycles 96 distinct batches)"),
-                   "forward_plan": "compact (2 bits per row)" if plan.compact else "u16 taps",
+                   "forward_plan": "compact (2 bits per row)" if plan.dense_plan(B)[1] else "u16 taps",
                    "grad_allreduce_bytes_per_step": 4 * 711164 if args.grad_allreduce else 0,
                    "launch": (f"{n_replay} replays of a HIP graph of {chunk} steps + {n_eager} steps launched from Python"
                               if graph is not None else "every step launched from Python")},

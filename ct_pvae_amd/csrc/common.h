@@ -68,7 +68,7 @@ struct SliceScale {
 enum Knob {
     kKnobNoPlan, kKnobForceGeneric, kKnobNs, kKnobG, kKnobWaves, kKnobBns, kKnobBw, kKnobSegNs, kKnobSegChunk,
     kKnobSegPpt, kKnobTiledNs, kKnobTiledG, kKnobSiddonNs, kKnobSiddonThreads, kKnobSiddonPpb, kKnobMaxSlices,
-    kKnobSiddonBwdNs, kKnobSiddonBwdChunks, kKnobNoCompact, kKnobSkew0, kKnobTiledSort, kKnobTiledPair, kKnobCount
+    kKnobSiddonBwdNs, kKnobSiddonBwdChunks, kKnobNoCompact, kKnobSkew0, kKnobTiledSort, kKnobTiledPair, kKnobAffine, kKnobCount
 };
 int knob(Knob k);
 

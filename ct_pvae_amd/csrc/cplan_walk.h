@@ -274,7 +274,7 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
     typedef typename SliceVec<NS>::type vec_t;
     vec_t acc = 0.0f;
     vec_t va[6], vb[6];
-    int an[6];
+    int an[6], nlast = 0;
     int la0 = lane8, la1 = lane8;   // table address registers: byte 0 = (lane & 31) * 8, byte 1 = the code
     LutPair l0 = lut_issue<0>(la0, la1, c0, c1), l1 = lut_issue<1>(la0, la1, c0, c1);
     const LutPair l2 = lut_issue<2>(la0, la1, c0, c1);
@@ -302,10 +302,9 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
         uint4 c2;
         if (more) c2 = pc[(size_t)q * st];
 #define CTPVAE_CSTEP(G, VCUR, VNXT, LNEW, LUSE)                                                    \
-        if (n + G + 1 >= ng) {   /* the task's last group: nothing more to issue (round 4: the gathers of a group */ \
-            CTPVAE_CSWITCH_ACC(n + G)                                                              \
-            _Pragma("unroll") for (int e = 0; e < 6; ++e) acc += VCUR[e];   /* behind the last were a tenth of */ \
-            break;                                                          /* the tile kernel's LDS cycles)   */ \
+        if (n + G + 1 >= ng) {   /* the task's last group: nothing more is issued (round 4: the gathers of a group behind */ \
+            nlast = n + G;   /* the last were a tenth of the tile kernel's LDS cycles); it is added behind the loop, */ \
+            break;           /* out of va (even G) or vb (odd G)                                                      */ \
         }                                                                                          \
         group_gather<NS>(an, VNXT);                        /* group n + G + 1 */             \
         LNEW = lut_issue<G + 3>(la0, la1, c0, c1);        /* table entries of group n + G + 3 */ \
@@ -326,6 +325,17 @@ __device__ __forceinline__ typename SliceVec<NS>::type cwalk(int adr, int ng, in
         n += 8;
         c0 = c1;
         c1 = more ? c2 : uint4{0u, 0u, 0u, 0u};
+    }
+    // The last group, gathered one step ago.  (Added inside the loop's exits instead, these adds were hoisted by hipcc above the
+    // branches -- "both paths begin with them" -- and with that above the steady path's gathers: a wave then waited for a group
+    // before it issued the next, and small launches lost what large ones gained.)
+    CTPVAE_CSWITCH_ACC(nlast)
+    if (nlast & 1) {   // (wave-uniform; no copy of the group into a third buffer: the four-slice kernels have no registers for one)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) acc += vb[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) acc += va[e];
     }
 #undef CTPVAE_CSWITCH_ACC
 #undef CTPVAE_CSWITCH_ADR

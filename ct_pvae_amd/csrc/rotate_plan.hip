@@ -376,16 +376,23 @@ template <int NS, bool EPI, bool SEL>
 __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *__restrict__ img, PlanGeom g, FwdLayout L,
                                                                   const char *__restrict__ plan, int wgs_per_slice,
                                                                   int g_S, float *__restrict__ sino, LogLikEpilogue epi,
-                                                                  const int *__restrict__ sel, int n_sel)
+                                                                  const int *__restrict__ sel, int n_sel, int affine)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
     lds_starts_at_zero(lds);
     // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only).  Slices (slice pairs) are dealt to the 8
     // XCDs so that all workgroups of one slice read it through the same L2: block = (u / 8) * 8 * wgs + wg * 8 + u % 8.
+    // `affine` (round 4; wgs_per_slice a multiple of 8): the ANGLES are dealt to the XCDs instead -- block = u * wgs + wg runs
+    // on XCD wg % 8 and takes the angles ai = gi (mod G) of its class, so an XCD's L2 sees one eighth of the plan, launch after
+    // launch (17 MB of u16 taps at 180 angles: streamed into all eight L2s otherwise), and every unit is staged through all of
+    // them (3.3 MB x 8 at B = 50) -- the smaller stream by far at many angles.
     const int units = (g_S + NS - 1) / NS;
     int u, wg;
-    {
+    if (affine) {
+        u = blockIdx.x / wgs_per_slice;
+        wg = blockIdx.x - u * wgs_per_slice;
+    } else {
         const int per8 = 8 * wgs_per_slice, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
         if ((octet + 1) * 8 <= units) {
             wg = rem >> 3;
@@ -433,7 +440,9 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     } else {
         ncls = clist[0];
     }
-    const int ntask = ncls * L.nJB;
+    // a workgroup's w-th task: round-robin over the class's (bin block, angle) list, or -- affine -- its own angles' blocks
+    const int n_gi = affine ? max(0, (ncls - gi + G - 1) / G) : 0;
+    const int ntask = affine ? n_gi * L.nJB : ncls * L.nJB;
 #ifdef CTPVAE_TUNE_NOIDX
     const size_t st = 0;   // timing only: every group re-reads the first index vector (no index streaming)
 #else
@@ -448,8 +457,9 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     };
     [[maybe_unused]] float epnm = 0.0f, einv = 0.0f;
     if constexpr (EPI) epnm = *epi.pnm, einv = 1.0f / epnm;   // the derivative multiplies by the reciprocal (loglik_math.h)
-    auto prepare = [&](int m) -> Task {
+    auto prepare = [&](int w) -> Task {   // w: the workgroup's own task number
         Task t;
+        const int m = affine ? w : w * G + gi;
         t.valid = m < ntask;
         t.a = t.k = t.j = t.ng = 0;
         t.p = idx;
@@ -457,7 +467,14 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 #pragma unroll
         for (int n = 0; n < NS; ++n) t.em[n] = t.ex[n] = 0.0f;
         if (t.valid) {   // wave-uniform
-            const int jb = m / ncls, ai = m - jb * ncls;
+            int jb, ai;
+            if (affine) {
+                jb = m / n_gi;
+                ai = gi + G * (m - jb * n_gi);
+            } else {
+                jb = m / ncls;
+                ai = m - jb * ncls;
+            }
             if constexpr (SEL) {
 #pragma unroll
                 for (int r = 0; r < kSelRounds; ++r)
@@ -495,7 +512,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
         }
         return t;
     };
-    Task cur = prepare(gi + G * wave);
+    Task cur = prepare(wave);
     int *next_task = reinterpret_cast<int *>(lds + (L.zero + 1) * NS);
     if (threadIdx.x == 0) *next_task = nwaves;
 
@@ -514,7 +531,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     while (cur.valid) {
         int m = 0;
         if (lane == 0) m = atomicAdd(next_task, 1);
-        const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m) * G + gi);
+        const Task nxt = prepare(__builtin_amdgcn_readfirstlane(m));
 
         const int ng = __builtin_amdgcn_readfirstlane(cur.ng);   // wave-uniform: the loop's exits are scalar branches
         const uint4 *p = cur.p;
@@ -525,32 +542,56 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
             vec_t va[8], vb[8];
             gather8(lds, q0, va);
             q0 = p[0];
+            if constexpr (EPI) {   // (the epilogue variants have no registers for the form below: they keep round 3's loop)
+                for (int n = 0;; n += 4) {
+                    gather8(lds, q1, vb);
+                    q1 = p[st];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += va[e];          // group n
+                    if (n + 1 >= ng) break;
+                    gather8(lds, q2, va);
+                    q2 = p[2 * st];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += vb[e];          // group n + 1
+                    if (n + 2 >= ng) break;
+                    gather8(lds, q3, vb);
+                    q3 = p[3 * st];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += va[e];          // group n + 2
+                    if (n + 3 >= ng) break;
+                    gather8(lds, q0, va);
+                    p += 4 * st;
+                    q0 = p[0];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc += vb[e];          // group n + 3
+                    if (n + 4 >= ng) break;
+                }
+            } else {
+            // (round 4: the task's last group issues nothing behind it -- the gathers of a group past the last were ~7 % of the
+            // launch's LDS instructions)
+#define CTPVAE_PSTEP(LAST, QN, VN, VC, LOADNEXT)                                                   \
+                if (LAST >= ng) {   /* VC is the last group: added behind the loop (see cplan_walk.h cwalk) */ \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) vt[e] = VC[e];                    \
+                    break;                                                                         \
+                }                                                                                  \
+                gather8(lds, QN, VN);                                                              \
+                LOADNEXT;                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) acc += VC[e];
+            vec_t vt[8];
             for (int n = 0;; n += 4) {
-                gather8(lds, q1, vb);
-                q1 = p[st];
-                __builtin_amdgcn_sched_barrier(0);
+                CTPVAE_PSTEP(n + 1, q1, vb, va, q1 = p[st])                 // adds group n
+                CTPVAE_PSTEP(n + 2, q2, va, vb, q2 = p[2 * st])             // group n + 1
+                CTPVAE_PSTEP(n + 3, q3, vb, va, q3 = p[3 * st])             // group n + 2
+                CTPVAE_PSTEP(n + 4, q0, va, vb, (p += 4 * st, q0 = p[0]))   // group n + 3
+            }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += va[e];          // group n
-                if (n + 1 >= ng) break;
-                gather8(lds, q2, va);
-                q2 = p[2 * st];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += vb[e];          // group n + 1
-                if (n + 2 >= ng) break;
-                gather8(lds, q3, vb);
-                q3 = p[3 * st];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += va[e];          // group n + 2
-                if (n + 3 >= ng) break;
-                gather8(lds, q0, va);
-                p += 4 * st;
-                q0 = p[0];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc += vb[e];          // group n + 3
-                if (n + 4 >= ng) break;
+            for (int e = 0; e < 8; ++e) acc += vt[e];
+#undef CTPVAE_PSTEP
             }
         }
         if ((unsigned)cur.j < (unsigned)g.PW) {
@@ -991,10 +1032,12 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     // as the model orders them).  Near-ties go to more workgroups (more staging overlaps tasks); every group re-stages
     // the unit, so beyond ~12 groups more workgroups cost more than they buy (B=5: 8.1 us at 12, 13.9 us at 30).
     const bool pairs_fit = (size_t)(L.zero + 1) * 8 + 16 <= (size_t)kMaxLdsBytes && S >= 2;
-    int ns = 1, G = 1;
+    int ns = 1, G = 1, affine = 0;
     {
         const double task_kb = 0.6 * L.NG;   // ~1 KB per row group, ~0.6 NG groups per task (rays aligned at their own first row)
-        double best = 0.0;
+        const double plan_kb = (double)L.bytes * A_run / A / 1024.0;
+        double best = 0.0, best_aff = 0.0;
+        int ns_aff = 1, G_aff = 4;
         for (int cand_ns = 1; cand_ns <= (pairs_fit ? 2 : 1); ++cand_ns) {
             const double fill_kb = (double)g.H * g.W * 4.0 * cand_ns / 1024.0;
             const long long cand_units = (S + cand_ns - 1) / cand_ns;
@@ -1002,7 +1045,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
             // octets); with few units and many angles that fabric traffic, not the CU's own path, is what pairing
             // halves (B=8, A=180: 19 us single, 12 us paired).  In the same KB-per-CU currency, fabric at ~2/3 of
             // the CUs' aggregate rate:
-            const double fabric_kb = 1.5 * ((double)L.bytes * A_run / A / 1024.0) * (double)std::min<long long>(8, cand_units) / 256.0;
+            const double fabric_kb = 1.5 * plan_kb * (double)std::min<long long>(8, cand_units) / 256.0;
             for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
                 const long long wgs = 2ll * cand_units * cand;
                 const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand)) + fabric_kb;
@@ -1012,12 +1055,37 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
                     G = cand;
                 }
             }
+            // angles dealt to the XCDs (round 4; see the kernel): the plan crosses the fabric once in all -- an eighth per XCD,
+            // resident from launch to launch --, every unit eight times.  Task groups in fours: workgroup wg runs on XCD wg % 8.
+            // Measured (tools/time_affine.py, profiles/r04_time_affine.txt): it wins where the plan stream was the bound -- 8 to
+            // 16 units at >= 90 angles (A = 180: B = 16 17.2 -> 10.5 us, B = 32 18.2 -> 14.2) -- and loses from 20 units on (B = 40
+            // 19.5 -> 20.4 us, B = 50 20.3 -> 22.7): an XCD's 4 MB L2 then holds its eighth of the plan (2.1 MB at 180 angles)
+            // plus a 128 KB fill per unit no longer, every workgroup's fill misses it (200 fills from the fabric at once), and
+            // task groups come in fours, which fills 256 CUs worse.
+            const double fabric_aff = 1.5 * (plan_kb / 8.0 + (double)cand_units * fill_kb * 8.0) / 256.0;
+            for (int cand = 4; cand <= 12 && 2 * cand <= std::max(8, T) && cand_units <= 16; cand += 4) {
+                const long long wgs = 2ll * cand_units * cand;
+                const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand)) + fabric_aff;
+                if (best_aff == 0.0 || cost <= best_aff * 1.03) {
+                    best_aff = best_aff == 0.0 ? cost : std::min(best_aff, cost);
+                    ns_aff = cand_ns;
+                    G_aff = cand;
+                }
+            }
+        }
+        // dense launches of plans larger than an XCD's L2 only (knob AFFINE: 0 never, 1 whenever the shape allows)
+        const bool can = !sel_dev && T >= 8 && best_aff > 0.0;
+        if (can && knob(kKnobAffine) != 0 && (knob(kKnobAffine) == 1 || (plan_kb > 3072.0 && best_aff < best))) {
+            affine = 1;
+            ns = ns_aff;
+            G = G_aff;
         }
     }
     if (knob(kKnobNs) >= 0) {
         const int want = knob(kKnobNs) == 2 ? 2 : 1;
         if (want != ns) {   // forced pairing: best G for it
             ns = want;
+            affine = 0;
             const double task_kb = 0.6 * L.NG, fill_kb = (double)g.H * g.W * 4.0 * ns / 1024.0;
             const long long cand_units = (S + ns - 1) / ns;
             double best = 0.0;
@@ -1032,7 +1100,10 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     }
     const size_t shmem = (size_t)(L.zero + 1) * sizeof(float) * ns + 16;   // + the task counter
     const int units = (S + ns - 1) / ns;
-    if (knob(kKnobG) > 0) G = knob(kKnobG);
+    if (knob(kKnobG) > 0) {
+        G = knob(kKnobG);
+        if (G % 4 != 0) affine = 0;
+    }
     // one wave per task of the busiest group, but never fewer than stage the unit in ONE batch of eight 16-byte loads
     // per lane (64 KiB -> 8 waves): a workgroup of 6 waves spends two load round trips on its fill (B=50, G=5:
     // 12.1 us with 6 waves, 8.7 us with 8)
@@ -1045,7 +1116,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel);
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
     };

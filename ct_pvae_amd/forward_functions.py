@@ -172,6 +172,13 @@ class RotatePlan:
     # dense plan, the training call: 7.8 vs 8.9 us), the u16 plan for few angles, where its taps are L2-resident anyway and
     # its shorter per-task prologue wins (B=50 A=20: 7.3 vs 7.65 us).
     COMPACT_MIN_ANGLES = 64
+    # Round 4: "auto" decides PER LAUNCH.  A many-angle plan keeps the compact form for what only it has (host-resident angle
+    # subsets, per-object sums inside the launch) and builds the u16 plan beside it -- on the first dense launch -- because that one
+    # wins the dense shapes of tools/time_compact_shapes.py (profiles/r04_time_compact_shapes.txt: A = 180: B = 50 20.6 vs 21.4 us,
+    # B = 200 73 vs 78; A = 90, B = 400 79 vs 87), since round 4 also between 16 and 32 slices, where its angles are dealt to the
+    # XCDs (A = 180, B = 16: 10.5 vs 12.2 us; the compact plan won that window in round 3: 12.1 vs 17.1).  Batch sizes inside
+    # COMPACT_DENSE_WINDOW (first, last) keep the compact plan for dense launches: empty today.
+    COMPACT_DENSE_WINDOW = (1, 0)
 
     def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True, _tables=None,
                  plan_format="auto"):
@@ -211,6 +218,8 @@ class RotatePlan:
         self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
         self._tile_ws = None
         self._compact = False      # the forward plan is a compact (step-coded) one: ctpvae_rotate_fwd_compact_f32 runs it
+        self._u16_plan = None      # "auto", many angles: the u16 plan of the same geometry for dense launches (built on demand)
+        self._auto_dense_u16 = False
         if use_plan:
             geo = (self.H, self.W, self.PH, self.PW, self.A, self.interp)
             want_compact = plan_format == "compact" or (plan_format == "auto" and self.A >= self.COMPACT_MIN_ANGLES)
@@ -219,6 +228,7 @@ class RotatePlan:
                 self._compact = self._fwd_plan is not None
             if self._fwd_plan is None and self._lib.ctpvae_rotate_plan_supported(*geo, 0):
                 self._fwd_plan = self._build_plan(0)
+            self._auto_dense_u16 = bool(plan_format == "auto" and self._compact and self._lib.ctpvae_rotate_plan_supported(*geo, 0))
             self._want_bwd_plan = bool(self.mode == _lib.BWD_TF_COMPAT and
                                        self._lib.ctpvae_rotate_plan_supported(*geo, 1))
         # slices larger than LDS: the tiled forward walks compact TILE plans when they can be built (csrc/rotate.hip)
@@ -323,6 +333,20 @@ class RotatePlan:
     def compact(self):
         """True if the forward plan is the compact (step-coded) form."""
         return self._compact
+
+    def dense_plan(self, S):
+        """(plan buffer, is_compact) for a DENSE forward launch over S slices (all plan angles, no in-launch sums): the plan
+        format "auto" measured faster at this shape -- see COMPACT_DENSE_WINDOW.  Same bits either way."""
+        if self._auto_dense_u16 and not (self.COMPACT_DENSE_WINDOW[0] <= S <= self.COMPACT_DENSE_WINDOW[1]):
+            if self._u16_plan is None:
+                self._u16_plan = self._build_plan(0)
+            return self._u16_plan, False
+        return self._fwd_plan, self._compact
+
+    def forward_kernel_name(self, S):
+        if self._fwd_plan is None:
+            return "rotate_fwd_fast_kernel"
+        return "rotate_fwd_compact_kernel" if self.dense_plan(S)[1] else "rotate_fwd_planned_kernel"
 
     def _run_compact(self, img_ptr, S, out_ptr, angles_i=None, n=0, mask=None, meas=None, dense=0, pnm=None, eps=0.0,
                      lp_ptr=None, dlp_ptr=None, part_ptr=None, sum_ptr=None):
@@ -516,7 +540,8 @@ class RotatePlan:
             self._check(out, (n, self.PW), "out")
             if out.shape[0] != S:
                 raise ValueError(f"out holds {out.shape[0]} sinograms for {S} slices")
-        if self._compact:
+        fplan, compact = (self._fwd_plan, self._compact) if (angles_i is not None or self._fwd_plan is None) else self.dense_plan(S)
+        if compact:
             rc = self._run_compact(img.data_ptr(), S, out.data_ptr(), angles_i, n if angles_i is not None else 0)
             if rc:
                 _lib.check(rc, "rotate_fwd_compact")
@@ -530,9 +555,9 @@ class RotatePlan:
                 _lib.check(rc, "rotate_fwd_planned_sel")
             return out
         ws = self._tile_workspace(S)
-        if self._fwd_plan is not None:
+        if fplan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
-                                                         self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+                                                         fplan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
         elif ws is not None and self._tplan is not None:
             rc = self._lib.ctpvae_rotate_fwd_tiled_compact_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
                                                                self.px, self.T8.data_ptr(), self.A, self._tplan.data_ptr(),
@@ -581,7 +606,8 @@ class RotatePlan:
                 if out_dlp.shape[0] != S:
                     raise ValueError("out_dlp must hold one sinogram per slice")
         dlp_ptr = out_dlp.data_ptr() if out_dlp is not None else None
-        if self._compact:
+        fplan, compact = (self._fwd_plan, self._compact) if (angles_i is not None or self._fwd_plan is None) else self.dense_plan(S)
+        if compact:
             rc = self._run_compact(img.data_ptr(), S, out.data_ptr(), angles_i, n if angles_i is not None else 0, mask, meas,
                                    1 if dense_inputs else 0, pnm, eps, out_lp.data_ptr(), dlp_ptr)
         elif angles_i is not None:
@@ -590,9 +616,9 @@ class RotatePlan:
                 img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), angles_i.data_ptr(), n,
                 mask.data_ptr(), meas.data_ptr(), 1 if dense_inputs else 0, pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
                 out_lp.data_ptr(), dlp_ptr, _stream_ptr(self._dev_index))
-        elif self._fwd_plan is not None:
+        elif fplan is not None:
             rc = self._lib.ctpvae_rotate_fwd_planned_loglik_f32(
-                img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, self._fwd_plan.data_ptr(), mask.data_ptr(),
+                img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A, fplan.data_ptr(), mask.data_ptr(),
                 meas.data_ptr(), pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(), out_lp.data_ptr(), dlp_ptr,
                 _stream_ptr(self._dev_index))
         elif self._tplan is not None:
@@ -715,11 +741,12 @@ class RotatePlan:
             return None
         S = x4.shape[0]
         out = torch.empty((S, self.A, self.PW, 1), dtype=torch.float32, device=self._tdev)
-        if self._compact:
+        fplan, compact = self.dense_plan(S)
+        if compact:
             rc = self._run_compact(x4.data_ptr(), S, out.data_ptr())
         else:
             rc = self._lib.ctpvae_rotate_fwd_planned_f32(x4.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
-                                                         self._fwd_plan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
+                                                         fplan.data_ptr(), out.data_ptr(), _stream_ptr(self._dev_index))
         if rc:
             _lib.check(rc, "rotate_fwd")
         return out
@@ -751,8 +778,9 @@ class RotatePlan:
             return None
         if self._bwd_plan is None:
             self._bwd_plan = self._build_plan(1)
-        return node.rotate_vae(x4, self._fwd_plan, self._bwd_plan, self.H, self.W, self.PH, self.PW, self.A,
-                               _stream_ptr(self._dev_index), int(self._compact))
+        fplan, compact = self.dense_plan(S)
+        return node.rotate_vae(x4, fplan, self._bwd_plan, self.H, self.W, self.PH, self.PW, self.A,
+                               _stream_ptr(self._dev_index), int(compact))
 
     def loglik_vae_cpp(self, x4, mask, meas, pnm, eps, angles_i):
         """calculate_log_prob_M_given_R through the C++ autograd node (one-launch forward that stores d lp / d sino, scaled

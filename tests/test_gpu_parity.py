@@ -1873,6 +1873,34 @@ def test_compact_plan_subsets_and_likelihood(oracle):
     assert torch.equal(s16, sino) and torch.equal(lp16, lp) and torch.equal(dlp16, dlp)
 
 
+# ---- round 4: the u16 planned forward with its ANGLES dealt to the XCDs ---------------------------------------------------------
+@pytest.mark.parametrize("A,S", [(180, 16), (180, 31), (90, 9), (20, 50), (7, 3)])
+def test_planned_forward_with_angles_dealt_to_the_xcds(oracle, A, S):
+    """Which workgroup walks which (angle, bin block) task is a launch-shape decision: dealing a class's angles to task groups
+    (knob AFFINE = 1: every XCD sees one eighth of the plan) or its task list round-robin (AFFINE = 0) gives the same bits, with
+    and without the likelihood epilogue, odd batches and angle counts below the group count included."""
+    d = dev()
+    rng = np.random.default_rng(A * 100 + S)
+    img = rng.random((S, 128, 128), dtype=np.float32)
+    theta = np.sort(rng.uniform(0, np.pi, A)).astype(np.float32)
+    plan = RotatePlan(theta, 128, 128, True, d, plan_format="u16")
+    x = torch.from_numpy(img).to(d)
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32)).to(d)
+    pnm = torch.tensor([1e4], device=d)
+    res = {}
+    for aff in (0, 1):
+        with _lib.tuned("AFFINE", aff):
+            res[aff] = (plan.forward(x),) + tuple(plan.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True))
+            for G in (4, 8):
+                _lib.tune("G", G)
+                assert torch.equal(plan.forward(x), res[aff][0]), (aff, G)
+            _lib.tune("G")
+    assert all(torch.equal(u, v) for u, v in zip(res[0], res[1]))
+    n = min(S, 3)
+    np.testing.assert_array_equal(to_np(res[1][0][:n]), oracle.rotate_fwd(img[:n], oracle.Geometry(128, 128, True), oT(oracle, theta, plan), 0))
+
+
 # ---- round 3: per-object log-likelihood sums inside the projector launch (SURVEY 8 f1) -------------------------------------
 @pytest.mark.parametrize("fmt,subset", [("compact", True), ("compact", False), ("u16", True), ("u16", False)])
 def test_per_object_loglik_sums_are_the_ordered_sum_of_the_two_step_path(oracle, fmt, subset):

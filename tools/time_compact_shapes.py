@@ -19,8 +19,13 @@ for A in (20, 90, 180):
     theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, A)] if A < 180 else phantoms.dense_theta(180)
     pc = RotatePlan(theta, 128, 128, True, dev, plan_format="compact")
     p16 = RotatePlan(theta, 128, 128, True, dev, plan_format="u16")
-    for B in (1, 2, 5, 10, 25, 50, 100, 200, 400):
+    pa = RotatePlan(theta, 128, 128, True, dev)        # plan_format="auto": decides per launch (RotatePlan.dense_plan)
+    for B in (1, 2, 5, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 100, 200, 400):
         x = torch.rand((B, 128, 128), device=dev)
-        oc, o16 = torch.empty((B, A, pc.PW), device=dev), torch.empty((B, A, pc.PW), device=dev)
-        tc, t16 = t_us(pc, x, oc), t_us(p16, x, o16)
-        print("A=%3d B=%3d  compact %7.2f us   u16 %7.2f us   %s %s" % (A, B, tc, t16, "equal" if torch.equal(oc, o16) else "DIFFER", "<<" if tc < 0.97 * t16 else (">>" if tc > 1.03 * t16 else "")), flush=True)
+        oc, o16, oa = (torch.empty((B, A, pc.PW), device=dev) for _ in range(3))
+        tc, t16, ta = t_us(pc, x, oc), t_us(p16, x, o16), t_us(pa, x, oa)
+        best = min(tc, t16)
+        print("A=%3d B=%3d  compact %7.2f us   u16 %7.2f us   auto %7.2f us = %.3f x best (%s)  %s %s" % (
+            A, B, tc, t16, ta, ta / best, pa.forward_kernel_name(B).replace("rotate_fwd_", "").replace("_kernel", ""),
+            "equal" if torch.equal(oc, o16) and torch.equal(oa, o16) else "DIFFER",
+            "<<" if tc < 0.97 * t16 else (">>" if tc > 1.03 * t16 else "")), flush=True)
