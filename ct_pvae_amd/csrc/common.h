@@ -61,6 +61,31 @@ struct SliceScale {
         }                                                                                                         \
     } while (0)
 
+// Kernels that address LDS by ABSOLUTE byte addresses (rotate_plan.hip, cplan_walk.h) rely on their dynamic LDS starting at
+// address 0, i.e. on having NO static LDS.  That is a property of the code object, knowable on the host: checked once per
+// (kernel instantiation, device) before the first launch -- a kernel that acquired static LDS (another hipcc, a __shared__ in
+// an inlined helper, a profiler's instrumentation) makes the entry point fail with CTPVAE_EHIP and a message, instead of the
+// device-side trap of round 3, which aborted the caller's process.  `seen` as in CTPVAE_SET_MAX_LDS_ONCE; the bit is
+// published only after the check passed.  (Knob FAKE_STATIC_LDS = n adds n bytes to what the runtime reports and forces the
+// check to run on every launch: the tests' stub for the failure path.)
+#define CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, name, seen)                                                           \
+    do {                                                                                                          \
+        int dev_ = 0;                                                                                             \
+        CTPVAE_HIP(hipGetDevice(&dev_));                                                                          \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                      \
+        const int fake_ = ::ctpvae::knob(::ctpvae::kKnobFakeStaticLds);                                            \
+        if (dev_ >= 64 || fake_ > 0 || !((seen).load(std::memory_order_acquire) & bit_)) {                        \
+            hipFuncAttributes fa_;                                                                                \
+            CTPVAE_HIP(hipFuncGetAttributes(&fa_, (const void *)(kernel)));                                       \
+            const long long static_ = (long long)fa_.sharedSizeBytes + (fake_ > 0 ? fake_ : 0);                    \
+            if (static_ != 0)                                                                                     \
+                return ::ctpvae::fail(CTPVAE_EHIP, "%s was built with %lld bytes of static LDS: its gathers address LDS " \
+                                      "absolutely and need the dynamic array at address 0 -- rebuild the library (no "    \
+                                      "__shared__ variables in these kernels)", name, static_);                   \
+            if (dev_ < 64 && fake_ <= 0) (seen).fetch_or(bit_, std::memory_order_release);                        \
+        }                                                                                                         \
+    } while (0)
+
 // Developer knobs (tools/ sweeps and the tests that force one code path against another).  None changes results.
 // They are NOT read from the environment in the launch path: the registry is filled once, when the library is loaded,
 // from CTPVAE_TUNE_<NAME> / CTPVAE_NO_PLAN / CTPVAE_FORCE_GENERIC, and changed afterwards only through
@@ -68,7 +93,7 @@ struct SliceScale {
 enum Knob {
     kKnobNoPlan, kKnobForceGeneric, kKnobNs, kKnobG, kKnobWaves, kKnobBns, kKnobBw, kKnobSegNs, kKnobSegChunk,
     kKnobSegPpt, kKnobTiledNs, kKnobTiledG, kKnobSiddonNs, kKnobSiddonThreads, kKnobSiddonPpb, kKnobMaxSlices,
-    kKnobSiddonBwdNs, kKnobSiddonBwdChunks, kKnobNoCompact, kKnobSkew0, kKnobTiledSort, kKnobTiledPair, kKnobAffine, kKnobCount
+    kKnobSiddonBwdNs, kKnobSiddonBwdChunks, kKnobNoCompact, kKnobSkew0, kKnobTiledSort, kKnobTiledPair, kKnobAffine, kKnobFakeStaticLds, kKnobCount
 };
 int knob(Knob k);
 

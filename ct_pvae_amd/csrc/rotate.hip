@@ -1697,7 +1697,6 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     constexpr bool SORTED = MODE != 0, PAIRED = MODE == 2;
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
-    if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();   // see cplan_walk.h lut_issue
     float *image = lds + kLutBytes / 4;
     const int nt = L.nt, v = blockIdx.y, t = v % nt, s = (v / nt) * NS, A = gfull.A;
     int y0, x0, h, w;
@@ -2020,7 +2019,8 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     };
     // compact tile plans (ctpvae_rotate_tplan_build_f32): the same partial sums without per-sample index arithmetic
     auto launch_compact = [&](auto kernel) -> int {
-        static std::atomic<unsigned long long> attr_set{0};
+        static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};
+        CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_tile_compact_kernel", abs_ok);   // the step table sits at LDS address 0
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         const TLayout TL = t_layout(ts, A);
         hipLaunchKernelGGL(kernel, dim3(2 * G, groups * nt), dim3(64 * waves), t_lds_bytes(TL, A, ns), (hipStream_t)stream, img_dev, g,

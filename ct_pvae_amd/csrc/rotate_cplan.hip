@@ -132,7 +132,6 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
     constexpr bool SEL = SELM != 0;
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
-    if ((unsigned)(size_t)(__attribute__((address_space(3))) float *)lds != 0u) __builtin_trap();   // see lut_issue
     float *image = lds + kLutBytes / 4;   // cell c of slice n: image[c * NS + n]
     const int units = (g_S + NS - 1) / NS;
     int u, wg;
@@ -421,7 +420,8 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
     const int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_compact: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
+        CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_compact_kernel", abs_ok);   // the step table sits at LDS address 0 (lut_issue)
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
                            img_dev, g, L, (const char *)cplan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_idx, selh);

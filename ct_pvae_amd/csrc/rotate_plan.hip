@@ -279,13 +279,10 @@ __device__ __forceinline__ void unpack2(unsigned pk, int &lo4, int &hi4)
         : "v"(pk));
 }
 // The gathers below address LDS by ABSOLUTE byte addresses: these kernels have no static LDS, so their dynamic LDS starts at
-// address 0 (checked once per workgroup, lds_starts_at_zero) and an unpacked tap is the ds_read's address as it stands.  Through
-// the `lds` pointer every tap paid a v_add_u32 of the array's link-time base -- zero -- that the compiler cannot fold: one of
-// the three vector operations per tap of a slice pair.
-__device__ __forceinline__ void lds_starts_at_zero(const float *lds)
-{
-    if ((unsigned)(size_t)(lds_cptr)lds != 0u) __builtin_trap();
-}
+// address 0 and an unpacked tap is the ds_read's address as it stands.  Through the `lds` pointer every tap paid a v_add_u32 of
+// the array's link-time base -- zero -- that the compiler cannot fold: one of the three vector operations per tap of a slice
+// pair.  That the kernel has no static LDS is checked on the HOST, once per kernel and device, before its first launch
+// (CTPVAE_REQUIRE_NO_STATIC_LDS, common.h; round 3 trapped on the device).
 __device__ __forceinline__ float lds_at(const float *, int byte_off) { return *(lds_cptr)(size_t)(unsigned)byte_off; }
 __device__ __forceinline__ void unpack2x8(unsigned pk, int &lo8, int &hi8)
 {
@@ -380,7 +377,6 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
-    lds_starts_at_zero(lds);
     // Workgroups b and b + 8 share an XCD (round-robin dispatch; speed only).  Slices (slice pairs) are dealt to the 8
     // XCDs so that all workgroups of one slice read it through the same L2: block = (u / 8) * 8 * wgs + wg * 8 + u % 8.
     // `affine` (round 4; wgs_per_slice a multiple of 8): the ANGLES are dealt to the XCDs instead -- block = u * wgs + wg runs
@@ -669,7 +665,6 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     typedef typename SliceVec<NS>::type vec_t;
     constexpr int kChunk = kBwdChunk / NS;
     extern __shared__ float lds[];
-    lds_starts_at_zero(lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int tiles = L.nXB * tiles_y;
     const int units = (g_S + NS - 1) / NS;
@@ -856,7 +851,6 @@ __global__ __launch_bounds__(256) void rotate_bwd_planned_sel_kernel(const float
     constexpr int kChunk = kBwdChunk / NS;          // staged rows per pass: row offsets stay ds_read immediates
     constexpr int ROW = kBwdPitch * 4 * NS;         // bytes per staged row
     extern __shared__ float lds[];
-    lds_starts_at_zero(lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int nXB = Wpad >> 6, tiles = nXB * tiles_y;
     const int units = (g_S + NS - 1) / NS;
@@ -1113,7 +1107,8 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     const int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
+        CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
                            img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine);
@@ -1209,7 +1204,8 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     const long long nblk = (long long)units * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
+        static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
+        CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_bwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
                            (const uint4 *)bwd_plan_dev, tiles_y, S, SliceScale{scale_dev, scale_stride}, gimg_dev);
@@ -1297,16 +1293,20 @@ int ctpvae_rotate_bwd_planned_sel_scaled_f32(const float *gsino_dev, int S, int 
         for (int k = 0; k < n_idx; ++k) selh.set(k, std::min(std::max(angle_idx_dev[k], 0), A - 1));
         angle_idx_dev = nullptr;
     }
-    auto launch = [&](auto kernel) {
+    auto launch = [&](auto kernel) -> int {
+        static std::atomic<unsigned long long> abs_ok{0};   // per kernel instantiation: devices checked
+        CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_bwd_planned_sel_kernel", abs_ok);
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, nXB * 64, HQ,
                            (const unsigned *)bwd4_plan_dev, angle_idx_dev, n_idx, tiles_y, S, SliceScale{scale_dev, scale_stride},
                            gimg_dev, selh);
+        return CTPVAE_OK;
     };
-    if (idx_on_host) {
-        if (ns == 2) launch(rotate_bwd_planned_sel_kernel<2, true>); else launch(rotate_bwd_planned_sel_kernel<1, true>);
-    } else {
-        if (ns == 2) launch(rotate_bwd_planned_sel_kernel<2, false>); else launch(rotate_bwd_planned_sel_kernel<1, false>);
-    }
+    int rc;
+    if (idx_on_host)
+        rc = ns == 2 ? launch(rotate_bwd_planned_sel_kernel<2, true>) : launch(rotate_bwd_planned_sel_kernel<1, true>);
+    else
+        rc = ns == 2 ? launch(rotate_bwd_planned_sel_kernel<2, false>) : launch(rotate_bwd_planned_sel_kernel<1, false>);
+    if (rc) return rc;
     CTPVAE_LAUNCH_CHECK("rotate_bwd_planned_sel_kernel");
     return CTPVAE_OK;
 }

@@ -166,3 +166,24 @@ def test_no_kernel_spills_registers():
             if m and int(m.group(1)) > 0:
                 bad.append((src, name, int(m.group(1))))
     assert not bad, f"kernels with scratch (register spills): {bad}"
+
+
+def test_no_device_trap_in_the_projector_kernels():
+    """Round 3 guarded "the dynamic LDS starts at address 0" with __builtin_trap() inside the planned / compact kernels: had it
+    ever fired, the caller's process would have died with a GPU abort.  The guard is a host-side check now
+    (CTPVAE_REQUIRE_NO_STATIC_LDS) and the kernels hold no s_trap."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    csrc = os.path.join(ROOT, "ct_pvae_amd", "csrc")
+    for src, kernels in (("rotate_cplan.hip", ("rotate_fwd_compact_kernel",)),
+                         ("rotate_plan.hip", ("rotate_fwd_planned_kernel", "rotate_bwd_planned_kernel", "rotate_bwd_planned_sel_kernel"))):
+        out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                              "--cuda-device-only", "-S", src, "-o", "-"], cwd=csrc, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        bodies = re.findall(r"^(_ZN6ctpvae\w+):.*?s_endpgm", out.stdout, re.S | re.M)
+        assert bodies
+        for m in re.finditer(r"^(_ZN6ctpvae\w+):(.*?)s_endpgm", out.stdout, re.S | re.M):
+            if any(k in m.group(1) for k in kernels):
+                assert "s_trap" not in m.group(2), m.group(1)

@@ -1873,6 +1873,35 @@ def test_compact_plan_subsets_and_likelihood(oracle):
     assert torch.equal(s16, sino) and torch.equal(lp16, lp) and torch.equal(dlp16, dlp)
 
 
+# ---- round 4: the absolute-LDS-address guard is a host-side error, not a device trap ------------------------------------------
+def test_static_lds_in_an_absolute_addressing_kernel_is_a_host_error():
+    """The planned / compact kernels address LDS absolutely and need their dynamic array at address 0, i.e. NO static LDS.  The
+    library checks the code object's static LDS size on the host before a kernel's first launch (hipFuncGetAttributes); the knob
+    FAKE_STATIC_LDS stubs a non-zero answer: every such entry point then fails with a message through ctpvae_last_error() --
+    nothing is launched, nothing aborts -- and works again once the stub is gone."""
+    d = dev()
+    rng = np.random.default_rng(2)
+    theta = phantoms.dense_theta(180)[::9]
+    x = torch.from_numpy(rng.random((4, 128, 128), dtype=np.float32)).to(d)
+    plans = {fmt: RotatePlan(theta, 128, 128, True, d, plan_format=fmt) for fmt in ("u16", "compact")}
+    ref = {fmt: p.forward(x) for fmt, p in plans.items()}
+    g = torch.from_numpy(rng.standard_normal((4, 20, 184)).astype(np.float32)).to(d)
+    gref = plans["u16"].backward(g)
+    sub = torch.from_numpy(np.array([3, 1, 7], np.int32))
+    gsub = plans["u16"].backward(g[:, :3].contiguous(), angles_i=sub)
+    big = RotatePlan(np.pi * np.arange(6) / 6, 300, 260, True, d)
+    xb = torch.from_numpy(rng.random((2, 300, 260), dtype=np.float32)).to(d)
+    bref = big.forward(xb)
+    with _lib.tuned("FAKE_STATIC_LDS", 16):
+        for call in (lambda: plans["u16"].forward(x), lambda: plans["compact"].forward(x), lambda: plans["u16"].backward(g),
+                     lambda: plans["u16"].backward(g[:, :3].contiguous(), angles_i=sub), lambda: big.forward(xb)):
+            with pytest.raises(_lib.RadonLibraryError, match="static LDS"):
+                call()
+    assert torch.equal(plans["u16"].forward(x), ref["u16"]) and torch.equal(plans["compact"].forward(x), ref["compact"])
+    assert torch.equal(plans["u16"].backward(g), gref) and torch.equal(big.forward(xb), bref)
+    assert torch.equal(plans["u16"].backward(g[:, :3].contiguous(), angles_i=sub), gsub)
+
+
 # ---- round 4: the u16 planned forward with its ANGLES dealt to the XCDs ---------------------------------------------------------
 @pytest.mark.parametrize("A,S", [(180, 16), (180, 31), (90, 9), (20, 50), (7, 3)])
 def test_planned_forward_with_angles_dealt_to_the_xcds(oracle, A, S):
@@ -2269,3 +2298,137 @@ def test_round3_operators_against_golden(golden_dir):
     for part, key in ((0, "s_sums_bands"), (1, "s_sums_blocks")):
         assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), lp.shape[0], lp.shape[1], lp.shape[2], part, out.data_ptr(), None) == 0
         np.testing.assert_array_equal(to_np(out), z[key])
+
+
+# ---- round 4: the dispatch matrix, enumerated ------------------------------------------------------------------------------------
+def _matrix_variants(tiled):
+    """(forward format, subset kind, epilogue / node, backward path) -- every combination the host code can reach for a geometry"""
+    fmts = ("tile_plan", "tile_direct") if tiled else ("u16", "compact")
+    out = []
+    for fmt in fmts:
+        for sel in ("dense", "device", "host"):
+            for epi in ("plain", "lp_py", "lp_cpp", "sums"):
+                if tiled and epi == "lp_cpp":
+                    continue                       # the C++ node serves planned geometries only
+                bwds = ("stepped", "segment") if tiled else (("planned", "stepped", "segment") if sel == "dense" else ("bwd4", "seg_sel"))
+                for bwd in bwds:
+                    out.append((fmt, sel, epi, bwd))
+    return out
+
+
+@pytest.mark.parametrize("shape,A,S", [((120, 140), 11, 5), ((512, 512), 5, 3)])
+def test_dispatch_matrix_against_the_oracle(oracle, torch_node, shape, A, S):
+    """Every reachable (forward plan format x angle-subset kind x epilogue x autograd node x backward path) combination of the
+    nearest / tf_compat operator pair on one geometry that fits LDS and one that does not, each forced explicitly, against the
+    oracle: ray-sums bit for bit, log-probabilities <= 1e-5, per-object sums = the oracle's ordered sum of the kernel's
+    log-probabilities, image gradients = (per-object weight) x the oracle's back-projection of the kernel's d lp / d ray-sum, bit
+    for bit -- and therefore all combinations equal to each other.  (Round 3's two dispatch bugs -- a plan of the wrong layout
+    handed to the C++ likelihood node in step-plan mode; a step plan overflowing near 90 degrees -- were found by random soaks;
+    this is the test that would have failed.)"""
+    from ct_pvae_amd import helper_functions as hf
+    from ct_pvae_amd.forward_functions import _RotateProject, _LAYOUT_VAE
+    d = dev()
+    H, W = shape
+    tiled = H * W > 200 * 200
+    rng = np.random.default_rng(H + A)
+    img = rng.random((S, H, W), dtype=np.float32)
+    theta = np.sort(rng.uniform(0.0, np.pi, A)).astype(np.float32)
+    theta[0] = 0.0
+    n_sub = 4
+    sub = np.array([A - 1, 2, 0, 2][:n_sub], np.int32)               # any order, a repeat
+    geom = oracle.Geometry(H, W, True)
+    mk = {"u16": dict(plan_format="u16"), "compact": dict(plan_format="compact"), "tile_plan": {}, "tile_direct": dict(plan_format="u16")}
+    x0 = torch.from_numpy(img[..., None]).to(d)
+    pnm, eps = torch.tensor([1e4], device=d), 1.2e-7
+    w = torch.from_numpy(rng.uniform(0.5, 2.0, S).astype(np.float32)).to(d)
+    ref = {}
+
+    def oracle_for(sel, plan):
+        key = sel is not None
+        if key not in ref:
+            T = oT(oracle, theta, plan)
+            Ts = T if sel is None else T[sub]
+            sino = (oracle.rotate_fwd_tiled(img, geom, Ts, tile=(96, 64)) if tiled else oracle.rotate_fwd(img, geom, Ts, 0))
+            n = Ts.shape[0]
+            mask = rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)
+            meas = rng.random((S, A, plan.PW), dtype=np.float32) * 3
+            g = rng.standard_normal((S, n, plan.PW)).astype(np.float32)
+            msub, xsub = (mask, meas) if sel is None else (mask[:, sub], meas[:, sub])
+            lp = oracle.loglik(sino, msub, xsub, 1e4, eps)
+            Tinv = oTinv(oracle, theta, plan)
+            Tinv = Tinv if sel is None else Tinv[sub]
+            ref[key] = dict(sino=sino, lp=lp, mask=mask, meas=meas, g=g, Tinv=Tinv,
+                            gimg_plain=oracle.rotate_bwd_tfcompat(g, geom, Tinv, 0))
+        return ref[key]
+
+    seen = set()
+    for fmt, selk, epi, bwd in _matrix_variants(tiled):
+        _lib.tune("*")
+        plan = RotatePlan(theta, H, W, True, d, **mk[fmt])
+        if tiled:
+            assert plan.tiled and (plan._tplan is not None) == (fmt == "tile_plan")
+        else:
+            assert plan.planned[0] and plan.compact == (fmt == "compact")
+        sel = None if selk == "dense" else (torch.from_numpy(sub).to(d) if selk == "device" else torch.from_numpy(sub))
+        R = oracle_for(sel, plan)
+        # force the backward path
+        if bwd == "planned":
+            plan.backward_uses_step_plan, plan.backward_uses_plan = (lambda S_: False), (lambda S_: True)
+        elif bwd == "stepped":
+            assert plan._step_plan is not None
+            plan.backward_uses_step_plan, plan.backward_uses_plan = (lambda S_: True), (lambda S_: False)
+        elif bwd == "segment":
+            plan._step_plan = None
+            plan.backward_uses_step_plan, plan.backward_uses_plan = (lambda S_: False), (lambda S_: False)
+        elif bwd == "seg_sel":
+            plan._want_bwd4, plan._bwd4_plan = False, None
+        elif bwd == "bwd4":
+            assert plan._get_bwd4_plan() is not None
+        tag = (fmt, selk, epi, bwd)
+        mask, meas = torch.from_numpy(R["mask"]).to(d), torch.from_numpy(R["meas"]).to(d)
+        run_plan, run_sel, run_mask, run_meas = plan, sel, mask, meas
+        if sel is not None and tiled:            # what calculate_log_prob_M_given_R does for a tiled geometry: gather, subset()
+            idx = torch.from_numpy(sub).to(d).long()
+            run_plan, run_sel = plan.subset(sel), None
+            run_mask, run_meas = mask.index_select(1, idx).contiguous(), meas.index_select(1, idx).contiguous()
+            if bwd == "segment":
+                run_plan._step_plan = None
+        x = x0.clone().requires_grad_(True)
+        if epi == "plain":
+            g = torch.from_numpy(R["g"]).to(d)
+            if sel is None:
+                out = plan.project_vae_cpp(x) if bwd == "planned" else None          # the C++ node (planned backward only) ...
+                node = "cpp" if out is not None else "py"
+                if out is None:
+                    out = _RotateProject.apply(x, plan, _LAYOUT_VAE)                  # ... else the Python node
+                out.backward(g[..., None])
+                sino, gimg = out.detach()[..., 0], x.grad[..., 0]
+            else:
+                node = "raw"
+                sino = run_plan.forward(x0[..., 0], angles_i=run_sel)
+                gimg = run_plan.backward(g, angles_i=run_sel)
+            np.testing.assert_array_equal(to_np(sino), R["sino"], err_msg=str(tag))
+            np.testing.assert_array_equal(to_np(gimg), R["gimg_plain"], err_msg=str(tag))
+            seen.add(tag + (node,))
+            continue
+        # the kernel's own d lp / d ray-sum (the backward's operand) from the raw call of THIS plan: the gradient reference
+        _, lp_k, dlp_k = run_plan.forward_loglik(x0[..., 0], run_mask, run_meas, pnm, eps, with_dlp=True, angles_i=run_sel,
+                                                 dense_inputs=run_sel is not None)
+        assert rel_err(to_np(lp_k), R["lp"]) <= REL, tag
+        want_g = to_np(w)[:, None, None] * oracle.rotate_bwd_tfcompat(to_np(dlp_k), geom, R["Tinv"], 0)
+        if epi == "sums":
+            sums = hf._ProjectLogLikSums.apply(x, run_plan, run_mask, run_meas, pnm, eps, run_sel)
+            np.testing.assert_array_equal(to_np(sums), oracle.loglik_object_sums(to_np(lp_k), 1 if tiled else 0), err_msg=str(tag))
+            (sums * w).sum().backward()
+        else:
+            if epi == "lp_cpp":
+                lp4 = run_plan.loglik_vae_cpp(x, run_mask, run_meas, pnm, eps, run_sel)
+                assert lp4 is not None, tag
+            else:
+                lp4 = hf._ProjectLogLik.apply(x, run_plan, run_mask, run_meas, pnm, eps, run_sel)
+            assert torch.equal(lp4.detach()[..., 0], lp_k), tag
+            (lp4.sum(dim=(1, 2, 3)) * w).sum().backward()                            # per-object weights: the scaled backward
+        np.testing.assert_array_equal(to_np(x.grad[..., 0]), want_g.astype(np.float32), err_msg=str(tag))
+        seen.add(tag)
+    _lib.tune("*")
+    assert len(seen) >= len(_matrix_variants(tiled))
