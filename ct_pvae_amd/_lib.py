@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
-ABI_VERSION = 3200   # ctpvae_abi_version() of the library this binding was written for
+ABI_VERSION = 3300   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -39,6 +39,7 @@ SIGNATURES = {
     "ctpvae_rotate_fwd_compact_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _vp,
                                                _vp, _c_int, _vp, _c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctpvae_loglik_tasks_per_row": (_c_int, [_c_int, _c_int]),
+    "ctpvae_loglik_part_floats": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
     "ctpvae_loglik_object_sums_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     "ctpvae_rotate_bwd_sel_scaled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int,
                                                   _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
@@ -164,8 +165,9 @@ def build_torch_node(verbose=False):
             spec = importlib.util.spec_from_file_location(NODE_NAME, NODE_PATH)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            return mod
-        except (ImportError, OSError):
+            if mod.compiled_abi() == ABI_VERSION:   # (file times do not survive a copy of the tree: the ABI it was built for does)
+                return mod
+        except (ImportError, OSError, AttributeError):
             pass
     tmp = tempfile.mkdtemp(prefix=".build-", dir=os.path.dirname(NODE_DIR))
     try:

@@ -113,6 +113,14 @@ int ctpvae_loglik_tasks_per_row(int PW, int partition)
     return partition == 0 ? num_bin_blocks(PW) : ceil_div(PW, 64);
 }
 
+long long ctpvae_loglik_part_floats(int S, int n_angles, int PW, int partition)
+{
+    if (S <= 0 || n_angles <= 0 || PW <= 0 || (partition != 0 && partition != 1))
+        return fail(CTPVAE_EINVAL, "loglik_part_floats: bad arguments");
+    const int tpr = partition == 0 ? num_bin_blocks(PW) : ceil_div(PW, 64);
+    return (long long)S * n_angles * tpr + S;   // the partial sums, then one arrival counter per slice
+}
+
 int ctpvae_loglik_object_sums_f32(const float *lp_dev, int S, int A, int PW, int partition, float *out_dev,
                                   ctpvae_stream_t stream)
 {

@@ -70,6 +70,19 @@ struct LogLikEpilogue {
     // the xor butterfly 32, 16, 8, 4, 2, 1; lanes without a bin add +0.0f) and lp / the ray-sum store become optional; a
     // second, tiny launch adds a slice's partials in the fixed order of object_sum_of_parts below.
     float *part = nullptr;
+    // round 4 (knob FOLD_SUMS = 1; measured slower than the second launch, so not the default): the ordered sum of a slice's
+    // partials happens INSIDE the launch -- the workgroup that finishes a slice (pair / group)
+    // last, told by an arrival counter, reads the partials back and adds them in object_sum_of_parts' order (fixed by the
+    // reader, not by arrival: the same bits as the separate loglik_sum_partials_kernel launch of round 3).  sum [S]; arrive: one
+    // zero-initialised counter per unit, left zero again.  Partials cross workgroups (and XCDs) inside one launch, so they are
+    // stored and re-read at agent scope (sc1) behind the arrival add -- MI355X_MICROARCH.md's counter hand-off, no L2 fence.
+    float *sum = nullptr;
+    unsigned *arrive = nullptr;
+    __device__ __forceinline__ void store_part(size_t i, float v) const
+    {
+        if (sum != nullptr) __hip_atomic_store(part + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else part[i] = v;   // read by the next launch: a plain store
+    }
 
     // o: offset of the ray-sum in the outputs; om / sa: offsets of its measured sample and its mask entry
     __device__ __forceinline__ void write(size_t o, size_t om, size_t sa, float raysum) const
@@ -117,8 +130,14 @@ __device__ __forceinline__ float wave_sum(float v)
 //   total = ((0 + B_0) + B_1) + ...,  B_g = wave_sum over lanes l of S_(64 g + l)  (angles past A add +0.0f)
 // -- every level is either a short sequential sum or the xor butterfly, so a wave computes it in a few hundred cycles whatever
 // A is (a plain ascending sum over all A * tpr task sums took 40 us at 90 angles x 12 tasks: 1080 dependent adds).
+// (AGENT: the partials were stored by other workgroups of this launch -- agent-scope loads, see LogLikEpilogue::store_part)
+template <bool AGENT = false>
 __device__ __forceinline__ float object_sum_of_parts(const float *__restrict__ part, int A, int tpr, int lane)
 {
+    auto ld = [](const float *q) -> float {
+        if constexpr (AGENT) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else return *q;
+    };
     float total = 0.0f;
     for (int a0 = 0; a0 < A; a0 += 64) {
         const int a = a0 + lane;
@@ -127,7 +146,7 @@ __device__ __forceinline__ float object_sum_of_parts(const float *__restrict__ p
             for (int k = 0; k < tpr; k += 4) {   // four loads in flight, added in order (one at a time: tpr round trips)
                 const float *p = part + (size_t)a * tpr + k;
                 const int n = tpr - k;
-                const float v0 = p[0], v1 = p[n > 1 ? 1 : 0], v2 = p[n > 2 ? 2 : 0], v3 = p[n > 3 ? 3 : 0];
+                const float v0 = ld(p), v1 = ld(p + (n > 1 ? 1 : 0)), v2 = ld(p + (n > 2 ? 2 : 0)), v3 = ld(p + (n > 3 ? 3 : 0));
                 sa += v0;
                 if (n > 1) sa += v1;
                 if (n > 2) sa += v2;
@@ -137,6 +156,23 @@ __device__ __forceinline__ float object_sum_of_parts(const float *__restrict__ p
     }
     return total;
 }
+// The arrival step of the in-launch sum: every wave has waited for its own partial stores, the workgroup meets, one lane adds to
+// the unit's counter; true (for the whole workgroup) if this workgroup's add was the last of `expected` -- it may then read every
+// partial of the unit at agent scope.  The counter is reset for the next launch.  `flag`: an LDS word of the workgroup.
+__device__ __forceinline__ bool arrived_last(unsigned *counter, unsigned expected, volatile int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old + 1u == expected;
+        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 // lp_sum[s] of the partial sums a fused epilogue wrote (LogLikEpilogue::part): one wave per slice
 [[maybe_unused]] static __global__ __launch_bounds__(64) void loglik_sum_partials_kernel(const float *__restrict__ part, int S, int A,
                                                                                        int tpr, float *__restrict__ out)

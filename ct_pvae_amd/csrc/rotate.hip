@@ -636,9 +636,8 @@ constexpr int kReduceSlices = 8;
 // are REDUCED -- one partial sum per (slice, angle, 64-bin block) into epi.part (LogLikEpilogue; partition 1 of
 // ctpvae_loglik_object_sums_f32), d lp / d ray-sum stored, ray-sums and log-probabilities only where buffers were given.
 template <int EPI>
-__global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
-                                                                  const float *__restrict__ T8, float *__restrict__ sino,
-                                                                  LogLikEpilogue epi)
+__device__ __forceinline__ void tile_reduce_wave(const float *__restrict__ partial, const RotGeom &g, const TileSpec &ts,
+                                                 const float *__restrict__ T8, float *__restrict__ sino, const LogLikEpilogue &epi)
 {
     __shared__ int list_tile[16][64], list_first[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -730,7 +729,7 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
                     lpv = epi.eval_loaded(o, em[q], ex[q], epnm, einv, acc[q]);
                 }
                 const float tot = wave_sum(lpv);
-                if (lane == 0) epi.part[((size_t)s * g.A + a) * tpr + (j0 >> 6)] = tot;
+                if (lane == 0) epi.store_part(((size_t)s * g.A + a) * tpr + (j0 >> 6), tot);
             }
         }
         return;
@@ -743,6 +742,29 @@ __global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *_
             const size_t o = ((size_t)s * g.A + a) * g.PW + j;
             sino[o] = acc[q];
             if constexpr (EPI == 1) epi.write_loaded(o, em[q], ex[q], epnm, einv, acc[q]);
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(1024) void rotate_tile_reduce_kernel(const float *__restrict__ partial, RotGeom g, TileSpec ts,
+                                                                  const float *__restrict__ T8, float *__restrict__ sino,
+                                                                  LogLikEpilogue epi)
+{
+    tile_reduce_wave<EPI>(partial, g, ts, T8, sino, epi);
+    if constexpr (EPI == 2) {
+        // round 4: the workgroup that finishes a group of kReduceSlices slices last (all angles, all bin blocks) adds their
+        // partials in the fixed order -- no loglik_sum_partials_kernel launch behind the pass
+        __shared__ int last_flag;
+        if (epi.sum != nullptr && arrived_last(epi.arrive + blockIdx.z * kReduceSlices, gridDim.x * gridDim.y, &last_flag)) {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, tpr = (g.PW + 63) >> 6;
+            for (int q = wave; q < kReduceSlices; q += nwaves) {
+                const int sl = blockIdx.z * kReduceSlices + q;
+                if (sl < g.S) {
+                    const float total = object_sum_of_parts<true>(epi.part + (size_t)sl * g.A * tpr, g.A, tpr, lane);
+                    if (lane == 0) epi.sum[sl] = total;
+                }
+            }
         }
     }
 }
@@ -1977,6 +1999,7 @@ static int launch_fwd_tiled(const float *img_dev, int S, int H, int W, int PH, i
             if (e.lp) e.lp += (size_t)s0 * A * PW;
             if (e.dlp) e.dlp += (size_t)s0 * A * PW;
             if (e.part) e.part += (size_t)s0 * A * ((PW + 63) >> 6);
+            if (e.sum) e.sum += s0, e.arrive += s0;
         }
         return launch_fwd_tiled_one(img_dev + (size_t)s0 * H * W, n, H, W, PH, PW, py, px, T8_dev, A, workspace_dev,
                                     sino_dev ? sino_dev + (size_t)s0 * A * PW : nullptr, e, stream, tplan_dev);
@@ -2143,10 +2166,15 @@ int ctpvae_rotate_fwd_tiled_compact_f32(const float *img_dev, int S, int H, int 
     CTPVAE_REQUIRE(!lik || (mask_dev && meas_dev && pnm_dev), "rotate_fwd_tiled_compact: the likelihood epilogue needs mask, meas and pnm");
     CTPVAE_REQUIRE(lik || dlp_dev == nullptr, "rotate_fwd_tiled_compact: dlp without lp");
     CTPVAE_REQUIRE(!red || lp_part_dev, "rotate_fwd_tiled_compact: per-object sums need the partial-sum workspace");
-    const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, 0, red ? lp_part_dev : nullptr}
-                                   : LogLikEpilogue{};
+    LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, 0, red ? lp_part_dev : nullptr}
+                             : LogLikEpilogue{};
+    const bool fold = red && knob(kKnobFoldSums) == 1;   // round 4 (measured negative, see ctpvae_rotate_fwd_compact_f32): the reduce pass's last workgroup per slice group adds the partials
+    if (fold) {
+        epi.sum = lp_sum_dev;
+        epi.arrive = reinterpret_cast<unsigned *>(lp_part_dev + (size_t)S * A * ((PW + 63) >> 6));   // ctpvae_loglik_part_floats
+    }
     if (int rc = launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev, epi, stream, tplan_dev)) return rc;
-    if (red) {   // a slice's partials (angle, 64-bin block) in ascending order: ctpvae_loglik_object_sums_f32, partition 1
+    if (red && !fold) {   // a slice's partials (angle, 64-bin block) in ascending order: ctpvae_loglik_object_sums_f32, partition 1
         hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S, A, (PW + 63) >> 6,
                            lp_sum_dev);
         CTPVAE_LAUNCH_CHECK("loglik_sum_partials_kernel");

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
                     lpv = epi.eval_loaded(o, cur.em[n], cur.ex[n], epnm, einv, v);
                 }
                 const float tot = wave_sum(lpv);
-                if (lane == 0) epi.part[((size_t)sl * A_out + cur.k) * L.nJB + cur.jb] = tot;
+                if (lane == 0) epi.store_part(((size_t)sl * A_out + cur.k) * L.nJB + cur.jb, tot);
             };
             if constexpr (NS == 1) {
                 reduce(0, acc);
@@ -300,6 +300,15 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
             }
         }
         cur = nxt;
+    }
+    if constexpr (EPI == 2) {
+        // round 4: the workgroup that finishes this unit last adds its slices' partials in the fixed order -- no second launch
+        if (epi.sum != nullptr && arrived_last(epi.arrive + u, (unsigned)wgs_per_slice, next_task + 1)) {
+            if (wave < NS && s + wave < g_S) {
+                const float total = object_sum_of_parts<true>(epi.part + (size_t)(s + wave) * A_out * L.nJB, A_out, L.nJB, lane);
+                if (lane == 0) epi.sum[s + wave] = total;
+            }
+        }
     }
 }
 
@@ -357,6 +366,13 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
 {
     const int *angle_idx_dev = angle_idx;
     const bool red = lp_sum_dev != nullptr;
+    // round 4, built and measured NEGATIVE (tools/time_fold.py, profiles/r04_time_fold.txt): with the knob FOLD_SUMS = 1 the
+    // ordered sum of a slice's partials happens inside this launch -- the partials' workspace ends with one arrival counter per
+    // slice (ctpvae_loglik_part_floats), zero before its first use and left zero by every launch; the workgroup that finishes a
+    // unit last re-reads the partials at agent scope and adds them.  Same bits, one launch less -- and 0.3 us MORE per training
+    // call (10.7 vs 10.4 us), 2 us more on config 5: the arrival add and the re-read are two fabric round trips on the last
+    // workgroup's critical path, a dependent launch in a stream costs less.  Default: round 3's loglik_sum_partials_kernel launch.
+    const bool fold = red && knob(kKnobFoldSums) == 1;
     CTPVAE_REQUIRE(img_dev && cplan_dev && (sino_dev || red), "rotate_fwd_compact: null pointer");
     CTPVAE_REQUIRE(!red || lp_part_dev, "rotate_fwd_compact: per-object sums need the partial-sum workspace");
     CTPVAE_REQUIRE(S > 0, "rotate_fwd_compact: need at least one slice");
@@ -377,10 +393,14 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
         for (int k = 0; k < n_idx; ++k) selh.set(k, std::min(std::max(sel_dev[k], 0), A - 1));
         sel_dev = nullptr;
     }
-    const LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0,
-                                                    red ? lp_part_dev : nullptr}
-                                   : LogLikEpilogue{};
     const int A_run = selm != 0 ? n_idx : A;    // angles this launch projects
+    LogLikEpilogue epi = lik ? LogLikEpilogue{mask_dev, meas_dev, pnm_dev, eps, lp_dev, dlp_dev, dense_inputs ? 1 : 0,
+                                              red ? lp_part_dev : nullptr}
+                             : LogLikEpilogue{};
+    if (fold) {
+        epi.sum = lp_sum_dev;
+        epi.arrive = reinterpret_cast<unsigned *>(lp_part_dev + (size_t)S * A_run * L.nJB);
+    }
     const int T = A_run * L.nJB;                // (angle, bin block) tasks per slice
     // Launch shape.  With 0.25 B of plan per sample the index stream no longer counts; what a workgroup costs is the fill of
     // its unit (a slice, or a pair of slices interleaved as float2) and its tasks, which are bound by the CU's LDS pipe when
@@ -440,6 +460,7 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
     };
     if (red) {
         if (int rc = by_ns(std::integral_constant<int, 2>{})) return rc;
+        if (fold) return CTPVAE_OK;
         hipLaunchKernelGGL(loglik_sum_partials_kernel, dim3(S), dim3(64), 0, (hipStream_t)stream, lp_part_dev, S,
                            A_run, L.nJB, lp_sum_dev);
         CTPVAE_LAUNCH_CHECK("loglik_sum_partials_kernel");

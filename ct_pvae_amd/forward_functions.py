@@ -218,6 +218,7 @@ class RotatePlan:
         self._use_tiles = bool(use_plan)   # slices larger than LDS: tiled forward (workspace grown on demand)
         self._tile_ws = None
         self._compact = False      # the forward plan is a compact (step-coded) one: ctpvae_rotate_fwd_compact_f32 runs it
+        self._part_ws = {}         # forward_loglik_sums: partial sums + arrival counters per (slices, angles, partition)
         self._u16_plan = None      # "auto", many angles: the u16 plan of the same geometry for dense launches (built on demand)
         self._auto_dense_u16 = False
         if use_plan:
@@ -380,8 +381,7 @@ class RotatePlan:
                 if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
                     raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
                 dlp = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=self._tdev) if with_dlp else None
-                tpr = self._lib.ctpvae_loglik_tasks_per_row(self.PW, 1)
-                part = torch.empty((S * self.A * tpr,), dtype=torch.float32, device=self._tdev)
+                part = self._part_workspace(S, self.A, 1)
                 rc = self._lib.ctpvae_rotate_fwd_tiled_compact_f32(
                     img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,
                     self._tplan.data_ptr() if self._tplan is not None else None, ws.data_ptr(), mask.data_ptr(), meas.data_ptr(),
@@ -407,14 +407,26 @@ class RotatePlan:
             if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
                 raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
             dlp = torch.empty((S, n, self.PW), dtype=torch.float32, device=self._tdev) if with_dlp else None
-            tpr = self._lib.ctpvae_loglik_tasks_per_row(self.PW, 0)
-            part = torch.empty((S * n * tpr,), dtype=torch.float32, device=self._tdev)
+            part = self._part_workspace(S, n, 0)
             rc = self._run_compact(img.data_ptr(), S, None, angles_i, n if angles_i is not None else 0, mask, meas,
                                    1 if dense_inputs else 0, pnm, eps, None, dlp.data_ptr() if dlp is not None else None,
                                    part.data_ptr(), sums.data_ptr())
             if rc:
                 _lib.check(rc, "rotate_fwd_compact")
             return sums, dlp
+
+    def _part_workspace(self, S, n, partition):
+        """The partial sums + arrival counters of forward_loglik_sums (ctpvae_loglik_part_floats): kept per (S, n) -- the counters
+        are zeroed once, here, and every launch leaves them zero -- and used by one launch at a time (this plan's launches go to
+        one stream, like its tile workspace)."""
+        ws = self._part_ws.get((S, n, partition))
+        if ws is None:
+            nfl = self._lib.ctpvae_loglik_part_floats(S, n, self.PW, partition)
+            _lib.check(nfl, "loglik_part_floats")
+            if len(self._part_ws) >= 8:
+                self._part_ws.clear()
+            ws = self._part_ws[(S, n, partition)] = torch.zeros((int(nfl),), dtype=torch.float32, device=self._tdev)
+        return ws
 
     def _sel_dev(self, angles_i):
         """The subset as a device vector (kernels without a host-index form; torch gathers)."""

@@ -67,7 +67,7 @@ typedef void *ctpvae_stream_t;
 /* Version of this ABI: major * 1000 + minor.  CTPVAE_ABI_VERSION is what THIS header describes: host code compiled against
  * it (csrc/torch_node.cpp, a maintainer's own binding) compares the macro with ctpvae_abi_version() of the library it loaded
  * and refuses a mismatch -- an entry point called with another version's argument list is a silent wrong-argument call. */
-#define CTPVAE_ABI_VERSION 3200
+#define CTPVAE_ABI_VERSION 3300
 int ctpvae_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *ctpvae_last_error(void);
@@ -133,7 +133,7 @@ int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W
  * _bytes: 0 if the slice is not tiled (or compact plans are switched off); _overflowed (SYNCHRONISES): 1 = do not use the plan.
  * tplan_dev NULL: the direct tiled kernel (this is then ctpvae_rotate_fwd_tiled{,_loglik}_f32 with the options below).
  * lp_dev NULL: ray-sums only; else the log-likelihood epilogue in the reduce pass (mask, meas, pnm required; dlp_dev optional).
- * lp_sum_dev [S] (with lp_part_dev: S * A * ctpvae_loglik_tasks_per_row(PW, 1) floats): the per-object log-likelihood sums
+ * lp_sum_dev [S] (with lp_part_dev: ctpvae_loglik_part_floats(S, A, PW, 1) floats, its counters zero): the per-object log-likelihood sums
  * reduced in the reduce pass, as ctpvae_rotate_fwd_compact_f32 does for slices that fit LDS -- the bits of
  * ctpvae_loglik_object_sums_f32(lp, partition 1); sino_dev and lp_dev may then be NULL. */
 long long ctpvae_rotate_tplan_bytes(int H, int W, int PH, int PW, int A);
@@ -216,8 +216,8 @@ int ctpvae_rotate_fwd_planned_loglik_sel_f32(const float *img_dev, int S, int H,
  *   lp_sum_dev     NULL, or [S]: the PER-OBJECT log-likelihood sums the loss takes (ctvae/helper_functions.py:305-312),
  *                  reduced inside the launch: every (angle, 64-bin) task adds its log-probabilities by a
  *                  fixed xor butterfly and writes one partial into lp_part_dev (workspace of
- *                  S * angles * ctpvae_loglik_tasks_per_row(PW, 0) floats), a second tiny launch adds a slice's partials
- *                  in the fixed order stated at ctpvae_loglik_object_sums_f32 -- its bits (partition 0).  sino_dev and lp_dev
+ *                  ctpvae_loglik_part_floats(S, angles, PW, 0) floats, its arrival counters zero), a second tiny launch adds a
+ *                  slice's partials in the fixed order stated at ctpvae_loglik_object_sums_f32 -- its bits (partition 0).  sino_dev and lp_dev
  *                  may then be NULL (nothing but dlp [S][n][PW] and the sums leaves the kernel).
  * _supported: 1 if the slice with its one-cell zero border fits LDS (interp NEAREST).  _overflowed (SYNCHRONISES): 1 if some
  * ray's steps do not fit the code (rows that are not a rotation, a ray still inside the slice at the canvas' last row, a
@@ -389,8 +389,17 @@ int ctpvae_gridrec_f32(const float *data_dev, int dy, int dt, int dx, const void
  * reduce pass's contiguous 64-bin blocks), a task's values are added by the xor butterfly 32, 16, 8, 4, 2, 1 (lanes
  * without a bin add +0.0f); an angle's task sums are added in ascending order (S_a), and the object's sum is
  * ((0 + B_0) + B_1) + ... with B_g = the same butterfly over S_(64 g) .. S_(64 g + 63) (angles past A add +0.0f).
- * _tasks_per_row: tasks per angle. */
+ * _tasks_per_row: tasks per angle.
+ * _part_floats (round 4, ABI 3300): the floats of the `lp_part_dev` workspace the fused per-object sums of
+ * ctpvae_rotate_fwd_compact_f32 (partition 0) / ctpvae_rotate_fwd_tiled_compact_f32 (partition 1) take for S slices and
+ * n_angles projected angles: one partial sum per (slice, angle, task) and, behind them, ONE ARRIVAL COUNTER PER SLICE, which
+ * must be ZERO before the workspace's first use (hipMemset once, when it is allocated); every launch leaves them zero.  The
+ * counters serve the developer knob FOLD_SUMS = 1 (the ordered sum of a slice's partials inside the projector launch, by the
+ * workgroup that finishes the slice last: same bits, one launch less, measured 0.3-2 us SLOWER than the default's second
+ * launch); the default does not touch them.  One workspace serves one launch at a time (launches on ONE
+ * stream, as every other caller-owned workspace of this header). */
 int ctpvae_loglik_tasks_per_row(int PW, int partition);
+long long ctpvae_loglik_part_floats(int S, int n_angles, int PW, int partition);
 int ctpvae_loglik_object_sums_f32(const float *lp_dev, int S, int A, int PW, int partition, float *out_dev,
                                   ctpvae_stream_t stream);
 

@@ -2300,6 +2300,44 @@ def test_round3_operators_against_golden(golden_dir):
         np.testing.assert_array_equal(to_np(out), z[key])
 
 
+# ---- round 4: the ordered sum of the partials inside the projector launch ------------------------------------------------------
+@pytest.mark.parametrize("shape,A,S,sub", [((128, 128), 180, 7, True), ((128, 128), 180, 50, False), ((128, 128), 20, 1, False),
+                                           ((300, 260), 17, 11, False), ((512, 512), 9, 5, False)])
+def test_per_object_sums_inside_the_launch(oracle, shape, A, S, sub):
+    """Knob FOLD_SUMS = 1 (round 4; built, measured slower than the second launch, kept for the record): forward_loglik_sums as
+    ONE projector launch (+ the tiled geometry's reduce pass) -- the workgroup that finishes a slice last adds the slice's
+    partials in the library's fixed order.  The reader fixes the order, so the sums are the bits of the default's second launch
+    and of the oracle's statement of the order; launch after launch (the arrival counters are left zero), for odd batches, angle
+    subsets, and batches cut into chunks."""
+    d = dev()
+    rng = np.random.default_rng(S * 7 + A)
+    H, W = shape
+    img = rng.random((S, H, W), dtype=np.float32)
+    theta = phantoms.dense_theta(180)[:: 180 // A][:A] if A in (20, 180) else np.sort(rng.uniform(0, np.pi, A)).astype(np.float32)
+    plan = RotatePlan(theta, H, W, True, d, plan_format="compact")
+    x = torch.from_numpy(img).to(d)
+    mask = torch.from_numpy(rng.uniform(0.01, 0.1, (S, A)).astype(np.float32)).to(d)
+    meas = torch.from_numpy(rng.random((S, A, plan.PW), dtype=np.float32) * 3).to(d)
+    pnm = torch.tensor([1e4], device=d)
+    ai = torch.from_numpy(rng.permutation(A)[:20].astype(np.int32)) if sub else None       # host-resident subset
+    kw = dict(angles_i=ai, dense_inputs=sub)
+    _, lp, dlp = plan.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True, **kw)
+    want = oracle.loglik_object_sums(to_np(lp), 1 if plan.tiled else 0)
+    two, _ = plan.forward_loglik_sums(x, mask, meas, pnm, 1.2e-7, **kw)            # the default: a second, tiny launch
+    np.testing.assert_array_equal(to_np(two), want)
+    with _lib.tuned("FOLD_SUMS", 1):
+        for rep in range(3):                      # the counters come back to zero
+            sums, dlp2 = plan.forward_loglik_sums(x, mask, meas, pnm, 1.2e-7, **kw)
+            np.testing.assert_array_equal(to_np(sums), want, err_msg=f"launch {rep}")
+            assert torch.equal(dlp2, dlp)
+        if not sub:
+            _lib.tune("MAX_SLICES", 4 if plan.tiled else 3)     # the batch in chunks (tiled: whole slice quads)
+            chunked, _ = plan.forward_loglik_sums(x, mask, meas, pnm, 1.2e-7)
+            np.testing.assert_array_equal(to_np(chunked), want)
+    ws = next(iter(plan._part_ws.values()))
+    assert int(ws[-S:].view(torch.int32).abs().sum()) == 0          # every arrival counter is back at zero
+
+
 # ---- round 4: the dispatch matrix, enumerated ------------------------------------------------------------------------------------
 def _matrix_variants(tiled):
     """(forward format, subset kind, epilogue / node, backward path) -- every combination the host code can reach for a geometry"""
