@@ -10,7 +10,8 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_range", "env_world", "init_from_env", "max_over_ranks", "allreduce_flat_", "gather_object_counts"]
+__all__ = ["shard_range", "env_world", "init_from_env", "max_over_ranks", "allreduce_flat_", "gather_object_counts",
+           "FlatGradBucket"]
 
 
 def shard_range(n_items, rank, world):
@@ -85,3 +86,41 @@ def allreduce_flat_(tensors, average=True):
         t.copy_(flat[off:off + n].view_as(t))
         off += n
     return tensors
+
+
+class FlatGradBucket:
+    """The gradients of a parameter list in ONE resident flat buffer (round 4): `fill(grads)` gathers them with one multi-tensor
+    copy, `allreduce_()` is one collective on that memory -- no torch.cat of ~40 tensors, no per-tensor copy back (what
+    allreduce_flat_ does every step: ~80 small launches around one 2.8 MB all-reduce) --, `views` are the per-parameter 1-D
+    slices (the NaN filter and the per-tensor clip run on them) and `attach(params)` points every p.grad at its slice, so the
+    optimiser reads the reduced, clipped gradients where they already are."""
+
+    def __init__(self, like):
+        like = list(like)
+        if not like:
+            raise ValueError("FlatGradBucket needs at least one tensor")
+        self.shapes = [tuple(t.shape) for t in like]
+        self.numels = [t.numel() for t in like]
+        self.flat = torch.zeros(sum(self.numels), dtype=like[0].dtype, device=like[0].device)
+        self.views = list(self.flat.split(self.numels))
+        self.shaped = [v.view(sh) for v, sh in zip(self.views, self.shapes)]
+
+    def matches(self, tensors):
+        return len(tensors) == len(self.shapes) and all(tuple(t.shape) == sh for t, sh in zip(tensors, self.shapes)) and \
+            tensors[0].device == self.flat.device and tensors[0].dtype == self.flat.dtype
+
+    def fill(self, grads):
+        torch._foreach_copy_(self.shaped, list(grads))
+        return self
+
+    def allreduce_(self, average=True):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if average:
+                self.flat /= dist.get_world_size()
+        return self
+
+    def attach(self, params):
+        for p, v in zip(params, self.shaped):
+            p.grad = v
+        return self

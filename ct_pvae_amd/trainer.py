@@ -324,6 +324,7 @@ class PVAETrainer:
             for p in list(self.enc.parameters()) + list(self.dec.parameters()):
                 torch.distributed.broadcast(p.data, 0)
         self.params = list(self.enc.parameters()) + list(self.dec.parameters())
+        self._bucket = None   # the gradients' resident flat bucket (built on the first step)
         self.pnm = torch.tensor(float(a.pnm), device=device, requires_grad=bool(a.train_pnm))
         # fused: the whole Adam update in one multi-tensor launch on the device (the default foreach form is ~10)
         self.opt = torch.optim.Adam(self.params + ([self.pnm] if a.train_pnm else []), lr=a.lr, eps=a.adam_epsilon,
@@ -423,18 +424,21 @@ class PVAETrainer:
         # (~50 us of hand-off, and the Python backward of the projector node then runs behind the GIL of that thread)
         with torch.autograd.set_multithreading_enabled(False):
             loss.backward()
-        grads = [p.grad for p in self.opt.param_groups[0]["params"] if p.grad is not None]
-        sharding.allreduce_flat_(grads, average=False)                     # ONE bucket, one all-reduce
+        with_grad = [p for p in self.opt.param_groups[0]["params"] if p.grad is not None]
+        grads = [p.grad for p in with_grad]
+        # ONE resident flat bucket (round 4): a multi-tensor copy in, one all-reduce on that memory, the filter and the clip on its
+        # slices, and p.grad pointed at the slices -- no torch.cat, no per-tensor copy back (sharding.FlatGradBucket)
+        if self._bucket is None or not self._bucket.matches(grads):
+            self._bucket = sharding.FlatGradBucket(grads)
+        bucket = self._bucket.fill(grads).allreduce_(average=False)
         # tf.where(is_nan, 0, grad), then tf.clip_by_norm(g, norm) per tensor (ctvae/main_ct_vae.py:482-484) -- in one
         # flat buffer and a handful of multi-tensor launches, with no host round trip (a Python `if norm > clip` per
         # tensor would synchronise 76 times a step)
-        flat = torch.cat([gr.reshape(-1) for gr in grads])
-        torch.nan_to_num_(flat, nan=0.0)
-        views = list(flat.split([gr.numel() for gr in grads]))
-        norms = torch.stack(torch._foreach_norm(views))
+        torch.nan_to_num_(bucket.flat, nan=0.0)
+        norms = torch.stack(torch._foreach_norm(bucket.views))
         scales = (a.norm / norms).clamp_(max=1.0)                          # norm / max(l2, norm); l2 = 0 -> 1
-        torch._foreach_mul_(views, list(scales.unbind()))
-        torch._foreach_copy_(grads, [v.view_as(gr) for v, gr in zip(views, grads)])
+        torch._foreach_mul_(bucket.views, list(scales.unbind()))
+        bucket.attach(with_grad)
         self.opt.step()
         return loss.detach()
 

@@ -51,6 +51,21 @@ def _worker(rank, world, port, tmp):
     mine = [torch.from_numpy(f * (rank + 1)) for f in full]
     sharding.allreduce_flat_(mine, average=True)
     np.testing.assert_allclose(mine[0].numpy(), full[0] * scale / world, rtol=1e-6)
+    # (2b) round 4: the resident flat bucket gives the bits of the cat / copy-back path, step after step, and leaves the reduced
+    # gradients where the optimiser reads them (p.grad = a slice of the bucket)
+    params = [torch.nn.Parameter(torch.zeros(f.shape)) for f in full]
+    bucket = None
+    for step in range(3):
+        grads = [torch.from_numpy(f * (rank + 1 + step)) for f in full]
+        ref = [g.clone() for g in grads]
+        sharding.allreduce_flat_(ref, average=False)
+        if bucket is None:
+            bucket = sharding.FlatGradBucket(grads)
+        assert bucket.matches(grads)
+        bucket.fill(grads).allreduce_(average=False).attach(params)
+        for p_, r_ in zip(params, ref):
+            assert torch.equal(p_.grad, r_) and p_.grad.data_ptr() >= bucket.flat.data_ptr()
+    assert not bucket.matches(grads[:2])
     # (3) sharded projection == unsharded projection, slice for slice (no collective on the data path)
     from oracle import radon_oracle as orc
     imgs = np.random.default_rng(1).random((5, 12, 12), dtype=np.float32)
