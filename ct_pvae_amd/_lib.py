@@ -93,6 +93,10 @@ SIGNATURES = {
     "ctpvae_siddon_fwd_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "ctpvae_siddon_fwd_ws_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp, _vp,
                                           _vp]),
+    "ctpvae_siddon_fwd_ws_tv_dual_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp,
+                                                  _vp, _vp]),
+    "ctpvae_siddon_bwd_tv_primal_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp,
+                                                 _c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ctpvae_siddon_fwd_resid_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp,
                                              _vp]),
     "ctpvae_siddon_bwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _c_int, _c_int, _c_float, _vp, _vp, _vp]),

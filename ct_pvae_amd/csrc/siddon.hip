@@ -172,6 +172,19 @@ __device__ __forceinline__ void siddon_walk_ray(const SidGeom &g, float sin_p, f
 
 // NS = 2: two slices per workgroup, interleaved as float2 in LDS -- the crossings, segment lengths and pixel indices of
 // a ray depend on the geometry only, so one walk serves both slices (the loop is VALU-bound on exactly that arithmetic).
+// What a forward kernel stores for ray-sum `sim` at output element o (ray r = its (angle, bin)):
+//   mode 0: sim                                                      (tomopy.project, helper_functions.py:33-38)
+//   mode 1: (meas - sim) / w where w = sum dist^2 != 0, else 0       (SIRT's update factor, libtomo sirt.c)
+//   mode 2: (data + w (sim - meas)) / (1 + w), data updated in place (round 4: the dual step of the TV stand-in's preconditioned
+//           Chambolle-Pock iteration, prox of 1/2 |. - b|^2's conjugate with step w = 1 / (the ray's sum of dist); recon.py _tv)
+__device__ __forceinline__ float siddon_fwd_store(int mode, float sim, const float *__restrict__ meas, const float *__restrict__ w_ray,
+                                                  const float *data, size_t o, size_t r)
+{
+    if (mode == 0) return sim;
+    const float w = w_ray[r];
+    if (mode == 1) return w != 0.0f ? (meas[o] - sim) / w : 0.0f;
+    return (data[o] + w * (sim - meas[o])) / (1.0f + w);
+}
 typedef float sid_f32x2 __attribute__((ext_vector_type(2)));
 template <int NS> struct SidVec { typedef float type; };
 template <> struct SidVec<2> { typedef sid_f32x2 type; };
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
                                                          const float *__restrict__ cos_t,
                                                          const int *__restrict__ quad_t, int p_per_blk,
                                                          const float *__restrict__ meas, const float *__restrict__ rn2,
-                                                         float *__restrict__ data)
+                                                         int mode, float *__restrict__ data)
 {
     typedef typename SidVec<NS>::type vec_t;
     static_assert(NS == 1 || USE_LDS, "paired slices live in LDS");
@@ -220,12 +233,7 @@ __global__ __launch_bounds__(1024) void siddon_fwd_kernel(const float *__restric
         });
         auto store = [&](int sl, float sim) {
             const size_t o = ((size_t)sl * g.dt + p) * g.dx + d;
-            if (meas) {
-                const float w = rn2[(size_t)p * g.dx + d];
-                data[o] = w != 0.0f ? (meas[o] - sim) / w : 0.0f;
-            } else {
-                data[o] = sim;
-            }
+            data[o] = siddon_fwd_store(mode, sim, meas, rn2, data, o, (size_t)p * g.dx + d);
         };
         if constexpr (NS == 1) {
             store(s, acc);
@@ -258,7 +266,7 @@ template <int NS>
 __global__ __launch_bounds__(256) void siddon_fwd_packed_kernel(const float *__restrict__ packed, SidGeom g,
                                                                const float *__restrict__ sin_t, const float *__restrict__ cos_t,
                                                                const int *__restrict__ quad_t, const float *__restrict__ meas,
-                                                               const float *__restrict__ rn2, float *__restrict__ data)
+                                                               const float *__restrict__ rn2, int mode, float *__restrict__ data)
 {
     const int grp = blockIdx.y, s0 = grp * NS;
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,12 +293,7 @@ __global__ __launch_bounds__(256) void siddon_fwd_packed_kernel(const float *__r
         const float sim = acc[k] + pm[k] * pd;
         if (s0 + k >= g.oy) break;
         const size_t o = ((size_t)(s0 + k) * g.dt + p) * g.dx + d;
-        if (meas) {
-            const float w = rn2[(size_t)p * g.dx + d];
-            data[o] = w != 0.0f ? (meas[o] - sim) / w : 0.0f;
-        } else {
-            data[o] = sim;
-        }
+        data[o] = siddon_fwd_store(mode, sim, meas, rn2, data, o, (size_t)p * g.dx + d);
     }
 }
 
@@ -580,13 +583,39 @@ __global__ __launch_bounds__(256) void siddon_bwd_degenerate_kernel(const float 
 
 template <int NS> struct GatherAcc { float v[NS]; };
 
+// Round 4: the primal step of the TV stand-in (recon.py _tv: preconditioned Chambolle-Pock on K = (A; grad)) as the back-projector's
+// store.  All arrays [oy][ox][oz]; xbar / q are read at neighbouring pixels, so they ping-pong (in != out); x is updated in place.
+//   grad u (i, j) = (u[i+1][j] - u[i][j], u[i][j+1] - u[i][j]), zero at the far edges
+//   q' = q + 0.5 grad xbar;  q_new = q' / (max(|q'|, lam) / lam)                            (dual step, projection onto |q| <= lam)
+//   div q (i, j) = ((qx[i][j] - qx[i-1][j]) + qy[i][j]) - qy[i][j-1], terms outside the image left out, in that order
+//   x_new = x - tau (A^T p - div q_new);  xbar_new = 2 x_new - x
+// A lane recomputes q_new at its own pixel and at the two neighbours its divergence needs (from the OLD xbar and q: no race).
+struct TvPrimal {
+    const float *tau;                 // [ox][oz]: 1 / (column sums of A + 4)
+    float lam;
+    float *x;
+    const float *xbar_in, *qx_in, *qy_in;
+    float *xbar_out, *qx_out, *qy_out;
+};
+__device__ __forceinline__ void tv_dual_q(const TvPrimal &t, const float *xb, const float *qx, const float *qy, int ox, int oz, int i,
+                                          int j, float &nx, float &ny)
+{
+    const size_t c = (size_t)i * oz + j;
+    const float u = xb[c];
+    const float gx = i + 1 < ox ? xb[c + oz] - u : 0.0f, gy = j + 1 < oz ? xb[c + 1] - u : 0.0f;
+    const float ax = qx[c] + 0.5f * gx, ay = qy[c] + 0.5f * gy;
+    const float nrm = fmaxf(sqrtf(ax * ax + ay * ay), t.lam) / t.lam;
+    nx = ax / nrm;
+    ny = ay / nrm;
+}
+
 // EPI 0: recon = A^T data.   EPI 1 (SIRT): recon += (A^T data) / colsum where colsum != 0 (libtomo sirt.c's last loop).
 template <int NS, int EPI>
 __global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
     const float *__restrict__ data, SidGeom g, const float *__restrict__ sin_t, const float *__restrict__ cos_t,
     const int *__restrict__ quad_t, const float4 *__restrict__ table, const unsigned *__restrict__ flags,
     const int *__restrict__ degen_angle, const float *__restrict__ D, const float *__restrict__ colsum, int CH, float tau,
-    float *__restrict__ recon)
+    float *__restrict__ recon, TvPrimal tv)
 {
     extern __shared__ float lds[];
     // LDS: lines [CH][SEG] float4 | vals [NS][kGatherPlane] | seg_lo [CH] | live [CH] | anyD
@@ -696,9 +725,27 @@ __global__ __launch_bounds__(kGatherRows * 64) void siddon_bwd_gather_kernel(
         float *out = recon + (size_t)(s0 + k) * npix + ix * g.oz + iy;
         if constexpr (EPI == 0) {
             *out = acc[k];
-        } else {
+        } else if constexpr (EPI == 1) {
             const float cs = colsum[ix * g.oz + iy];
             if (cs != 0.0f) *out += acc[k] / cs;
+        } else {   // EPI 2: the TV stand-in's primal step (TvPrimal above); `recon` is not written
+            const size_t so = (size_t)(s0 + k) * npix, c = (size_t)ix * g.oz + iy;
+            const float *xb = tv.xbar_in + so, *qxi = tv.qx_in + so, *qyi = tv.qy_in + so;
+            float qx0, qy0, qxu = 0.0f, qyl = 0.0f, unused;
+            tv_dual_q(tv, xb, qxi, qyi, g.ox, g.oz, ix, iy, qx0, qy0);
+            if (ix >= 1) tv_dual_q(tv, xb, qxi, qyi, g.ox, g.oz, ix - 1, iy, qxu, unused);
+            if (iy >= 1) tv_dual_q(tv, xb, qxi, qyi, g.ox, g.oz, ix, iy - 1, unused, qyl);
+            float dv = 0.0f;
+            if (ix + 1 < g.ox) dv += qx0;
+            if (ix >= 1) dv -= qxu;
+            if (iy + 1 < g.oz) dv += qy0;
+            if (iy >= 1) dv -= qyl;
+            const float xo = tv.x[so + c];
+            const float xn = xo - tv.tau[c] * (acc[k] - dv);
+            tv.x[so + c] = xn;
+            tv.xbar_out[so + c] = 2.0f * xn - xo;
+            tv.qx_out[so + c] = qx0;
+            tv.qy_out[so + c] = qy0;
         }
     }
 }
@@ -751,18 +798,18 @@ int ctpvae_siddon_tables_f32(const float *theta, int dt, float *sin_out, float *
 
 static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
                           const float *cos_dev, const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
-                          const float *rn2_dev, float *data_dev, ctpvae_stream_t stream);
+                          const float *rn2_dev, int mode, float *data_dev, ctpvae_stream_t stream);
 static float siddon_mov(int dx, float center);
 
 static int siddon_fwd_chunks(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
                              const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev,
-                             float *data_dev, ctpvae_stream_t stream)
+                             int mode, float *data_dev, ctpvae_stream_t stream)
 {
     const int chunk = std::max(2, max_slices_per_launch() / 2 * 2);   // even: whole slice pairs per chunk
     for (int s0 = 0; s0 < oy; s0 += chunk) {
         const int n = std::min(chunk, oy - s0);
         if (int rc = siddon_fwd_one(obj_dev + (size_t)s0 * ox * oz, n, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center,
-                                    meas_dev ? meas_dev + (size_t)s0 * dt * dx : nullptr, rn2_dev,
+                                    meas_dev ? meas_dev + (size_t)s0 * dt * dx : nullptr, rn2_dev, mode,
                                     data_dev + (size_t)s0 * dt * dx, stream))
             return rc;
     }
@@ -775,7 +822,7 @@ int ctpvae_siddon_fwd_f32(const float *obj_dev, int oy, int ox, int oz, const fl
                           float *data_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(obj_dev && data_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0, "siddon_fwd: null pointer or empty sizes");
-    return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, nullptr, nullptr, data_dev, stream);
+    return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, nullptr, nullptr, 0, data_dev, stream);
 }
 
 // slices per walk of the packed forward: 0 = keep the LDS kernels (few slices, or a grid whose PAIRS fit LDS and ... see below)
@@ -798,7 +845,7 @@ long long ctpvae_siddon_fwd_workspace_bytes(int oy, int ox, int oz)
 template <int NS>
 static int siddon_fwd_packed(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
                              const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev,
-                             float *packed, float *data_dev, hipStream_t stream)
+                             int mode, float *packed, float *data_dev, hipStream_t stream)
 {
     const int npix = ox * oz, groups = ceil_div(oy, NS);
     CTPVAE_REQUIRE(groups <= 65535, "siddon_fwd: at most %d slices per call with a workspace (got %d)", 65535 * NS, oy);
@@ -806,29 +853,48 @@ static int siddon_fwd_packed(const float *obj_dev, int oy, int ox, int oz, const
     CTPVAE_LAUNCH_CHECK("siddon_pack_kernel");
     const SidGeom g{oy, ox, oz, dt, dx, siddon_mov(dx, center)};
     hipLaunchKernelGGL(siddon_fwd_packed_kernel<NS>, dim3(ceil_div(dt * dx, 256), groups), dim3(256), 0, stream, packed, g, sin_dev,
-                       cos_dev, quad_dev, meas_dev, rn2_dev, data_dev);
+                       cos_dev, quad_dev, meas_dev, rn2_dev, mode, data_dev);
     CTPVAE_LAUNCH_CHECK("siddon_fwd_packed_kernel");
     return CTPVAE_OK;
 }
 
 extern "C" {
 
+static int siddon_fwd_ws(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                         const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev, int mode,
+                         void *workspace_dev, float *data_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(obj_dev && data_dev && sin_dev && cos_dev && quad_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
+                   "siddon_fwd: null pointer or empty sizes");
+    CTPVAE_REQUIRE((meas_dev == nullptr) == (rn2_dev == nullptr), "siddon_fwd: meas and the per-ray weights go together");
+    const int ns = siddon_packed_ns(oy, ox, oz);
+    if (ns == 0)
+        return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, mode, data_dev, stream);
+    CTPVAE_REQUIRE(workspace_dev, "siddon_fwd: %d slices need the workspace", oy);
+    CTPVAE_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, "siddon_fwd: the workspace must be 16-byte aligned");
+    return ns == 8 ? siddon_fwd_packed<8>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, mode,
+                                          (float *)workspace_dev, data_dev, (hipStream_t)stream)
+                   : siddon_fwd_packed<4>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, mode,
+                                          (float *)workspace_dev, data_dev, (hipStream_t)stream);
+}
+
 int ctpvae_siddon_fwd_ws_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
                              const int *quad_dev, int dt, int dx, float center, const float *meas_dev, const float *rn2_dev,
                              void *workspace_dev, float *data_dev, ctpvae_stream_t stream)
 {
-    CTPVAE_REQUIRE(obj_dev && data_dev && sin_dev && cos_dev && quad_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
-                   "siddon_fwd: null pointer or empty sizes");
-    CTPVAE_REQUIRE((meas_dev == nullptr) == (rn2_dev == nullptr), "siddon_fwd: meas and rn2 go together");
-    const int ns = siddon_packed_ns(oy, ox, oz);
-    if (ns == 0)
-        return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, data_dev, stream);
-    CTPVAE_REQUIRE(workspace_dev, "siddon_fwd: %d slices need the workspace", oy);
-    CTPVAE_REQUIRE(((uintptr_t)workspace_dev & 15) == 0, "siddon_fwd: the workspace must be 16-byte aligned");
-    return ns == 8 ? siddon_fwd_packed<8>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev,
-                                          (float *)workspace_dev, data_dev, (hipStream_t)stream)
-                   : siddon_fwd_packed<4>(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev,
-                                          (float *)workspace_dev, data_dev, (hipStream_t)stream);
+    return siddon_fwd_ws(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, meas_dev ? 1 : 0,
+                         workspace_dev, data_dev, stream);
+}
+
+// Round 4, the TV stand-in's dual step as the projector's own store (recon.py _tv; tomopy.recon(algorithm='tv') is NOT restated):
+//   p <- (p + sigma (A xbar - b)) / (1 + sigma),  sigma_dev [dt][dx] the per-ray step, p_dev [oy][dt][dx] updated in place.
+int ctpvae_siddon_fwd_ws_tv_dual_f32(const float *xbar_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                     const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
+                                     const float *sigma_dev, void *workspace_dev, float *p_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(meas_dev && sigma_dev, "siddon_fwd_tv_dual: null pointer");
+    return siddon_fwd_ws(xbar_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, sigma_dev, 2, workspace_dev,
+                         p_dev, stream);
 }
 
 int ctpvae_siddon_fwd_resid_f32(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
@@ -837,12 +903,12 @@ int ctpvae_siddon_fwd_resid_f32(const float *obj_dev, int oy, int ox, int oz, co
 {
     CTPVAE_REQUIRE(obj_dev && upd_dev && meas_dev && rn2_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
                    "siddon_fwd_resid: null pointer or empty sizes");
-    return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, upd_dev, stream);
+    return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, 1, upd_dev, stream);
 }
 
 static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const float *sin_dev,
                           const float *cos_dev, const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
-                          const float *rn2_dev, float *data_dev, ctpvae_stream_t stream)
+                          const float *rn2_dev, int mode, float *data_dev, ctpvae_stream_t stream)
 {
     CTPVAE_REQUIRE(obj_dev && sin_dev && cos_dev && quad_dev && data_dev, "siddon_fwd: null pointer");
     CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
@@ -869,7 +935,7 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
             CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem));
         hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, obj_dev, g, sin_dev, cos_dev, quad_dev,
-                           ppb, meas_dev, rn2_dev, data_dev);
+                           ppb, meas_dev, rn2_dev, mode, data_dev);
         CTPVAE_LAUNCH_CHECK("siddon_fwd_kernel");
         return CTPVAE_OK;
     };
@@ -943,7 +1009,7 @@ int ctpvae_siddon_bwd_prepare_f32(int ox, int oz, const float *sin_dev, const fl
 template <int NS>
 static int siddon_gather_launch(const float *data, const SidGeom &g, const float *sin_dev, const float *cos_dev,
                                 const int *quad_dev, const float4 *table, const unsigned *flags, const int *degen,
-                                const float *D, const float *colsum, float *recon, hipStream_t stream)
+                                const float *D, const float *colsum, float *recon, hipStream_t stream, const TvPrimal *tv = nullptr)
 {
     // angles per LDS chunk: two staging rounds of the 512 threads, ~50 KB with eight slices -> three workgroups per CU
     int CH = std::max(1, std::min(g.dt, kGatherMaxCh));
@@ -955,20 +1021,21 @@ static int siddon_gather_launch(const float *data, const SidGeom &g, const float
         static std::atomic<unsigned long long> attr_set{0};
         if (shmem > 64 * 1024) CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, D, colsum,
-                           CH, tau, recon);
+                           CH, tau, recon, tv ? *tv : TvPrimal{});
         CTPVAE_LAUNCH_CHECK("siddon_bwd_gather_kernel");
         return CTPVAE_OK;
     };
+    if (tv) return launch(siddon_bwd_gather_kernel<NS, 2>);
     return colsum ? launch(siddon_bwd_gather_kernel<NS, 1>) : launch(siddon_bwd_gather_kernel<NS, 0>);
 }
 
 extern "C" {
 
-int ctpvae_siddon_bwd_prepared_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
-                                   const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
-                                   const float *colsum_dev, float *recon_dev, ctpvae_stream_t stream)
+static int siddon_bwd_prepared(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                               const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
+                               const float *colsum_dev, float *recon_dev, ctpvae_stream_t stream, const TvPrimal *tv)
 {
-    CTPVAE_REQUIRE(data_dev && sin_dev && cos_dev && quad_dev && recon_dev && workspace_dev, "siddon_bwd: null pointer");
+    CTPVAE_REQUIRE(data_dev && sin_dev && cos_dev && quad_dev && (recon_dev || tv) && workspace_dev, "siddon_bwd: null pointer");
     CTPVAE_REQUIRE(oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
                    "siddon_bwd: sizes must be positive (oy=%d ox=%d oz=%d dt=%d dx=%d)", oy, ox, oz, dt, dx);
     CTPVAE_REQUIRE(((uintptr_t)workspace_dev & 255) == 0, "siddon_bwd: the workspace must be 256-byte aligned");
@@ -985,20 +1052,52 @@ int ctpvae_siddon_bwd_prepared_f32(const float *data_dev, int oy, int ox, int oz
     for (int s0 = 0; s0 < oy; s0 += chunk) {
         SidGeom g{std::min(chunk, oy - s0), ox, oz, dt, dx, siddon_mov(dx, center)};
         const float *data = data_dev + (size_t)s0 * dt * dx;
-        float *Ds = D + (size_t)s0 * npix, *recon = recon_dev + (size_t)s0 * npix;
+        float *Ds = D + (size_t)s0 * npix, *recon = recon_dev ? recon_dev + (size_t)s0 * npix : nullptr;
+        TvPrimal tvs{};
+        if (tv) {   // this chunk's slices
+            const size_t so = (size_t)s0 * npix;
+            tvs = TvPrimal{tv->tau, tv->lam, tv->x + so, tv->xbar_in + so, tv->qx_in + so, tv->qy_in + so, tv->xbar_out + so,
+                           tv->qx_out + so, tv->qy_out + so};
+        }
+        const TvPrimal *tvp = tv ? &tvs : nullptr;
         hipLaunchKernelGGL(siddon_bwd_degenerate_kernel, dim3(g.oy), dim3(256), 0, (hipStream_t)stream, data, g, sin_dev, cos_dev,
                            quad_dev, degen, Ds);
         CTPVAE_LAUNCH_CHECK("siddon_bwd_degenerate_kernel");
         int rc;
         switch (ns) {
-        case 8: rc = siddon_gather_launch<8>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
-        case 4: rc = siddon_gather_launch<4>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
-        case 2: rc = siddon_gather_launch<2>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
-        default: rc = siddon_gather_launch<1>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream); break;
+        case 8: rc = siddon_gather_launch<8>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream, tvp); break;
+        case 4: rc = siddon_gather_launch<4>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream, tvp); break;
+        case 2: rc = siddon_gather_launch<2>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream, tvp); break;
+        default: rc = siddon_gather_launch<1>(data, g, sin_dev, cos_dev, quad_dev, table, flags, degen, Ds, colsum_dev, recon, (hipStream_t)stream, tvp); break;
         }
         if (rc) return rc;
     }
     return CTPVAE_OK;
+}
+
+int ctpvae_siddon_bwd_prepared_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                   const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
+                                   const float *colsum_dev, float *recon_dev, ctpvae_stream_t stream)
+{
+    return siddon_bwd_prepared(data_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, workspace_dev, colsum_dev, recon_dev,
+                               stream, nullptr);
+}
+
+// Round 4: the TV stand-in's primal step as the back-projector's store (TvPrimal above; recon.py _tv).  p_dev [oy][dt][dx] the dual
+// variable of the data term; x updated in place; xbar / qx / qy read from *_in and written to *_out (distinct buffers).
+int ctpvae_siddon_bwd_tv_primal_f32(const float *p_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                    const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
+                                    const float *tau_dev, float lam, float *x_dev, const float *xbar_in_dev, float *xbar_out_dev,
+                                    const float *qx_in_dev, const float *qy_in_dev, float *qx_out_dev, float *qy_out_dev,
+                                    ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(tau_dev && x_dev && xbar_in_dev && xbar_out_dev && qx_in_dev && qy_in_dev && qx_out_dev && qy_out_dev,
+                   "siddon_bwd_tv_primal: null pointer");
+    CTPVAE_REQUIRE(lam > 0.0f, "siddon_bwd_tv_primal: the TV weight must be positive");
+    CTPVAE_REQUIRE(xbar_in_dev != xbar_out_dev && qx_in_dev != qx_out_dev && qy_in_dev != qy_out_dev,
+                   "siddon_bwd_tv_primal: xbar and q are read at neighbouring pixels -- in and out must be distinct buffers");
+    const TvPrimal tv{tau_dev, lam, x_dev, xbar_in_dev, qx_in_dev, qy_in_dev, xbar_out_dev, qx_out_dev, qy_out_dev};
+    return siddon_bwd_prepared(p_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, workspace_dev, nullptr, nullptr, stream, &tv);
 }
 
 int ctpvae_siddon_bwd_f32(const float *data_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,

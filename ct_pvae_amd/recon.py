@@ -162,47 +162,48 @@ def _sirt(data, tables, gx, gy, num_iter, init):
     return x
 
 
+_TV_WARNED = False
+
+
 def _tv(data, tables, gx, gy, num_iter, init, lam):
     """min_x 1/2 |A x - b|^2 + lam TV(x) by preconditioned Chambolle-Pock (Pock & Chambolle, ICCV 2011, alpha = 1):
-    dual steps 1 / (row sums of |K|), primal steps 1 / (column sums of |K|) for K = (A; grad).  Flagged stand-in for
-    tomopy's 'tv' (see the module docstring)."""
+    dual steps 1 / (row sums of |K|), primal steps 1 / (column sums of |K|) for K = (A; grad).  STAND-IN for tomopy's 'tv'
+    (see the module docstring; warns once).  Round 4: an iteration is TWO projector launches -- the forward stores the data
+    term's dual step, the back-projector's store does the TV dual step, the divergence, the primal step and the over-relaxation
+    (ctpvae_siddon_fwd_ws_tv_dual_f32 / ctpvae_siddon_bwd_tv_primal_f32) -- and equals oracle.tv_standin bit for bit."""
+    global _TV_WARNED
+    if not _TV_WARNED:
+        import warnings
+        warnings.warn("recon(algorithm='tv') is a STAND-IN: total-variation reconstruction by preconditioned Chambolle-Pock on the "
+                      "TomoPy-style projector pair, not libtomo's tv.c -- the same family, not TomoPy's numbers", stacklevel=3)
+        _TV_WARNED = True
+    lib = _lib.load()
+    sin_t, cos_t, quad = tables
     oy, dt, dx = data.shape
     dev = data.device
     ones_img = torch.ones((1, gx, gy), dtype=torch.float32, device=dev)
     rowsum = _project(ones_img, tables, dx)[0]                                          # sum_n dist[n] of every ray
+    ws = _bp_workspace(tables, oy, gx, gy, dt, dx, dev)
     colsum = _backproject(torch.ones((1, dt, dx), dtype=torch.float32, device=dev), tables, gx, gy)[0]
-    sigma_a = torch.where(rowsum > 0, 1.0 / rowsum.clamp_min(1e-30), torch.zeros_like(rowsum))
-    tau = 1.0 / (colsum + 4.0)                                                          # |grad| has column sums <= 4
-    sigma_g = 0.5                                                                       # and row sums 2
-
-    def grad(u):
-        gxu = torch.zeros_like(u)
-        gyu = torch.zeros_like(u)
-        gxu[:, :-1] = u[:, 1:] - u[:, :-1]
-        gyu[:, :, :-1] = u[:, :, 1:] - u[:, :, :-1]
-        return gxu, gyu
-
-    def div(px, py):                                                                    # -grad^T
-        out = torch.zeros_like(px)
-        out[:, :-1] += px[:, :-1]
-        out[:, 1:] -= px[:, :-1]
-        out[:, :, :-1] += py[:, :, :-1]
-        out[:, :, 1:] -= py[:, :, :-1]
-        return out
-
-    x = init.clone()
-    xbar = x.clone()
+    sigma_a = torch.where(rowsum > 0, 1.0 / rowsum.clamp_min(1e-30), torch.zeros_like(rowsum)).contiguous()
+    tau = (1.0 / (colsum + 4.0)).contiguous()                                           # |grad| has column sums <= 4, row sums 2
+    need = lib.ctpvae_siddon_fwd_workspace_bytes(oy, gx, gy)
+    _lib.check(need, "siddon_fwd_workspace_bytes")
+    fws = torch.empty(int(need), dtype=torch.uint8, device=dev) if need else None
+    x = init.contiguous().clone()
+    xbar, xbar2 = x.clone(), torch.empty_like(x)
     p = torch.zeros_like(data)
-    qx, qy = torch.zeros_like(x), torch.zeros_like(x)
+    qx, qy, qx2, qy2 = torch.zeros_like(x), torch.zeros_like(x), torch.empty_like(x), torch.empty_like(x)
+    center, sp = ctypes.c_float(dx / 2.0), _stream_ptr()
     for _ in range(int(num_iter)):
-        p = (p + sigma_a * (_project(xbar, tables, dx) - data)) / (1.0 + sigma_a)      # prox of 1/2 |. - b|^2 conjugate
-        gxu, gyu = grad(xbar)
-        qx, qy = qx + sigma_g * gxu, qy + sigma_g * gyu
-        norm = torch.sqrt(qx * qx + qy * qy).clamp_min(lam) / lam                       # project onto |q| <= lam
-        qx, qy = qx / norm, qy / norm
-        x_new = x - tau * (_backproject(p, tables, gx, gy) - div(qx, qy))      # K^T y = A^T p + grad^T q, grad^T = -div
-        xbar = 2.0 * x_new - x
-        x = x_new
+        _lib.check(lib.ctpvae_siddon_fwd_ws_tv_dual_f32(xbar.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(),
+                                                        dt, dx, center, data.data_ptr(), sigma_a.data_ptr(),
+                                                        fws.data_ptr() if fws is not None else None, p.data_ptr(), sp), "siddon_fwd_tv_dual")
+        _lib.check(lib.ctpvae_siddon_bwd_tv_primal_f32(p.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
+                                                       center, ws.data_ptr(), tau.data_ptr(), ctypes.c_float(lam), x.data_ptr(),
+                                                       xbar.data_ptr(), xbar2.data_ptr(), qx.data_ptr(), qy.data_ptr(), qx2.data_ptr(),
+                                                       qy2.data_ptr(), sp), "siddon_bwd_tv_primal")
+        xbar, xbar2, qx, qx2, qy, qy2 = xbar2, xbar, qx2, qx, qy2, qy
     return x
 
 

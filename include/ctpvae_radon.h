@@ -340,6 +340,23 @@ int ctpvae_siddon_fwd_ws_f32(const float *obj_dev, int oy, int ox, int oz, const
                              void *workspace_dev, float *data_dev, ctpvae_stream_t stream);
 int ctpvae_siddon_rownorm_f32(int ox, int oz, const float *sin_dev, const float *cos_dev, const int *quad_dev, int dt,
                               int dx, float center, float *rn2_dev, ctpvae_stream_t stream);
+/* Round 4: an iteration of the TV STAND-IN of tomopy.recon(algorithm='tv') (README.md:221 of the reference asks for 'tv';
+ * libtomo's tv.c is NOT restated -- ct_pvae_amd/recon.py says so on every call) as TWO projector launches instead of ~15 torch
+ * ops around them: the diagonally preconditioned Chambolle-Pock iteration for min 1/2 |A x - b|^2 + lam TV(x) on K = (A; grad),
+ *   _fwd_ws_tv_dual:  p <- (p + sigma (A xbar - b)) / (1 + sigma)         sigma_dev [dt][dx] = 1 / (row sums of A), p in place
+ *   _bwd_tv_primal:   q' = q + 0.5 grad xbar; q <- q' / (max(|q'|, lam) / lam); x <- x - tau (A^T p - div q); xbar <- 2 x - x_old
+ *                     tau_dev [ox][oz] = 1 / (column sums of A + 4); x in place; xbar / qx / qy read at neighbouring pixels:
+ *                     *_in and *_out must be distinct buffers (the caller swaps them every iteration)
+ * with forward differences (zero at the far edges) and their negative transpose, every operation in the order
+ * oracle/radon_oracle.py tv_standin() states: the kernels give its bits. */
+int ctpvae_siddon_fwd_ws_tv_dual_f32(const float *xbar_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                     const int *quad_dev, int dt, int dx, float center, const float *meas_dev,
+                                     const float *sigma_dev, void *workspace_dev, float *p_dev, ctpvae_stream_t stream);
+int ctpvae_siddon_bwd_tv_primal_f32(const float *p_dev, int oy, int ox, int oz, const float *sin_dev, const float *cos_dev,
+                                    const int *quad_dev, int dt, int dx, float center, const void *workspace_dev,
+                                    const float *tau_dev, float lam, float *x_dev, const float *xbar_in_dev, float *xbar_out_dev,
+                                    const float *qx_in_dev, const float *qy_in_dev, float *qx_out_dev, float *qy_out_dev,
+                                    ctpvae_stream_t stream);
 
 /* ---- a6: filtered back-projection (float64, as the reference runs it) -----------------------
  * filter: circular convolution of every sinogram row with hker_dev [P] = Re(ifft(filter_1d)), which

@@ -265,6 +265,60 @@ def gridrec_pswf_tables(dx):
     return wtbl, winv
 
 
+def tv_standin(data, theta, num_iter=1, lam=1.0, init=1e-6, ngridx=None, ngridy=None):
+    """The build's STAND-IN for tomopy.recon(algorithm='tv') -- NOT libtomo's tv.c (ct_pvae_amd/recon.py says so): total-variation
+    reconstruction min_x 1/2 |A x - b|^2 + lam TV(x) by the diagonally preconditioned Chambolle-Pock iteration (Pock & Chambolle
+    2011, alpha = 1) on K = (A; grad), A = tomopy.project restated above.  This function IS the statement of the iteration the HIP
+    epilogues compute (csrc/siddon.hip siddon_fwd_store mode 2, TvPrimal), operation by operation in fp32:
+        sigma = 1 / rowsum(A) (0 where a ray misses the grid);  tau = 1 / (colsum(A) + 4)
+        p     <- (p + sigma (A xbar - b)) / (1 + sigma)
+        q'    = q + 0.5 grad xbar;  q <- q' / (max(sqrt(qx'^2 + qy'^2), lam) / lam)         grad: forward differences, 0 at the far edges
+        x_new = x - tau (A^T p - div q);  div q = ((qx[i][j] - qx[i-1][j]) + qy[i][j]) - qy[i][j-1], missing terms left out
+        xbar  <- 2 x_new - x;  x <- x_new
+    data [oy][dt][dx] -> [oy][gx][gy]."""
+    data, theta = _c32(data), _c32(theta)
+    oy, dt, dx = data.shape
+    gx, gy = int(ngridx or dx), int(ngridy or dx)
+    f32 = np.float32
+    rowsum = _project_grid(np.ones((1, gx, gy), f32), theta, dx)[0]
+    colsum = siddon_backproject(np.ones((1, dt, dx), f32), theta, gx, gy)[0]
+    with np.errstate(divide="ignore"):
+        sigma = np.where(rowsum > 0, f32(1.0) / np.maximum(rowsum, f32(1e-30)), f32(0.0)).astype(f32)
+    tau = (f32(1.0) / (colsum + f32(4.0))).astype(f32)
+    lam = f32(lam)
+    x = np.full((oy, gx, gy), init, f32) if np.isscalar(init) else _c32(init).copy()
+    xbar = x.copy()
+    p = np.zeros_like(data)
+    qx, qy = np.zeros_like(x), np.zeros_like(x)
+    for _ in range(int(num_iter)):
+        sim = _project_grid(xbar, theta, dx)
+        p = ((p + sigma * (sim - data)) / (f32(1.0) + sigma)).astype(f32)
+        gxu, gyu = np.zeros_like(xbar), np.zeros_like(xbar)
+        gxu[:, :-1] = xbar[:, 1:] - xbar[:, :-1]
+        gyu[:, :, :-1] = xbar[:, :, 1:] - xbar[:, :, :-1]
+        ax, ay = qx + f32(0.5) * gxu, qy + f32(0.5) * gyu
+        nrm = np.maximum(np.sqrt(ax * ax + ay * ay), lam) / lam
+        qx, qy = (ax / nrm).astype(f32), (ay / nrm).astype(f32)
+        dv = np.zeros_like(x)
+        dv[:, :-1] += qx[:, :-1]
+        dv[:, 1:] -= qx[:, :-1]
+        dv[:, :, :-1] += qy[:, :, :-1]
+        dv[:, :, 1:] -= qy[:, :, :-1]
+        x_new = (x - tau * (siddon_backproject(p, theta, gx, gy) - dv)).astype(f32)
+        xbar = (f32(2.0) * x_new - x).astype(f32)
+        x = x_new
+    return x
+
+
+def _project_grid(obj, theta, dx):
+    """tomopy.project of a [oy][gx][gy] grid onto a dx-wide detector with center = dx / 2 (the projector inside sirt / tv)."""
+    obj, theta = _c32(obj), _c32(theta)
+    oy, ox, oz = obj.shape
+    out = np.empty((oy, theta.size, dx), np.float32)
+    lib().oracle_siddon_project(obj, oy, ox, oz, theta, theta.size, dx, dx / 2.0, out)
+    return out
+
+
 def loglik_task_bins(PW, partition=0):
     """The 64-lane tasks a detector row is cut into (list of 64 bin numbers each; a bin outside [0, PW) = an idle lane).
     partition 0: the planned projector kernels' (angle, bin block) tasks -- block k = the two 32-bin bands mirrored about the

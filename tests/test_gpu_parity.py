@@ -2338,6 +2338,36 @@ def test_per_object_sums_inside_the_launch(oracle, shape, A, S, sub):
     assert int(ws[-S:].view(torch.int32).abs().sum()) == 0          # every arrival counter is back at zero
 
 
+# ---- round 4: the TV stand-in as two projector launches per iteration, against its restatement ----------------------------------
+@pytest.mark.parametrize("oy,N,dt,iters,lam", [(3, 32, 24, 4, 0.05), (9, 48, 30, 3, 1.0), (1, 20, 9, 5, 0.3)])
+def test_tv_standin_iteration_against_its_restatement(oracle, oy, N, dt, iters, lam):
+    """recon(algorithm='tv') is a flagged STAND-IN for tomopy's tv.c (preconditioned Chambolle-Pock on the TomoPy-style projector
+    pair).  Since round 4 an iteration is two projector launches whose stores do the dual and primal steps; oracle.tv_standin
+    states the same iteration operation by operation -- the kernels give its values (<= 1e-5; in practice the bits), it still
+    warns that it is not TomoPy's algorithm, and it still denoises (lower TV than the back-projection it starts from)."""
+    import importlib
+    import warnings
+    recon_mod = importlib.import_module("ct_pvae_amd.recon")      # (the package exports the function under the same name)
+    d = dev()
+    rng = np.random.default_rng(oy + N)
+    img = phantoms.foam_batch(oy, N, seed=3, supersample=2)
+    theta = np.sort(rng.uniform(0, np.pi, dt)).astype(np.float32)
+    data = np.ascontiguousarray(oracle.siddon_project(img, theta, pad=True).transpose(1, 0, 2))
+    data = (data + 0.05 * rng.standard_normal(data.shape)).astype(np.float32)
+    want = oracle.tv_standin(data, theta, num_iter=iters, lam=lam)
+    recon_mod._TV_WARNED = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = recon_mod.recon(torch.from_numpy(data).to(d), theta, sinogram_order=True, algorithm="tv", num_iter=iters,
+                              reg_par=np.array([lam]))
+    assert any("STAND-IN" in str(x.message) for x in w)
+    err = rel_err(to_np(got), want)
+    print(f"tv stand-in {oy}x{N} {iters} iterations: max rel-err {err:.2e}, {int((to_np(got) != want).sum())} of {want.size} values differ")
+    assert err <= REL
+    again = recon_mod.recon(torch.from_numpy(data).to(d), theta, sinogram_order=True, algorithm="tv", num_iter=iters, reg_par=np.array([lam]))
+    assert torch.equal(again, got)
+
+
 # ---- round 4: the dispatch matrix, enumerated ------------------------------------------------------------------------------------
 def _matrix_variants(tiled):
     """(forward format, subset kind, epilogue / node, backward path) -- every combination the host code can reach for a geometry"""

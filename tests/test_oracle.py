@@ -583,6 +583,27 @@ def test_gridrec_grid_as_wide_as_the_padded_row(oracle):
     assert np.abs(sub - rec[8:56, 8:56]).max() <= 1e-6 * np.abs(rec).max()
 
 
+def test_tv_standin_restatement_reconstructs_and_regularises(oracle):
+    """oracle.tv_standin states the iteration the build runs under algorithm='tv' (a flagged STAND-IN: preconditioned
+    Chambolle-Pock total-variation reconstruction on the TomoPy-style projector pair, not libtomo's tv.c).  What pins it: with a
+    small weight it converges to the projected phantom (0.2 % after 200 iterations at 32 x 32), a larger weight lowers the
+    total variation of the result monotonically, and one iteration from the default start is a finite, non-trivial image."""
+    from ct_pvae_amd import phantoms
+    N = 32
+    img = phantoms.foam_batch(2, N, seed=3, supersample=2)
+    theta = np.linspace(0, np.pi, 30, endpoint=False).astype(np.float32)
+    data = np.ascontiguousarray(oracle.siddon_project(img, theta, pad=True).transpose(1, 0, 2))
+    pad = (data.shape[2] - N) // 2
+    core = lambda x: x[:, pad:pad + N, pad:pad + N]
+    errs = [np.linalg.norm(core(oracle.tv_standin(data, theta, num_iter=k, lam=0.05)) - img) / np.linalg.norm(img) for k in (1, 10, 100)]
+    assert errs[0] > errs[1] > errs[2] and errs[2] < 0.02, errs
+    tv = lambda x: float(np.abs(np.diff(x, axis=1)).sum() + np.abs(np.diff(x, axis=2)).sum())
+    tvs = [tv(oracle.tv_standin(data, theta, num_iter=60, lam=lam)) for lam in (0.01, 0.3, 3.0)]
+    assert tvs[0] > tvs[1] > tvs[2], tvs
+    one = oracle.tv_standin(data, theta)           # tomopy's defaults: one iteration from 1e-6
+    assert np.isfinite(one).all() and one.max() > 0.01
+
+
 def _skimage_mapped(ours, theta):
     """Our ray-driven sinogram [A][184] resampled at scikit-image's 182 bin positions: skimage pads the 128 x 128 image to
     182 x 182 and rotates about pixel 91, half a pixel off the phantom's centre (90.5, 90.5) in both axes, and its bin j is

@@ -39,6 +39,10 @@ print(f"siddon_backproject sparse (20 of 180 angles) -> 184^2: {timed(lambda: si
 print(f"siddon_backproject dense  -> 128^2: {timed(lambda: siddon_backproject(sino, theta, 128, 128)):.3f} ms")
 print(f"recon sirt num_iter=1: {timed(lambda: recon(sino, theta, sinogram_order=True, algorithm='sirt'), 5):.3f} ms")
 print(f"recon sirt num_iter=20: {timed(lambda: recon(sino, theta, sinogram_order=True, algorithm='sirt', num_iter=20), 2):.3f} ms")
+import warnings
+warnings.simplefilter("ignore")
+print(f"recon tv (stand-in) num_iter=1: {timed(lambda: recon(sino, theta, sinogram_order=True, algorithm='tv'), 5):.3f} ms")
+print(f"recon tv (stand-in) num_iter=20: {timed(lambda: recon(sino, theta, sinogram_order=True, algorithm='tv', num_iter=20), 2):.3f} ms")
 print(f"recon gridrec (parzen): {timed(lambda: recon(sino, theta, sinogram_order=True, algorithm='gridrec'), 5):.3f} ms")
 print(f"poisson_measure 50 x 180 x 184, pnm 1e4: {timed(lambda: poisson_measure(sino, masks, 1e4, 0)):.3f} ms")
 dense_mask = torch.full((50, 180), 0.05, device=d)
