@@ -256,6 +256,41 @@ def train_mode(args, world, rank, dev):
                                             "timed alone; includes all per-step set-up"}))
 
 
+LDS_PEAK_TAPS = 150e12 / 4.0     # MI355X_MICROARCH.md: ~150 TB/s aggregate for conflict-free ds_read_b64 / b128 = 3.75e13 fp32 taps/s
+
+
+def committed_counters(tag, kernel_substr, samples_per_launch, kernel_seconds):
+    """What this run cannot observe itself, from the COMMITTED counter files of the same command (separate rocprofv3 --pmc
+    passes, tools/collect_r04.sh): (traffic bytes per launch of the kernel, its source, the `lds` object of the roofline).
+    traffic = 2 * FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction).  lds: busy_frac = LDS-array cycles per CU / kernel
+    cycles; conflict_frac = bank-conflict cycles / LDS-array cycles; taps_per_s = algorithmic samples of this launch / its live
+    duration; bound_taps_per_s = the conflict-free gather rate of the chip; frac = their ratio ("vs the LDS bound")."""
+    import glob
+    traffic = source = None
+    lds = None
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{tag}traffic_pmc.json")))[-1]
+        pmc = json.load(open(f))
+        traffic = max((v for k, v in pmc["kernels"].items() if kernel_substr in k),
+                      key=lambda v: v.get("dispatches", 0))["traffic_bytes_per_launch"]
+        source = f"profiles/{os.path.basename(f)}"
+    except Exception:
+        pass
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_sq_{tag or 'a20_'}counters.json")))[-1]
+        sq = json.load(open(f))
+        c = max((v for k, v in sq.items() if kernel_substr in k and isinstance(v, dict)), key=lambda v: v.get("SQ_INSTS_LDS", 0))
+        lds = {"busy_frac": c["SQ_LDS_IDX_ACTIVE"] / (8.0 * c["SQ_BUSY_CYCLES"]),       # 256 CUs / 32 shader engines
+               "conflict_frac": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"],
+               "lds_instructions_per_launch": c["SQ_INSTS_LDS"], "lds_array_cycles_per_launch": c["SQ_LDS_IDX_ACTIVE"],
+               "taps_per_s": samples_per_launch / kernel_seconds, "bound_taps_per_s": LDS_PEAK_TAPS,
+               "frac": samples_per_launch / kernel_seconds / LDS_PEAK_TAPS,
+               "source": f"profiles/{os.path.basename(f)} (counters: committed passes of this command; taps_per_s: this run)"}
+    except Exception:
+        pass
+    return traffic, source, lds
+
+
 def _time_loop(fn, steps, warmup, world):
     for _ in range(warmup):
         fn()
@@ -344,6 +379,17 @@ def n512_mode(args, world, rank, dev):
     if rank == 0:
         bytes_step = 8.0 * B * (N * N + A * plan.PW)
         bytes_fwd = 4.0 * B * (N * N + A * plan.PW)
+        committed = B == 32
+        traffic, traffic_source, lds = committed_counters("n512_", "rotate_fwd_tile_compact_kernel", B * A * plan.PW * plan.PW,
+                                                          t_fwd) if committed else (None, None, None)
+        traffic_all = None
+        if traffic is not None:   # the forward is three launches: tile kernel + reduce pass + ordered sum
+            try:
+                pmc = json.load(open(os.path.join(ROOT, traffic_source)))["kernels"]
+                traffic_all = sum(v["traffic_bytes_per_launch"] for k, v in pmc.items()
+                                  if any(n_ in k for n_ in ("rotate_fwd_tile_compact_kernel", "rotate_tile_reduce_kernel<2>", "loglik_sum_partials_kernel")))
+            except Exception:
+                pass
         print(json.dumps({"metric": "projections/sec (fwd + log-lik + adj), 512x512, 90 angles, pnm 1e4",
                           "value": world * B * A * steps / el, "unit": "projections/s", "n_gpus": world, "steps": steps,
                           "warmup": 3, "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -354,7 +400,8 @@ def n512_mode(args, world, rank, dev):
                           "hbm_fraction_whole_step": bytes_step / (el / steps) / 1e9 / HBM_PEAK_GBS,
                           "roofline": {"bound": "hbm", "kernel": "rotate_fwd_tile_compact_kernel + rotate_tile_reduce_kernel<loglik, per-object sums>",
                                        "achieved": bytes_fwd / t_fwd / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": bytes_fwd / t_fwd / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "frac": bytes_fwd / t_fwd / 1e9 / HBM_PEAK_GBS, "traffic": traffic_all,
+                                       "traffic_tile_kernel_alone": traffic, "traffic_source": traffic_source, "lds": lds,
                                        "algorithmic_bytes_per_launch": bytes_fwd,
                                        "kernel_us": {"tiled_fwd_plus_reduce_loglik": t_fwd * 1e6, "segment_adj_scaled": t_bwd * 1e6},
                                        "note": "bound by the LDS gathers (ds_read_b128 of four interleaved slices, 2-way bank conflicts at oblique angles), not by HBM (DESIGN.md section 9)"}}))
@@ -609,19 +656,14 @@ def main():
     achieved = bytes_dir / dom[1] / 1e9
     # HBM-side bytes per launch of the dominant kernel: a COMMITTED measurement (separate rocprofv3 --pmc passes of this
     # command, tools/collect_profiles.sh -> profiles/rNN_traffic_pmc.json), not something this run can observe itself
-    traffic, traffic_source = None, None
-    try:
-        if (B, N, A) != (50, N_PIX, 20) or args.plan_format != "auto":
-            raise LookupError("the committed counters are for the default workload only")
-        import glob
-        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_pmc.json")))[-1]
-        pmc = json.load(open(newest))
-        # the instantiation the timed loop launches is the one with the most dispatches in that run
-        traffic = max((v for k, v in pmc["kernels"].items() if dom[0] in k),
-                      key=lambda v: v.get("dispatches", 0))["traffic_bytes_per_launch"]
-        traffic_source = f"profiles/{os.path.basename(newest)}" + (f" (commit {pmc['commit']})" if "commit" in pmc else "")
-    except Exception:
-        pass
+    traffic, traffic_source, lds = None, None, None
+    if (B, N) == (50, N_PIX) and A in (20, 180) and args.plan_format == "auto" and not args.cold:
+        # committed for the two workloads BASELINE names at this size: the headline (tag "") and config 4's per-GPU share ("angles180_")
+        traffic, traffic_source, lds = committed_counters("" if A == 20 else "angles180_", dom[0],
+                                                          B * A * (P * P if dom[0] == fwd_name else N * N), dom[1])
+        _, _, lds_fwd = committed_counters("" if A == 20 else "angles180_", fwd_name, B * A * P * P, t_fwd)
+        if lds_fwd is not None and dom[0] != fwd_name:
+            lds = dict(lds or {}, forward=lds_fwd)
     from ct_pvae_amd import _lib
     tune_env = {k: v for k, v in os.environ.items() if k.startswith("CTPVAE_")}
     proj_per_s = world * B * A * args.steps / elapsed
@@ -649,7 +691,7 @@ def main():
         "hbm_fraction_whole_step": (2 * bytes_dir / (elapsed / args.steps)) / 1e9 / HBM_PEAK_GBS,
         "roofline": {"bound": "hbm", "kernel": dom[0], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": bytes_dir,
+                     "traffic": traffic, "traffic_source": traffic_source, "lds": lds, "algorithmic_bytes_per_launch": bytes_dir,
                      "kernel_us": {"rotate_fwd": t_fwd * 1e6, "rotate_bwd_tfcompat": t_bwd * 1e6},
                      "note": "object lives in LDS for all angles; the launch is bound by dispatch + L2->CU bytes (indices, fills) + per-task LDS latency chains, so the HBM fraction is small by construction (DESIGN.md section 6)"},
         "samples_per_s": {"fwd": B * A * P * P / t_fwd, "bwd": B * A * N * N / t_bwd},
