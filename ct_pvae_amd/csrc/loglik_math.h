@@ -139,6 +139,29 @@ __device__ __forceinline__ float object_sum_of_parts(const float *__restrict__ p
         else return *q;
     };
     float total = 0.0f;
+    if (tpr <= 16) {
+        // round 4: ALL of an angle's task sums -- and those of the next group of 64 angles -- are requested before the first add
+        // (512 x 512 at 90 angles: 12 tasks per angle in two groups were six dependent batches of four loads, 4.7 us per launch)
+        for (int a0 = 0; a0 < A; a0 += 128) {
+            const int a = a0 + lane, b = a0 + 64 + lane;
+            float v0[16], v1[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v0[k] = (a < A && k < tpr) ? ld(part + (size_t)a * tpr + k) : 0.0f;
+                v1[k] = (b < A && k < tpr) ? ld(part + (size_t)b * tpr + k) : 0.0f;
+            }
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < tpr) {   // (wave-uniform) ascending, one at a time
+                    s0 += v0[k];
+                    s1 += v1[k];
+                }
+            total += wave_sum(s0);
+            if (a0 + 64 < A) total += wave_sum(s1);
+        }
+        return total;
+    }
     for (int a0 = 0; a0 < A; a0 += 64) {
         const int a = a0 + lane;
         float sa = 0.0f;

@@ -1714,17 +1714,31 @@ constexpr bool kTilePermuteLanes = CTPVAE_TILE_PERMUTE != 0;
 template <int NS, int MODE>
 __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                        TLayout L, const char *__restrict__ plan,
-                                                                       float *__restrict__ partial)
+                                                                       float *__restrict__ partial, int xcd_order)
 {
     constexpr bool SORTED = MODE != 0, PAIRED = MODE == 2;
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
     float *image = lds + kLutBytes / 4;
-    const int nt = L.nt, v = blockIdx.y, t = v % nt, s = (v / nt) * NS, A = gfull.A;
+    // Which (tile, slice group, class) a workgroup takes.  Workgroups are dispatched in the order of their linear number, round
+    // robin over the 8 XCDs; round 3 numbered them slice group-major, so the workgroups that walk one tile's plan section (one
+    // per slice group) ran on one XCD but ROUNDS apart, and every one of them pulled the section (0.6 MB per tile) through the
+    // fabric again: 207 MB of traffic per launch at 32 x 512 x 512 x 90 angles, five times the algorithmic bytes.  Round 4
+    // (`xcd_order`: one task group, tiles in whole octets): linear number = octet of tiles | slice group | class | tile % 8 --
+    // the 2 x groups workgroups of a tile sit on ONE XCD at the SAME time and share its plan section in that XCD's L2.
+    const int nt = L.nt, A = gfull.A, G = gridDim.x >> 1;
+    int v = blockIdx.y, cls = blockIdx.x & 1;
+    const int gi = blockIdx.x >> 1;
+    if (xcd_order) {
+        const int groups = gridDim.y / nt, lin = blockIdx.y * 2 + blockIdx.x;   // (G == 1)
+        const int per_octet = 16 * groups, o = lin / per_octet, r = lin - o * per_octet;
+        cls = (r >> 3) & 1;
+        v = (r >> 4) * nt + o * 8 + (r & 7);
+    }
+    const int t = v % nt, s = (v / nt) * NS;
     int y0, x0, h, w;
     tile_rect(gfull, ts, t, y0, x0, h, w);
     const float *im = img + ((size_t)s * gfull.H + y0) * gfull.W + x0;
-    const int cls = blockIdx.x & 1, gi = blockIdx.x >> 1, G = gridDim.x >> 1;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
     const int *clsw = reinterpret_cast<const int *>(plan + L.off_cls);
     const int *ngt = reinterpret_cast<const int *>(plan + L.off_ng) + (size_t)t * A * L.nbk;
@@ -2046,8 +2060,9 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_tile_compact_kernel", abs_ok);   // the step table sits at LDS address 0
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         const TLayout TL = t_layout(ts, A);
+        const int xcd_order = (G == 1 && nt % 8 == 0 && knob(kKnobTiledXcd) != 0) ? 1 : 0;
         hipLaunchKernelGGL(kernel, dim3(2 * G, groups * nt), dim3(64 * waves), t_lds_bytes(TL, A, ns), (hipStream_t)stream, img_dev, g,
-                           ts, TL, (const char *)tplan_dev, (float *)workspace_dev);
+                           ts, TL, (const char *)tplan_dev, (float *)workspace_dev, xcd_order);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_tile_compact_kernel");
         return CTPVAE_OK;
     };

@@ -31,9 +31,9 @@ def timed(n=20):
     return float(np.median(r))
 ref = plan.forward(x).clone()
 for rnd in range(3):
-    for name, knobs in (("pairs", {"TILED_PAIR": 1}), ("sorted bands", {}), ("blocks", {"TILED_SORT": 0})):
+    for name, knobs in (("pairs", {"TILED_PAIR": 1}), ("sorted bands", {}), ("sorted bands, round-3 workgroup order", {"TILED_XCD": 0}), ("blocks", {"TILED_SORT": 0})):
         for k, v in knobs.items(): _lib.tune(k, v)
         t = timed()
         same = torch.equal(plan.forward(x), ref)
         _lib.tune("*")
-        print(f"round {rnd} B={B} forward + reduce, {name:13s}: {t:7.2f} us  {'equal' if same else 'DIFFER'}", flush=True)
+        print(f"round {rnd} B={B} forward + reduce, {name:38s}: {t:7.2f} us  {'equal' if same else 'DIFFER'}", flush=True)
