@@ -1282,6 +1282,13 @@ def test_random_geometries_against_the_oracle(oracle):
             gb = to_np(plan.backward(torch.from_numpy(g).to(d)))
             np.testing.assert_array_equal(gb, oracle.rotate_bwd_tfcompat(g, geom, oTinv(oracle, theta, plan), 0),
                                           err_msg=f"bwd case {case}: {H}x{W} pad={pad} A={A} S={S} plan={use_plan}")
+        # round 4: the launch shapes a large plan would take -- angles dealt to the XCDs, both plan formats -- forced on this one
+        for fmt in ("u16", "compact"):
+            pf = RotatePlan(theta, H, W, pad, d, plan_format=fmt)
+            if pf.planned[0]:
+                with _lib.tuned("AFFINE", 1):
+                    np.testing.assert_array_equal(to_np(pf.forward(torch.from_numpy(img).to(d))), want,
+                                                  err_msg=f"affine / {fmt} case {case}: {H}x{W} pad={pad} A={A} S={S}")
         ex = RotatePlan(theta, H, W, pad, d, backward="exact")
         gx = to_np(ex.backward(torch.from_numpy(g).to(d)))
         lhs = float((to_np(ex.forward(torch.from_numpy(img).to(d))).astype(np.float64) * g).sum())
