@@ -646,6 +646,27 @@ __device__ __forceinline__ void gather16(const float *lds, const uint4 q, int n_
     }
 }
 
+// eight taps (two index dwords w0, w1) of staged rows AL0 .. AL0+7; n_live counted from AL0 (a partial group skips whole dwords)
+template <int AL0, int NS, int DUP = 1>
+__device__ __forceinline__ void gather8(const float *lds, unsigned w0, unsigned w1, int n_live, typename SliceVec<NS>::type (&v)[8])
+{
+    constexpr int ROW = kBwdPitch * 4 * NS;
+    const unsigned w[2] = {w0, w1};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if (4 * d < n_live) {
+            int b0, b1, b2, b3;
+            unpack4<NS == 1 ? 2 : 3>(w[d], b0, b1, b2, b3);
+            v[4 * d + 0] = lds_at_vec<NS>(lds, b0 + ((AL0 + 4 * d + 0) / DUP) * ROW);
+            v[4 * d + 1] = lds_at_vec<NS>(lds, b1 + ((AL0 + 4 * d + 1) / DUP) * ROW);
+            v[4 * d + 2] = lds_at_vec<NS>(lds, b2 + ((AL0 + 4 * d + 2) / DUP) * ROW);
+            v[4 * d + 3] = lds_at_vec<NS>(lds, b3 + ((AL0 + 4 * d + 3) / DUP) * ROW);
+        } else {
+            v[4 * d + 0] = v[4 * d + 1] = v[4 * d + 2] = v[4 * d + 3] = 0.0f;
+        }
+    }
+}
+
 // Backward (TensorFlow-compatible).  Workgroup = (slice s, 64-column x (waves x PPT)-row tile): stages a chunk of the
 // slice's cotangent rows (257-cell rows, zeros behind the bins), then every lane owns one column and PPT rows; for
 // each group of sixteen angles it loads the PPT index vectors (16 B = 16 taps), gathers and adds in angle order.
@@ -692,23 +713,28 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
 #pragma unroll
     for (int k = 0; k < PPT; ++k) acc[k] = 0.0f;
     const uint4 *p = idx + (size_t)xcol;
-    uint4 q[PPT];
-    auto load_group = [&](int a16) {
+    // Index vectors of TWO groups of sixteen angles in flight (round 4; SHORT launches hold both of theirs anyway): with one,
+    // every wave of a many-angle launch waited out an L2 round trip per group -- SQ_WAIT_ANY was 46 % of the wave cycles at
+    // B = 50 x 180 angles with the LDS array 22 % busy -- and all sixteen waves of the CU's one workgroup did so together.
+    uint4 q[2][PPT];
+    auto load_group = [&](int a16, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             const int y = min(y0 + k * nwaves, g.H - 1);   // rows past the slice re-read the last row, never stored
 #ifdef CTPVAE_TUNE_BWD_NOIDX
             if (a16 > 0) continue;   // timing only: every group reuses the first index vectors (no index streaming)
 #endif
-            q[k] = p[((size_t)a16 * g.H + y) * L.Wpad];
+            q[SLOT][k] = p[((size_t)a16 * g.H + y) * L.Wpad];
         }
     };
-    load_group(0);       // index loads fly while the cotangent rows land
+    load_group(0, std::integral_constant<int, 0>{});       // index loads fly while the cotangent rows land
+    if constexpr (!SHORT) load_group(min(1, L.NA16 - 1), std::integral_constant<int, 1>{});
     [[maybe_unused]] uint4 q2nd[PPT];
     if constexpr (SHORT) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            q2nd[k] = p[((size_t)min(1, L.NA16 - 1) * g.H + min(y0 + k * nwaves, g.H - 1)) * L.Wpad];
+            q2nd[k] = p[((size_t)min(1, L.NA16 - 1) * g.H + min(y0 + k * nwaves, g.H - 1)) * L.Wpad];   // (its second group)
     }
 
     const int VA = g.A * DUP;                            // virtual angles (= angles unless DUP = 2)
@@ -759,26 +785,64 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
             if constexpr (AL < kChunk * DUP) {
                 if (AL >= na4) return;                       // wave-uniform
                 const int n_live = min(16, na4 - AL);
-                vec_t v[PPT][16];
+                if constexpr (SHORT) {
+                    vec_t v[PPT][16];
 #pragma unroll
 #ifdef CTPVAE_TUNE_BWD_NOLDS
-                for (int k = 0; k < PPT; ++k)   // timing only: no gathers, the index words stand in for the taps
-                    for (int e = 0; e < 16; ++e) v[k][e] = __uint_as_float((&q[k].x)[e & 3] & 0x3fffffu);
+                    for (int k = 0; k < PPT; ++k)   // timing only: no gathers, the index words stand in for the taps
+                        for (int e = 0; e < 16; ++e) v[k][e] = __uint_as_float((&q[0][k].x)[e & 3] & 0x3fffffu);
 #else
-                for (int k = 0; k < PPT; ++k) gather16<AL, NS, DUP>(lds, q[k], n_live, v[k]);
+                    for (int k = 0; k < PPT; ++k) gather16<AL, NS, DUP>(lds, q[0][k], n_live, v[k]);
 #endif
-                const int next = (acv + AL) / 16 + 1;        // all index vectors of this group consumed: prefetch the next
-                if constexpr (SHORT) {
 #pragma unroll
-                    for (int k = 0; k < PPT; ++k) q[k] = q2nd[k];
-                } else if (next < L.NA16) {
-                    load_group(next);
+                    for (int k = 0; k < PPT; ++k) q[0][k] = q2nd[k];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < PPT; ++k)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[k] += v[k][e];   // skipped taps hold +0.0f
+                } else {
+                    // the chunks hold an even number of groups, so a group's slot in the two-deep index queue is a constant;
+                    // taps in two halves of eight (a wave holds at most 15 LDS operations in flight anyway): the registers of
+                    // the other half are what pays for the second index group
+                    constexpr int SLOT = (AL / 16) & 1;
+                    constexpr int ROW = kBwdPitch * 4 * NS;   // bytes per staged row
+                    // one index dword = four angles at a time for all PPT rows: PPT x 4 gathers in flight, added in angle order
+                    auto quarter = [&](auto d_tag) {
+                        constexpr int D = decltype(d_tag)::value;
+                        if (4 * D >= n_live) return;                 // wave-uniform: a partial last group skips whole dwords
+                        vec_t v[PPT][4];
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k) {
+                            const unsigned w = D == 0 ? q[SLOT][k].x : D == 1 ? q[SLOT][k].y : D == 2 ? q[SLOT][k].z : q[SLOT][k].w;
+#ifdef CTPVAE_TUNE_BWD_NOLDS
+                            for (int e = 0; e < 4; ++e) v[k][e] = __uint_as_float(w & 0x3fffffu);
+#else
+                            int b0, b1, b2, b3;
+                            unpack4<NS == 1 ? 2 : 3>(w, b0, b1, b2, b3);
+                            v[k][0] = lds_at_vec<NS>(lds, b0 + ((AL + 4 * D + 0) / DUP) * ROW);
+                            v[k][1] = lds_at_vec<NS>(lds, b1 + ((AL + 4 * D + 1) / DUP) * ROW);
+                            v[k][2] = lds_at_vec<NS>(lds, b2 + ((AL + 4 * D + 2) / DUP) * ROW);
+                            v[k][3] = lds_at_vec<NS>(lds, b3 + ((AL + 4 * D + 3) / DUP) * ROW);
+#endif
+                        }
+                        if constexpr (D == 3) {   // this group's index vectors are consumed: request the group after next
+                            const int next = (acv + AL) / 16 + 2;
+                            if (next < L.NA16) load_group(next, std::integral_constant<int, SLOT>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < PPT; ++k)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[k] += v[k][e];
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    quarter(std::integral_constant<int, 0>{});
+                    quarter(std::integral_constant<int, 1>{});
+                    quarter(std::integral_constant<int, 2>{});
+                    quarter(std::integral_constant<int, 3>{});
+                    // (a partial group is the launch's last: nothing is requested behind it)
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < PPT; ++k)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[k] += v[k][e];   // skipped taps hold +0.0f
             }
         };
         group(std::integral_constant<int, 0>{});

@@ -10,6 +10,6 @@ if [ "${2:-tests}" = "tests" ]; then
   grep -q passed gpurun_out/r04/${TAG}_gputests.log && ! grep -q failed gpurun_out/r04/${TAG}_gputests.log || exit 1
 fi
 python3 tools/ab_compare.py > gpurun_out/r04/${TAG}_ab_new.txt 2>&1 || exit 1
-CTPVAE_VARIANT_LIB=tools/libctpvae_radon_r04_session_start.bin python3 tools/ab_compare.py > gpurun_out/r04/${TAG}_ab_start.txt 2>&1 || exit 1
+CTPVAE_VARIANT_LIB=tools/libctpvae_radon_prev.bin python3 tools/ab_compare.py > gpurun_out/r04/${TAG}_ab_start.txt 2>&1 || exit 1
 python3 tools/ab_compare.py > gpurun_out/r04/${TAG}_ab_new2.txt 2>&1 || exit 1
 paste -d'\n' gpurun_out/r04/${TAG}_ab_start.txt gpurun_out/r04/${TAG}_ab_new.txt gpurun_out/r04/${TAG}_ab_new2.txt | grep -v amdgpu.ids
