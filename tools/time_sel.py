@@ -82,7 +82,7 @@ for bns in (1, 2):
         _lib.tune("BNS", bns); _lib.tune("BW", bw)
         print(f"  bwd4 sel BNS={bns} BW={bw}: {timed(bwd_sel_host):.2f} us")
 _lib.tune("BNS"); _lib.tune("BW")
-for g in (1, 2, 3, 4, 6):
+for g in (1, 2, 3, 4, 5, 6, 8, 10, 12):
     _lib.tune("G", g)
     print(f"G={g}: sel rotating {timed(fwd_sel):.2f} us, own plan {timed(fwd_small):.2f} us")
 _lib.tune("G")
