@@ -421,9 +421,9 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
                 const double tasks_wg = T / (2.0 * cand);
                 const double cost = (double)((wgs + 255) / 256) *
                                     (fill_us + std::max(tasks_wg * task_lds_us, std::ceil(tasks_wg / 16.0) * chain_us));
-                if (best == 0.0 || cost < best) {
-                    best = cost;
-                    ns = cand_ns;
+                if (best == 0.0 || cost < best || (cost == best && cand_ns == ns)) {   // ties (chain-bound launches) go to more
+                    best = cost;                                                        // workgroups: S=10, 20 of 180 angles
+                    ns = cand_ns;                                                       // G=8 7.78 us, G=10 7.58, G=12 7.61
                     G = cand;
                 }
             }
