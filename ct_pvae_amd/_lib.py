@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
-ABI_VERSION = 3300   # ctpvae_abi_version() of the library this binding was written for
+ABI_VERSION = 3310   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -49,6 +49,7 @@ SIGNATURES = {
                                                           _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
     "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                        _c_int, _vp, _vp]),
+    "ctpvae_rotate_tile_shape": (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ctpvae_rotate_fwd_tiled_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctpvae_rotate_fwd_tiled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp,
                                              _vp, _vp]),
@@ -240,6 +241,16 @@ class tuned:
     def __exit__(self, *exc):
         tune(self.name)
         return False
+
+
+def tile_shape(H, W, interp=0):
+    """(tile_h, tile_w) of the tiled forward for H x W slices (the association of its sum, include/ctpvae_radon.h), or None
+    when the geometry is not tiled."""
+    th, tw = ctypes.c_int(0), ctypes.c_int(0)
+    rc = load().ctpvae_rotate_tile_shape(int(H), int(W), int(interp), ctypes.byref(th), ctypes.byref(tw))
+    if rc < 0:
+        check(rc, "rotate_tile_shape")
+    return (th.value, tw.value) if rc == 1 else None
 
 
 def last_error():

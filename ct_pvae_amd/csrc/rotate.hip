@@ -1467,6 +1467,7 @@ static int pick_tile_ns(int S, bool tie_fix)
     }
     return tie_fix ? 1 : ns;   // the negative-tie fix of an unpadded canvas is not in the interleaved (asm) path
 }
+constexpr int kTileRowsMax = 128;
 static TileSpec pick_tiles(int H, int W, int interp)
 {
     TileSpec ts{};
@@ -1475,7 +1476,17 @@ static TileSpec pick_tiles(int H, int W, int interp)
     const size_t whole = (size_t)(H + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
     if (whole <= (size_t)kMaxLdsBytes) return ts;
     ts.tw = std::min(W, 64);
-    ts.th = std::min(H, 96);
+    // EQUAL rows of tiles, as tall as four interleaved slices allow in LDS (128 rows = 143 KB with the step table), round 4.
+    // Rounds 1-3 cut 96-row tiles: 512 rows were five rows of tiles and a 32-row remainder -- 768 workgroups of unequal cost,
+    // three per CU, a launch as long as three FULL tiles.  Six rows of 86 are the same 768 workgroups at 0.9 of that (forward
+    // + reduce 103.7 -> 97.4 us); four rows of 128 are 512 workgroups, two per CU: a fill, a third of the per-ray set-up and a
+    // third of the partial sums less (91.9 us; profiles/r04_tile_heights.txt).  The shape is part of the result (association
+    // of the sum): a function of (H, W) alone, reported by ctpvae_rotate_tile_shape.
+    ts.th = ceil_div(H, ceil_div(H, kTileRowsMax));
+    {
+        const int v = knob(kKnobTiledTh);   // developer knob: another tile height (read when plans are built AND used)
+        if (v >= 16 && v <= kTileRowsMax) ts.th = std::min(H, v);
+    }
     ts.ntx = ceil_div(W, ts.tw);
     ts.nty = ceil_div(H, ts.th);
     const float diag = sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th));
@@ -1981,6 +1992,15 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
     });
 }
 
+int ctpvae_rotate_tile_shape(int H, int W, int interp, int *tile_h, int *tile_w)
+{
+    if (H <= 0 || W <= 0 || !tile_h || !tile_w) return fail(CTPVAE_EINVAL, "rotate_tile_shape: bad sizes / null pointer");
+    const TileSpec ts = pick_tiles(H, W, interp);
+    *tile_h = ts.ntx ? ts.th : 0;
+    *tile_w = ts.ntx ? ts.tw : 0;
+    return ts.ntx ? 1 : 0;
+}
+
 long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, int PW, int A, int interp)
 {
     if (S <= 0 || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_fwd_tiled_workspace_bytes: bad sizes");
@@ -2028,9 +2048,13 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     if (int rc = check_geom("rotate_fwd_tiled", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
     const RotGeom g{S, H, W, PH, PW, py, px, A};
     const bool tie_fix = (px == 0 || py == 0);
-    const int ns = pick_tile_ns(S, tie_fix);
+    int ns = pick_tile_ns(S, tie_fix);
     const TileSpec ts = pick_tiles(H, W, CTPVAE_NEAREST);
     CTPVAE_REQUIRE(ts.ntx > 0, "rotate_fwd_tiled: a %dx%d slice fits LDS whole; call ctpvae_rotate_fwd_f32", H, W);
+    // the direct kernel's rows are 97 floats apart (two bank classes of one buffer; the compact plans' are 65): four slices of a
+    // 128-row tile do not fit its LDS, two do -- same tiles, same partial sums
+    while (!tplan_dev && ns > 1 && tile_lds_bytes(ts, ns) > (size_t)kMaxLdsBytes) ns >>= 1;
+    CTPVAE_REQUIRE(tplan_dev || tile_lds_bytes(ts, ns) <= (size_t)kMaxLdsBytes, "rotate_fwd_tiled: a %d-row tile does not fit LDS", ts.th);
     const int nt = ts.ntx * ts.nty, groups = ceil_div(S, ns);
     CTPVAE_REQUIRE((long long)groups * nt <= 65535, "rotate_fwd_tiled: at most 65535 tiles per call (got %lld)", (long long)groups * nt);
     const size_t lds_bytes = tile_lds_bytes(ts, ns);
@@ -2045,7 +2069,8 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     int G = std::max(1, 256 / (2 * groups * nt));
     G = std::min(G, std::max(1, tasks / 8));
     if (knob(kKnobTiledG) > 0) G = knob(kKnobTiledG);
-    const int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
+    int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
+    if (knob(kKnobTiledWaves) > 0) waves = std::min(16, knob(kKnobTiledWaves));
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0};   // per kernel instantiation: devices done
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);

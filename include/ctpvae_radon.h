@@ -67,7 +67,7 @@ typedef void *ctpvae_stream_t;
 /* Version of this ABI: major * 1000 + minor.  CTPVAE_ABI_VERSION is what THIS header describes: host code compiled against
  * it (csrc/torch_node.cpp, a maintainer's own binding) compares the macro with ctpvae_abi_version() of the library it loaded
  * and refuses a mismatch -- an entry point called with another version's argument list is a silent wrong-argument call. */
-#define CTPVAE_ABI_VERSION 3300
+#define CTPVAE_ABI_VERSION 3310
 int ctpvae_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *ctpvae_last_error(void);
@@ -110,12 +110,17 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
                           ctpvae_stream_t stream);
 
 /* ---- a2 for slices larger than LDS (512 x 512): tiled forward, NEAREST -----------------------
- * The slice is cut into tiles 64 wide x 96 tall; every tile is staged once and serves all angles, the tiles' partial sums
- * (workspace) are then added in ascending tile order (row-major over the slice):
+ * The slice is cut into tiles 64 wide x tile_h tall, tile_h = ceil(H / ceil(H / 128)) (EQUAL rows of tiles, ABI 3310: 128 for
+ * H = 512; up to ABI 3300 it was 96 with a 32-row remainder -- the same taps, another association of the sum);
+ * every tile is staged once and serves all angles, the tiles' partial sums (workspace) are then added in ascending tile order
+ * (row-major over the slice):
  *     sino[s][a][j] = ((0 + p_0) + p_1) + ...,  p_t = sum over canvas rows i, ascending, of the taps inside tile t.
  * Tap indices are exactly those of ctpvae_rotate_fwd_f32; only the association of the fp32 sum differs.
+ * ctpvae_rotate_tile_shape: 1 and the tile shape when (H, W, interp) is a tiled geometry, 0 (and zeros) when it is not --
+ * what a checker needs to restate the sum (oracle_rotate_fwd_tiled); a function of its arguments alone, not of the device.
  * _workspace_bytes returns 0 when the slice fits LDS whole or interp is not NEAREST (use ctpvae_rotate_fwd_f32),
  * otherwise the size of the caller-owned device workspace (contents undefined on return). */
+int ctpvae_rotate_tile_shape(int H, int W, int interp, int *tile_h, int *tile_w);
 long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, int PW, int A, int interp);
 int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                                 const float *T8_dev, int A, void *workspace_dev, float *sino_dev,

@@ -42,7 +42,7 @@ def test_binding_table_matches_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == declared_symbols()
     lib = built_lib.load()
     macro = int(re.search(r"#define\s+CTPVAE_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3300
+    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3310
 
 
 def test_torch_node_refuses_a_library_of_another_abi(built_lib, monkeypatch):
@@ -81,11 +81,18 @@ def test_host_only_entry_points(built_lib):
 
 def test_tiled_workspace_rule(built_lib):
     """Host-only size rule of the tiled forward: 0 when the slice fits LDS whole or the interpolation is bilinear,
-    else S x tiles x A x slots fp32 (512x512: 8 x 6 tiles of 64 x 96, 128 slots)."""
+    else S x tiles x A x slots fp32 (512x512: 8 x 4 tiles of 64 x 128 -- equal rows of tiles, ABI 3310 --, 192 slots)."""
     lib = built_lib.load()
+    assert built_lib.tile_shape(512, 512) == (128, 64) and built_lib.tile_shape(1000, 1024) == (125, 64)
+    assert built_lib.tile_shape(300, 200) == (100, 64) and built_lib.tile_shape(96 * 3, 640) == (96, 64)
+    assert built_lib.tile_shape(128, 128) is None and built_lib.tile_shape(512, 512, 1) is None
+    with built_lib.tuned("TILED_TH", 96):     # the shape up to ABI 3300
+        assert built_lib.tile_shape(512, 512) == (96, 64)
+    with pytest.raises(ValueError):
+        built_lib.tile_shape(0, 512)
     assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(50, 128, 128, 184, 184, 20, 0) == 0
     assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 1) == 0
-    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 0) == 8 * 48 * 90 * 128 * 4
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 0) == 8 * 32 * 90 * 192 * 4
     assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(0, 512, 512, 728, 728, 90, 0) == built_lib.EINVAL
 
 

@@ -31,7 +31,9 @@ def timed(n=20):
     return float(np.median(r))
 ref = plan.forward(x).clone()
 for rnd in range(3):
-    for name, knobs in (("pairs", {"TILED_PAIR": 1}), ("sorted bands", {}), ("sorted bands, round-3 workgroup order", {"TILED_XCD": 0}), ("blocks", {"TILED_SORT": 0})):
+    for name, knobs in (("pairs", {"TILED_PAIR": 1}), ("sorted bands (default)", {}),
+                        ("sorted bands, round-3 workgroup order", {"TILED_XCD": 0}), ("blocks", {"TILED_SORT": 0}),
+                        ("sorted bands, 12 waves", {"TILED_WAVES": 12}), ("sorted bands, 8 waves", {"TILED_WAVES": 8})):
         for k, v in knobs.items(): _lib.tune(k, v)
         t = timed()
         same = torch.equal(plan.forward(x), ref)
