@@ -260,6 +260,8 @@ struct TileSpec {
     int ntx, nty;   // tiles per slice
     int tw, th;     // nominal tile size (edge tiles are smaller)
     int nb;         // ray slots per (tile, angle), a multiple of 64
+    int span;       // ... of which the first `span` can touch the tile (the rest pad nb to whole waves): only those are stored
+                    // by the tile kernels and read back by the reduce pass
     float radius;   // half the tile diagonal + 3 px
 };
 __host__ __device__ __forceinline__ void tile_rect(const RotGeom &g, const TileSpec &ts, int t, int &y0, int &x0, int &h, int &w)
@@ -422,8 +424,9 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
             for (int e = 0; e < 6; ++e) t6[e] = t[e];
         }
         if (TILED) {
+            q.live = q.live && j < ts.span;                    // slots past the span pass the tile by (partial sum +0) and ...
             j += tile_first_bin(t6, tile_cx, tile_cy, ts.radius);
-            q.live = q.live && (unsigned)j < (unsigned)g.PW;   // slots off the detector are never read back
+            q.live = q.live && (unsigned)j < (unsigned)g.PW;   // ... slots off the detector: neither is ever read back
         }
         const float t0 = t6[0], t3 = t6[3];
         q.t1 = t6[1]; q.t2 = t6[2]; q.t4 = t6[4]; q.t5 = t6[5];
@@ -679,7 +682,7 @@ __device__ __forceinline__ void tile_reduce_wave(const float *__restrict__ parti
             tile_rect(g, ts, tile, y0, x0, h, w);
             const float cx = (float)(g.px + x0) + 0.5f * (float)(w - 1), cy = (float)(g.py + y0) + 0.5f * (float)(h - 1);
             fb = tile_first_bin(t, cx, cy, ts.radius);   // the same expression as the tile kernel's
-            rel = fb <= j0 + 63 && fb + ts.nb > j0;
+            rel = fb <= j0 + 63 && fb + ts.span > j0;
         }
         const unsigned long long m = __ballot(rel);
         const int n = __popcll(m);
@@ -696,7 +699,7 @@ __device__ __forceinline__ void tile_reduce_wave(const float *__restrict__ parti
         bool ok[D];
         auto issue = [&](int i, f32x4 (&dst)[kQuads], bool &okd) {
             const int slot = j - list_first[wave][i];
-            okd = j < g.PW && (unsigned)slot < (unsigned)ts.nb;
+            okd = j < g.PW && (unsigned)slot < (unsigned)ts.span;
             const size_t off = (size_t)list_tile[wave][i] * tstride + (okd ? slot : 0);
 #pragma unroll
             for (int q = 0; q < kQuads; ++q) dst[q] = pa[q][off];
@@ -1491,7 +1494,8 @@ static TileSpec pick_tiles(int H, int W, int interp)
     ts.nty = ceil_div(H, ts.th);
     const float diag = sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th));
     ts.radius = 0.5f * diag + 3.0f;
-    ts.nb = ((int)ceilf(2.0f * ts.radius) + 2 + 63) / 64 * 64;
+    ts.span = (int)ceilf(2.0f * ts.radius) + 2;
+    ts.nb = (ts.span + 63) / 64 * 64;
     return ts;
 }
 static size_t tile_lds_bytes(const TileSpec &ts, int ns)
@@ -1582,9 +1586,11 @@ __global__ __launch_bounds__(64) void rotate_tplan_kernel(RotGeom gfull, TileSpe
     const size_t ta = (size_t)t * gfull.A + a;
     if (lane == 0) ngt[ta * L.nbk + blk] = ng;
     if ((lane & 15) == 0) ng16[ta * L.nq16 + (slot >> 4)] = (n16 + kRowsPerGroup - 1) / kRowsPerGroup;
-    start[ta * L.nb + slot] = (unsigned)rs.start | (valid ? 0x80000000u : 0u);
+    // stored (and read back by the reduce pass) only inside the span; a ray past it that touches the tile would contradict
+    // the span's derivation: the plan is then flagged unusable
+    start[ta * L.nb + slot] = (unsigned)rs.start | (valid && slot < ts.span ? 0x80000000u : 0u);
     bool bad = cplan_encode_ray(g, t6, j, rs, kRowsPerChunk * L.NQ, L.pitch, L.NQ, codes + ta * L.NQ * L.nb + slot, (size_t)L.nb);
-    bad = bad || kRowsPerGroup * ng > kRowsPerChunk * L.NQ || ng > 127;
+    bad = bad || kRowsPerGroup * ng > kRowsPerChunk * L.NQ || ng > 127 || (slot >= ts.span && rs.n > 0);
     if (__any(bad) && lane == 0) atomicOr(reinterpret_cast<int *>(plan + L.off_flag), 1);
 }
 
@@ -1625,9 +1631,9 @@ __global__ __launch_bounds__(64) void rotate_tplan_pairs_kernel(RotGeom gfull, T
     const size_t unit = ((size_t)t * gfull.A + a) * L.nu + u;
     unsigned *pstart = reinterpret_cast<unsigned *>(plan + L.off_pstart) + (unit * 16 + k) * 2;
     if (isA)
-        pstart[0] = (unsigned)rs.start | ((unsigned)gA << 16) | (valid ? 0x80000000u : 0u);
+        pstart[0] = (unsigned)rs.start | ((unsigned)gA << 16) | (valid && slot < ts.span ? 0x80000000u : 0u);
     else
-        pstart[1] = (unsigned)rs.start | (valid ? 0x80000000u : 0u);
+        pstart[1] = (unsigned)rs.start | (valid && slot < ts.span ? 0x80000000u : 0u);
     int tot = gA + gB;   // the same on both partner lanes
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) tot = max(tot, __shfl_xor(tot, off, 64));
@@ -1649,8 +1655,10 @@ __global__ __launch_bounds__(64) void rotate_tplan_pairs_kernel(RotGeom gfull, T
 // Task word: angle | band << 16 | the band's row groups << 20 | sigma < 0 << 28 | 1 << 31 (0: an empty quarter).
 // One wave per (tile, class); the sort is a stable counting sort over keys (sign, 127 - groups).
 // (round 4: the same sort over the PAIRED units -- nq units per angle, lengths at off_len, lists at off_tcount / off_tasks)
+// nq_used: units >= nq_used of an angle hold no slot inside the tile's span (TileSpec::span) -- nothing to walk, nothing stored,
+// no task.
 __global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L, char *__restrict__ plan, int nq, long long off_len,
-                                                                long long off_tcount, long long off_tasks, int maxT)
+                                                                long long off_tcount, long long off_tasks, int maxT, int nq_used)
 {
     const int t = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
     const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
@@ -1665,7 +1673,7 @@ __global__ __launch_bounds__(64) void rotate_tplan_tasks_kernel(int A, TLayout L
         in = false;
         if (u >= U) return 0;
         const int a = u / nq, w = cls[a];
-        in = (w & 1) == c;
+        in = (w & 1) == c && u - a * nq < nq_used;
         return ((w >> 1) & 1) * 128 + (127 - min(ng16[u], 127));
     };
     for (int u0 = 0; u0 < U; u0 += 64) {
@@ -2113,7 +2121,8 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     else
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 1>);
     if (rc) return rc;
-    const int rwaves = std::min(16, ceil_div(PW, 64));   // waves per workgroup: 64 bins each
+    int rwaves = std::min(16, ceil_div(PW, 64));   // waves per workgroup: 64 bins each
+    if (knob(kKnobReduceWaves) > 0) rwaves = std::min(16, knob(kKnobReduceWaves));
     const dim3 rgrid(ceil_div(PW, 64 * rwaves), A, ceil_div(S, kReduceSlices)), rblock(64 * rwaves);
     if (epi.part)
         hipLaunchKernelGGL(rotate_tile_reduce_kernel<2>, rgrid, rblock, 0, (hipStream_t)stream,
@@ -2170,7 +2179,7 @@ int ctpvae_rotate_tplan_build_f32(const float *T8_dev, int A, int H, int W, int 
     hipLaunchKernelGGL(rotate_tplan_kernel, dim3(L.nbk, A, L.nt), dim3(64), 0, (hipStream_t)stream, g, ts, T8_dev, L, (char *)tplan_dev);
     CTPVAE_LAUNCH_CHECK("rotate_tplan_kernel");
     hipLaunchKernelGGL(rotate_tplan_tasks_kernel, dim3(L.nt, 2), dim3(64), 0, (hipStream_t)stream, A, L, (char *)tplan_dev, L.nq16,
-                       L.off_ng16, L.off_tcount, L.off_tasks, L.maxT);
+                       L.off_ng16, L.off_tcount, L.off_tasks, L.maxT, ceil_div(ts.span, 16));
     CTPVAE_LAUNCH_CHECK("rotate_tplan_tasks_kernel");
     if (knob(kKnobTiledPair) != 1) return CTPVAE_OK;
     // paired units (round 4, knob TILED_PAIR = 1): lane streams, then the same sort over them
@@ -2178,7 +2187,7 @@ int ctpvae_rotate_tplan_build_f32(const float *T8_dev, int A, int H, int W, int 
     hipLaunchKernelGGL(rotate_tplan_pairs_kernel, dim3(L.nbk, A, L.nt), dim3(64), (size_t)32 * L.NQP * 16, (hipStream_t)stream, g, ts, T8_dev, L, (char *)tplan_dev);
     CTPVAE_LAUNCH_CHECK("rotate_tplan_pairs_kernel");
     hipLaunchKernelGGL(rotate_tplan_tasks_kernel, dim3(L.nt, 2), dim3(64), 0, (hipStream_t)stream, A, L, (char *)tplan_dev, L.nu,
-                       L.off_ngu, L.off_ptcount, L.off_ptasks, L.maxTP);
+                       L.off_ngu, L.off_ptcount, L.off_ptasks, L.maxTP, L.nu);
     CTPVAE_LAUNCH_CHECK("rotate_tplan_tasks_kernel (pairs)");
     return CTPVAE_OK;
 }
