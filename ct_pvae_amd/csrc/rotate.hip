@@ -1218,34 +1218,44 @@ __global__ __launch_bounds__(64) void rotate_bwd_step_plan_kernel(RotGeom g, con
     if (!ok) *reinterpret_cast<int *>(plan + L.off_flag) = 1;
 }
 
+// NS = 2: a slice pair per workgroup.  NS = 4 (round 4): TWO pairs -- the second pair's segments in a second array of float2
+// cells kStepPairGap bytes above the first's, read with the SAME address registers (the gap rides in the ds_read's offset
+// field): the plan word, its unpacking and the eight address adds of an angle serve four slices instead of two, 26 instead
+// of 2 x 18 vector instructions per angle and lane.  Same taps, same order of the angles: same bits.
+constexpr int kStepChunk4 = 30;                                        // angles per staged chunk of the two-pair kernel
+constexpr int kStepPairGap = kStepChunk4 * kSegPitch * kStepCell;      // bytes between the pairs' arrays (ds_read offset: < 64 KB)
 template <int NS>
 __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__restrict__ gsino, RotGeom g,
                                                                  const float *__restrict__ Tinv8, int chunk_a, StepLayout L,
                                                                  const char *__restrict__ plan, SliceScale scale,
                                                                  float *__restrict__ gimg)
 {
-    typedef typename PixVec<NS>::type vec_t;
+    static_assert(NS == 2 || NS == 4, "the step plan's offsets are in float2 cells: slices ride as (half-empty) pairs");
+    constexpr int NP = NS / 2;           // pairs per workgroup
     constexpr int PPT = kStepRows;
-    // [chunk_a][kSegPitch] segment cells (NS floats each), then per angle (first bin) and (segment byte base as the plan's
-    // offsets count from it, the first row's distance above it)
+    // [chunk_a][kSegPitch] segment cells (a float2 each) per pair, then per angle (first bin) and (segment byte base as the
+    // plan's offsets count from it, the first row's distance above it)
     extern __shared__ float lds[];
-    int *first_s = reinterpret_cast<int *>(lds + chunk_a * kSegPitch * NS);
-    int2 *meta2 = reinterpret_cast<int2 *>(lds + ((chunk_a * (kSegPitch * NS + 1) + 1) & ~1));
+    const int cell_floats = NP == 1 ? chunk_a * kSegPitch * 2 : kStepPairGap / 4 + chunk_a * kSegPitch * 2;
+    int *first_s = reinterpret_cast<int *>(lds + cell_floats);
     const int s = blockIdx.z * NS;
-    const bool has2 = NS == 2 && s + 1 < g.S;
-    const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
+    const int nlive = min(NS, g.S - s);          // slices past the batch re-read slice s and are never stored
+    float kscale[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) kscale[n] = n < nlive ? scale.at(s + n) : 1.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int rg = blockIdx.y * (kStepTileRows / kStepRows) + wave;     // this lane's rows: rg * 8 .. rg * 8 + 7
     const float X0 = (float)(blockIdx.x * 64 + g.px), Y0 = (float)(blockIdx.y * kStepTileRows + g.py);
     const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
-    static_assert(NS == 2, "the step plan's offsets are in float2 cells: single slices ride as half-empty pairs");
     const uint2 *pl = reinterpret_cast<const uint2 *>(plan) + (size_t)rg * L.Wpad + c;
     const size_t astride = (size_t)L.H8 * L.Wpad;
 
-    vec_t acc[PPT];
+    f32x2 acc[NP][PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) acc[k] = 0.0f;
+    for (int h = 0; h < NP; ++h)
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) acc[h][k] = 0.0f;
 
     for (int ac = 0; ac < g.A; ac += chunk_a) {
         const int na = min(chunk_a, g.A - ac);
@@ -1255,19 +1265,21 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             int first;
             step_segment_first(t, X0, Y0, first);
             first_s[al] = first;
-            const float t1 = t[1];
-            // (segment base as the plan's offsets count from it, what the first row's tap lies above it)
-            const int drop = t1 < 0.0f ? kStepCell * kStepMax : 0;
-            meta2[al] = make_int2(al * kSegPitch * kStepCell + lds_base - drop, drop);
         }
+        // which of the chunk's angles step DOWN the bins (their offsets count from a base kStepMax cells lower): one bit per
+        // angle in a scalar register pair.  (Round 4: this and the segment's base were an LDS word per angle, read in the walk;
+        // LDS reads return in order, so waiting for that word drained the sixteen gathers in flight, twice per angle pair.)
+        const unsigned long long down = __ballot(lane < na && Tinv8[8 * (size_t)(ac + min(lane, na - 1)) + 1] < 0.0f);
         __syncthreads();
         const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
-        const size_t src2 = has2 ? (size_t)g.A * g.PW : 0;
+        size_t soff[NS];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) soff[n] = n < nlive ? (size_t)n * g.A * g.PW : 0;
         {
             constexpr int U = 8 / NS;
             const int ncell = na * kSegPitch;
             for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
-                vec_t v[U];
+                f32x2 v[U][NP];
                 bool ok[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -1276,53 +1288,73 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
                     const int j = first_s[al] + q;
                     ok[u] = q < kSegBins && (unsigned)j < (unsigned)g.PW;
                     const float *cell = src + al * g.PW + min(max(j, 0), g.PW - 1);
-                    if constexpr (NS == 1) {
-                        v[u] = cell[0];
-                    } else {
-                        v[u].x = cell[0];
-                        v[u].y = cell[src2];
+#pragma unroll
+                    for (int h = 0; h < NP; ++h) {
+                        v[u][h].x = cell[soff[2 * h]];
+                        v[u][h].y = cell[soff[2 * h + 1]];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int p = p0 + u * (int)blockDim.x;
-                    if (p < ncell) reinterpret_cast<vec_t *>(lds)[p] = ok[u] ? v[u] : vec_t(0.0f);
+                    if (p < ncell) {
+#pragma unroll
+                        for (int h = 0; h < NP; ++h)
+                            reinterpret_cast<f32x2 *>(lds + h * (kStepPairGap / 4))[p] = ok[u] ? v[u][h] : f32x2(0.0f);
+                    }
                 }
             }
         }
         __syncthreads();
 
-        // per angle: the plan word (fetched kAhead angles ahead), the segment base (one broadcast ds_read_b64), eight gathers
-        // whose addresses are one SDWA add of a plan byte apart from the base; the adds of an angle run under the next angle's
-        // gathers
-        auto taps = [&](const uint2 w, const int2 m, vec_t (&v)[PPT]) {
+        // per angle: the plan word (fetched kAhead angles ahead), the segment base (scalar arithmetic), eight gathers per pair
+        // whose addresses are one SDWA add of a plan byte apart from the base
+        auto addr = [&](const uint2 w, const int ang, int (&a)[PPT]) {
             static_assert(PPT == 8, "eight rows per plan word");
-            int t, base, a1, a2, a3, a4, a5, a6, a7;
+            // (segment base as the plan's offsets count from it, what the first row's tap lies above it)
+            const int drop = ((down >> ang) & 1ull) ? kStepCell * kStepMax : 0;
+            const int seg = ang * (kSegPitch * kStepCell) + lds_base - drop;
+            int t, base;
             asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(t) : "v"(w.x));
-            base = t + m.x;
-            v[0] = lds_abs_vec<NS>(base + m.y);
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a1) : "v"(base), "v"(w.x));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a2) : "v"(base), "v"(w.x));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a3) : "v"(base), "v"(w.x));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a4) : "v"(base), "v"(w.y));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a5) : "v"(base), "v"(w.y));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a6) : "v"(base), "v"(w.y));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a7) : "v"(base), "v"(w.y));
-            v[1] = lds_abs_vec<NS>(a1);
-            v[2] = lds_abs_vec<NS>(a2);
-            v[3] = lds_abs_vec<NS>(a3);
-            v[4] = lds_abs_vec<NS>(a4);
-            v[5] = lds_abs_vec<NS>(a5);
-            v[6] = lds_abs_vec<NS>(a6);
-            v[7] = lds_abs_vec<NS>(a7);
+            base = t + seg;
+            a[0] = base + drop;
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a[1]) : "v"(base), "v"(w.x));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a[2]) : "v"(base), "v"(w.x));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a[3]) : "v"(base), "v"(w.x));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a[4]) : "v"(base), "v"(w.y));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a[5]) : "v"(base), "v"(w.y));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a[6]) : "v"(base), "v"(w.y));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a[7]) : "v"(base), "v"(w.y));
+        };
+        auto gather = [&](const int (&a)[PPT], auto h_tag, f32x2 (&v)[PPT]) {
+            constexpr int OFF = decltype(h_tag)::value * kStepPairGap;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) v[k] = lds_abs_vec<2>(a[k] + OFF);
+        };
+        auto add = [&](f32x2 (&sum)[PPT], const f32x2 (&v)[PPT]) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) sum[k] += v[k];
         };
         // plan words are fetched kAhead angles ahead of their use (an L2 round trip is several angles long)
         constexpr int kAhead = 6;
         const uint2 *pa = pl + (size_t)ac * astride;
         uint2 wq[kAhead];
+        f32x2 va[NP][PPT], vb[NP][PPT];
+        int a[PPT];
+        // (a finer pipeline for two pairs -- angle n + 1's first pair requested as soon as angle n's first pair is added, 8 to 16
+        // gathers in flight all the time -- needed a wave-uniform branch per angle for the chunk's tail and ran 57.9 us against
+        // this loop's 47.5: profiles/r04_step_pairs.txt)
+        auto taps = [&](const uint2 w, const int ang, f32x2 (&v)[NP][PPT]) {
+            addr(w, ang, a);
+            gather(a, std::integral_constant<int, 0>{}, v[0]);
+            if constexpr (NP == 2) gather(a, std::integral_constant<int, 1>{}, v[1]);
+        };
+        auto add_all = [&](const f32x2 (&v)[NP][PPT]) {
+#pragma unroll
+            for (int h = 0; h < NP; ++h) add(acc[h], v[h]);
+        };
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) wq[q] = pa[(size_t)min(q, na - 1) * astride];
-        vec_t va[PPT], vb[PPT];
         int al = 0;
         for (; al + kAhead <= na; al += kAhead) {      // kAhead angles per trip, two register sets of gathers in flight
 #pragma unroll
@@ -1330,22 +1362,19 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
                 const uint2 w0 = wq[q], w1 = wq[q + 1];
                 wq[q] = pa[(size_t)min(al + kAhead + q, na - 1) * astride];
                 wq[q + 1] = pa[(size_t)min(al + kAhead + q + 1, na - 1) * astride];
-                taps(w0, meta2[al + q], va);
-                taps(w1, meta2[al + q + 1], vb);
+                taps(w0, al + q, va);
+                taps(w1, al + q + 1, vb);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) acc[k] += va[k];
-#pragma unroll
-                for (int k = 0; k < PPT; ++k) acc[k] += vb[k];
+                add_all(va);
+                add_all(vb);
             }
         }
         for (int q = 0; al < na; ++al, ++q) {          // the chunk's last angles (wq holds their words in order)
             uint2 w = wq[0];
 #pragma unroll
             for (int j = 1; j < kAhead; ++j) w = q == j ? wq[j] : w;
-            taps(w, meta2[al], va);
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) acc[k] += va[k];
+            taps(w, al, va);
+            add_all(va);
         }
     }
     if (c < g.W) {
@@ -1353,12 +1382,9 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
         for (int k = 0; k < PPT; ++k) {
             const int r = rg * kStepRows + k;
             if (r < g.H) {
-                if constexpr (NS == 1) {
-                    gimg[((size_t)s * g.H + r) * g.W + c] = k0 * acc[k];
-                } else {
-                    gimg[((size_t)s * g.H + r) * g.W + c] = k0 * acc[k].x;
-                    if (has2) gimg[((size_t)(s + 1) * g.H + r) * g.W + c] = k1 * acc[k].y;
-                }
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    if (n < nlive) gimg[((size_t)(s + n) * g.H + r) * g.W + c] = kscale[n] * ((n & 1) ? acc[n >> 1][k].y : acc[n >> 1][k].x);
             }
         }
     }
@@ -2293,28 +2319,38 @@ int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, i
                    "rotate_bwd_stepped: null pointer or empty sizes");
     if (int rc = check_geom("rotate_bwd_stepped", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
     const StepLayout L = step_layout(H, W, A);
-    return for_slice_chunks(S, std::min(65534, max_slices_per_launch() / 2 * 2), [&](int s0, int n) {
+    return for_slice_chunks(S, std::min(65532, max_slices_per_launch() / 4 * 4), [&](int s0, int n) {
         const float *gs = gsino_dev + (size_t)s0 * A * PW;
         const float *sc = scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr;
         float *gi = gimg_dev + (size_t)s0 * H * W;
         // the plan is for slice PAIRS (a lone or last odd slice rides as a half-empty pair) in 64 x 32 tiles, which small launches
         // trade for 64 x 16 ones -- those keep the direct kernel
-        const int units = ceil_div(n, 2);
+        const int pairs = ceil_div(n, 2);
         // (SEG_PPT = 8 / 4: a developer's way to force the 64 x 32 stepped tiles / the direct kernel whatever the launch size)
-        const bool big = knob(kKnobSegPpt) >= 0 ? knob(kKnobSegPpt) == 8
-                                                : (long long)units * ceil_div(W, 64) * ceil_div(H, kStepTileRows) >= 512;
+        const long long tiles = (long long)ceil_div(W, 64) * ceil_div(H, kStepTileRows);
+        const bool big = knob(kKnobSegPpt) >= 0 ? knob(kKnobSegPpt) == 8 : pairs * tiles >= 512;
         if (knob(kKnobForceGeneric) >= 0 || knob(kKnobNoPlan) >= 0 || !big)
             return rotate_bwd_one(gs, n, A, PH, PW, Tinv8_dev, CTPVAE_NEAREST, CTPVAE_BWD_TF_COMPAT, H, W, py, px, sc, scale_stride, gi,
                                   stream);
         const RotGeom g{n, H, W, PH, PW, py, px, A};
+        // two pairs per workgroup (round 4) while that leaves every CU three workgroups (knob STEP_NS = 2 / 4 forces).  Measured
+        // (tools/time_step_ns.py, two pairs against one): 1024 workgroups 47.1 vs 57.1 us (32 x 512 x 512 x 90 angles), 800: 88.9 vs
+        // 99.0 (400 x 128 x 128 x 180); 512: 35.0 vs 33.3 (16 x 512 x 512), 400: 65.7 vs 62.6 (200 x 128 x 128 x 180)
+        const int ns = knob(kKnobStepNs) == 2 ? 2 : (knob(kKnobStepNs) == 4 || (long long)ceil_div(n, 4) * tiles >= 768) ? 4 : 2;
         // angles per staged chunk (knob SEG_CHUNK; measured with warm clocks at 32 x 512 x 512 x 90 angles, tools/sweep_step_chunk.py:
         // 48 + 42 angles 56.5-57.0 us, 45 + 45 56.8, 3 x 30 57.6, 4 x 23 57.4, 5 x 18 62.3 -- flat down to chunks of 23)
-        const int max_chunk = knob(kKnobSegChunk) > 0 ? knob(kKnobSegChunk) : 48;
-        const int chunk_a = std::min(A, max_chunk);
-        const size_t shmem = (size_t)chunk_a * (kSegPitch * sizeof(float) * 2 + sizeof(int) + 2 * sizeof(int)) + 16;
-        const dim3 grid(ceil_div(W, 64), ceil_div(H, kStepTileRows), units), block(256);
-        hipLaunchKernelGGL(rotate_bwd_stepped_kernel<2>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
-                           (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
+        const int max_chunk = knob(kKnobSegChunk) > 0 ? std::min(64, knob(kKnobSegChunk)) : 48;   // (<= 64: one mask bit per angle)
+        const int chunk_a = std::min(A, ns == 4 ? std::min(max_chunk, kStepChunk4) : max_chunk);
+        const size_t cells = ns == 4 ? (size_t)kStepPairGap + (size_t)chunk_a * kSegPitch * kStepCell : (size_t)chunk_a * kSegPitch * kStepCell;
+        size_t shmem = cells + (size_t)chunk_a * sizeof(int) + 16;
+        if (knob(kKnobStepLdsKb) > 0) shmem = std::max(shmem, (size_t)knob(kKnobStepLdsKb) * 1024);   // timing: fewer workgroups per CU
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, kStepTileRows), ceil_div(n, ns)), block(256);
+        if (ns == 4)
+            hipLaunchKernelGGL(rotate_bwd_stepped_kernel<4>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
+                               (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
+        else
+            hipLaunchKernelGGL(rotate_bwd_stepped_kernel<2>, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, L,
+                               (const char *)step_plan_dev, SliceScale{sc, scale_stride}, gi);
         CTPVAE_LAUNCH_CHECK("rotate_bwd_stepped_kernel");
         return CTPVAE_OK;
     });

@@ -1405,9 +1405,18 @@ def test_step_plan_backward_equals_the_direct_kernel(oracle, shape, A, S):
     with _lib.tuned("NO_PLAN", 1):
         direct, direct_s = plan.backward(gt), plan.backward(gt, scale=scale)
     assert torch.equal(got, direct) and torch.equal(got_s, direct_s)
+    # round 4: one slice pair per workgroup, or two pairs sharing the plan word and the address arithmetic (large launches);
+    # batches that are no multiple of four, angle counts that end a chunk of 30 in a partial trip
+    for ns in (2, 4):
+        with _lib.tuned("STEP_NS", ns):
+            assert torch.equal(plan.backward(gt), direct) and torch.equal(plan.backward(gt, scale=scale), direct_s), ns
+            assert torch.equal(plan.backward(gt[:S - 2]), direct[:S - 2]), ns
     n_chk = 3
     geom = oracle.Geometry(shape[0], shape[1], True)
     np.testing.assert_array_equal(to_np(got[:n_chk]), oracle.rotate_bwd_tfcompat(g[:n_chk], geom, oTinv(oracle, theta, plan), 0))
+    with _lib.tuned("STEP_NS", 4):
+        np.testing.assert_array_equal(to_np(plan.backward(gt)[S - n_chk:]),
+                                      oracle.rotate_bwd_tfcompat(g[S - n_chk:], geom, oTinv(oracle, theta, plan), 0))
     assert RotatePlan(theta, shape[0], shape[1], False, d)._step_plan is None
 
 
@@ -1438,7 +1447,8 @@ def test_random_step_plan_geometries(oracle):
                                           orc.rotate_bwd_tfcompat(to_np(g[:2]), geom, oTinv(orc, theta, plan), 0), err_msg=tag)
             continue
         plan.backward_uses_step_plan = lambda S: True          # (shapes the planned backward serves would take it at this S)
-        got = plan.backward(g)
+        with _lib.tuned("STEP_NS", (2, 4)[case % 2]):          # one slice pair per workgroup / two
+            got = plan.backward(g)
         with _lib.tuned("NO_PLAN", 1):
             ref = plan.backward(g)
         assert torch.equal(got, ref), tag
@@ -1456,9 +1466,11 @@ def test_step_plan_holds_two_bin_steps_near_a_right_angle():
     g = torch.from_numpy(np.random.default_rng(1).standard_normal((25, len(theta), plan.PW)).astype(np.float32)).to(d)
     plan.backward_uses_step_plan = lambda S: True
     got = plan.backward(g)
+    with _lib.tuned("STEP_NS", 4):
+        got4 = plan.backward(g)
     with _lib.tuned("NO_PLAN", 1):
         ref = plan.backward(g)
-    assert torch.equal(got, ref)
+    assert torch.equal(got, ref) and torch.equal(got4, ref)
 
 
 def test_large_batches_of_small_slices_take_the_step_plan_too():
