@@ -1222,7 +1222,12 @@ __global__ __launch_bounds__(64) void rotate_bwd_step_plan_kernel(RotGeom g, con
 // cells kStepPairGap bytes above the first's, read with the SAME address registers (the gap rides in the ds_read's offset
 // field): the plan word, its unpacking and the eight address adds of an angle serve four slices instead of two, 26 instead
 // of 2 x 18 vector instructions per angle and lane.  Same taps, same order of the angles: same bits.
-constexpr int kStepChunk4 = 30;                                        // angles per staged chunk of the two-pair kernel
+#ifdef CTPVAE_TUNE_STEP_CHUNK4
+constexpr int kStepChunk4 = CTPVAE_TUNE_STEP_CHUNK4;
+#else
+constexpr int kStepChunk4 = 30;
+#endif
+//                                       // angles per staged chunk of the two-pair kernel
 constexpr int kStepPairGap = kStepChunk4 * kSegPitch * kStepCell;      // bytes between the pairs' arrays (ds_read offset: < 64 KB)
 template <int NS>
 __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__restrict__ gsino, RotGeom g,
@@ -1275,8 +1280,16 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
         size_t soff[NS];
 #pragma unroll
         for (int n = 0; n < NS; ++n) soff[n] = n < nlive ? (size_t)n * g.A * g.PW : 0;
+#ifndef CTPVAE_TUNE_STEP_NOSTAGE   // (timing builds only)
         {
-            constexpr int U = 8 / NS;
+            // ALL of a chunk's cells are requested before the first is written (round 4): ceil(30 x 81 / 256) = 10 per thread with two
+            // pairs, 2 x 8 with one -- two cells per pass made a chunk five dependent round trips to memory, with every
+            // workgroup of the CU waiting at the same time
+#ifdef CTPVAE_TUNE_STEP_U
+            constexpr int U = CTPVAE_TUNE_STEP_U;
+#else
+            constexpr int U = NS == 4 ? 10 : 8;
+#endif
             const int ncell = na * kSegPitch;
             for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
                 f32x2 v[U][NP];
@@ -1305,6 +1318,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
                 }
             }
         }
+#endif
         __syncthreads();
 
         // per angle: the plan word (fetched kAhead angles ahead), the segment base (scalar arithmetic), eight gathers per pair
@@ -1336,7 +1350,11 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             for (int k = 0; k < PPT; ++k) sum[k] += v[k];
         };
         // plan words are fetched kAhead angles ahead of their use (an L2 round trip is several angles long)
+#ifdef CTPVAE_TUNE_STEP_AHEAD
+        constexpr int kAhead = CTPVAE_TUNE_STEP_AHEAD;
+#else
         constexpr int kAhead = 6;
+#endif
         const uint2 *pa = pl + (size_t)ac * astride;
         uint2 wq[kAhead];
         f32x2 va[NP][PPT], vb[NP][PPT];
@@ -1353,6 +1371,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
 #pragma unroll
             for (int h = 0; h < NP; ++h) add(acc[h], v[h]);
         };
+#ifndef CTPVAE_TUNE_STEP_NOWALK   // (timing builds only)
 #pragma unroll
         for (int q = 0; q < kAhead; ++q) wq[q] = pa[(size_t)min(q, na - 1) * astride];
         int al = 0;
@@ -1362,6 +1381,19 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
                 const uint2 w0 = wq[q], w1 = wq[q + 1];
                 wq[q] = pa[(size_t)min(al + kAhead + q, na - 1) * astride];
                 wq[q + 1] = pa[(size_t)min(al + kAhead + q + 1, na - 1) * astride];
+#ifdef CTPVAE_TUNE_STEP_SINGLE   // timing only: one angle's gathers in flight (fewer registers, a full wait per angle)
+                if constexpr (NP == 2) {
+                    taps(w0, al + q, va);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add_all(va);
+                    __builtin_amdgcn_sched_barrier(0);
+                    taps(w1, al + q + 1, va);
+                    __builtin_amdgcn_sched_barrier(0);
+                    add_all(va);
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
+#endif
                 taps(w0, al + q, va);
                 taps(w1, al + q + 1, vb);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1376,6 +1408,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_stepped_kernel(const float *__
             taps(w, al, va);
             add_all(va);
         }
+#endif
     }
     if (c < g.W) {
 #pragma unroll
