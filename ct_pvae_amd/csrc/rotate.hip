@@ -694,7 +694,11 @@ __device__ __forceinline__ void tile_reduce_wave(const float *__restrict__ parti
         __builtin_amdgcn_wave_barrier();              // the list is this wave's own: LDS writes are in order
         // tiles in ascending order; loads unconditional (slot clamped).  The loads of tile i + 2 are requested before tile i is
         // added: one tile at a time the pass was a chain of ~12 dependent round trips to memory per wave.
+#ifdef CTPVAE_TUNE_REDUCE_D
+        constexpr int D = CTPVAE_TUNE_REDUCE_D;
+#else
         constexpr int D = 3;
+#endif
         f32x4 v[D][kQuads];
         bool ok[D];
         auto issue = [&](int i, f32x4 (&dst)[kQuads], bool &okd) {

@@ -3,6 +3,10 @@ the reduce pass's workgroup size (knob REDUCE_WAVES: waves of 64 bins per workgr
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ct_pvae_amd import _lib
+if os.environ.get("CTPVAE_VARIANT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["CTPVAE_VARIANT_LIB"])
+    _lib.torch_node = lambda: None
+print("library:", _lib.LIB_PATH)
 from ct_pvae_amd.forward_functions import RotatePlan
 d = torch.device('cuda', 0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
@@ -29,7 +33,7 @@ def timed(n=20):
     return float(np.median(r))
 ref = [t.clone() for t in step()]
 for rnd in range(2):
-    for w in (0, 16, 12, 8, 6, 4, 3, 2, 1):
+    for w in (0, 16, 6):
         if w: _lib.tune("REDUCE_WAVES", w)
         t = timed()
         same = all(torch.equal(a, b) for a, b in zip(step(), ref))
