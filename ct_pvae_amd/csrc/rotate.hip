@@ -1540,7 +1540,7 @@ static TileSpec pick_tiles(int H, int W, int interp)
     if (interp != CTPVAE_NEAREST) return ts;   // a bilinear sample straddles tiles: it stays on the generic kernel
     const int wb = W + 2;
     const size_t whole = (size_t)(H + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
-    if (whole <= (size_t)kMaxLdsBytes) return ts;
+    if (whole <= (size_t)kMaxLdsBytes && knob(kKnobTiledForce) != 1) return ts;   // (TILED_FORCE = 1: timing, tiles for slices that fit)
     ts.tw = std::min(W, 64);
     // EQUAL rows of tiles, as tall as four interleaved slices allow in LDS (128 rows = 143 KB with the step table), round 4.
     // Rounds 1-3 cut 96-row tiles: 512 rows were five rows of tiles and a 32-row remainder -- 768 workgroups of unequal cost,

@@ -321,7 +321,7 @@ extern "C" {
 int ctpvae_rotate_cplan_supported(int H, int W, int PH, int PW, int A, int interp)
 {
     if (interp != CTPVAE_NEAREST || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return 0;
-    if (knob(kKnobNoPlan) >= 0 || knob(kKnobNoCompact) >= 0) return 0;
+    if (knob(kKnobNoPlan) >= 0 || knob(kKnobNoCompact) >= 0 || knob(kKnobTiledForce) == 1) return 0;
     return cplan_fits(PlanGeom{H, W, PH, PW, 0, 0, A}) ? 1 : 0;
 }
 
@@ -419,8 +419,11 @@ int ctpvae_rotate_fwd_compact_f32(const float *img_dev, int S, int H, int W, int
             for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
                 const long long wgs = 2ll * cand_units * cand;
                 const double tasks_wg = T / (2.0 * cand);
-                const double cost = (double)((wgs + 255) / 256) *
-                                    (fill_us + std::max(tasks_wg * task_lds_us, std::ceil(tasks_wg / 16.0) * chain_us));
+                // (several rounds: each costs ~3 us of ramp and drain on top, and r.x rounds take nearer to ceil(r.x) than to r.x
+                // of them -- round 4, fitted to tools/sweep_fwd.py at 100 to 400 slices: profiles/r04_sweep_G.txt)
+                const double real = (double)wgs / 256.0, whole = std::ceil(real);
+                const double rounds = whole > 1.0 ? real + 0.75 * (whole - real) : 1.0;
+                const double cost = rounds * (fill_us + 3.0 + std::max(tasks_wg * task_lds_us, std::ceil(tasks_wg / 16.0) * chain_us));
                 if (best == 0.0 || cost < best || (cost == best && cand_ns == ns)) {   // ties (chain-bound launches) go to more
                     best = cost;                                                        // workgroups: S=10, 20 of 180 angles
                     ns = cand_ns;                                                       // G=8 7.78 us, G=10 7.58, G=12 7.61

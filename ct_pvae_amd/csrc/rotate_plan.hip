@@ -1020,6 +1020,7 @@ int ctpvae_rotate_plan_supported(int H, int W, int PH, int PW, int A, int interp
 {
     if (interp != CTPVAE_NEAREST || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return 0;
     if (knob(kKnobNoPlan) >= 0) return 0;
+    if (which == 0 && knob(kKnobTiledForce) == 1) return 0;
     const PlanGeom g{H, W, PH, PW, 0, 0, A};
     return which == 0 ? (fwd_plan_fits(g) ? 1 : 0) : (bwd_plan_fits(g) ? 1 : 0);
 }
@@ -1067,6 +1068,17 @@ int ctpvae_rotate_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, in
 
 // sel_dev == nullptr: all A angles of the plan; otherwise the n_sel plan angles sel_dev[0..n_sel) (device int32), in
 // that order, are projected -- the launch shape is then sized for n_sel angles.
+// Launches of several rounds (round 4, tools/sweep_fwd.py at 100 to 400 slices x 20 / 90 / 180 angles, profiles/r04_sweep_G.txt):
+// a round of workgroups costs its fill and tasks plus ~2.5 us of ramp and drain (kRoundKb in the model's KB-per-CU currency), and
+// a launch of r.x rounds takes nearer to ceil(r.x) than to r.x of them.  Fitted so that the model picks the measured best task
+// groups on all eight shapes, both plan formats (the previous model: up to 10 % off, e.g. G = 5 where G = 3 was 9 % faster).
+constexpr double kRoundKb = 150.0;
+static inline double launch_rounds(long long wgs)
+{
+    const double real = (double)wgs / 256.0, whole = std::ceil(real);
+    return whole > 1.0 ? real + 0.75 * (whole - real) : 1.0;
+}
+
 static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH, int PW, int A, const void *fwd_plan_dev,
                               float *sino_dev, const LogLikEpilogue &epi, const int *sel_dev, int n_sel,
                               ctpvae_stream_t stream)
@@ -1106,8 +1118,10 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
             const double fabric_kb = 1.5 * plan_kb * (double)std::min<long long>(8, cand_units) / 256.0;
             for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
                 const long long wgs = 2ll * cand_units * cand;
-                const double cost = (double)((wgs + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand)) + fabric_kb;
-                if (best == 0.0 || cost <= best * 1.03) {
+                const double cost = launch_rounds(wgs) * (fill_kb + kRoundKb + task_kb * T / (2.0 * cand)) + fabric_kb;
+                // near-ties go to more workgroups -- inside ONE round only (more staging overlaps tasks); a launch of several
+                // rounds pays for every extra workgroup
+                if (best == 0.0 || cost <= best * (wgs <= 256 ? 1.03 : 1.0)) {
                     best = best == 0.0 ? cost : std::min(best, cost);
                     ns = cand_ns;
                     G = cand;
@@ -1148,8 +1162,9 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
             const long long cand_units = (S + ns - 1) / ns;
             double best = 0.0;
             for (int cand = 1; cand <= std::min(12, std::max(1, T / 2)); ++cand) {
-                const double cost = (double)((2ll * cand_units * cand + 255) / 256) * (fill_kb + task_kb * T / (2.0 * cand));
-                if (best == 0.0 || cost <= best * 1.03) {
+                const long long wgs = 2ll * cand_units * cand;
+                const double cost = launch_rounds(wgs) * (fill_kb + kRoundKb + task_kb * T / (2.0 * cand));
+                if (best == 0.0 || cost <= best * (wgs <= 256 ? 1.03 : 1.0)) {
                     best = best == 0.0 ? cost : std::min(best, cost);
                     G = cand;
                 }

@@ -11,24 +11,26 @@ FMT = sys.argv[3] if len(sys.argv) > 3 else "auto"     # u16 | compact | auto
 plan = RotatePlan(theta, 128, 128, True, dev, plan_format=FMT)
 print("B", B, "A", A, "plan format", FMT, "->", "compact" if plan._compact else "u16")
 x = torch.rand((B, 128, 128), device=dev); out = torch.empty((B, A, plan.PW), device=dev)
+REP = 200 if B * A <= 4000 else 30
 def t_us():
     plan.forward(x, out=out); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(200): plan.forward(x, out=out)
+        for _ in range(REP): plan.forward(x, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r = []
     for _ in range(5):
         torch.cuda.synchronize(); e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-        r.append(e0.elapsed_time(e1) * 1e3 / 200)
+        r.append(e0.elapsed_time(e1) * 1e3 / REP)
     return float(np.median(r))
 print("library choice: %.2f us" % t_us())
 res = []
-for ns, G, w in itertools.product((1, 2), (1, 2, 3, 4, 5, 6, 8, 10), (8, 12, 16)):
+grid = itertools.product((2,), (1, 2, 3, 4, 5, 6, 7, 8, 10, 12), (16,)) if os.environ.get('SWEEP_FAST') else itertools.product((1, 2), (1, 2, 3, 4, 5, 6, 8, 10), (8, 12, 16))
+for ns, G, w in grid:
     _lib.tune("NS", ns); _lib.tune("G", G); _lib.tune("WAVES", w)
     try:
         res.append((t_us(), ns, G, w))
     except Exception as e:
         print("skip", ns, G, w, type(e).__name__)
-for t, ns, G, w in sorted(res)[:12]:
+for t, ns, G, w in sorted(res)[:int(os.environ.get('SWEEP_TOP', 12))]:
     print("NS=%d G=%2d waves=%2d: %.2f us" % (ns, G, w, t))

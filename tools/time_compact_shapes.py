@@ -2,25 +2,30 @@
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ct_pvae_amd import _lib, phantoms
+if os.environ.get("CTPVAE_VARIANT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["CTPVAE_VARIANT_LIB"])
+    _lib.torch_node = lambda: None
+print("library:", _lib.LIB_PATH)
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
+REP = 40
 def t_us(plan, x, out):
     plan.forward(x, out=out); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for _ in range(100): plan.forward(x, out=out)
+        for _ in range(REP): plan.forward(x, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r = []
     for _ in range(5):
         torch.cuda.synchronize(); e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-        r.append(e0.elapsed_time(e1) * 1e3 / 100)
+        r.append(e0.elapsed_time(e1) * 1e3 / REP)
     return float(np.median(r))
 for A in (20, 90, 180):
     theta = phantoms.dense_theta(180)[phantoms.sparse_angle_indices(180, A)] if A < 180 else phantoms.dense_theta(180)
     pc = RotatePlan(theta, 128, 128, True, dev, plan_format="compact")
     p16 = RotatePlan(theta, 128, 128, True, dev, plan_format="u16")
     pa = RotatePlan(theta, 128, 128, True, dev)        # plan_format="auto": decides per launch (RotatePlan.dense_plan)
-    for B in (1, 2, 5, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 100, 200, 400):
+    for B in (1, 2, 5, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 100, 128, 160, 200, 256, 300, 400):
         x = torch.rand((B, 128, 128), device=dev)
         oc, o16, oa = (torch.empty((B, A, pc.PW), device=dev) for _ in range(3))
         tc, t16, ta = t_us(pc, x, oc), t_us(p16, x, o16), t_us(pa, x, oa)
