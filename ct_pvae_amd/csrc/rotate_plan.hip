@@ -1272,9 +1272,22 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     // barrier waits while one 16-wave workgroup (114 VGPRs: one per CU) cannot (B=400 A=20: 34 us vs 45 us).
     const int Aeff = A * dup;
     int waves = 4;
-    if (ns == 2)   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many; half as tall below 32 slices (sweeps)
+    if (ns == 2) {   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many; half as tall below 32 slices (sweeps)
         waves = Aeff >= 64 ? (S >= 32 ? 16 : 8) : (S > 16 ? 8 : 4);
-    else if (Aeff >= 32)
+        // Many angles (round 4, tools/sweep_bwd_waves.py, profiles/r04_sweep_bwd_waves.txt): a workgroup's cost is mostly the
+        // staging of ALL its pair's cotangent rows (~14 of 18 us at 180 angles), whatever its height -- so (a) while 16-row tiles
+        // are at most one workgroup per CU they win (B=32: 15.2 vs 17.3 us), and (b) one more row of tiles (26-row tiles of 13
+        // waves for H = 128) is free while it adds no round: 250 instead of 200 workgroups at B=50, 17.3 vs 18.1 us.
+        if (Aeff >= 64 && S >= 32) {
+            auto wgs = [&](int w) { return (long long)units * L.nXB * ceil_div(H, w * ppt); };
+            const int w_more = ceil_div(H, ppt * (ceil_div(H, 16 * ppt) + 1));   // waves of a tile one row of tiles shorter
+            if (wgs(8) <= 256)
+                waves = 8;
+            else if (w_more >= 9 && w_more < 16 && ceil_div((int)wgs(w_more), 256) == ceil_div((int)wgs(16), 256))
+                waves = w_more;
+        }
+    }
+    if (ns != 2 && Aeff >= 32)
         while (waves < 16 && (long long)units * L.nXB * ceil_div(H, 2 * waves * ppt) >= 200 && waves * ppt < H) waves *= 2;
     while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has
     if (knob(kKnobBw) > 0) waves = std::min(16, knob(kKnobBw));
