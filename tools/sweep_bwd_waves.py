@@ -3,6 +3,10 @@ a few batch sizes -- which tile height fills 256 CUs best?   python tools/sweep_
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from ct_pvae_amd import _lib
+if os.environ.get("CTPVAE_VARIANT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["CTPVAE_VARIANT_LIB"])
+    _lib.torch_node = lambda: None
+print("library:", _lib.LIB_PATH)
 from ct_pvae_amd.forward_functions import RotatePlan
 dev = torch.device('cuda', 0)
 A = int(sys.argv[1]) if len(sys.argv) > 1 else 180
