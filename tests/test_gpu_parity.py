@@ -2272,6 +2272,16 @@ def test_tiled_forward_through_compact_tile_plans(oracle, shape, A, S):
     pnm = torch.tensor([1e4], device=d)
     a3, b3 = plan.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True), direct.forward_loglik(x, mask, meas, pnm, 1.2e-7, with_dlp=True)
     assert all(torch.equal(u, v) for u, v in zip(a3, b3))
+    # round 4: the tile shape is a rule of the library (equal rows of tiles, at most 128 tall), reported by ctpvae_rotate_tile_shape;
+    # other heights (developer knob; 96 = the shape of rounds 1-3) are the same code and must give THEIR tiled sum's bits
+    for th in (96, 40):
+        with _lib.tuned("TILED_TH", th):
+            assert _lib.tile_shape(*shape) == (min(th, shape[0]), 64)
+            other = RotatePlan(theta, shape[0], shape[1], True, d)
+            assert other.tiled and other._tplan is not None
+            np.testing.assert_array_equal(to_np(other.forward(x)),
+                                          oracle.rotate_fwd_tiled(img, oracle.Geometry(shape[0], shape[1], True), oT(oracle, theta, plan),
+                                                                  tile=(min(th, shape[0]), 64)))
 
 
 @pytest.mark.parametrize("fmt", ["auto", "u16"])
