@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libctpvae_radon.so")
 NEAREST, BILINEAR = 0, 1
 BWD_TF_COMPAT, BWD_EXACT = 0, 1
 EINVAL, EHIP, ENODEV = -1, -2, -3
-ABI_VERSION = 3310   # ctpvae_abi_version() of the library this binding was written for
+ABI_VERSION = 3400   # ctpvae_abi_version() of the library this binding was written for
 
 _c_int, _c_float, _vp = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -53,6 +53,8 @@ SIGNATURES = {
     "ctpvae_rotate_fwd_tiled_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctpvae_rotate_fwd_tiled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp,
                                              _vp, _vp]),
+    "ctpvae_rotate_fwd_tiled_interp_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int,
+                                                    _vp, _vp, _vp]),
     "ctpvae_rotate_fwd_tiled_loglik_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                                     _vp, _vp, _vp, _vp, _c_float, _vp, _vp, _vp, _vp]),
     "ctpvae_rotate_tplan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int]),

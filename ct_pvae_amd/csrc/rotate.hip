@@ -27,14 +27,10 @@
 #include "loglik_math.h"
 #include "rotate_plan.h"
 #include "cplan_walk.h"
+#include "rotate_dev.h"
 
 namespace ctpvae {
 
-struct RotGeom {
-    int S, H, W, PH, PW, py, px, A;
-};
-
-__device__ __forceinline__ float round_half_away(float v) { return __builtin_roundf(v); }
 
 // ---- forward ---------------------------------------------------------------------------------
 template <bool USE_LDS>
@@ -120,43 +116,6 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float *__restrict
 // idle.  So the per-sample instruction count is what is minimised here: packed fp32 for the coordinates of
 // TWO consecutive rows at once, one asm block per pair (hipcc pads every asm statement and every packed-op
 // consumer with s_nop), gathers software-pipelined two groups deep with one s_waitcnt per group.
-__device__ __forceinline__ int cvt_rpi(float v)
-{
-    int r;
-    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ int cvt_flr(float v)
-{
-    int r;
-    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ int med3i(int v, int lo, int hi)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef const __attribute__((address_space(3))) float *lds_cptr;
-typedef __attribute__((address_space(3))) float *lds_ptr;
-typedef const __attribute__((address_space(1))) float *glb_cptr;
-
-// smallest pitch >= wb with pitch == +1 (mod 32) if want_plus else == -1 (mod 32)
-__host__ __device__ __forceinline__ int pitch_for(int wb, bool want_plus)
-{
-    const int r = want_plus ? 1 : 31;
-    return wb + ((r - (wb & 31)) & 31);
-}
-
-// an opaque copy in a VGPR: keeps loop-invariant operands of the asm helpers out of the loop body
-__device__ __forceinline__ int pin_vgpr(int v)
-{
-    int r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
-    return r;
-}
 
 // Two consecutive rows (i, i+1) of one ray, NEAREST: LDS byte addresses (absolute: the LDS base is folded
 // into off4) of the two clamped taps.
@@ -196,43 +155,6 @@ __device__ __forceinline__ void nearest_pair_addr(f32x2 &fi, f32x2 basex, f32x2 
           [sh] "i"(SHIFT)
         : "v60", "v61", "v62", "v63");
 }
-__device__ __forceinline__ float lds_abs(int byte_addr) { return *(lds_cptr)(uintptr_t)(unsigned)byte_addr; }
-// NS interleaved slices per LDS pixel: one ds_read_b32 / _b64 / _b128 per tap
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int NS> struct PixVec { typedef float type; };
-template <> struct PixVec<2> { typedef f32x2 type; };
-template <> struct PixVec<4> { typedef f32x4 type; };
-template <int NS> __device__ __forceinline__ typename PixVec<NS>::type lds_abs_vec(int byte_addr)
-{
-    typedef const __attribute__((address_space(3))) typename PixVec<NS>::type *vptr;
-    return *(vptr)(uintptr_t)(unsigned)byte_addr;
-}
-
-// max over the 64 lanes of a wave of a non-negative int, as an SGPR value (DPP row shifts + row broadcasts)
-__device__ __forceinline__ int wave_max_nonneg(int v)
-{
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));  // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));  // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));  // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-// rows [lo, hi) of the canvas on which base + slope*i may fall inside [L, U]
-__device__ __forceinline__ void clip_rows(float base, float slope, float L, float U, float &lo, float &hi)
-{
-    if (fabsf(slope) < 1e-6f) {
-        // |slope * i| < 1e-6 * 2^24: treat as constant, with a margin far above that drift
-        if (base < L - 1.0f || base > U + 1.0f) hi = -1.0f;
-    } else {
-        const float inv = __builtin_amdgcn_rcpf(slope);   // 1 ulp is ample: the range is widened by whole rows
-        const float i1 = (L - base) * inv, i2 = (U - base) * inv;
-        lo = fmaxf(lo, fminf(i1, i2));
-        hi = fminf(hi, fmaxf(i1, i2));
-    }
-}
 
 #ifdef CTPVAE_TUNE_STAMPS
 __device__ long long g_stamps[8 * 65536];
@@ -256,36 +178,6 @@ __device__ long long g_stamps[8 * 65536];
 //     sino[s][a][j] = ((0 + p_0) + p_1) + ... ,   p_t = sum over canvas rows, ascending, of the taps inside tile t.
 // (A different association of the same terms than the row-sequential sum of a slice that fits LDS; the CPU
 // restatement has the same tiled mode, oracle_rotate_fwd_tiled.)
-struct TileSpec {
-    int ntx, nty;   // tiles per slice
-    int tw, th;     // nominal tile size (edge tiles are smaller)
-    int nb;         // ray slots per (tile, angle), a multiple of 64
-    int span;       // ... of which the first `span` can touch the tile (the rest pad nb to whole waves): only those are stored
-                    // by the tile kernels and read back by the reduce pass
-    float radius;   // half the tile diagonal + 3 px
-};
-__host__ __device__ __forceinline__ void tile_rect(const RotGeom &g, const TileSpec &ts, int t, int &y0, int &x0, int &h, int &w)
-{
-    const int ty = t / ts.ntx, tx = t - ty * ts.ntx;
-    y0 = ty * ts.th;
-    x0 = tx * ts.tw;
-    h = min(ts.th, g.H - y0);
-    w = min(ts.tw, g.W - x0);
-}
-// first ray slot's bin: the orthonormal transform maps canvas (x, y) to bin t0*(x - t2) + t3*(y - t5)
-__device__ __forceinline__ int tile_first_bin(const float *t, float cx, float cy, float radius)
-{
-    const float jc = t[0] * (cx - t[2]) + t[3] * (cy - t[5]);
-    return (int)floorf(jc - radius);
-}
-// The workspace of partial sums: [slice / 4][tile][angle][slot][slice % 4] -- the four slices a tile workgroup walks together
-// leave it as ONE 16-byte store per ray and reach the reduce pass as one 16-byte load (per-slice planes cost four 4-byte
-// accesses each way).  Sized for a whole number of slice quads (ctpvae_rotate_fwd_tiled_workspace_bytes).
-constexpr int kPartialQuad = 4;
-__device__ __forceinline__ size_t partial_index(int s, int nt, int t, size_t nrays, size_t ray)
-{
-    return ((((size_t)(s >> 2) * nt + t) * nrays + ray) << 2) + (size_t)(s & 3);
-}
 
 template <int INTERP, bool TIE_FIX, bool TILED, int NS = 1>
 __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
@@ -1534,10 +1426,25 @@ static int pick_tile_ns(int S, bool tie_fix)
     return tie_fix ? 1 : ns;   // the negative-tie fix of an unpadded canvas is not in the interleaved (asm) path
 }
 constexpr int kTileRowsMax = 128;
-static TileSpec pick_tiles(int H, int W, int interp)
+// Bilinear tiles (round 5, rotate_bilin.hip): 16-byte cells (four slices) at a pitch of 81 cells leave room for 96 + 3 rows.  A
+// sample's 2 x 2 footprint belongs to the tile of its FLOOR tap (the tile stages a one-pixel halo below and to the right), so a
+// tile's rays lie within half the diagonal of (tw + 1) x (th + 1) of its centre.
+constexpr int kTileRowsMaxBilinear = 96;
+TileSpec pick_tiles(int H, int W, int interp)
 {
     TileSpec ts{};
-    if (interp != CTPVAE_NEAREST) return ts;   // a bilinear sample straddles tiles: it stays on the generic kernel
+    if (interp != CTPVAE_NEAREST) {
+        if (bilin_fwd_whole_geometry(H, W) && knob(kKnobTiledForce) != 1) return ts;
+        ts.tw = std::min(W, 64);
+        ts.th = ceil_div(H, ceil_div(H, kTileRowsMaxBilinear));
+        ts.ntx = ceil_div(W, ts.tw);
+        ts.nty = ceil_div(H, ts.th);
+        const float diag = sqrtf((float)((ts.tw + 1) * (ts.tw + 1) + (ts.th + 1) * (ts.th + 1)));
+        ts.radius = 0.5f * diag + 3.0f;
+        ts.span = (int)ceilf(2.0f * ts.radius) + 2;
+        ts.nb = (ts.span + 63) / 64 * 64;
+        return ts;
+    }
     const int wb = W + 2;
     const size_t whole = (size_t)(H + 2) * std::max(pitch_for(wb, true), pitch_for(wb, false)) * sizeof(float);
     if (whole <= (size_t)kMaxLdsBytes && knob(kKnobTiledForce) != 1) return ts;   // (TILED_FORCE = 1: timing, tiles for slices that fit)
@@ -1979,19 +1886,28 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     }
 }
 
+int launch_tile_reduce(const float *workspace_dev, const RotGeom &g, const TileSpec &ts, const float *T8_dev, float *sino_dev,
+                       const LogLikEpilogue &epi, ctpvae_stream_t stream)
+{
+    int rwaves = std::min(16, ceil_div(g.PW, 64));   // waves per workgroup: 64 bins each
+    if (knob(kKnobReduceWaves) > 0) rwaves = std::min(16, knob(kKnobReduceWaves));
+    const dim3 rgrid(ceil_div(g.PW, 64 * rwaves), g.A, ceil_div(g.S, kReduceSlices)), rblock(64 * rwaves);
+    if (epi.part)
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<2>, rgrid, rblock, 0, (hipStream_t)stream, workspace_dev, g, ts, T8_dev, sino_dev, epi);
+    else if (epi.lp)
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<1>, rgrid, rblock, 0, (hipStream_t)stream, workspace_dev, g, ts, T8_dev, sino_dev, epi);
+    else
+        hipLaunchKernelGGL(rotate_tile_reduce_kernel<0>, rgrid, rblock, 0, (hipStream_t)stream, workspace_dev, g, ts, T8_dev, sino_dev, epi);
+    CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
+    return CTPVAE_OK;
+}
+
 }  // namespace ctpvae
 
 using namespace ctpvae;
 
 // The direct kernels index slices with a grid dimension (<= 65535): the entry points below hand them a longer batch in
 // chunks, back to back on the caller's stream (slices are independent: same results as one launch).
-template <class F>
-static int for_slice_chunks(int S, int chunk, F launch_chunk)
-{
-    for (int s0 = 0; s0 < S; s0 += chunk)
-        if (int rc = launch_chunk(s0, std::min(chunk, S - s0))) return rc;
-    return CTPVAE_OK;
-}
 
 extern "C" {
 
@@ -2002,6 +1918,9 @@ static int rotate_fwd_one(const float *img_dev, int S, int H, int W, int PH, int
     if (int rc = check_geom("rotate_fwd", S, H, W, PH, PW, py, px, A, interp)) return rc;
     const RotGeom g{S, H, W, PH, PW, py, px, A};
 
+    // bilinear (round 5): slices interleaved per LDS cell behind one coordinate-and-weight computation (rotate_bilin.hip)
+    if (interp == CTPVAE_BILINEAR && knob(kKnobForceGeneric) < 0 && knob(kKnobNoPlan) < 0 && bilin_fwd_whole_ok(H, W, A))
+        return bilin_fwd_whole(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, sino_dev, stream);
     // fast path: the zero-bordered slice must fit LDS (row pitch == +-1 mod 32, see the kernel)
     const int border = interp == CTPVAE_NEAREST ? 1 : 2;
     const int wb = W + 2 * border;
@@ -2184,26 +2103,34 @@ static int launch_fwd_tiled_one(const float *img_dev, int S, int H, int W, int P
     else
         rc = launch(rotate_fwd_fast_kernel<CTPVAE_NEAREST, false, true, 1>);
     if (rc) return rc;
-    int rwaves = std::min(16, ceil_div(PW, 64));   // waves per workgroup: 64 bins each
-    if (knob(kKnobReduceWaves) > 0) rwaves = std::min(16, knob(kKnobReduceWaves));
-    const dim3 rgrid(ceil_div(PW, 64 * rwaves), A, ceil_div(S, kReduceSlices)), rblock(64 * rwaves);
-    if (epi.part)
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<2>, rgrid, rblock, 0, (hipStream_t)stream,
-                           (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
-    else if (epi.lp)
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<1>, rgrid, rblock, 0, (hipStream_t)stream,
-                           (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
-    else
-        hipLaunchKernelGGL(rotate_tile_reduce_kernel<0>, rgrid, rblock, 0, (hipStream_t)stream,
-                           (const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi);
-    CTPVAE_LAUNCH_CHECK("rotate_tile_reduce_kernel");
-    return CTPVAE_OK;
+    return launch_tile_reduce((const float *)workspace_dev, g, ts, T8_dev, sino_dev, epi, stream);
 }
 
 int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                                 const float *T8_dev, int A, void *workspace_dev, float *sino_dev, ctpvae_stream_t stream)
 {
     return launch_fwd_tiled(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev, LogLikEpilogue{}, stream);
+}
+
+int ctpvae_rotate_fwd_tiled_interp_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev,
+                                       int A, int interp, void *workspace_dev, float *sino_dev, ctpvae_stream_t stream)
+{
+    if (interp == CTPVAE_NEAREST)
+        return ctpvae_rotate_fwd_tiled_f32(img_dev, S, H, W, PH, PW, py, px, T8_dev, A, workspace_dev, sino_dev, stream);
+    CTPVAE_REQUIRE(img_dev && T8_dev && workspace_dev && sino_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0,
+                   "rotate_fwd_tiled: null pointer or empty sizes");
+    if (int rc = check_geom("rotate_fwd_tiled", 1, H, W, PH, PW, py, px, A, interp)) return rc;
+    const TileSpec ts = pick_tiles(H, W, interp);
+    CTPVAE_REQUIRE(ts.ntx > 0, "rotate_fwd_tiled: a %dx%d slice fits LDS whole; call ctpvae_rotate_fwd_f32", H, W);
+    CTPVAE_REQUIRE(knob(kKnobForceGeneric) < 0, "rotate_fwd_tiled: not available with FORCE_GENERIC");
+    const int nt = ts.ntx * ts.nty;
+    const int chunk = std::max(4, std::min(max_slices_per_launch(), 65535 / nt) / 4 * 4);
+    return for_slice_chunks(S, chunk, [&](int s0, int n) {
+        if (int rc = bilin_fwd_tiles(img_dev + (size_t)s0 * H * W, n, H, W, PH, PW, py, px, T8_dev, A, ts, (float *)workspace_dev, stream))
+            return rc;
+        const RotGeom g{n, H, W, PH, PW, py, px, A};
+        return launch_tile_reduce((const float *)workspace_dev, g, ts, T8_dev, sino_dev + (size_t)s0 * A * PW, LogLikEpilogue{}, stream);
+    });
 }
 
 int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,

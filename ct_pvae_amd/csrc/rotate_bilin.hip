@@ -1,0 +1,410 @@
+// rotate_bilin.hip -- the BILINEAR quadrants of the rotate-and-sum projector for gfx950 (round 5): forward
+// (project_tf_low_mem, ctvae/forward_functions.py:69-77), TensorFlow-compatible backward, exact adjoint.
+//
+// A bilinear sample of TensorFlow's ImageProjectiveTransformV3 (a3) is
+//     x = (t0 j + t1 i) + t2, y = (t3 j + t4 i) + t5            (unfused fp32; this file is compiled -ffp-contract=off)
+//     xf = floor(x), xc = xf + 1, yf = floor(y), yc = yf + 1
+//     v = (yc - y) * ((xc - x) * I[yf][xf] + (x - xf) * I[yf][xc]) + (y - yf) * ((xc - x) * I[yc][xf] + (x - xf) * I[yc][xc])
+// with every tap zero-filled outside the canvas.  Coordinates, the four weights and the tap address depend on (angle, row, bin)
+// only -- not on the slice -- so the kernels here compute them ONCE per sample for NS slices interleaved per LDS cell (the fact
+// the nearest path exploits with slice pairs and quads): ~14 vector instructions of index / weight arithmetic per sample
+// whatever NS, plus 10 unfused fp32 operations per slice for the blend (packed two slices at a time: v_pk_mul_f32 /
+// v_pk_add_f32 round each half like the scalar operation).
+//
+// Where x >= 0 the weights come from v_fract_f32: x - floor(x) is exact there, and (floor(x) + 1) - x and 1 - fract(x) round the
+// same real number (tools/probe_bilin.hip: 0 of 4 M values differ); below zero they differ, so a canvas without padding
+// (px == 0 or py == 0: a sample at x in (-1, 0) is live there) takes the literal expressions (PADDED = false).
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "lds_stage.h"
+#include "loglik_math.h"
+#include "rotate_plan.h"
+#include "rotate_dev.h"
+
+namespace ctpvae {
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------
+//
+// LDS image of one unit (a whole slice, or one tile of a slice larger than LDS), NS slices interleaved per cell:
+//     rows 0, 1      zero                      (row 1 = canvas row Y0 - 1: the zero fill above the slice; other tiles never own
+//                                               a sample whose floor tap lies above them)
+//     rows 2 .. h+1  the unit's rows
+//     row  h+2       the HALO: slice row y0 + h (a sample's 2 x 2 footprint belongs to the unit of its floor tap), zero at the
+//                    slice's last row
+//     cols 0 .. w-1  the unit's columns, col w the halo column; col -1 of row r is col pitch-1 of row r-1 and is ZERO
+// (column-MIRRORED for the angles whose lane step and row step have opposite signs, like the planned kernels: the pitch is
+// == +1 (mod 32 cells; mod 16 for 16-byte cells) for both classes, and a sample's pair of cells is then (xc, xf) instead of
+// (xf, xc) -- the two products are added in the other order, which fp32 addition does not notice).
+// A sample is OWNED by the unit iff its floor tap lies in [Y0 - first_row, Y0 + h) x [X0 - first_col, X0 + w); every other
+// sample reads the all-zero 2 x 2 block at cell (0, 0) and adds +0.  For a whole slice that is TensorFlow's zero fill; for tiles
+// it makes the sinogram the sum of the tiles' partial sums (rotate_tile_reduce_kernel adds them in tile order:
+// oracle_rotate_fwd_tiled(interp = 1) restates that association).
+template <int NS> struct BilinCell { static constexpr int kBytes = 4 * NS; static constexpr int kShift = NS == 1 ? 2 : (NS == 2 ? 3 : 4); };
+
+__host__ __device__ inline int bilin_pitch(int w, bool tiled, int ns)
+{
+    const int wb = w + (tiled ? 2 : 1);          // + halo column (+ a zero column of its own when the halo can hold data)
+    const int m = ns == 4 ? 16 : 32;             // cells per bank sweep of one hardware lane group
+    return wb + ((1 - (wb % m)) + m) % m;        // smallest pitch >= wb with pitch == 1 (mod m)
+}
+__host__ __device__ inline size_t bilin_lds_cells(int h, int w, bool tiled, int ns) { return (size_t)(h + 3) * bilin_pitch(w, tiled, ns); }
+
+struct BilinRay {
+    float t1, t2, t4, t5, xj, yj;
+    int ray, ilo, kmax;   // kmax: rows walked in pairs (even)
+    bool live, tail;      // tail: one more row behind the pairs (an odd canvas height walked whole)
+};
+
+template <int NS, bool TILED, bool PADDED>
+__global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
+                                                                const float *__restrict__ T8, int t8_lds_off, float *__restrict__ out)
+{
+    typedef typename PixVec<NS>::type vec_t;
+    constexpr int SHIFT = BilinCell<NS>::kShift, CELL = BilinCell<NS>::kBytes;
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+    const int cls = blockIdx.x & 1, gi = blockIdx.x >> 1, G = gridDim.x >> 1;
+    const bool mirror = cls != 0;
+    // the unit: a whole slice (nt = 1) or tile t of the slice, for slices s .. s + NS - 1
+    const int nt = TILED ? ts.ntx * ts.nty : 1;
+    const int t = TILED ? blockIdx.y % nt : 0;
+    const int s = (TILED ? blockIdx.y / nt : blockIdx.y) * NS;
+    RotGeom g = gfull;
+    int y0 = 0, x0 = 0;
+    if (TILED) tile_rect(gfull, ts, t, y0, x0, g.H, g.W);
+    g.py = gfull.py + y0;
+    g.px = gfull.px + x0;
+    const int h = g.H, w = g.W;
+    const int lowy = y0 == 0 ? 1 : 0, lowx = x0 == 0 ? 1 : 0;            // the first row / column of units owns the floor taps at -1
+    const bool halo_y = y0 + h < gfull.H, halo_x = x0 + w < gfull.W;     // ... and the others stage a halo of real pixels
+    const int pitch = bilin_pitch(w, TILED, NS);
+    const float *srcs[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) srcs[n] = img + ((size_t)min(s + n, gfull.S - 1) * gfull.H + y0) * gfull.W + x0;
+
+    // ---- stage ---------------------------------------------------------------------------------------------------------------
+    {
+        vec_t *cells = reinterpret_cast<vec_t *>(lds);
+        // LDS column of canvas column X0 + c (c = -1 .. w), relative to the row's first cell
+        auto col_of = [&](int c) { return mirror ? w - 1 - c : c; };
+        if constexpr (NS == 1)
+            stage_rows(lds + 2 * pitch, srcs[0], h, w, gfull.W, pitch, mirror, lane, wave, nwaves);
+        else
+            stage_rows_interleaved<NS>(lds + (size_t)2 * pitch * NS, srcs, h, w, gfull.W, pitch, mirror, lane, wave, nwaves);
+        // rows 0 and 1 (but the last cell of row 1: it is "column -1" of row 2, written below)
+        for (int p = threadIdx.x; p < 2 * pitch - 1; p += blockDim.x) cells[p] = vec_t(0.0f);
+        // the halo row
+        for (int c = threadIdx.x; c < w; c += blockDim.x) {
+            vec_t v = vec_t(0.0f);
+            if (halo_y) {
+#pragma unroll
+                for (int n = 0; n < NS; ++n) {
+                    const float pv = srcs[n][(size_t)h * gfull.W + c];
+                    if constexpr (NS == 1) v = pv; else v[n] = pv;
+                }
+            }
+            cells[(h + 2) * pitch + col_of(c)] = v;
+        }
+        // columns -1 (zero) and w (halo) of rows 2 .. h + 2
+        for (int p = threadIdx.x; p < 2 * (h + 1); p += blockDim.x) {
+            const int r = p >> 1, right = p & 1;                       // tile row r (r = h: the halo row)
+            vec_t v = vec_t(0.0f);
+            if (right && halo_x && (r < h || halo_y)) {
+#pragma unroll
+                for (int n = 0; n < NS; ++n) {
+                    const float pv = srcs[n][(size_t)r * gfull.W + w];
+                    if constexpr (NS == 1) v = pv; else v[n] = pv;
+                }
+            }
+            // (a whole slice's pitch is w + 1: columns -1 and w share cells, and both are zero)
+            cells[(r + 2) * pitch + col_of(right ? w : -1)] = v;
+        }
+    }
+
+    // behind the image: a copy of the transform rows, the ascending list of this class's angles ([0] = their count), a task counter
+    int *cls_list = reinterpret_cast<int *>(lds + t8_lds_off + 8 * g.A);
+    for (int p = threadIdx.x; p < 8 * g.A; p += blockDim.x) lds[t8_lds_off + p] = T8[p];
+    if (threadIdx.x < 64) {
+        int n = 0;
+        for (int a0 = 0; a0 < g.A; a0 += 64) {
+            const float *tm = T8 + 8 * min(a0 + lane, g.A - 1);
+            const bool in_cls = a0 + lane < g.A && ((((tm[0] >= 0.0f) == (tm[3] >= 0.0f)) ? 0 : 1) == cls);
+            const unsigned long long m = __ballot(in_cls);
+            if (in_cls) cls_list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
+            n += __popcll(m);
+        }
+        if (lane == 0) {
+            cls_list[0] = n;
+            cls_list[1 + g.A] = 0;
+        }
+    }
+
+    const int nb = TILED ? ts.nb : ((g.PW + 63) & ~63);   // ray slots per angle
+    const int span = TILED ? ts.span : g.PW;
+    const float tile_cx = (float)g.px + 0.5f * (float)(w - 1), tile_cy = (float)g.py + 0.5f * (float)(h - 1);
+    const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
+    // ownership window and address constants (canvas coordinates): cy = iy - ylo in [0, ny), LDS row = iy - g.py + 2
+    const int xlo = g.px - lowx, nx = w + lowx, ylo = g.py - lowy, ny = h + lowy;
+    const int pitchB = pitch * CELL;
+    // byte address of the sample's LOW cell: row (iy - g.py + 2), column (ix - g.px), or mirrored (w - 2 - (ix - g.px))
+    const int off_rows = (2 - g.py) * pitchB + lds_base;
+    const int off_cols = mirror ? (w - 2 + g.px) * CELL : -g.px * CELL;
+    int off_v = pin_vgpr(off_rows + off_cols);   // (not const: a const int is not captured by the nested generic lambdas)
+
+    auto setup = [&](int a, int slot) -> BilinRay {
+        BilinRay q;
+        const int ad = (t8_lds_off + 8 * a) * 4 + lds_base;
+        const f32x4 u = lds_abs_vec<4>(ad);
+        const f32x2 v2 = lds_abs_vec<2>(ad + 16);
+        const float t6[6] = {u.x, u.y, u.z, u.w, v2.x, v2.y};
+        int j = slot;
+        q.live = slot < span;
+        if (TILED) j += tile_first_bin(t6, tile_cx, tile_cy, ts.radius);
+        q.live = q.live && (unsigned)j < (unsigned)g.PW;
+        q.ray = a * nb + slot;
+        if (!TILED) q.ray = a * g.PW + j;
+        q.t1 = t6[1]; q.t2 = t6[2]; q.t4 = t6[4]; q.t5 = t6[5];
+        q.xj = t6[0] * (float)j;
+        q.yj = t6[3] * (float)j;
+        float lo = 0.0f, hi = (float)g.PH;
+        clip_rows(q.xj + q.t2, q.t1, (float)(g.px - 2), (float)(g.px + w + 1), lo, hi);
+        clip_rows(q.yj + q.t5, q.t4, (float)(g.py - 2), (float)(g.py + h + 1), lo, hi);
+        lo = fminf(fmaxf(lo, 0.0f), (float)g.PH);
+        hi = fminf(fmaxf(hi, -1.0f), (float)g.PH);
+        const int ilo = max((int)floorf(lo) - 1, 0);
+        const int ihi = min((int)ceilf(hi) + 2, g.PH);
+        const int cnt = q.live ? max(ihi - ilo, 0) : 0;
+        const int need = wave_max_nonneg(cnt);                  // wave-uniform trip count (SGPR)
+        q.kmax = min((need + 1) & ~1, g.PH & ~1);               // whole row pairs ...
+        q.tail = need > q.kmax;                                 // ... and the last row of an odd canvas alone
+        q.ilo = max(min(ilo, g.PH - q.kmax - (q.tail ? 1 : 0)), 0);   // only legitimate rows are visited
+        return q;
+    };
+
+    auto walk = [&](const BilinRay &q, auto mirror_tag) {
+        constexpr bool MIRROR = decltype(mirror_tag)::value;
+        const f32x2 basex = {q.xj, q.xj}, basey = {q.yj, q.yj}, stepx = {q.t1, q.t1}, stepy = {q.t4, q.t4};
+        const f32x2 shiftx = {q.t2, q.t2}, shifty = {q.t5, q.t5};
+        f32x2 fi = {(float)q.ilo, (float)q.ilo + 1.0f};
+        vec_t acc = vec_t(0.0f);
+        const int offv = off_v;     // (named here: an outer variable used only inside an asm operand of a nested lambda is not captured)
+        struct Pair {               // two consecutive rows of one ray
+            f32x2 wl, wh, wy0, wy1;   // weights of the low / high cell of a pair, of the floor / ceil row
+            vec_t tp[2][4];           // taps: [row][low cell of the floor row, high, low cell of the ceil row, high]
+        };
+        // One row: floor taps -> ownership test -> byte address of the low cell of the floor row (the all-zero block at LDS
+        // address 0 for a sample this unit does not own), as ONE asm statement of 12 vector instructions (the select is a
+        // v_cndmask; hipcc's own code branches around the address arithmetic with s_and_saveexec); then the four cells with
+        // plain ds_read_b32 / _b64 / _b128 at immediate offsets -- VOLATILE loads: hipcc pairs ordinary ones into ds_read2_b64,
+        // which tools/probe_bilin.hip measured at 7.1 ns per cell pair against 4.1 for two ds_read_b64.  (The loads stay C++:
+        // issued inside the asm statement they were invisible to hipcc's s_waitcnt insertion, and hipcc copied the pending tap
+        // registers on a loop edge before the hand-written wait -- stale taps, found by the fuzz test.)
+        auto row_taps = [&](float x, float y, vec_t (&tp)[4]) {
+            int ix, iy, tmp, ad, ad2;
+            asm volatile("s_nop 0\n\t"   // x / y may come straight out of a packed op, whose result the next instruction cannot read
+                         "v_cvt_flr_i32_f32 %[ix], %[x]\n\t"
+                         "v_cvt_flr_i32_f32 %[iy], %[y]\n\t"
+                         "v_subrev_u32 %[tmp], %[xlo], %[ix]\n\t"
+                         "v_subrev_u32 %[ad2], %[ylo], %[iy]\n\t"
+                         "v_cmp_gt_u32 vcc, %[nx], %[tmp]\n\t"
+                         "v_mad_i32_i24 %[iy], %[iy], %[pB], %[off]\n\t"
+                         "v_cndmask_b32 %[tmp], -1, %[ad2], vcc\n\t"      // column not owned: row index 0xffffffff fails the next test
+                         "v_mad_i32_i24 %[ix], %[ix], %[cs], %[iy]\n\t"
+                         "v_cmp_gt_u32 vcc, %[ny], %[tmp]\n\t"
+                         "v_cndmask_b32 %[ad], 0, %[ix], vcc\n\t"
+                         "v_add_u32 %[ad2], %[pB], %[ad]"
+                         : [ix] "=&v"(ix), [iy] "=&v"(iy), [tmp] "=&v"(tmp), [ad] "=&v"(ad), [ad2] "=&v"(ad2)
+                         : [x] "v"(x), [y] "v"(y), [xlo] "s"(xlo), [nx] "s"(nx), [ylo] "s"(ylo), [ny] "s"(ny), [pB] "s"(pitchB),
+                           [off] "v"(offv), [cs] "n"(MIRROR ? -CELL : CELL)
+                         : "vcc");
+            typedef const volatile __attribute__((address_space(3))) vec_t *vptr;
+            tp[0] = *(vptr)(uintptr_t)(unsigned)ad;
+            tp[1] = *(vptr)(uintptr_t)(unsigned)(ad + CELL);
+            tp[2] = *(vptr)(uintptr_t)(unsigned)ad2;
+            tp[3] = *(vptr)(uintptr_t)(unsigned)(ad2 + CELL);
+        };
+        auto issue = [&](Pair &P) {
+            const f32x2 x = (basex + stepx * fi) + shiftx;
+            const f32x2 y = (basey + stepy * fi) + shifty;
+            fi += 2.0f;
+            f32x2 wx0, wx1;
+            if constexpr (PADDED) {
+                wx1 = f32x2{__builtin_amdgcn_fractf(x.x), __builtin_amdgcn_fractf(x.y)};
+                P.wy1 = f32x2{__builtin_amdgcn_fractf(y.x), __builtin_amdgcn_fractf(y.y)};
+                wx0 = 1.0f - wx1;
+                P.wy0 = 1.0f - P.wy1;
+            } else {
+                const f32x2 xf = {floorf(x.x), floorf(x.y)}, yf = {floorf(y.x), floorf(y.y)};
+                const f32x2 xc = xf + 1.0f, yc = yf + 1.0f;
+                wx0 = xc - x; wx1 = x - xf;
+                P.wy0 = yc - y; P.wy1 = y - yf;
+            }
+            P.wl = MIRROR ? wx1 : wx0;
+            P.wh = MIRROR ? wx0 : wx1;
+            row_taps(x.x, y.x, P.tp[0]);
+            row_taps(x.y, y.y, P.tp[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto consume = [&](const Pair &P) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float wl = r ? P.wl.y : P.wl.x, wh = r ? P.wh.y : P.wh.x;
+                const float w0 = r ? P.wy0.y : P.wy0.x, w1 = r ? P.wy1.y : P.wy1.x;
+                const vec_t v_yf = wl * P.tp[r][0] + wh * P.tp[r][1];
+                const vec_t v_yc = wl * P.tp[r][2] + wh * P.tp[r][3];
+                acc += w0 * v_yf + w1 * v_yc;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const int npairs = q.kmax >> 1;
+        Pair A, B;
+        if (npairs > 0) {
+            issue(A);
+            int b = 1;
+            for (; b + 1 < npairs; b += 2) {
+                issue(B);
+                consume(A);
+                issue(A);
+                consume(B);
+            }
+            if (b < npairs) {
+                issue(B);
+                consume(A);
+                consume(B);
+            } else {
+                consume(A);
+            }
+        }
+        if (q.tail) {               // an odd canvas height walked whole: its last row
+            const float fr = fi.x;
+            const float x = (q.xj + q.t1 * fr) + q.t2, y = (q.yj + q.t4 * fr) + q.t5;
+            const float xf = floorf(x), yf = floorf(y), xc = xf + 1.0f, yc = yf + 1.0f;
+            const int ixr = cvt_flr(x), iyr = cvt_flr(y);
+            const bool own = (unsigned)(ixr - xlo) < (unsigned)nx && (unsigned)(iyr - ylo) < (unsigned)ny;
+            int ad = __mul24(iyr, pitchB) + off_rows;
+            ad = MIRROR ? ad - (ixr << SHIFT) + off_cols : ad + (ixr << SHIFT) + off_cols;
+            ad = own ? ad : lds_base;
+            const float wl = MIRROR ? x - xf : xc - x, wh = MIRROR ? xc - x : x - xf;
+            const vec_t v_yf = wl * lds_abs_vec<NS>(ad) + wh * lds_abs_vec<NS>(ad + CELL);
+            const vec_t v_yc = wl * lds_abs_vec<NS>(ad + pitchB) + wh * lds_abs_vec<NS>(ad + pitchB + CELL);
+            acc += (yc - y) * v_yf + (y - yf) * v_yc;
+        }
+        if (q.live) {
+            if constexpr (TILED) {
+                const size_t nrays = (size_t)g.A * nb;
+                float *dst = out + partial_index(s, nt, t, nrays, (size_t)q.ray);
+                if constexpr (NS == 1) *dst = acc; else *reinterpret_cast<vec_t *>(dst) = acc;
+            } else {
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    if (s + n < gfull.S) {
+                        float av;
+                        if constexpr (NS == 1) av = acc; else av = acc[n];
+                        out[(size_t)(s + n) * g.A * g.PW + q.ray] = av;
+                    }
+            }
+        }
+    };
+
+    __syncthreads();
+    // (angle, 64-slot block) tasks of this class, handed out through an LDS counter, the innermost blocks (longest rays) first;
+    // a wave takes two MIRRORED 32-slot runs of the slot range (equal chords: one trip count serves both)
+    const int nbk = nb >> 6;
+    const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
+    int *next_task = cls_list + 1 + g.A;
+    const int ntask = ncls * nbk;
+    for (;;) {
+        int m = 0;
+        if (lane == 0) m = atomicAdd(next_task, 1);
+        m = __builtin_amdgcn_readfirstlane(m) * G + gi;
+        if (m >= ntask) break;
+        const int bi = m / ncls, ai = m - bi * ncls;
+        const int a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]), blk = nbk - 1 - bi;
+        const int slot = lane < 32 ? blk * 32 + lane : nb - 32 * (blk + 1) + (lane - 32);
+        const BilinRay q = setup(a, slot);
+        if (mirror) walk(q, std::true_type{}); else walk(q, std::false_type{});
+    }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------------------
+static size_t bilin_extra_bytes(int A) { return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16; }
+static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
+
+bool bilin_fwd_whole_geometry(int H, int W) { return bilin_img_bytes(H, W, false, 1) + kBilinLdsReserve <= (size_t)kMaxLdsBytes; }
+bool bilin_fwd_whole_ok(int H, int W, int A)
+{
+    return bilin_fwd_whole_geometry(H, W) && bilin_img_bytes(H, W, false, 1) + bilin_extra_bytes(A) <= (size_t)kMaxLdsBytes;
+}
+
+template <int NS, bool TILED>
+static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSpec &ts, const float *T8_dev, float *out_dev,
+                            ctpvae_stream_t stream)
+{
+    const int th = TILED ? ts.th : g.H, tw = TILED ? ts.tw : g.W, nt = TILED ? ts.ntx * ts.nty : 1;
+    const size_t img_bytes = bilin_img_bytes(th, tw, TILED, NS), extra = bilin_extra_bytes(g.A);
+    CTPVAE_REQUIRE(img_bytes + extra <= (size_t)kMaxLdsBytes, "rotate_fwd (bilinear): a %d x %d unit of %d slices and %d angles does not fit LDS",
+                   th, tw, NS, g.A);
+    const int groups = ceil_div(g.S, NS), units = groups * nt;
+    CTPVAE_REQUIRE(units <= 65535, "rotate_fwd (bilinear): at most 65535 units per launch (got %d)", units);
+    const int nb = TILED ? ts.nb : ((g.PW + 63) & ~63);
+    const int tasks = g.A * (nb / 64);
+    // task groups per class: fill the chip once, leave every workgroup >= 4 waves of tasks
+    int G = std::max(1, 256 / (2 * units));
+    G = std::min(G, std::max(1, tasks / 8));
+    if (knob(kKnobBw) > 0) G = knob(kKnobBw);
+    int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
+    if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
+    const bool padded = g.px >= 1 && g.py >= 1;
+    auto launch = [&](auto kernel) -> int {
+        static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};
+        CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_bilin_kernel", abs_ok);   // the all-zero block sits at LDS address 0
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
+        hipLaunchKernelGGL(kernel, dim3(2 * G, units), dim3(64 * waves), img_bytes + extra, (hipStream_t)stream, img_dev, g, ts, T8_dev,
+                           (int)(img_bytes / sizeof(float)), out_dev);
+        CTPVAE_LAUNCH_CHECK("rotate_fwd_bilin_kernel");
+        return CTPVAE_OK;
+    };
+    return padded ? launch(rotate_fwd_bilin_kernel<NS, TILED, true>) : launch(rotate_fwd_bilin_kernel<NS, TILED, false>);
+}
+
+// slices per LDS cell: as many as fit beside the transform copy (every one shares the sample's index instructions)
+static int bilin_fwd_ns(int S, int h, int w, bool tiled, int A)
+{
+    int ns = S >= 3 ? 4 : (S == 2 ? 2 : 1);
+    if (knob(kKnobBns) == 1 || knob(kKnobBns) == 2 || knob(kKnobBns) == 4) ns = knob(kKnobBns);
+    while (ns > 1 && bilin_img_bytes(h, w, tiled, ns) + bilin_extra_bytes(A) > (size_t)kMaxLdsBytes) ns >>= 1;
+    return ns;
+}
+
+// whole slices in LDS: [S][H][W] -> [S][A][PW]
+int bilin_fwd_whole(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev, int A,
+                    float *sino_dev, ctpvae_stream_t stream)
+{
+    const int ns = bilin_fwd_ns(S, H, W, false, A);
+    const TileSpec none{};
+    return for_slice_chunks(S, std::max(4, std::min(max_slices_per_launch(), 65532) / 4 * 4), [&](int s0, int n) {
+        const RotGeom g{n, H, W, PH, PW, py, px, A};
+        const float *im = img_dev + (size_t)s0 * H * W;
+        float *so = sino_dev + (size_t)s0 * A * PW;
+        if (ns == 4) return launch_bilin_fwd<4, false>(im, g, none, T8_dev, so, stream);
+        if (ns == 2) return launch_bilin_fwd<2, false>(im, g, none, T8_dev, so, stream);
+        return launch_bilin_fwd<1, false>(im, g, none, T8_dev, so, stream);
+    });
+}
+
+// tiles of a slice larger than LDS: partial sums [S / 4][tiles][A][nb][4] into the workspace; the caller runs the reduce pass
+int bilin_fwd_tiles(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev, int A,
+                    const TileSpec &ts, float *workspace_dev, ctpvae_stream_t stream)
+{
+    const RotGeom g{S, H, W, PH, PW, py, px, A};
+    const int ns = bilin_fwd_ns(S, ts.th, ts.tw, true, A);
+    if (ns == 4) return launch_bilin_fwd<4, true>(img_dev, g, ts, T8_dev, workspace_dev, stream);
+    if (ns == 2) return launch_bilin_fwd<2, true>(img_dev, g, ts, T8_dev, workspace_dev, stream);
+    return launch_bilin_fwd<1, true>(img_dev, g, ts, T8_dev, workspace_dev, stream);
+}
+
+}  // namespace ctpvae

@@ -576,9 +576,9 @@ class RotatePlan:
                                                                ws.data_ptr(), None, None, None, ctypes.c_float(0.0),
                                                                out.data_ptr(), None, None, None, None, _stream_ptr(self._dev_index))
         elif ws is not None:
-            rc = self._lib.ctpvae_rotate_fwd_tiled_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
-                                                       self.px, self.T8.data_ptr(), self.A, ws.data_ptr(), out.data_ptr(),
-                                                       _stream_ptr(self._dev_index))
+            rc = self._lib.ctpvae_rotate_fwd_tiled_interp_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
+                                                              self.px, self.T8.data_ptr(), self.A, self.interp, ws.data_ptr(),
+                                                              out.data_ptr(), _stream_ptr(self._dev_index))
         else:
             rc = self._lib.ctpvae_rotate_fwd_f32(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py,
                                                  self.px, self.T8.data_ptr(), self.A, self.interp, out.data_ptr(),
@@ -592,7 +592,7 @@ class RotatePlan:
         self._check(img, (self.H, self.W), "img")
         S = img.shape[0]
         ws = self._tile_workspace(S)
-        if self._fwd_plan is None and ws is None:
+        if (self._fwd_plan is None and ws is None) or self.interp != _lib.NEAREST:
             raise ValueError("forward_loglik needs a planned or tiled forward (nearest)")
         n = self.A if angles_i is None else self._check_sel(angles_i)
         n_in = self.A if (angles_i is None or dense_inputs) else n     # angle rows of mask / meas

@@ -67,7 +67,7 @@ typedef void *ctpvae_stream_t;
 /* Version of this ABI: major * 1000 + minor.  CTPVAE_ABI_VERSION is what THIS header describes: host code compiled against
  * it (csrc/torch_node.cpp, a maintainer's own binding) compares the macro with ctpvae_abi_version() of the library it loaded
  * and refuses a mismatch -- an entry point called with another version's argument list is a silent wrong-argument call. */
-#define CTPVAE_ABI_VERSION 3310
+#define CTPVAE_ABI_VERSION 3400
 int ctpvae_abi_version(void);
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *ctpvae_last_error(void);
@@ -118,13 +118,23 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
  * Tap indices are exactly those of ctpvae_rotate_fwd_f32; only the association of the fp32 sum differs.
  * ctpvae_rotate_tile_shape: 1 and the tile shape when (H, W, interp) is a tiled geometry, 0 (and zeros) when it is not --
  * what a checker needs to restate the sum (oracle_rotate_fwd_tiled); a function of its arguments alone, not of the device.
- * _workspace_bytes returns 0 when the slice fits LDS whole or interp is not NEAREST (use ctpvae_rotate_fwd_f32),
+ * _workspace_bytes returns 0 when the slice fits LDS whole (use ctpvae_rotate_fwd_f32),
  * otherwise the size of the caller-owned device workspace (contents undefined on return). */
 int ctpvae_rotate_tile_shape(int H, int W, int interp, int *tile_h, int *tile_w);
 long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, int PW, int A, int interp);
 int ctpvae_rotate_fwd_tiled_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
                                 const float *T8_dev, int A, void *workspace_dev, float *sino_dev,
                                 ctpvae_stream_t stream);
+
+/* BILINEAR slices larger than LDS (round 5, ABI 3400; ctvae/forward_functions.py:69-77 at 512 x 512): tiles 64 wide x
+ * ceil(H / ceil(H / 96)) tall (86 for H = 512), each staged with a one-pixel halo below and to its right.  A sample's 2 x 2
+ * footprint belongs to the tile of its FLOOR tap and is evaluated there exactly as ctpvae_rotate_fwd_f32 evaluates it; a tile's
+ * partial sum adds its samples in ascending canvas-row order and the tiles are added in ascending order as above
+ * (oracle_rotate_fwd_tiled with interp = 1).  interp = CTPVAE_NEAREST: ctpvae_rotate_fwd_tiled_f32.  Workspace and tile shape:
+ * the two functions above with the same interp. */
+int ctpvae_rotate_fwd_tiled_interp_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                                       const float *T8_dev, int A, int interp, void *workspace_dev, float *sino_dev,
+                                       ctpvae_stream_t stream);
 
 /* ... and with the log-likelihood epilogue of ctpvae_rotate_fwd_planned_loglik_f32 (below) in its reduce pass. */
 int ctpvae_rotate_fwd_tiled_loglik_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,

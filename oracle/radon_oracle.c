@@ -181,15 +181,19 @@ void oracle_rotate_fwd(const float *img, int S, int H, int W, int PH, int PW, in
 }
 
 /* ---------------------------------------------------------------------------------------------
- * a2 with the tile-blocked association of the row sum (NEAREST).  reduce_sum(axis=1)
- * (ctvae/forward_functions.py:108,114) fixes the terms, not the order in which fp32 adds them; the
- * build's kernels for slices larger than LDS add the taps of each th x tw tile of the slice first
+ * a2 / a5 with the tile-blocked association of the row sum.  reduce_sum(axis=1)
+ * (ctvae/forward_functions.py:76,108,114) fixes the terms, not the order in which fp32 adds them; the
+ * build's kernels for slices larger than LDS add the samples of each th x tw tile of the slice first
  * (rows ascending) and then the tile sums in ascending row-major tile order:
- *   sino[s][a][j] = ((0 + p_0) + p_1) + ...,   p_t = sum_{i ascending, tap in tile t} canvas[tap].
- * Same taps as oracle_rotate_fwd; the two differ by fp32 rounding of the sum only.
+ *   sino[s][a][j] = ((0 + p_0) + p_1) + ...,   p_t = sum_{i ascending, sample in tile t} sample(i, j).
+ * NEAREST: a sample belongs to the tile that holds its tap.  BILINEAR (round 5): to the tile that holds
+ * its FLOOR tap (yf, xf), taps at -1 counting to the first row / column of tiles; the sample itself is
+ * TensorFlow's four-tap expression, unchanged (sample_canvas).  Samples whose taps all lie outside the
+ * slice are exact zeros and belong to no tile.  Same terms as oracle_rotate_fwd; the two differ by fp32
+ * rounding of the sum only.
  * ------------------------------------------------------------------------------------------- */
-int oracle_rotate_fwd_tiled(const float *img, int S, int H, int W, int PH, int PW, int py, int px,
-                            const float *T8, int A, int th, int tw, float *sino)
+int oracle_rotate_fwd_tiled_interp(const float *img, int S, int H, int W, int PH, int PW, int py, int px,
+                                   const float *T8, int A, int interp, int th, int tw, float *sino)
 {
     if (th <= 0 || tw <= 0) return -1;
     const int ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th, nt = ntx * nty;
@@ -205,8 +209,14 @@ int oracle_rotate_fwd_tiled(const float *img, int S, int H, int W, int PH, int P
                 for (int i = 0; i < PH; ++i) {
                     float x, y;
                     map_coord(t, j, i, &x, &y);
-                    const long r = (long)roundf(y) - py, c = (long)roundf(x) - px;
-                    if (r >= 0 && r < H && c >= 0 && c < W) part[(r / th) * ntx + c / tw] += im[r * W + c];
+                    if (interp == ORACLE_NEAREST) {
+                        const long r = (long)roundf(y) - py, c = (long)roundf(x) - px;
+                        if (r >= 0 && r < H && c >= 0 && c < W) part[(r / th) * ntx + c / tw] += im[r * W + c];
+                    } else {
+                        const long r = (long)floorf(y) - py, c = (long)floorf(x) - px;
+                        if (r >= -1 && r < H && c >= -1 && c < W)
+                            part[((r < 0 ? 0 : r) / th) * ntx + (c < 0 ? 0 : c) / tw] += sample_canvas(im, H, W, py, px, y, x, interp);
+                    }
                 }
                 float acc = 0.0f;
                 for (int k = 0; k < nt; ++k) acc += part[k];
@@ -216,6 +226,12 @@ int oracle_rotate_fwd_tiled(const float *img, int S, int H, int W, int PH, int P
     }
     free(part);
     return 0;
+}
+
+int oracle_rotate_fwd_tiled(const float *img, int S, int H, int W, int PH, int PW, int py, int px,
+                            const float *T8, int A, int th, int tw, float *sino)
+{
+    return oracle_rotate_fwd_tiled_interp(img, S, H, W, PH, PW, py, px, T8, A, ORACLE_NEAREST, th, tw, sino);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -45,6 +45,8 @@ def lib():
         L.oracle_rotate_fwd.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _f32p]
         L.oracle_rotate_fwd_tiled.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _i, _f32p]
         L.oracle_rotate_fwd_tiled.restype = _i
+        L.oracle_rotate_fwd_tiled_interp.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _f32p]
+        L.oracle_rotate_fwd_tiled_interp.restype = _i
         L.oracle_rotate_bwd_tfcompat.argtypes = [_f32p, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _i, _f32p]
         L.oracle_rotate_bwd_exact.argtypes = [_f32p, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _i, _f32p]
         L.oracle_siddon_dx.restype = _i
@@ -138,13 +140,14 @@ def rotate_fwd(img, geom, T8, interp=NEAREST):
     return sino
 
 
-def rotate_fwd_tiled(img, geom, T8, tile=(128, 128)):
-    """Same taps as rotate_fwd (NEAREST), summed tile by tile (the association the build uses for slices > LDS)."""
+def rotate_fwd_tiled(img, geom, T8, tile=(128, 128), interp=NEAREST):
+    """Same samples as rotate_fwd, summed tile by tile (the association the build uses for slices > LDS; a bilinear sample
+    belongs to the tile of its floor tap)."""
     img, T8 = _c32(img), _c32(T8)
     S, A = img.shape[0], T8.shape[0]
     sino = np.empty((S, A, geom.PW), np.float32)
-    rc = lib().oracle_rotate_fwd_tiled(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A,
-                                       int(tile[0]), int(tile[1]), sino)
+    rc = lib().oracle_rotate_fwd_tiled_interp(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A, int(interp),
+                                              int(tile[0]), int(tile[1]), sino)
     if rc:
         raise ValueError("rotate_fwd_tiled: bad tile size")
     return sino

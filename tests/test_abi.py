@@ -42,7 +42,7 @@ def test_binding_table_matches_header(built_lib):
     assert sorted(built_lib.SIGNATURES) == declared_symbols()
     lib = built_lib.load()
     macro = int(re.search(r"#define\s+CTPVAE_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
-    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3310
+    assert lib.ctpvae_abi_version() == built_lib.ABI_VERSION == macro == 3400
 
 
 def test_torch_node_refuses_a_library_of_another_abi(built_lib, monkeypatch):

@@ -1,0 +1,121 @@
+"""The BILINEAR quadrants of the rotate projector (project_tf_low_mem, ctvae/forward_functions.py:69-77; round 5) against the
+CPU oracle, on a real MI355X, to the depth the nearest path is tested: random geometries, unpadded canvases, axis-aligned
+angles, every slices-per-cell variant, tiles, and the old direct kernels as a second implementation.
+
+Bars: forward and TensorFlow-compatible backward BIT-EXACT (same expression per sample, same order of the sums); the exact
+adjoint <= 1e-5 of the oracle's scatter, equal bits run to run, and still the transpose."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ct_pvae_amd import _lib, phantoms
+from ct_pvae_amd.forward_functions import RotatePlan
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+def to_np(t):
+    return t.detach().cpu().numpy()
+
+
+def rel_err(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def oT(oracle, theta, plan):
+    return oracle.rotate_transforms(np.asarray(theta, dtype=np.float32), plan.PH, plan.PW)
+
+
+def fuzz_cases(rng, n):
+    """(H, W, pad, theta, S): odd sizes, one-pixel slices, unpadded canvases, axis-aligned angles, 1..7 slices."""
+    fixed = [(1, 1), (1, 77), (93, 1), (3, 2), (2, 2), (128, 128), (129, 127), (64, 160)]
+    for case in range(n):
+        H, W = fixed[case] if case < len(fixed) else (int(rng.integers(1, 150)), int(rng.integers(1, 150)))
+        pad, A, S = bool(rng.integers(0, 2)), int(rng.integers(1, 25)), int(rng.integers(1, 8))
+        theta = rng.uniform(-2 * np.pi, 2 * np.pi, A)
+        if case % 3 == 0:
+            theta[: min(A, 4)] = [0.0, np.pi / 2, np.pi, -np.pi / 2][: min(A, 4)]
+        yield case, H, W, pad, theta, S
+
+
+def test_bilinear_forward_random_geometries(oracle):
+    d = dev()
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 20261005)))
+    for case, H, W, pad, theta, S in fuzz_cases(rng, int(os.environ.get("CTPVAE_FUZZ_CASES", 28))):
+        img = rng.standard_normal((S, H, W)).astype(np.float32)
+        geom = oracle.Geometry(H, W, pad)
+        plan = RotatePlan(theta, H, W, pad, d, interp="bilinear")
+        want = oracle.rotate_fwd(img, geom, oT(oracle, theta, plan), 1)
+        x = torch.from_numpy(img).to(d)
+        msg = f"case {case}: {H}x{W} pad={pad} A={len(theta)} S={S}"
+        np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg="fwd " + msg)
+        for ns in (1, 2, 4):                       # slices per LDS cell, forced
+            with _lib.tuned("BNS", ns):
+                np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"fwd BNS={ns} " + msg)
+        with _lib.tuned("NO_PLAN", 1):             # round 1's direct kernel: a second implementation of the same sums
+            np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg="fwd direct " + msg)
+
+
+def test_bilinear_slice_independence_and_launch_shapes(oracle):
+    """A slice's sinogram does not depend on what it is batched with (1 / 2 / 3 / 5 / 9 slices: singles, pairs, quads and their
+    half-empty remainders), nor on the number of task groups or waves."""
+    d = dev()
+    rng = np.random.default_rng(3)
+    theta = phantoms.dense_theta(180)[::12]
+    img = rng.random((9, 128, 128)).astype(np.float32)
+    geom = oracle.Geometry(128, 128, True)
+    plan = RotatePlan(theta, 128, 128, True, d, interp="bilinear")
+    want = oracle.rotate_fwd(img, geom, oT(oracle, theta, plan), 1)
+    x = torch.from_numpy(img).to(d)
+    for S in (1, 2, 3, 5, 9):
+        np.testing.assert_array_equal(to_np(plan.forward(x[:S].contiguous())), want[:S], err_msg=f"S={S}")
+    for G, waves in ((1, 16), (3, 5), (7, 2), (2, 1)):
+        with _lib.tuned("BW", G), _lib.tuned("WAVES", waves):
+            np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"G={G} waves={waves}")
+
+
+@pytest.mark.parametrize("H,W,S,A", [(512, 512, 3, 6), (300, 200, 5, 4), (190, 260, 2, 5)])
+def test_bilinear_tiles_against_the_tiled_oracle(oracle, H, W, S, A):
+    """Slices larger than LDS: tiles with a one-pixel halo; a sample belongs to the tile of its floor tap, the tiles' partial
+    sums are added in ascending order -- oracle_rotate_fwd_tiled(interp = 1) with the shape the library reports."""
+    d = dev()
+    rng = np.random.default_rng(H + W)
+    theta = np.concatenate([[0.0, np.pi / 2], rng.uniform(0, np.pi, A - 2)])
+    img = rng.random((S, H, W)).astype(np.float32)
+    geom = oracle.Geometry(H, W, True)
+    plan = RotatePlan(theta, H, W, True, d, interp="bilinear")
+    shape = _lib.tile_shape(H, W, 1)
+    assert plan.tiled and shape == (-(-H // -(-H // 96)), 64)
+    T = oT(oracle, theta, plan)
+    got = to_np(plan.forward(torch.from_numpy(img).to(d)))
+    np.testing.assert_array_equal(got, oracle.rotate_fwd_tiled(img, geom, T, shape, interp=1))
+    assert rel_err(got, oracle.rotate_fwd(img, geom, T, 1)) <= REL
+    for ns in (1, 2):
+        with _lib.tuned("BNS", ns):
+            np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))), got, err_msg=f"BNS={ns}")
+
+
+def test_bilinear_forced_tiles_on_small_unpadded_slices(oracle):
+    """TILED_FORCE cuts slices that fit LDS into tiles: ragged edge tiles, one-row / one-column tiles, unpadded canvases."""
+    d = dev()
+    rng = np.random.default_rng(11)
+    for H, W, pad in ((150, 100, True), (97, 65, False), (130, 129, False), (64, 64, True), (1, 200, True)):
+        theta = rng.uniform(-np.pi, np.pi, 5)
+        img = rng.standard_normal((3, H, W)).astype(np.float32)
+        geom = oracle.Geometry(H, W, pad)
+        with _lib.tuned("TILED_FORCE", 1):
+            plan = RotatePlan(theta, H, W, pad, d, interp="bilinear")
+            shape = _lib.tile_shape(H, W, 1)
+            assert shape is not None and plan.tiled
+            got = to_np(plan.forward(torch.from_numpy(img).to(d)))
+        np.testing.assert_array_equal(got, oracle.rotate_fwd_tiled(img, geom, oT(oracle, theta, plan), shape, interp=1),
+                                      err_msg=f"{H}x{W} pad={pad} tiles {shape}")
