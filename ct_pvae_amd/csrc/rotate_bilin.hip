@@ -356,7 +356,9 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     int G = std::max(1, 256 / (2 * units));
     G = std::min(G, std::max(1, tasks / 8));
     if (knob(kKnobBw) > 0) G = knob(kKnobBw);
-    int waves = std::min(16, std::max(1, ceil_div(tasks, 2 * G)));
+    // >= 8 waves: a workgroup's fill is shared by its waves, and two waves per SIMD issue LDS reads and waits under each other's
+    // vector instructions (tools/sweep_bilin.py, B = 50 x 128 x 128 x 20 angles, G = 5: 27.1 / 24.3 / 22.1 / 21.8 us at 4 / 6 / 8 / 16)
+    int waves = std::min(16, std::max(8, ceil_div(tasks, 2 * G)));
     if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
     const bool padded = g.px >= 1 && g.py >= 1;
     auto launch = [&](auto kernel) -> int {
