@@ -2376,6 +2376,8 @@ static int rotate_bwd_one(const float *gsino_dev, int S, int A, int PH, int PW, 
         return CTPVAE_OK;
     }
     CTPVAE_REQUIRE(sel_dev == nullptr, "rotate_bwd_sel: only the NEAREST / TF_COMPAT segment kernel takes an angle subset (S <= 65535)");
+    if (mode == CTPVAE_BWD_TF_COMPAT && knob(kKnobForceGeneric) < 0 && knob(kKnobNoPlan) < 0)   // round 5: segments, slices per cell
+        return bilin_bwd_tfcompat(gsino_dev, S, A, PH, PW, T8_dev, H, W, py, px, gimg_dev, stream);
     if (mode == CTPVAE_BWD_TF_COMPAT && knob(kKnobForceGeneric) < 0 && S <= 65535) {
         // BILINEAR: 64-column x (4 waves x PPT rows) tiles; whole cotangent rows in LDS, <= 48 KiB per chunk
         constexpr int kPpt = 8;

@@ -330,6 +330,192 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
     }
 }
 
+// ---- backward, TensorFlow-compatible ------------------------------------------------------------------------------------------
+//
+// TensorFlow's registered gradient of ImageProjectiveTransformV3 (a4) samples the row-broadcast image of g[a][:] with the
+// inverted transform and the same interpolation:
+//     x = (t0 X + t1 Y) + t2, y = (t3 X + t4 Y) + t5 for pixel (X, Y) of the canvas,  h = (xc - x) g[xf] + (x - xf) g[xc]
+//     G_a = (yc - y) * (row yf on the canvas ? h : 0) + (y - yf) * (row yc on the canvas ? h : 0),  gimg = sum over angles, ascending
+// (both rows of the broadcast image hold the same h; a tap off the detector is zero-filled).  Round 1's kernel kept whole
+// cotangent rows in LDS and one slice per workgroup (~27 vector operations per pixel and angle).  Here, as in the nearest
+// segment kernel (rotate.hip): a 64-column x (4 waves x PPT rows) pixel tile stages, per angle, only the <= 80 bins its
+// rectangle projects to -- cells off the detector staged as zeros, so no tap needs a bounds test --, NS slices interleaved per
+// cell; coordinates, the four weights and the tap address are computed once per (pixel, angle) for all NS slices (12 vector
+// instructions + 7 per slice, packed two slices at a time).  Every angle is classified once from the tile's corners:
+//   0  every pixel of the tile maps inside the canvas with both taps (always, on a padded canvas): weights from v_fract_f32
+//      (x, y >= 0: exact), no row test;
+//   1  some pixel may map outside: the literal floor expressions and the reference's zero fill of rows off the canvas;
+//   2  the segment would not hold the span (the table row is not a rotation): bounds-tested reads from global memory.
+// Every pixel adds its angles in ascending order: bit-identical to the oracle whatever the class.
+constexpr int kBSegBins = 80, kBSegPitch = kBSegBins + 1;
+template <int PPT, int NS>
+__global__ __launch_bounds__(256) void rotate_bwd_bilin_seg_kernel(const float *__restrict__ gsino, RotGeom g,
+                                                                   const float *__restrict__ Tinv8, int chunk_a,
+                                                                   float *__restrict__ gimg)
+{
+    typedef typename PixVec<NS>::type vec_t;
+    constexpr int SHIFT = BilinCell<NS>::kShift, CELL = BilinCell<NS>::kBytes;
+    // [chunk_a][kBSegPitch] cells, then per angle (first bin, class) ints, then per angle eight floats (t0, t1, t2, segment byte
+    // base, t3, t4, t5, 0): the fast loop reads them with two broadcast ds_read_b128
+    extern __shared__ float lds[];
+    int *meta = reinterpret_cast<int *>(lds + chunk_a * kBSegPitch * NS);
+    f32x4 *meta8 = reinterpret_cast<f32x4 *>(lds + ((chunk_a * (kBSegPitch * NS + 2) + 3) & ~3));
+    const int s = blockIdx.z * NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
+    const float fx = (float)(c + g.px);
+    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + 63.0f;
+    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)(nwaves * PPT - 1);
+    const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
+    const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
+    size_t soff[NS];                                   // slices past the batch re-read the last one (never stored)
+#pragma unroll
+    for (int n = 0; n < NS; ++n) soff[n] = (size_t)(min(s + n, g.S - 1) - s) * g.A * g.PW;
+
+    vec_t acc[PPT];
+    float fy[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        acc[k] = vec_t(0.0f);
+        fy[k] = (float)(r0 + k * nwaves + g.py);
+    }
+
+    for (int ac = 0; ac < g.A; ac += chunk_a) {
+        const int na = min(chunk_a, g.A - ac);
+        if (ac > 0) __syncthreads();
+        int any_outside = 0;
+        for (int al = threadIdx.x; al < na; al += blockDim.x) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+            const float xa = (t0 * X0 + t1 * Y0) + t2, xb = (t0 * X1 + t1 * Y0) + t2;
+            const float xc = (t0 * X0 + t1 * Y1) + t2, xd = (t0 * X1 + t1 * Y1) + t2;
+            const float ya = (t3 * X0 + t4 * Y0) + t5, yb = (t3 * X1 + t4 * Y0) + t5;
+            const float yc = (t3 * X0 + t4 * Y1) + t5, yd = (t3 * X1 + t4 * Y1) + t5;
+            const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+            const float ymin = fminf(fminf(ya, yb), fminf(yc, yd)), ymax = fmaxf(fmaxf(ya, yb), fmaxf(yc, yd));
+            int cls = 0, first = 0;
+            if (!(xmax - xmin <= (float)(kBSegBins - 6)) || !(fabsf(xmin) < 1.0e6f)) {
+                cls = 2;   // (also NaN / absurd rows)
+            } else {
+                first = (int)floorf(xmin) - 2;     // taps floor(x), floor(x) + 1 of every pixel lie in [first + 1, first + 78]
+                if (!(xmin > 0.5f && xmax < x_hi - 1.0f && ymin > 0.5f && ymax < y_hi - 1.0f)) cls = 1;
+            }
+            meta[2 * al] = first;
+            meta[2 * al + 1] = cls;
+            meta8[2 * al] = f32x4{t0, t1, t2, __int_as_float((al * kBSegPitch - first) * CELL + lds_base)};
+            meta8[2 * al + 1] = f32x4{t3, t4, t5, 0.0f};
+            any_outside |= cls;
+        }
+        const bool all_inside = __syncthreads_or(any_outside) == 0;   // (also the barrier behind the table)
+        const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
+        {
+            constexpr int U = NS == 4 ? 2 : 8 / NS;   // cells in flight per thread; loads unconditional (clamped), the select comes after
+            const int ncell = na * kBSegPitch;
+            for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
+                vec_t v[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = min(p0 + u * (int)blockDim.x, ncell - 1);
+                    const int al = p / kBSegPitch, q = p - al * kBSegPitch;
+                    const int j = meta[2 * al] + q;
+                    ok[u] = q < kBSegBins && (unsigned)j < (unsigned)g.PW;
+                    const float *cell = src + al * g.PW + min(max(j, 0), g.PW - 1);
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) {
+                        if constexpr (NS == 1) v[u] = cell[0]; else v[u][n] = cell[soff[n]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * (int)blockDim.x;
+                    if (p < ncell) reinterpret_cast<vec_t *>(lds)[p] = ok[u] ? v[u] : vec_t(0.0f);
+                }
+            }
+        }
+        __syncthreads();
+
+        typedef const volatile __attribute__((address_space(3))) vec_t *vptr;   // (volatile: no ds_read2_b64 pairing, see the forward)
+        if (all_inside) {
+            // class 0 throughout (a padded canvas always): two broadcast reads per angle, then per pixel 12 shared instructions
+            // and two cells
+            for (int al = 0; al < na; ++al) {
+                const f32x4 m = meta8[2 * al], n4 = meta8[2 * al + 1];
+                const float xa = m.x * fx, ya = n4.x * fx;
+                const int k4 = __float_as_int(m.w);
+                vec_t g0[PPT], g1[PPT];
+                float wx1[PPT], wy1[PPT];
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const float x = (xa + m.y * fy[k]) + m.z;
+                    const float y = (ya + n4.y * fy[k]) + n4.z;
+                    wx1[k] = __builtin_amdgcn_fractf(x);
+                    wy1[k] = __builtin_amdgcn_fractf(y);
+                    int addr;   // (floor(x) - first) * cell bytes + segment base: one convert, one shift-add
+                    asm("v_cvt_flr_i32_f32 %0, %1\n\tv_lshl_add_u32 %0, %0, %3, %2" : "=&v"(addr) : "v"(x), "v"(k4), "i"(SHIFT));
+                    g0[k] = *(vptr)(uintptr_t)(unsigned)addr;
+                    g1[k] = *(vptr)(uintptr_t)(unsigned)(addr + CELL);
+                }
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const float wx0 = 1.0f - wx1[k], wy0 = 1.0f - wy1[k];
+                    const vec_t h = wx0 * g0[k] + wx1[k] * g1[k];
+                    acc[k] += wy0 * h + wy1[k] * h;
+                }
+            }
+        } else
+        for (int al = 0; al < na; ++al) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);   // wave-uniform: scalar loads
+            const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+            const int first = __builtin_amdgcn_readfirstlane(meta[2 * al]);
+            const int cls = __builtin_amdgcn_readfirstlane(meta[2 * al + 1]);
+            const float xa = t0 * fx, ya = t3 * fx;
+            const vec_t *seg = reinterpret_cast<const vec_t *>(lds) + al * kBSegPitch;
+            const float *grow = src + (size_t)al * g.PW;
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const float x = (xa + t1 * fy[k]) + t2;
+                const float y = (ya + t4 * fy[k]) + t5;
+                const float xf = floorf(x), yf = floorf(y), xc = xf + 1.0f, yc = yf + 1.0f;
+                vec_t a0, a1;
+                if (cls != 2) {     // the segment holds both taps; cells off the detector are zeros
+                    const int ix = cvt_flr(x) - first;
+                    a0 = seg[ix];
+                    a1 = seg[ix + 1];
+                } else {
+                    const bool ok0 = xf >= 0.0f && xf < (float)g.PW, ok1 = xc >= 0.0f && xc < (float)g.PW;
+                    const int i0 = ok0 ? (int)xf : 0, i1 = ok1 ? (int)xc : 0;
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) {
+                        const float p0 = ok0 ? grow[soff[n] + i0] : 0.0f, p1 = ok1 ? grow[soff[n] + i1] : 0.0f;
+                        if constexpr (NS == 1) { a0 = p0; a1 = p1; } else { a0[n] = p0; a1[n] = p1; }
+                    }
+                }
+                const vec_t h = (xc - x) * a0 + (x - xf) * a1;
+                const vec_t v_yf = (yf >= 0.0f && yf < (float)g.PH) ? h : vec_t(0.0f);
+                const vec_t v_yc = (yc >= 0.0f && yc < (float)g.PH) ? h : vec_t(0.0f);
+                acc[k] += (yc - y) * v_yf + (y - yf) * v_yc;
+            }
+        }
+    }
+    if (c < g.W) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int r = r0 + k * nwaves;
+            if (r < g.H) {
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    if (s + n < g.S) {
+                        float av;
+                        if constexpr (NS == 1) av = acc[k]; else av = acc[k][n];
+                        gimg[((size_t)(s + n) * g.H + r) * g.W + c] = av;
+                    }
+            }
+        }
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------
 static size_t bilin_extra_bytes(int A) { return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16; }
 static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
@@ -407,6 +593,39 @@ int bilin_fwd_tiles(const float *img_dev, int S, int H, int W, int PH, int PW, i
     if (ns == 4) return launch_bilin_fwd<4, true>(img_dev, g, ts, T8_dev, workspace_dev, stream);
     if (ns == 2) return launch_bilin_fwd<2, true>(img_dev, g, ts, T8_dev, workspace_dev, stream);
     return launch_bilin_fwd<1, true>(img_dev, g, ts, T8_dev, workspace_dev, stream);
+}
+
+// cotangents [S][A][PW] -> gradient images [S][H][W], TensorFlow-compatible, bilinear
+int bilin_bwd_tfcompat(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H, int W, int py, int px,
+                       float *gimg_dev, ctpvae_stream_t stream)
+{
+    return for_slice_chunks(S, std::max(4, std::min(max_slices_per_launch(), 65532) / 4 * 4), [&](int s0, int n) {
+        const RotGeom g{n, H, W, PH, PW, py, px, A};
+        const float *gs = gsino_dev + (size_t)s0 * A * PW;
+        float *gi = gimg_dev + (size_t)s0 * H * W;
+        // slices per cell and rows per lane: the most sharing that still puts about two workgroups on every CU
+        const long long tiles8 = (long long)ceil_div(W, 64) * ceil_div(H, 32), tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
+        int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 8;
+        while (ns > 1 && ceil_div(n, ns) * tiles4 < 400) ns >>= 1;
+        if (ceil_div(n, ns) * tiles8 < 400) ppt = 4;
+        if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
+        if (ns == 3) ns = 2;
+        if (knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
+        if (ns == 4) ppt = 4;                     // (eight rows of four slices: the taps of an angle alone are 64 registers)
+        // ~48 KiB of segments per chunk of angles: three 4-wave workgroups per CU
+        int chunk_a = std::max(1, std::min(A, (48 * 1024) / (kBSegPitch * 4 * ns + 40)));
+        if (knob(kKnobSegChunk) > 0) chunk_a = std::max(1, std::min(A, std::min(knob(kKnobSegChunk), chunk_a)));
+        const size_t shmem = (((size_t)chunk_a * (kBSegPitch * ns + 2) + 3) & ~(size_t)3) * 4 + (size_t)chunk_a * 32 + 16;
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), ceil_div(n, ns)), block(256);
+        auto launch = [&](auto kernel) -> int {
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, gi);
+            CTPVAE_LAUNCH_CHECK("rotate_bwd_bilin_seg_kernel");
+            return CTPVAE_OK;
+        };
+        if (ns == 4) return launch(rotate_bwd_bilin_seg_kernel<4, 4>);
+        if (ns == 2) return ppt == 8 ? launch(rotate_bwd_bilin_seg_kernel<8, 2>) : launch(rotate_bwd_bilin_seg_kernel<4, 2>);
+        return ppt == 8 ? launch(rotate_bwd_bilin_seg_kernel<8, 1>) : launch(rotate_bwd_bilin_seg_kernel<4, 1>);
+    });
 }
 
 }  // namespace ctpvae

@@ -147,5 +147,8 @@ int bilin_fwd_whole(const float *img_dev, int S, int H, int W, int PH, int PW, i
                     float *sino_dev, ctpvae_stream_t stream);
 int bilin_fwd_tiles(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev, int A,
                     const TileSpec &ts, float *workspace_dev, ctpvae_stream_t stream);
+// bilinear TensorFlow-compatible backward (rotate_bilin.hip): cotangent segments, slices interleaved per cell
+int bilin_bwd_tfcompat(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H, int W, int py, int px,
+                       float *gimg_dev, ctpvae_stream_t stream);
 
 }  // namespace ctpvae

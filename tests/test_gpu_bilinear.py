@@ -119,3 +119,45 @@ def test_bilinear_forced_tiles_on_small_unpadded_slices(oracle):
             got = to_np(plan.forward(torch.from_numpy(img).to(d)))
         np.testing.assert_array_equal(got, oracle.rotate_fwd_tiled(img, geom, oT(oracle, theta, plan), shape, interp=1),
                                       err_msg=f"{H}x{W} pad={pad} tiles {shape}")
+
+
+def oTinv(oracle, theta, plan):
+    return oracle.invert_transforms(oT(oracle, theta, plan))
+
+
+def test_bilinear_tfcompat_backward_random_geometries(oracle):
+    """What tf.GradientTape computes for the bilinear projector (a4 with interpolation BILINEAR): bit-exact, for every
+    slices-per-cell / rows-per-lane variant of the segment kernel and for round 1's whole-row kernel."""
+    d = dev()
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 20261006)))
+    for case, H, W, pad, theta, S in fuzz_cases(rng, int(os.environ.get("CTPVAE_FUZZ_CASES", 28))):
+        geom = oracle.Geometry(H, W, pad)
+        plan = RotatePlan(theta, H, W, pad, d, interp="bilinear")
+        g = rng.standard_normal((S, len(theta), geom.PW)).astype(np.float32)
+        want = oracle.rotate_bwd_tfcompat(g, geom, oTinv(oracle, theta, plan), 1)
+        gt = torch.from_numpy(g).to(d)
+        msg = f"case {case}: {H}x{W} pad={pad} A={len(theta)} S={S}"
+        np.testing.assert_array_equal(to_np(plan.backward(gt)), want, err_msg="bwd " + msg)
+        for ns, ppt in ((1, 4), (1, 8), (2, 4), (2, 8), (4, 4)):
+            with _lib.tuned("SEG_NS", ns), _lib.tuned("SEG_PPT", ppt):
+                np.testing.assert_array_equal(to_np(plan.backward(gt)), want, err_msg=f"bwd SEG_NS={ns} SEG_PPT={ppt} " + msg)
+        with _lib.tuned("SEG_CHUNK", 3):           # several chunks of angles
+            np.testing.assert_array_equal(to_np(plan.backward(gt)), want, err_msg="bwd SEG_CHUNK=3 " + msg)
+        with _lib.tuned("NO_PLAN", 1):
+            np.testing.assert_array_equal(to_np(plan.backward(gt)), want, err_msg="bwd whole rows " + msg)
+
+
+@pytest.mark.parametrize("H,S,A", [(128, 9, 20), (512, 3, 6)])
+def test_bilinear_tfcompat_backward_full_sizes(oracle, H, S, A):
+    d = dev()
+    rng = np.random.default_rng(H)
+    theta = phantoms.dense_theta(180)[:: 180 // A][:A]
+    geom = oracle.Geometry(H, H, True)
+    plan = RotatePlan(theta, H, H, True, d, interp="bilinear")
+    g = rng.standard_normal((S, A, geom.PW)).astype(np.float32)
+    want = oracle.rotate_bwd_tfcompat(g, geom, oTinv(oracle, theta, plan), 1)
+    gt = torch.from_numpy(g).to(d)
+    np.testing.assert_array_equal(to_np(plan.backward(gt)), want)
+    for n in (1, 2, 3, 5):                         # slice independence: singles, pairs, quads and their remainders
+        if n <= S:
+            np.testing.assert_array_equal(to_np(plan.backward(gt[:n].contiguous())), want[:n], err_msg=f"S={n}")
