@@ -516,6 +516,208 @@ __global__ __launch_bounds__(256) void rotate_bwd_bilin_seg_kernel(const float *
     }
 }
 
+// ---- backward, exact transpose -------------------------------------------------------------------------------------------------
+//
+// The forward adds, for every canvas sample (a, i, j), four weighted taps into sino[a][j]; its transpose adds
+// w(a, i, j -> pixel) * g[a][j] into each of the four pixels.  Round 1 did that as a scatter: four atomic adds per sample into an
+// LDS image (global atomics at 512 x 512), order not fixed.  Here it is a GATHER through an inverse plan: for a rotation the
+// samples that touch a pixel lie within sqrt(2) of its inverse-rotated position, i.e. in at most THREE consecutive detector
+// bins, so the plan stores, per (angle, pixel), the first of those bins and the pixel's summed weight in each of the three --
+//     W_k = sum over canvas rows i, ascending, of wy * wx of sample (a, i, first + k),
+// wy, wx the forward's own fp32 weights ((yc - y) or (y - yf), (xc - x) or (x - xf)) evaluated from the forward's own
+// coordinates -- and the backward is
+//     gimg[pixel] = sum over angles, ascending, of ((W_0 g[first] + W_1 g[first + 1]) + W_2 g[first + 2]):
+// no atomics at any size, equal bits run to run, <= 1e-5 of the oracle's in-order scatter (the weights are summed before
+// they meet g, the scatter multiplies first), and the transpose of the forward to fp32 rounding.  16 bytes per (angle, pixel):
+// 5.2 MB for 128 x 128 x 20 angles, 377 MB for 512 x 512 x 90.  The builder scans the 5 x 5 samples around the pixel's inverse
+// position and raises the overflow word when the touching bins do not fit three (the rows are not a rotation): the caller then
+// keeps the scatter kernel.
+constexpr int kXSegBins = 80, kXSegPitch = kXSegBins + 1;
+
+__global__ __launch_bounds__(64) void rotate_exact_bilin_plan_kernel(RotGeom g, const float *__restrict__ T8,
+                                                                     const float *__restrict__ Tinv8, float4 *__restrict__ plan,
+                                                                     int *__restrict__ overflow)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y, a = blockIdx.z;
+    if (c >= g.W) return;
+    const float *ti = Tinv8 + 8 * a, *t = T8 + 8 * a;
+    const int X = c + g.px, Y = r + g.py;
+    const float fx = (float)X, fy = (float)Y;
+    const float j0 = (ti[0] * fx + ti[1] * fy) + ti[2], i0 = (ti[3] * fx + ti[4] * fy) + ti[5];
+    int jc = 0, ic = 0;
+    if (fabsf(j0) < 1.0e7f && fabsf(i0) < 1.0e7f) {
+        jc = (int)__builtin_roundf(j0);
+        ic = (int)__builtin_roundf(i0);
+    }
+    float wb[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned touched = 0;
+    for (int i = ic - 2; i <= ic + 2; ++i) {
+        if ((unsigned)i >= (unsigned)g.PH) continue;
+#pragma unroll
+        for (int dj = 0; dj < 5; ++dj) {
+            const int j = jc - 2 + dj;
+            if ((unsigned)j >= (unsigned)g.PW) continue;
+            const float x = (t[0] * (float)j + t[1] * (float)i) + t[2];
+            const float y = (t[3] * (float)j + t[4] * (float)i) + t[5];
+            if (!(fabsf(x) < 1.0e7f && fabsf(y) < 1.0e7f)) continue;
+            const float xf = floorf(x), yf = floorf(y), xc = xf + 1.0f, yc = yf + 1.0f;
+            const int ixf = (int)xf, iyf = (int)yf;
+            float wx, wy;
+            if (ixf == X) wx = xc - x; else if (ixf + 1 == X) wx = x - xf; else continue;
+            if (iyf == Y) wy = yc - y; else if (iyf + 1 == Y) wy = y - yf; else continue;
+            wb[dj] += wy * wx;
+            touched |= 1u << dj;
+        }
+    }
+    int lo = 2, hi = 2;
+    if (touched) {
+        lo = __ffs(touched) - 1;
+        hi = 31 - __clz(touched);
+    }
+    if (hi - lo > 2) atomicOr(overflow, 1);
+    float w3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float v = 0.0f;
+#pragma unroll
+        for (int dj = 0; dj < 5; ++dj) v = (dj == lo + k) ? wb[dj] : v;
+        w3[k] = v;
+    }
+    plan[((size_t)a * g.H + r) * g.W + c] = make_float4(w3[0], w3[1], w3[2], __int_as_float(jc - 2 + lo));
+}
+
+template <int PPT, int NS>
+__global__ __launch_bounds__(256) void rotate_bwd_exact_bilin_kernel(const float *__restrict__ gsino, RotGeom g,
+                                                                     const float *__restrict__ Tinv8, int chunk_a,
+                                                                     const float4 *__restrict__ plan, float *__restrict__ gimg)
+{
+    typedef typename PixVec<NS>::type vec_t;
+    constexpr int SHIFT = BilinCell<NS>::kShift, CELL = BilinCell<NS>::kBytes;
+    // [chunk_a][kXSegPitch] cells (cell kXSegBins of every segment is zero), then per angle (first bin, class) ints
+    extern __shared__ float lds[];
+    int *meta = reinterpret_cast<int *>(lds + chunk_a * kXSegPitch * NS);
+    const int s = blockIdx.z * NS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int c = blockIdx.x * 64 + lane, cl = min(c, g.W - 1);
+    const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
+    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + 63.0f;
+    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)(nwaves * PPT - 1);
+    const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
+    size_t soff[NS];
+#pragma unroll
+    for (int n = 0; n < NS; ++n) soff[n] = (size_t)(min(s + n, g.S - 1) - s) * g.A * g.PW;
+    vec_t acc[PPT];
+    size_t prow[PPT];                                    // plan index of (angle 0, this lane's k-th pixel)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        acc[k] = vec_t(0.0f);
+        prow[k] = (size_t)min(r0 + k * nwaves, g.H - 1) * g.W + cl;
+    }
+    const size_t pstride = (size_t)g.H * g.W;
+
+    for (int ac = 0; ac < g.A; ac += chunk_a) {
+        const int na = min(chunk_a, g.A - ac);
+        if (ac > 0) __syncthreads();
+        for (int al = threadIdx.x; al < na; al += blockDim.x) {
+            const float *t = Tinv8 + 8 * (size_t)(ac + al);
+            const float t0 = t[0], t1 = t[1], t2 = t[2];
+            const float xa = (t0 * X0 + t1 * Y0) + t2, xb = (t0 * X1 + t1 * Y0) + t2;
+            const float xc = (t0 * X0 + t1 * Y1) + t2, xd = (t0 * X1 + t1 * Y1) + t2;
+            const float xmin = fminf(fminf(xa, xb), fminf(xc, xd)), xmax = fmaxf(fmaxf(xa, xb), fmaxf(xc, xd));
+            int cls = 0, first = 0;
+            // a pixel's three bins lie in [floor(j0) - 1, floor(j0) + 3], j0 its inverse position: the segment holds them all
+            if (!(xmax - xmin <= (float)(kXSegBins - 8)) || !(fabsf(xmin) < 1.0e6f)) cls = 2;
+            else first = (int)floorf(xmin) - 2;
+            meta[2 * al] = first;
+            meta[2 * al + 1] = cls;
+        }
+        __syncthreads();
+        const float *src = gsino + ((size_t)s * g.A + ac) * g.PW;
+        {
+            constexpr int U = NS == 4 ? 2 : 8 / NS;
+            const int ncell = na * kXSegPitch;
+            for (int p0 = threadIdx.x; p0 < ncell; p0 += U * blockDim.x) {
+                vec_t v[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = min(p0 + u * (int)blockDim.x, ncell - 1);
+                    const int al = p / kXSegPitch, q = p - al * kXSegPitch;
+                    const int j = meta[2 * al] + q;
+                    ok[u] = q < kXSegBins && (unsigned)j < (unsigned)g.PW && meta[2 * al + 1] == 0;
+                    const float *cell = src + al * g.PW + min(max(j, 0), g.PW - 1);
+#pragma unroll
+                    for (int n = 0; n < NS; ++n) {
+                        if constexpr (NS == 1) v[u] = cell[0]; else v[u][n] = cell[soff[n]];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * (int)blockDim.x;
+                    if (p < ncell) reinterpret_cast<vec_t *>(lds)[p] = ok[u] ? v[u] : vec_t(0.0f);
+                }
+            }
+        }
+        __syncthreads();
+
+        typedef const volatile __attribute__((address_space(3))) vec_t *vptr;
+        const float4 *pl = plan + (size_t)ac * pstride;
+        for (int al = 0; al < na; ++al) {
+            const int first = __builtin_amdgcn_readfirstlane(meta[2 * al]);
+            const int cls = __builtin_amdgcn_readfirstlane(meta[2 * al + 1]);
+            float4 w[PPT];
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) w[k] = pl[(size_t)al * pstride + prow[k]];
+            if (cls == 0) {
+                const int base = (al * kXSegPitch - first) * CELL + lds_base;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    // the plan's first bin relative to the segment, clamped into it (a bin the segment does not hold -- never, for
+                    // a rotation -- would otherwise leave the workgroup's LDS)
+                    const int rel = min(max(__float_as_int(w[k].w) - first, 0), kXSegBins - 3);
+                    const int addr = ((rel + first) << SHIFT) + base;
+                    const vec_t g0 = *(vptr)(uintptr_t)(unsigned)addr;
+                    const vec_t g1 = *(vptr)(uintptr_t)(unsigned)(addr + CELL);
+                    const vec_t g2 = *(vptr)(uintptr_t)(unsigned)(addr + 2 * CELL);
+                    acc[k] += (w[k].x * g0 + w[k].y * g1) + w[k].z * g2;
+                }
+            } else {   // the tile's span does not fit a segment (not a rotation): bounds-tested reads from global memory
+                const float *grow = src + (size_t)al * g.PW;
+#pragma unroll
+                for (int k = 0; k < PPT; ++k) {
+                    const int j = __float_as_int(w[k].w);
+                    vec_t gv[3];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const bool ok = (unsigned)(j + e) < (unsigned)g.PW;
+#pragma unroll
+                        for (int n = 0; n < NS; ++n) {
+                            const float pv = ok ? grow[soff[n] + (ok ? j + e : 0)] : 0.0f;
+                            if constexpr (NS == 1) gv[e] = pv; else gv[e][n] = pv;
+                        }
+                    }
+                    acc[k] += (w[k].x * gv[0] + w[k].y * gv[1]) + w[k].z * gv[2];
+                }
+            }
+        }
+    }
+    if (c < g.W) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int r = r0 + k * nwaves;
+            if (r < g.H) {
+#pragma unroll
+                for (int n = 0; n < NS; ++n)
+                    if (s + n < g.S) {
+                        float av;
+                        if constexpr (NS == 1) av = acc[k]; else av = acc[k][n];
+                        gimg[((size_t)(s + n) * g.H + r) * g.W + c] = av;
+                    }
+            }
+        }
+    }
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------
 static size_t bilin_extra_bytes(int A) { return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16; }
 static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
@@ -628,4 +830,95 @@ int bilin_bwd_tfcompat(const float *gsino_dev, int S, int A, int PH, int PW, con
     });
 }
 
+// ---- exact bilinear adjoint through the inverse plan ----
+static size_t exact_bilin_plan_floats(int H, int W, int A) { return (size_t)A * H * W * 4; }
+
+int exact_bilin_plan_build(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py, int px,
+                           void *plan_dev, ctpvae_stream_t stream)
+{
+    const RotGeom g{1, H, W, PH, PW, py, px, A};
+    int *flag = reinterpret_cast<int *>(reinterpret_cast<float *>(plan_dev) + exact_bilin_plan_floats(H, W, A));
+    CTPVAE_HIP(hipMemsetAsync(flag, 0, 256, (hipStream_t)stream));
+    for (int a0 = 0; a0 < A; a0 += 65535) {
+        const int na = std::min(65535, A - a0);
+        RotGeom gc = g;
+        gc.A = na;
+        hipLaunchKernelGGL(rotate_exact_bilin_plan_kernel, dim3(ceil_div(W, 64), H, na), dim3(64), 0, (hipStream_t)stream, gc,
+                           T8_dev + 8 * (size_t)a0, Tinv8_dev + 8 * (size_t)a0,
+                           reinterpret_cast<float4 *>(plan_dev) + (size_t)a0 * H * W, flag);
+        CTPVAE_LAUNCH_CHECK("rotate_exact_bilin_plan_kernel");
+    }
+    return CTPVAE_OK;
+}
+
+int exact_bilin_bwd(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H, int W, int py, int px,
+                    const void *plan_dev, float *gimg_dev, ctpvae_stream_t stream)
+{
+    return for_slice_chunks(S, std::max(4, std::min(max_slices_per_launch(), 65532) / 4 * 4), [&](int s0, int n) {
+        const RotGeom g{n, H, W, PH, PW, py, px, A};
+        const float *gs = gsino_dev + (size_t)s0 * A * PW;
+        float *gi = gimg_dev + (size_t)s0 * H * W;
+        // every slice of a cell shares the 16-byte plan word of its (angle, pixel): as many slices per cell as the batch has
+        const long long tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
+        int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 4;
+        if (ceil_div(n, ns) * tiles4 >= 1024) ppt = 8;
+        if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
+        if (ns == 3) ns = 2;
+        if (knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
+        if (ns == 4) ppt = 4;
+        int chunk_a = std::max(1, std::min(A, (48 * 1024) / (kXSegPitch * 4 * ns + 8)));
+        if (knob(kKnobSegChunk) > 0) chunk_a = std::max(1, std::min(A, std::min(knob(kKnobSegChunk), chunk_a)));
+        const size_t shmem = (size_t)chunk_a * (kXSegPitch * ns * 4 + 8) + 16;
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), ceil_div(n, ns)), block(256);
+        auto launch = [&](auto kernel) -> int {
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a,
+                               reinterpret_cast<const float4 *>(plan_dev), gi);
+            CTPVAE_LAUNCH_CHECK("rotate_bwd_exact_bilin_kernel");
+            return CTPVAE_OK;
+        };
+        if (ns == 4) return launch(rotate_bwd_exact_bilin_kernel<4, 4>);
+        if (ns == 2) return ppt == 8 ? launch(rotate_bwd_exact_bilin_kernel<8, 2>) : launch(rotate_bwd_exact_bilin_kernel<4, 2>);
+        return ppt == 8 ? launch(rotate_bwd_exact_bilin_kernel<8, 1>) : launch(rotate_bwd_exact_bilin_kernel<4, 1>);
+    });
+}
+
 }  // namespace ctpvae
+
+using namespace ctpvae;
+
+extern "C" {
+
+long long ctpvae_rotate_exact_bilinear_plan_bytes(int H, int W, int A)
+{
+    if (H <= 0 || W <= 0 || A <= 0) return fail(CTPVAE_EINVAL, "rotate_exact_bilinear_plan_bytes: bad sizes");
+    return (long long)(exact_bilin_plan_floats(H, W, A) * sizeof(float)) + 256;
+}
+
+int ctpvae_rotate_exact_bilinear_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
+                                                int py, int px, void *plan_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(T8_dev && Tinv8_dev && plan_dev, "rotate_exact_bilinear_plan_build: null pointer");
+    if (int rc = check_plan_geom("rotate_exact_bilinear_plan_build", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(H <= 65535, "rotate_exact_bilinear_plan_build: at most 65535 rows (got %d)", H);
+    return exact_bilin_plan_build(T8_dev, Tinv8_dev, A, H, W, PH, PW, py, px, plan_dev, stream);
+}
+
+int ctpvae_rotate_exact_bilinear_plan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(plan_dev && H > 0 && W > 0 && A > 0, "rotate_exact_bilinear_plan_overflowed: bad arguments");
+    int flag = 0;
+    CTPVAE_HIP(hipMemcpyAsync(&flag, reinterpret_cast<const float *>(plan_dev) + exact_bilin_plan_floats(H, W, A), sizeof(int),
+                              hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CTPVAE_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return flag != 0;
+}
+
+int ctpvae_rotate_bwd_exact_bilinear_planned_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H,
+                                                 int W, int py, int px, const void *plan_dev, float *gimg_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(gsino_dev && Tinv8_dev && plan_dev && gimg_dev && S > 0, "rotate_bwd_exact_bilinear_planned: null pointer or empty batch");
+    if (int rc = check_plan_geom("rotate_bwd_exact_bilinear_planned", H, W, PH, PW, py, px, A)) return rc;
+    return exact_bilin_bwd(gsino_dev, S, A, PH, PW, Tinv8_dev, H, W, py, px, plan_dev, gimg_dev, stream);
+}
+
+}  // extern "C"

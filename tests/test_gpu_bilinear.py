@@ -161,3 +161,71 @@ def test_bilinear_tfcompat_backward_full_sizes(oracle, H, S, A):
     for n in (1, 2, 3, 5):                         # slice independence: singles, pairs, quads and their remainders
         if n <= S:
             np.testing.assert_array_equal(to_np(plan.backward(gt[:n].contiguous())), want[:n], err_msg=f"S={n}")
+
+
+def test_bilinear_exact_adjoint_random_geometries(oracle):
+    """The true transpose of the bilinear forward as a deterministic gather (inverse plan of summed weights): within 1e-5 of the
+    oracle's in-order scatter, the same bits from every slices-per-cell / rows-per-lane variant and from run to run, and
+    <Ax, g> = <x, A^T g>."""
+    d = dev()
+    rng = np.random.default_rng(int(os.environ.get("CTPVAE_FUZZ_SEED", 20261007)))
+    for case, H, W, pad, theta, S in fuzz_cases(rng, int(os.environ.get("CTPVAE_FUZZ_CASES", 28))):
+        geom = oracle.Geometry(H, W, pad)
+        plan = RotatePlan(theta, H, W, pad, d, interp="bilinear", backward="exact")
+        assert plan._exact_bilin_plan is not None, "a rotation always fits three bins"
+        img = rng.standard_normal((S, H, W)).astype(np.float32)
+        g = rng.standard_normal((S, len(theta), geom.PW)).astype(np.float32)
+        want = oracle.rotate_bwd_exact(g, geom, oT(oracle, theta, plan), 1)
+        gt = torch.from_numpy(g).to(d)
+        msg = f"case {case}: {H}x{W} pad={pad} A={len(theta)} S={S}"
+        got = plan.backward(gt)
+        assert rel_err(to_np(got), want) <= REL, msg
+        assert torch.equal(got, plan.backward(gt)), "run to run " + msg
+        for ns, ppt in ((1, 4), (1, 8), (2, 4), (2, 8), (4, 4)):
+            with _lib.tuned("SEG_NS", ns), _lib.tuned("SEG_PPT", ppt):
+                assert torch.equal(got, plan.backward(gt)), f"SEG_NS={ns} SEG_PPT={ppt} " + msg
+        with _lib.tuned("SEG_CHUNK", 3):
+            assert torch.equal(got, plan.backward(gt)), "SEG_CHUNK=3 " + msg
+        lhs = float((to_np(plan.forward(torch.from_numpy(img).to(d))).astype(np.float64) * g).sum())
+        rhs = float((to_np(got).astype(np.float64) * img).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (msg, lhs, rhs)
+
+
+@pytest.mark.parametrize("H,S,A", [(128, 50, 20), (512, 4, 12)])
+def test_bilinear_exact_adjoint_full_sizes(oracle, H, S, A):
+    """Full-size: the transpose property at the headline shape and at 512 x 512; the oracle's scatter on a sample of slices."""
+    d = dev()
+    rng = np.random.default_rng(H + 1)
+    theta = phantoms.dense_theta(180)[:: 180 // A][:A]
+    geom = oracle.Geometry(H, H, True)
+    plan = RotatePlan(theta, H, H, True, d, interp="bilinear", backward="exact")
+    assert plan._exact_bilin_plan is not None
+    img = rng.random((S, H, H)).astype(np.float32)
+    g = rng.standard_normal((S, A, geom.PW)).astype(np.float32)
+    x, gt = torch.from_numpy(img).to(d), torch.from_numpy(g).to(d)
+    got = plan.backward(gt)
+    assert torch.equal(got, plan.backward(gt))
+    lhs = float((to_np(plan.forward(x)).astype(np.float64) * g).sum())
+    rhs = float((to_np(got).astype(np.float64) * img).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (lhs, rhs)
+    n = min(S, 3)
+    assert rel_err(to_np(got[:n]), oracle.rotate_bwd_exact(g[:n], geom, oT(oracle, theta, plan), 1)) <= REL
+
+
+def test_bilinear_exact_plan_refuses_a_non_rotation(oracle):
+    """A table row that is not a rotation (a 2x zoom: a pixel's samples span five bins) raises the plan's overflow word; the
+    backward then keeps the scatter kernel and still agrees with the oracle."""
+    d = dev()
+    H = W = 40
+    geom = oracle.Geometry(H, W, True)
+    theta = np.array([0.3, 1.1])
+    T = oracle.rotate_transforms(theta.astype(np.float32), geom.PH, geom.PW).copy()
+    c = (geom.PW - 1) / 2
+    T[1, :6] = [0.5, 0.0, c * 0.5, 0.0, 0.5, c * 0.5]          # sample positions at half pitch
+    Tinv = oracle.invert_transforms(T)
+    tabs = (torch.from_numpy(T).to(d), torch.from_numpy(Tinv).to(d))
+    plan = RotatePlan(None, H, W, True, d, interp="bilinear", backward="exact", _tables=tabs)
+    assert plan._exact_bilin_plan is None
+    g = np.random.default_rng(0).standard_normal((2, 2, geom.PW)).astype(np.float32)
+    got = to_np(plan.backward(torch.from_numpy(g).to(d)))
+    assert rel_err(got, oracle.rotate_bwd_exact(g, geom, T, 1)) <= REL
