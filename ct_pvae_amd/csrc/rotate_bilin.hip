@@ -261,8 +261,16 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
             __builtin_amdgcn_sched_barrier(0);
         };
         const int npairs = q.kmax >> 1;
-        Pair A, B;
-        if (npairs > 0) {
+        Pair A;
+        if constexpr (NS == 4) {
+            // four slices per cell: one pair in flight (two would be 64 registers of taps; the workgroup's other waves cover
+            // the LDS latency -- the loop is bound by vector instructions either way)
+            for (int b = 0; b < npairs; ++b) {
+                issue(A);
+                consume(A);
+            }
+        } else if (npairs > 0) {
+            Pair B;
             issue(A);
             int b = 1;
             for (; b + 1 < npairs; b += 2) {

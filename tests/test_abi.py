@@ -80,18 +80,22 @@ def test_host_only_entry_points(built_lib):
 
 
 def test_tiled_workspace_rule(built_lib):
-    """Host-only size rule of the tiled forward: 0 when the slice fits LDS whole or the interpolation is bilinear,
-    else S x tiles x A x slots fp32 (512x512: 8 x 4 tiles of 64 x 128 -- equal rows of tiles, ABI 3310 --, 192 slots)."""
+    """Host-only size rule of the tiled forward: 0 when the slice fits LDS whole, else S x tiles x A x slots fp32 (512x512
+    nearest: 8 x 4 tiles of 64 x 128 -- equal rows of tiles, ABI 3310 --, 192 slots; bilinear, ABI 3400: 8 x 6 tiles of 64 x 86
+    with a one-pixel halo, 128 slots)."""
     lib = built_lib.load()
     assert built_lib.tile_shape(512, 512) == (128, 64) and built_lib.tile_shape(1000, 1024) == (125, 64)
     assert built_lib.tile_shape(300, 200) == (100, 64) and built_lib.tile_shape(96 * 3, 640) == (96, 64)
-    assert built_lib.tile_shape(128, 128) is None and built_lib.tile_shape(512, 512, 1) is None
+    assert built_lib.tile_shape(128, 128) is None and built_lib.tile_shape(128, 128, 1) is None
+    assert built_lib.tile_shape(512, 512, 1) == (86, 64) and built_lib.tile_shape(300, 200, 1) == (75, 64)
+    assert built_lib.tile_shape(184, 184, 1) is None and built_lib.tile_shape(192, 192, 1) == (96, 64)
     with built_lib.tuned("TILED_TH", 96):     # the shape up to ABI 3300
         assert built_lib.tile_shape(512, 512) == (96, 64)
     with pytest.raises(ValueError):
         built_lib.tile_shape(0, 512)
     assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(50, 128, 128, 184, 184, 20, 0) == 0
-    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 1) == 0
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 1) == 8 * 48 * 90 * 128 * 4
+    assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(50, 128, 128, 184, 184, 20, 1) == 0
     assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(8, 512, 512, 728, 728, 90, 0) == 8 * 32 * 90 * 192 * 4
     assert lib.ctpvae_rotate_fwd_tiled_workspace_bytes(0, 512, 512, 728, 728, 90, 0) == built_lib.EINVAL
 
@@ -159,7 +163,7 @@ def test_no_kernel_spills_registers():
         pytest.skip("no hipcc here")
     csrc = os.path.join(ROOT, "ct_pvae_amd", "csrc")
     bad = []
-    for src in ("rotate_cplan.hip", "rotate_plan.hip", "rotate.hip"):
+    for src in ("rotate_cplan.hip", "rotate_plan.hip", "rotate.hip", "rotate_bilin.hip"):
         out = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
                               "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull],
                              cwd=csrc, capture_output=True, text=True)
