@@ -61,6 +61,14 @@ def parse():
     ap.add_argument("--cold", action="store_true",
                     help="cycle 96 distinct input batches (objects + cotangents, 385 MB at the default shape: more than the "
                          "256 MB Infinity Cache) instead of re-projecting ONE resident batch; config.inputs says which")
+    ap.add_argument("--total-batch", type=int, default=0,
+                    help="STRONG scaling (BASELINE configs[3]: a fixed batch of 400 across the ranks): the ranks share this many "
+                         "objects (sharding.shard_range), `scaling` reads \"strong\"; 0 = weak scaling, --batch objects per rank")
+    ap.add_argument("--project-scaling", action="store_true",
+                    help="one GPU: time the per-rank shares a fixed batch of --total-batch (default 400) objects at --angles would "
+                         "leave each of 1 / 2 / 4 / 8 ranks and print the implied strong-scaling speed-ups (a projection from "
+                         "single-GPU timings, not a multi-GPU measurement)")
+    ap.add_argument("--no-modes", action="store_true", help="skip the four (interp x backward) modes and the cold figure")
     ap.add_argument("--n512-batch", type=int, default=32,
                     help="objects per GPU in --mode n512 (32: 768 tile workgroups = 3 full rounds on 256 CUs; 8: 192)")
     return ap.parse_args()
@@ -407,6 +415,112 @@ def n512_mode(args, world, rank, dev):
                                        "note": "bound by the LDS gathers (ds_read_b128 of four interleaved slices, 2-way bank conflicts at oblique angles), not by HBM (DESIGN.md section 9)"}}))
 
 
+def _event_graph_seconds(fn, n):
+    """Average seconds per call of fn over n calls replayed from ONE HIP graph between two events (the method of
+    `roofline.achieved`), median of 5."""
+    fn()
+    graph = capture_graph(lambda: [fn() for _ in range(n)])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    runs = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        e0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(n):
+                fn()
+        e1.record()
+        torch.cuda.synchronize()
+        runs.append(e0.elapsed_time(e1) * 1e-3 / n)
+    return float(np.median(runs))
+
+
+def four_modes(theta, B, N, A, dev, x, g, n=200):
+    """all four (interpolation x backward) modes of the rotate projector at the headline shape -- forward and
+    backward launch time (HIP events around a graph of n launches of ONE kernel), projections/s of the pair, fraction of the
+    HBM roofline of each launch's algorithmic bytes.  `nearest_tf_compat` is the headline pair (`value`)."""
+    out = {}
+    for interp in ("nearest", "bilinear"):
+        for back in ("tf_compat", "exact"):
+            plan = RotatePlan(theta, N, N, True, dev, interp=interp, backward=back)
+            sino = torch.empty((B, A, plan.PW), dtype=torch.float32, device=dev)
+            gimg = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+            tf = _event_graph_seconds(lambda: plan.forward(x, out=sino), n)
+            tb = _event_graph_seconds(lambda: plan.backward(g, out=gimg), n)
+            bytes_dir = 4.0 * B * (N * N + A * plan.PW)
+            out[f"{interp}_{back}"] = {"fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "projections_per_s": B * A / (tf + tb),
+                                       "hbm_frac": {"fwd": bytes_dir / tf / 1e9 / HBM_PEAK_GBS, "bwd": bytes_dir / tb / 1e9 / HBM_PEAK_GBS}}
+    out["what"] = (f"B={B} {N}x{N} foam, {A} angles, 1 GPU; per-launch times from one HIP event pair around a graph of {n} launches of "
+                   "one kernel; exact = the true transpose (nearest: planned gather; bilinear: inverse plan of summed weights, no "
+                   "atomics); hbm_frac = 4 B (N^2 + A P) bytes / launch time / 8 TB/s")
+    return out
+
+
+def cold_figure(plan, x, g, sino, gimg, B, A, n_cold=96):
+    """The headline pair with its inputs coming from HBM: n_cold distinct batches (more than the 256 MB Infinity Cache) walked by
+    one HIP graph, the median of repeated replays."""
+    xb, gb = [x], [g]
+    for k in range(1, n_cold):
+        xb.append(torch.roll(x, shifts=(k, 3 * k), dims=(1, 2)) * (1.0 - 0.002 * k))
+        gb.append(torch.roll(g, shifts=k, dims=2).contiguous())
+
+    def walk():
+        for i in range(n_cold):
+            plan.forward(xb[i], out=sino)
+            plan.backward(gb[i], out=gimg)
+
+    walk()
+    graph = capture_graph(walk)
+    regions = []
+    while (sum(regions) < 0.05 and len(regions) < 1000) or len(regions) < 3:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        (graph.replay if graph is not None else walk)()
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    sec = float(np.median(regions))
+    return {"value": B * A * n_cold / sec, "ms_per_step": sec / n_cold * 1e3, "repeats": len(regions),
+            "what": f"{n_cold} distinct batches ({n_cold * (x.numel() + g.numel()) * 4 / 1e6:.0f} MB > the 256 MB Infinity Cache) walked "
+                    "by one HIP graph per region: every step's objects and cotangents come from HBM"}
+
+
+def project_scaling_mode(args, dev):
+    """Strong scaling of BASELINE configs[3] projected from ONE GPU: the fixed batch splits into equal shares (the path has no
+    data-path collective), so N ranks take the time of ONE share of total / N objects.  Timed here: each share's
+    forward + backward (graph replay, HIP events); printed: the implied speed-ups t(total) / t(total / N)."""
+    total, A, N = (args.total_batch or 400), args.angles, N_PIX
+    theta_dense = phantoms.dense_theta(180)
+    theta = theta_dense[phantoms.sparse_angle_indices(180, A)] if A < 180 else theta_dense
+    plan = RotatePlan(theta, N, N, True, dev, interp="nearest", backward="tf_compat", plan_format=args.plan_format)
+    rng = np.random.default_rng(0)
+    shares = {}
+    for ranks in (1, 2, 4, 8):
+        lo, hi = sharding.shard_range(total, 0, ranks)      # rank 0 holds the largest share
+        b = hi - lo
+        x = torch.from_numpy(rng.random((b, N, N), dtype=np.float32)).to(dev)
+        g = torch.from_numpy(rng.standard_normal((b, A, plan.PW)).astype(np.float32)).to(dev)
+        sino, gimg = torch.empty_like(g), torch.empty_like(x)
+        n = 100 if b * A <= 20000 else 30
+        tf = _event_graph_seconds(lambda: plan.forward(x, out=sino), n)
+        tb = _event_graph_seconds(lambda: plan.backward(g, out=gimg), n)
+        shares[str(ranks)] = {"objects_per_rank": b, "fwd_us": tf * 1e6, "bwd_us": tb * 1e6, "step_us": (tf + tb) * 1e6,
+                              "forward_kernel": plan.forward_kernel_name(b), "backward_kernel": plan.backward_kernel_name(b)}
+    t1 = shares["1"]["step_us"]
+    for ranks in ("1", "2", "4", "8"):
+        shares[ranks]["projected_speedup"] = t1 / shares[ranks]["step_us"]
+        shares[ranks]["projected_projections_per_s"] = total * A / (shares[ranks]["step_us"] * 1e-6)
+    limit = min(("2", "4", "8"), key=lambda r: shares[r]["projected_speedup"] / int(r))
+    print(json.dumps({"metric": "projected strong scaling of the rotate nearest fwd + tf_compat adj pair (single-GPU timings)",
+                      "value": shares["8"]["projected_speedup"], "unit": "x at 8 GPUs (projected)", "n_gpus": 1, "scaling": "strong (projected)",
+                      "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"total batch {total} x {N}x{N}, {A} angles, split over 1 / 2 / 4 / 8 ranks "
+                                             "(sharding.shard_range; no data-path collective)"},
+                      "shares": shares, "least_efficient_share": limit,
+                      "note": "a projection, NOT a multi-GPU measurement: N ranks each run one share concurrently; the data-parallel "
+                              "trainer adds one ~3 MB gradient all-reduce per step (not included)"}))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -419,7 +533,17 @@ def main():
         return siddon_mode(args, world, rank, dev)
     if args.mode == "n512":
         return n512_mode(args, world, rank, dev)
+    if args.project_scaling:
+        if world > 1:
+            raise SystemExit("--project-scaling is a single-GPU projection")
+        return project_scaling_mode(args, dev)
     B, N, A = args.batch, N_PIX, args.angles
+    strong = args.total_batch > 0
+    if strong:      # a FIXED batch shared by the ranks: rank r projects objects [lo, hi) of it
+        lo, hi = sharding.shard_range(args.total_batch, rank, world)
+        B = hi - lo
+        if B == 0:
+            raise SystemExit(f"--total-batch {args.total_batch} leaves rank {rank} of {world} without an object")
 
     theta_dense = phantoms.dense_theta(180)
     theta = theta_dense[phantoms.sparse_angle_indices(180, A)] if A < 180 else theta_dense
@@ -666,18 +790,26 @@ def main():
             lds = dict(lds or {}, forward=lds_fwd)
     from ct_pvae_amd import _lib
     tune_env = {k: v for k, v in os.environ.items() if k.startswith("CTPVAE_")}
-    proj_per_s = world * B * A * args.steps / elapsed
+    total_objects = args.total_batch if strong else world * B
+    proj_per_s = total_objects * A * args.steps / elapsed
+    # the four (interp x backward) modes and the cold-input figure beside the headline (one GPU, the headline shape)
+    modes, cold = None, None
+    if world == 1 and not args.no_modes and not args.cold and not strong:
+        modes = four_modes(theta, B, N, A, dev, x, g)
+        cold = cold_figure(plan, x, g, sino, gimg, B, A)
     out = {
         "metric": "projections/sec (fwd+adj) 128x128 foam, 20 angles; fraction of HBM roofline",
         "value": proj_per_s, "unit": "projections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "repeats": len(regions),
         "region_ms": {"min": min(regions) * 1e3, "median": elapsed * 1e3, "max": max(regions) * 1e3,
                       "what": f"{len(regions)} timed regions of exactly {args.steps} steps each (barrier + synchronize on both "
                               "sides, max over ranks); value and ms_per_step are from the median region"},
         "developer_knobs": {"library_knobs_set": _lib.load().ctpvae_tune_active(), "env": tune_env},
-        "config": {"workload": f"batch={B}/GPU {N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
+        "config": {"workload": (f"total batch {args.total_batch} shared by {world} GPU(s) ({B} on rank 0), " if strong else f"batch={B}/GPU ")
+                               + f"{N}x{N} foam, {A} angles, P={P}, rotate nearest fwd + tf_compat adj",
                    "objects_per_gpu": B, "n_pixel": N, "angles": A, "num_proj_pix": P, "parallelism": f"batch-shard x{world}",
                    "inputs": (f"cold: {n_cold} distinct batches cycled, {n_cold * (x.numel() + g.numel()) * 4 / 1e6:.0f} MB > the "
                               "256 MB Infinity Cache" if args.cold else
@@ -699,6 +831,9 @@ def main():
                                 "p90": float(np.percentile(step_us, 90)), "n": len(step_us)},
         "api": api,
     }
+    if modes is not None:
+        out["modes"] = modes
+        out["cold"] = cold
     if with_allreduce is not None:
         out["value_with_grad_allreduce"] = world * B * A * args.steps / with_allreduce["seconds"]
         out["ms_per_step_with_grad_allreduce"] = with_allreduce["seconds"] / args.steps * 1e3

@@ -1588,6 +1588,37 @@ def test_bench_single_process_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 1e7                      # tens of millions of projections per second on an MI355X
+    # round 5: all four (interp x backward) modes and the cold-input figure ride in the driver's line
+    m = d["modes"]
+    assert {"nearest_tf_compat", "nearest_exact", "bilinear_tf_compat", "bilinear_exact"} <= set(m)
+    for k in ("nearest_tf_compat", "nearest_exact", "bilinear_tf_compat", "bilinear_exact"):
+        assert 1.0 < m[k]["fwd_us"] < 100.0 and 1.0 < m[k]["bwd_us"] < 100.0 and m[k]["projections_per_s"] > 5e6, (k, m[k])
+        assert abs(m[k]["hbm_frac"]["fwd"] - 4.0 * 50 * (128 * 128 + 20 * 184) / (m[k]["fwd_us"] * 1e-6) / 8e12) < 1e-9
+    assert m["bilinear_exact"]["bwd_us"] < 40.0          # the scatter kernel took 367 us (profiles/r05_modes_baseline_*)
+    assert 0.5 * d["value"] < d["cold"]["value"] <= 1.1 * d["value"] and d["cold"]["ms_per_step"] > 0
+
+
+def test_bench_strong_scaling_two_ranks_and_projection():
+    """BASELINE configs[3] fixes the batch: `--total-batch` shares ONE batch between the ranks (sharding.shard_range) and says
+    "strong"; two ranks rehearsed on this box's one GPU over gloo.  `--project-scaling`: the 1 / 2 / 4 / 8-rank shares of a
+    fixed batch timed on one GPU and the speed-ups they imply."""
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-batch", "101", "--steps", "20",
+                          "--warmup", "5", "--min-ms", "5"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["objects_per_gpu"] == 51
+    assert abs(d["value"] - 101 * 20 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--project-scaling", "--total-batch", "96", "--angles", "20"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert [d["shares"][k]["objects_per_rank"] for k in ("1", "2", "4", "8")] == [96, 48, 24, 12]
+    assert d["shares"]["1"]["projected_speedup"] == 1.0 and 1.0 < d["value"] <= 8.5 and d["scaling"].startswith("strong")
 
 
 def test_raw_operator_checks_its_operands():
