@@ -49,6 +49,8 @@ SIGNATURES = {
                                                           _c_int, _vp, ctypes.c_longlong, _vp, _vp]),
     "ctpvae_rotate_fwd_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
                                        _c_int, _vp, _vp]),
+    "ctpvae_rotate_fwd_f64": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int,
+                                       _c_int, _vp, _vp]),
     "ctpvae_rotate_tile_shape": (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "ctpvae_rotate_fwd_tiled_workspace_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int]),
     "ctpvae_rotate_fwd_tiled_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp,

@@ -33,25 +33,29 @@ namespace ctpvae {
 
 
 // ---- forward ---------------------------------------------------------------------------------
-template <bool USE_LDS>
-__device__ __forceinline__ float core_read(const float *__restrict__ im, const float *lds, int H, int W,
-                                           int pitch, int r, int c)
+template <bool USE_LDS, typename T>
+__device__ __forceinline__ T core_read(const T *__restrict__ im, const T *lds, int H, int W, int pitch, int r, int c)
 {
     if ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W)
         return USE_LDS ? lds[r * pitch + c] : im[(size_t)r * W + c];
-    return 0.0f;
+    return T(0);
 }
 
-template <int INTERP, bool USE_LDS>
-__global__ __launch_bounds__(256) void rotate_fwd_kernel(const float *__restrict__ img, RotGeom g,
+// T = float: the generic fallback of the fp32 path.  T = double (round 5): the reference's float64 callers
+// (ctvae/tomopy_forward_compare.py:52,56 hands xdesign's float64 phantoms to both projectors): TensorFlow computes the
+// coordinates and the weights in fp32 whatever the image type, casts each weight to T and multiplies, adds and row-sums in T
+// (ImageProjectiveTransformV3's bilinear_interpolation: static_cast<T>(x_ceil - x) * value) -- exactly this loop with T = double.
+template <typename T, int INTERP, bool USE_LDS>
+__global__ __launch_bounds__(256) void rotate_fwd_kernel(const T *__restrict__ img, RotGeom g,
                                                          const float *__restrict__ T8, int a_per_blk,
-                                                         float *__restrict__ sino)
+                                                         T *__restrict__ sino)
 {
-    extern __shared__ float lds[];
+    extern __shared__ float lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const int s = blockIdx.y;
     const int a0 = blockIdx.x * a_per_blk;
     const int na = min(a_per_blk, g.A - a0);
-    const float *im = img + (size_t)s * g.H * g.W;
+    const T *im = img + (size_t)s * g.H * g.W;
     const int pitch = g.W + 1;
 
     if (USE_LDS) {
@@ -69,12 +73,12 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float *__restrict
         const float *t = T8 + 8 * a;
         const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
         const float xj = t0 * (float)j, yj = t3 * (float)j;
-        float acc = 0.0f;
+        T acc = T(0);
         for (int i = 0; i < g.PH; ++i) {
             const float fi = (float)i;
             const float x = (xj + t1 * fi) + t2;
             const float y = (yj + t4 * fi) + t5;
-            float v;
+            T v;
             if (INTERP == CTPVAE_NEAREST) {
                 const int ix = (int)round_half_away(x) - g.px;
                 const int iy = (int)round_half_away(y) - g.py;
@@ -84,11 +88,11 @@ __global__ __launch_bounds__(256) void rotate_fwd_kernel(const float *__restrict
                 const float yc = yf + 1.0f, xc = xf + 1.0f;
                 const int ix0 = (int)xf - g.px, iy0 = (int)yf - g.py;
                 const int ix1 = (int)xc - g.px, iy1 = (int)yc - g.py;
-                const float v_yf = (xc - x) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy0, ix0) +
-                                   (x - xf) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy0, ix1);
-                const float v_yc = (xc - x) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy1, ix0) +
-                                   (x - xf) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy1, ix1);
-                v = (yc - y) * v_yf + (y - yf) * v_yc;
+                const T v_yf = (T)(xc - x) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy0, ix0) +
+                               (T)(x - xf) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy0, ix1);
+                const T v_yc = (T)(xc - x) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy1, ix0) +
+                               (T)(x - xf) * core_read<USE_LDS>(im, lds, g.H, g.W, pitch, iy1, ix1);
+                v = (T)(yc - y) * v_yf + (T)(y - yf) * v_yc;
             }
             acc += v;
         }
@@ -1966,10 +1970,38 @@ static int rotate_fwd_one(const float *img_dev, int S, int H, int W, int PH, int
         return CTPVAE_OK;
     };
     if (interp == CTPVAE_NEAREST)
-        return use_lds ? launch(rotate_fwd_kernel<CTPVAE_NEAREST, true>, lds_bytes)
-                       : launch(rotate_fwd_kernel<CTPVAE_NEAREST, false>, 0);
-    return use_lds ? launch(rotate_fwd_kernel<CTPVAE_BILINEAR, true>, lds_bytes)
-                   : launch(rotate_fwd_kernel<CTPVAE_BILINEAR, false>, 0);
+        return use_lds ? launch(rotate_fwd_kernel<float, CTPVAE_NEAREST, true>, lds_bytes)
+                       : launch(rotate_fwd_kernel<float, CTPVAE_NEAREST, false>, 0);
+    return use_lds ? launch(rotate_fwd_kernel<float, CTPVAE_BILINEAR, true>, lds_bytes)
+                   : launch(rotate_fwd_kernel<float, CTPVAE_BILINEAR, false>, 0);
+}
+
+int ctpvae_rotate_fwd_f64(const double *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev, int A,
+                          int interp, double *sino_dev, ctpvae_stream_t stream)
+{
+    CTPVAE_REQUIRE(img_dev && T8_dev && sino_dev && S > 0 && H > 0 && W > 0 && A > 0 && PW > 0, "rotate_fwd_f64: null pointer or empty sizes");
+    if (int rc = check_geom("rotate_fwd_f64", 1, H, W, PH, PW, py, px, A, interp)) return rc;
+    const size_t lds_bytes = (size_t)H * (W + 1) * sizeof(double);
+    const bool use_lds = lds_bytes <= (size_t)kMaxLdsBytes;
+    return for_slice_chunks(S, max_slices_per_launch(), [&](int s0, int n) {
+        const RotGeom g{n, H, W, PH, PW, py, px, A};
+        const int apb = pick_angles_per_block(n, A, PW);
+        const dim3 grid(ceil_div(A, apb), n), block(256);
+        const double *im = img_dev + (size_t)s0 * H * W;
+        double *so = sino_dev + (size_t)s0 * A * PW;
+        auto launch = [&](auto kernel, size_t shmem) -> int {
+            if (shmem > 64 * 1024)
+                CTPVAE_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, im, g, T8_dev, apb, so);
+            CTPVAE_LAUNCH_CHECK("rotate_fwd_kernel<double>");
+            return CTPVAE_OK;
+        };
+        if (interp == CTPVAE_NEAREST)
+            return use_lds ? launch(rotate_fwd_kernel<double, CTPVAE_NEAREST, true>, lds_bytes)
+                           : launch(rotate_fwd_kernel<double, CTPVAE_NEAREST, false>, 0);
+        return use_lds ? launch(rotate_fwd_kernel<double, CTPVAE_BILINEAR, true>, lds_bytes)
+                       : launch(rotate_fwd_kernel<double, CTPVAE_BILINEAR, false>, 0);
+    });
 }
 
 int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px,

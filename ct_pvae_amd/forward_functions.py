@@ -481,6 +481,24 @@ class RotatePlan:
         with torch.cuda.device(self._dev_index):
             return self._forward(img, out, angles_i)
 
+    def forward_f64(self, img):
+        """float64 slices [S][H][W] -> float64 sinograms [S][A][PW]: fp32 coordinates and weights, float64 taps, products and
+        row sum -- TensorFlow's arithmetic for a float64 image (ctvae/tomopy_forward_compare.py:52,56 projects xdesign's float64
+        phantoms).  A correctness-first kernel (ctpvae_rotate_fwd_f64); the float32 paths are untouched."""
+        if (img.dim() != 3 or tuple(img.shape[1:]) != (self.H, self.W) or img.dtype is not torch.float64 or not img.is_contiguous()
+                or img.device != self._tdev):
+            raise ValueError(f"img must be a contiguous float64 tensor [S][{self.H}][{self.W}] on {self._tdev} "
+                             f"(got {tuple(img.shape)}, {img.dtype}, {img.device})")
+        S = img.shape[0]
+        out = torch.empty((S, self.A, self.PW), dtype=torch.float64, device=img.device)
+        if S == 0:
+            return out
+        with torch.cuda.device(self._dev_index):
+            _lib.check(self._lib.ctpvae_rotate_fwd_f64(img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px,
+                                                       self.T8.data_ptr(), self.A, self.interp, out.data_ptr(),
+                                                       _stream_ptr(self._dev_index)), "rotate_fwd_f64")
+        return out
+
     def forward_loglik(self, img, mask, meas, pnm, eps, out=None, out_lp=None, out_dlp=None, with_dlp=False,
                        angles_i=None, dense_inputs=False):
         """Forward with the log-likelihood epilogue (one launch): returns (sino, lp), both [S][A][PW];
@@ -872,11 +890,14 @@ class _RotateProject(torch.autograd.Function):
             x = phantom[None]
         else:
             x = phantom
-        if x.dtype is not torch.float32:     # the reference keeps float64 pixel data (coordinates are fp32 either way)
-            x = x.to(torch.float32)
-        if not x.is_contiguous():
-            x = x.contiguous()
-        sino = plan.forward(x)               # [S][A][PW]
+        if x.dtype is torch.float64:         # the reference's float64 callers: fp32 coordinates and weights, float64 sums
+            sino = plan.forward_f64(x.contiguous())
+        else:
+            if x.dtype is not torch.float32:
+                x = x.to(torch.float32)
+            if not x.is_contiguous():
+                x = x.contiguous()
+            sino = plan.forward(x)           # [S][A][PW]
         if layout == _LAYOUT_VAE:
             out = sino.unsqueeze(-1)         # batch x angles x P x 1   (ctvae/forward_functions.py:116-121)
         elif layout in (_LAYOUT_DIM3, _LAYOUT_DIM2):

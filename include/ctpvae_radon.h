@@ -109,6 +109,13 @@ int ctpvae_rotate_fwd_f32(const float *img_dev, int S, int H, int W, int PH, int
                           const float *T8_dev, int A, int interp, float *sino_dev,
                           ctpvae_stream_t stream);
 
+/* The reference's float64 callers (ctvae/tomopy_forward_compare.py:52,56: xdesign's float64 phantoms through both projectors):
+ * TensorFlow keeps the coordinates and the interpolation weights in fp32 whatever the image type, casts each weight to the
+ * image type and multiplies, adds and row-sums in it.  Same geometry arguments as ctpvae_rotate_fwd_f32; img / sino are
+ * double; a correctness-first kernel (one ray per lane, the slice in LDS when 8 H (W + 1) bytes fit).  Round 5, ABI 3400. */
+int ctpvae_rotate_fwd_f64(const double *img_dev, int S, int H, int W, int PH, int PW, int py, int px,
+                          const float *T8_dev, int A, int interp, double *sino_dev, ctpvae_stream_t stream);
+
 /* ---- a2 for slices larger than LDS (512 x 512): tiled forward, NEAREST -----------------------
  * The slice is cut into tiles 64 wide x tile_h tall, tile_h = ceil(H / ceil(H / 128)) (EQUAL rows of tiles, ABI 3310: 128 for
  * H = 512; up to ABI 3300 it was 96 with a 32-row remainder -- the same taps, another association of the sum);

@@ -181,6 +181,50 @@ void oracle_rotate_fwd(const float *img, int S, int H, int W, int PH, int PW, in
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * a2 / a5 on FLOAT64 pixels (ctvae/tomopy_forward_compare.py:52,56 feeds xdesign's float64 phantoms to
+ * project_tf_fast and project_tf_low_mem).  TensorFlow 2.8.1's ImageProjectiveTransformV3<T = double>
+ * keeps the coordinates and the interpolation weights in fp32 (ProjectiveGenerator: `const float
+ * input_x = ...`; bilinear_interpolation: `static_cast<T>(x_ceil - x) * value`) and multiplies, adds and
+ * (reduce_sum) row-sums in T.
+ * ------------------------------------------------------------------------------------------- */
+static inline double canvas_read_f64(const double *img, int H, int W, int py, int px, long iy, long ix)
+{
+    const long r = iy - py, c = ix - px;
+    return (r >= 0 && r < H && c >= 0 && c < W) ? img[r * W + c] : 0.0;
+}
+
+void oracle_rotate_fwd_f64(const double *img, int S, int H, int W, int PH, int PW, int py, int px,
+                           const float *T8, int A, int interp, double *sino)
+{
+    for (int s = 0; s < S; ++s) {
+        const double *im = img + (size_t)s * H * W;
+        for (int a = 0; a < A; ++a) {
+            const float *t = T8 + 8 * a;
+            double *out = sino + ((size_t)s * A + a) * PW;
+            for (int j = 0; j < PW; ++j) {
+                double acc = 0.0;
+                for (int i = 0; i < PH; ++i) {
+                    float x, y;
+                    map_coord(t, j, i, &x, &y);
+                    if (interp == ORACLE_NEAREST) {
+                        acc += canvas_read_f64(im, H, W, py, px, (long)roundf(y), (long)roundf(x));
+                    } else {
+                        const float yf = floorf(y), xf = floorf(x);
+                        const float yc = yf + 1.0f, xc = xf + 1.0f;
+                        const double v_yf = (double)(xc - x) * canvas_read_f64(im, H, W, py, px, (long)yf, (long)xf) +
+                                            (double)(x - xf) * canvas_read_f64(im, H, W, py, px, (long)yf, (long)xc);
+                        const double v_yc = (double)(xc - x) * canvas_read_f64(im, H, W, py, px, (long)yc, (long)xf) +
+                                            (double)(x - xf) * canvas_read_f64(im, H, W, py, px, (long)yc, (long)xc);
+                        acc += (double)(yc - y) * v_yf + (double)(y - yf) * v_yc;
+                    }
+                }
+                out[j] = acc;
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
  * a2 / a5 with the tile-blocked association of the row sum.  reduce_sum(axis=1)
  * (ctvae/forward_functions.py:76,108,114) fixes the terms, not the order in which fp32 adds them; the
  * build's kernels for slices larger than LDS add the samples of each th x tw tile of the slice first

@@ -43,6 +43,7 @@ def lib():
         L.oracle_rotate_transforms.argtypes = [_f32p, _i, _i, _i, _f32p]
         L.oracle_invert_transforms.argtypes = [_f32p, _i, _f32p]
         L.oracle_rotate_fwd.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _f32p]
+        L.oracle_rotate_fwd_f64.argtypes = [_f64p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _f64p]
         L.oracle_rotate_fwd_tiled.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _i, _f32p]
         L.oracle_rotate_fwd_tiled.restype = _i
         L.oracle_rotate_fwd_tiled_interp.argtypes = [_f32p, _i, _i, _i, _i, _i, _i, _i, _f32p, _i, _i, _i, _i, _f32p]
@@ -137,6 +138,16 @@ def rotate_fwd(img, geom, T8, interp=NEAREST):
     S, A = img.shape[0], T8.shape[0]
     sino = np.empty((S, A, geom.PW), np.float32)
     lib().oracle_rotate_fwd(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A, interp, sino)
+    return sino
+
+
+def rotate_fwd_f64(img, geom, T8, interp=NEAREST):
+    """rotate_fwd on float64 pixels: fp32 coordinates and weights, float64 products and row sum (TF's T = double)."""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    T8 = _c32(T8)
+    S, A = img.shape[0], T8.shape[0]
+    sino = np.empty((S, A, geom.PW), np.float64)
+    lib().oracle_rotate_fwd_f64(img, S, geom.H, geom.W, geom.PH, geom.PW, geom.py, geom.px, T8, A, interp, sino)
     return sino
 
 

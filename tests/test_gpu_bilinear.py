@@ -229,3 +229,25 @@ def test_bilinear_exact_plan_refuses_a_non_rotation(oracle):
     g = np.random.default_rng(0).standard_normal((2, 2, geom.PW)).astype(np.float32)
     got = to_np(plan.backward(torch.from_numpy(g).to(d)))
     assert rel_err(got, oracle.rotate_bwd_exact(g, geom, T, 1)) <= REL
+
+
+@pytest.mark.parametrize("interp,code", [("bilinear", 1), ("nearest", 0)])
+def test_float64_pixels_are_projected_in_float64(oracle, interp, code):
+    """ctvae/tomopy_forward_compare.py:52,56 hands xdesign's float64 phantoms to project_tf_fast and project_tf_low_mem;
+    TensorFlow interpolates and sums in the image type with fp32 coordinates and weights (oracle_rotate_fwd_f64): the same
+    double operations in the same order -- equal bits; and the float32 call of the same data is a different (narrower) sum."""
+    import ct_pvae_amd as cp
+    d = dev()
+    rng = np.random.default_rng(64)
+    for H, W, Z, pad, A in ((128, 128, 2, True, 100), (33, 57, 3, False, 7), (200, 180, 1, True, 5)):
+        theta = np.linspace(0.0, np.pi, A, endpoint=False)
+        x = rng.random((H, W, Z))                                     # float64, the reference's [X][Y][Z] layout
+        geom = oracle.Geometry(H, W, pad)
+        T = oracle.rotate_transforms(theta.astype(np.float32), geom.PH, geom.PW)
+        want = oracle.rotate_fwd_f64(np.ascontiguousarray(x.transpose(2, 0, 1)), geom, T, code).transpose(1, 2, 0)
+        fn = cp.project_tf_low_mem if interp == "bilinear" else cp.project_tf_fast
+        got = fn(torch.from_numpy(x).to(d), theta, pad=pad) if interp == "bilinear" else fn(torch.from_numpy(x).to(d), theta, pad=pad, dim=3)
+        assert got.dtype == torch.float64 and tuple(got.shape) == (A, geom.PW, Z)
+        np.testing.assert_array_equal(to_np(got), want)
+        got32 = fn(torch.from_numpy(x.astype(np.float32)).to(d), theta, pad=pad)
+        assert got32.dtype == torch.float32 and rel_err(to_np(got32), want) <= REL

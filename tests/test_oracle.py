@@ -651,3 +651,27 @@ def test_ray_driven_and_fbp_restatements_against_scikit_image(oracle, golden_dir
     d_sk = np.linalg.norm((g - b) / a - z["sk_rec"]) / np.linalg.norm(z["sk_rec"])
     print(f"gridrec(ramlak): gain {a:.3f}, offset {b:.4f}, vs skimage.iradon after the fit {d_sk:.3f}")
     assert 1.05 < a < 1.2 and -0.03 < b <= 0 and d_sk < 0.12
+
+
+def test_float64_forward_and_tiled_bilinear_restatements(oracle):
+    """Round 5's two additions to the checker: (i) the float64 forward (fp32 coordinates and weights, double sums) agrees with
+    the float32 one to fp32 rounding and is exact on the 2 x 2 toy; (ii) the tile-blocked bilinear sum equals the row-sequential
+    one bit for bit when one tile holds the slice, and to rounding otherwise -- a sample belongs to the tile of its floor tap."""
+    rng = np.random.default_rng(5)
+    geom = oracle.Geometry(40, 48, True)
+    theta = np.linspace(0, 3.1, 7).astype(np.float32)
+    T = oracle.rotate_transforms(theta, geom.PH, geom.PW)
+    x = rng.random((2, 40, 48)).astype(np.float32)
+    for interp in (oracle.NEAREST, oracle.BILINEAR):
+        f32 = oracle.rotate_fwd(x, geom, T, interp)
+        f64 = oracle.rotate_fwd_f64(x.astype(np.float64), geom, T, interp)
+        assert f64.dtype == np.float64 and np.abs(f64 - f32).max() <= 1e-5 * np.abs(f64).max()
+    toy = np.array([[[0.1, 0.2], [0.3, 0.4]]])
+    g2 = oracle.Geometry(2, 2, False)
+    T2 = oracle.rotate_transforms(np.array([0.0, np.pi / 2], np.float32), 2, 2)   # theta; the wrapper hands -theta to rotate
+    for interp in (oracle.NEAREST, oracle.BILINEAR):
+        np.testing.assert_allclose(oracle.rotate_fwd_f64(toy, g2, T2, interp)[0], [[0.4, 0.6], [0.7, 0.3]], atol=1e-6)
+    whole = oracle.rotate_fwd(x, geom, T, oracle.BILINEAR)
+    np.testing.assert_array_equal(oracle.rotate_fwd_tiled(x, geom, T, (64, 64), interp=oracle.BILINEAR), whole)
+    tiled = oracle.rotate_fwd_tiled(x, geom, T, (16, 16), interp=oracle.BILINEAR)
+    assert (tiled != whole).any() and np.abs(tiled - whole).max() <= 1e-5 * np.abs(whole).max()

@@ -3,8 +3,8 @@ workgroup (WAVES).   python tools/sweep_bilin.py [B N A]"""
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
-sys.path.insert(0, "tools")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 from ct_pvae_amd.forward_functions import RotatePlan  # noqa: E402
 from ct_pvae_amd import _lib, phantoms  # noqa: E402
 from time_modes import graph_time  # noqa: E402

@@ -12,7 +12,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from ct_pvae_amd.forward_functions import RotatePlan  # noqa: E402
 from ct_pvae_amd import phantoms  # noqa: E402
 
