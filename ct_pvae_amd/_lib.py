@@ -82,10 +82,10 @@ SIGNATURES = {
     "ctpvae_rotate_exact_plan_build_f32": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     "ctpvae_rotate_exact_plan_overflowed": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ctpvae_rotate_bwd_exact_planned_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
-    "ctpvae_rotate_exact_bilinear_plan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
-    "ctpvae_rotate_exact_bilinear_plan_build_f32": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
-    "ctpvae_rotate_exact_bilinear_plan_overflowed": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp]),
-    "ctpvae_rotate_bwd_exact_bilinear_planned_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp,
+    "ctpvae_rotate_exact_wplan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "ctpvae_rotate_exact_wplan_build_f32": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "ctpvae_rotate_exact_wplan_overflowed": (_c_int, [_vp, _c_int, _c_int, _c_int, _vp]),
+    "ctpvae_rotate_bwd_exact_wplan_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _vp,
                                                               _vp, _vp]),
     "ctpvae_rotate_bwd_step_plan_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "ctpvae_rotate_bwd_step_plan_build_f32": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),

@@ -542,6 +542,7 @@ __global__ __launch_bounds__(256) void rotate_bwd_bilin_seg_kernel(const float *
 // keeps the scatter kernel.
 constexpr int kXSegBins = 80, kXSegPitch = kXSegBins + 1;
 
+template <int INTERP>
 __global__ __launch_bounds__(64) void rotate_exact_bilin_plan_kernel(RotGeom g, const float *__restrict__ T8,
                                                                      const float *__restrict__ Tinv8, float4 *__restrict__ plan,
                                                                      int *__restrict__ overflow)
@@ -568,12 +569,18 @@ __global__ __launch_bounds__(64) void rotate_exact_bilin_plan_kernel(RotGeom g, 
             const float x = (t[0] * (float)j + t[1] * (float)i) + t[2];
             const float y = (t[3] * (float)j + t[4] * (float)i) + t[5];
             if (!(fabsf(x) < 1.0e7f && fabsf(y) < 1.0e7f)) continue;
-            const float xf = floorf(x), yf = floorf(y), xc = xf + 1.0f, yc = yf + 1.0f;
-            const int ixf = (int)xf, iyf = (int)yf;
-            float wx, wy;
-            if (ixf == X) wx = xc - x; else if (ixf + 1 == X) wx = x - xf; else continue;
-            if (iyf == Y) wy = yc - y; else if (iyf + 1 == Y) wy = y - yf; else continue;
-            wb[dj] += wy * wx;
+            if constexpr (INTERP == CTPVAE_NEAREST) {
+                // the nearest forward's one tap (round half away from zero): weight 1; a pixel is the tap of at most two samples
+                if ((int)__builtin_roundf(x) != X || (int)__builtin_roundf(y) != Y) continue;
+                wb[dj] += 1.0f;
+            } else {
+                const float xf = floorf(x), yf = floorf(y), xc = xf + 1.0f, yc = yf + 1.0f;
+                const int ixf = (int)xf, iyf = (int)yf;
+                float wx, wy;
+                if (ixf == X) wx = xc - x; else if (ixf + 1 == X) wx = x - xf; else continue;
+                if (iyf == Y) wy = yc - y; else if (iyf + 1 == Y) wy = y - yf; else continue;
+                wb[dj] += wy * wx;
+            }
             touched |= 1u << dj;
         }
     }
@@ -842,7 +849,7 @@ int bilin_bwd_tfcompat(const float *gsino_dev, int S, int A, int PH, int PW, con
 static size_t exact_bilin_plan_floats(int H, int W, int A) { return (size_t)A * H * W * 4; }
 
 int exact_bilin_plan_build(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW, int py, int px,
-                           void *plan_dev, ctpvae_stream_t stream)
+                           int interp, void *plan_dev, ctpvae_stream_t stream)
 {
     const RotGeom g{1, H, W, PH, PW, py, px, A};
     int *flag = reinterpret_cast<int *>(reinterpret_cast<float *>(plan_dev) + exact_bilin_plan_floats(H, W, A));
@@ -851,9 +858,14 @@ int exact_bilin_plan_build(const float *T8_dev, const float *Tinv8_dev, int A, i
         const int na = std::min(65535, A - a0);
         RotGeom gc = g;
         gc.A = na;
-        hipLaunchKernelGGL(rotate_exact_bilin_plan_kernel, dim3(ceil_div(W, 64), H, na), dim3(64), 0, (hipStream_t)stream, gc,
-                           T8_dev + 8 * (size_t)a0, Tinv8_dev + 8 * (size_t)a0,
-                           reinterpret_cast<float4 *>(plan_dev) + (size_t)a0 * H * W, flag);
+        if (interp == CTPVAE_NEAREST)
+            hipLaunchKernelGGL(rotate_exact_bilin_plan_kernel<CTPVAE_NEAREST>, dim3(ceil_div(W, 64), H, na), dim3(64), 0,
+                               (hipStream_t)stream, gc, T8_dev + 8 * (size_t)a0, Tinv8_dev + 8 * (size_t)a0,
+                               reinterpret_cast<float4 *>(plan_dev) + (size_t)a0 * H * W, flag);
+        else
+            hipLaunchKernelGGL(rotate_exact_bilin_plan_kernel<CTPVAE_BILINEAR>, dim3(ceil_div(W, 64), H, na), dim3(64), 0,
+                               (hipStream_t)stream, gc, T8_dev + 8 * (size_t)a0, Tinv8_dev + 8 * (size_t)a0,
+                               reinterpret_cast<float4 *>(plan_dev) + (size_t)a0 * H * W, flag);
         CTPVAE_LAUNCH_CHECK("rotate_exact_bilin_plan_kernel");
     }
     return CTPVAE_OK;
@@ -896,24 +908,25 @@ using namespace ctpvae;
 
 extern "C" {
 
-long long ctpvae_rotate_exact_bilinear_plan_bytes(int H, int W, int A)
+long long ctpvae_rotate_exact_wplan_bytes(int H, int W, int A)
 {
-    if (H <= 0 || W <= 0 || A <= 0) return fail(CTPVAE_EINVAL, "rotate_exact_bilinear_plan_bytes: bad sizes");
+    if (H <= 0 || W <= 0 || A <= 0) return fail(CTPVAE_EINVAL, "rotate_exact_wplan_bytes: bad sizes");
     return (long long)(exact_bilin_plan_floats(H, W, A) * sizeof(float)) + 256;
 }
 
-int ctpvae_rotate_exact_bilinear_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
-                                                int py, int px, void *plan_dev, ctpvae_stream_t stream)
+int ctpvae_rotate_exact_wplan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
+                                        int py, int px, int interp, void *plan_dev, ctpvae_stream_t stream)
 {
-    CTPVAE_REQUIRE(T8_dev && Tinv8_dev && plan_dev, "rotate_exact_bilinear_plan_build: null pointer");
-    if (int rc = check_plan_geom("rotate_exact_bilinear_plan_build", H, W, PH, PW, py, px, A)) return rc;
-    CTPVAE_REQUIRE(H <= 65535, "rotate_exact_bilinear_plan_build: at most 65535 rows (got %d)", H);
-    return exact_bilin_plan_build(T8_dev, Tinv8_dev, A, H, W, PH, PW, py, px, plan_dev, stream);
+    CTPVAE_REQUIRE(T8_dev && Tinv8_dev && plan_dev, "rotate_exact_wplan_build: null pointer");
+    CTPVAE_REQUIRE(interp == CTPVAE_NEAREST || interp == CTPVAE_BILINEAR, "rotate_exact_wplan_build: unknown interpolation %d", interp);
+    if (int rc = check_plan_geom("rotate_exact_wplan_build", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(H <= 65535, "rotate_exact_wplan_build: at most 65535 rows (got %d)", H);
+    return exact_bilin_plan_build(T8_dev, Tinv8_dev, A, H, W, PH, PW, py, px, interp, plan_dev, stream);
 }
 
-int ctpvae_rotate_exact_bilinear_plan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream)
+int ctpvae_rotate_exact_wplan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream)
 {
-    CTPVAE_REQUIRE(plan_dev && H > 0 && W > 0 && A > 0, "rotate_exact_bilinear_plan_overflowed: bad arguments");
+    CTPVAE_REQUIRE(plan_dev && H > 0 && W > 0 && A > 0, "rotate_exact_wplan_overflowed: bad arguments");
     int flag = 0;
     CTPVAE_HIP(hipMemcpyAsync(&flag, reinterpret_cast<const float *>(plan_dev) + exact_bilin_plan_floats(H, W, A), sizeof(int),
                               hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -921,11 +934,11 @@ int ctpvae_rotate_exact_bilinear_plan_overflowed(const void *plan_dev, int H, in
     return flag != 0;
 }
 
-int ctpvae_rotate_bwd_exact_bilinear_planned_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H,
+int ctpvae_rotate_bwd_exact_wplan_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev, int H,
                                                  int W, int py, int px, const void *plan_dev, float *gimg_dev, ctpvae_stream_t stream)
 {
-    CTPVAE_REQUIRE(gsino_dev && Tinv8_dev && plan_dev && gimg_dev && S > 0, "rotate_bwd_exact_bilinear_planned: null pointer or empty batch");
-    if (int rc = check_plan_geom("rotate_bwd_exact_bilinear_planned", H, W, PH, PW, py, px, A)) return rc;
+    CTPVAE_REQUIRE(gsino_dev && Tinv8_dev && plan_dev && gimg_dev && S > 0, "rotate_bwd_exact_wplan: null pointer or empty batch");
+    if (int rc = check_plan_geom("rotate_bwd_exact_wplan", H, W, PH, PW, py, px, A)) return rc;
     return exact_bilin_bwd(gsino_dev, S, A, PH, PW, Tinv8_dev, H, W, py, px, plan_dev, gimg_dev, stream);
 }
 

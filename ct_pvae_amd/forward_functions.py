@@ -247,9 +247,11 @@ class RotatePlan:
             # built here, not on the first backward: reading its overflow word synchronises the stream, which must not
             # happen inside a caller's HIP-graph capture
             self._build_exact_plan()
-        # exact transpose of the BILINEAR forward (round 5): a deterministic gather through an inverse plan of summed weights
+        # exact transpose through an inverse plan of SUMMED WEIGHTS (round 5): the bilinear forward's at every size, the nearest
+        # forward's where the byte plan above does not hold the geometry (512 x 512: the scatter there is 6 G global atomics)
         self._exact_bilin_plan = None
-        if use_plan and self.mode == _lib.BWD_EXACT and self.interp == _lib.BILINEAR and self.H <= 65535:
+        if (use_plan and self.mode == _lib.BWD_EXACT and self.H <= 65535
+                and (self.interp == _lib.BILINEAR or self._exact_plan is None)):
             self._build_exact_bilinear_plan()
 
     def _build_plan(self, which):
@@ -333,15 +335,15 @@ class RotatePlan:
         """Inverse plan of the bilinear forward: per (angle, pixel) the first of <= 3 contributing bins and the pixel's summed
         weight in each -- 16 bytes per (angle, pixel) (5.2 MB at 128 x 128 x 20 angles, 377 MB at 512 x 512 x 90).  Falls back
         to the scatter kernel (atomics) when the rows are not a rotation (the build says so)."""
-        nbytes = self._lib.ctpvae_rotate_exact_bilinear_plan_bytes(self.H, self.W, self.A)
-        _lib.check(nbytes, "rotate_exact_bilinear_plan_bytes")
+        nbytes = self._lib.ctpvae_rotate_exact_wplan_bytes(self.H, self.W, self.A)
+        _lib.check(nbytes, "rotate_exact_wplan_bytes")
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self._lib.ctpvae_rotate_exact_bilinear_plan_build_f32(
+            _lib.check(self._lib.ctpvae_rotate_exact_wplan_build_f32(
                 self.T8.data_ptr(), self.Tinv8.data_ptr(), self.A, self.H, self.W, self.PH, self.PW, self.py, self.px,
-                buf.data_ptr(), _stream_ptr()), "rotate_exact_bilinear_plan_build")
-            over = self._lib.ctpvae_rotate_exact_bilinear_plan_overflowed(buf.data_ptr(), self.H, self.W, self.A, _stream_ptr())
-        _lib.check(over, "rotate_exact_bilinear_plan_overflowed")
+                self.interp, buf.data_ptr(), _stream_ptr()), "rotate_exact_wplan_build")
+            over = self._lib.ctpvae_rotate_exact_wplan_overflowed(buf.data_ptr(), self.H, self.W, self.A, _stream_ptr())
+        _lib.check(over, "rotate_exact_wplan_overflowed")
         if over == 0:
             self._exact_bilin_plan = buf
 
@@ -759,7 +761,7 @@ class RotatePlan:
         if self._want_exact_plan:            # first exact backward of a nearest plan: build the inverse plan
             self._build_exact_plan()
         if self._exact_bilin_plan is not None:
-            rc = self._lib.ctpvae_rotate_bwd_exact_bilinear_planned_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW,
+            rc = self._lib.ctpvae_rotate_bwd_exact_wplan_f32(gsino.data_ptr(), S, self.A, self.PH, self.PW,
                                                                         self.Tinv8.data_ptr(), self.H, self.W, self.py, self.px,
                                                                         self._exact_bilin_plan.data_ptr(), out.data_ptr(),
                                                                         _stream_ptr(self._dev_index))

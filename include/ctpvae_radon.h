@@ -313,21 +313,23 @@ int ctpvae_rotate_exact_plan_overflowed(const void *plan_dev, int H, int W, int 
 int ctpvae_rotate_bwd_exact_planned_f32(const float *gsino_dev, int S, int H, int W, int PH, int PW, int A,
                                         const void *exact_plan_dev, float *gimg_dev, ctpvae_stream_t stream);
 
-/* Exact transpose of the BILINEAR forward as a deterministic gather (round 5, ABI 3400; north_star: "bilinear sample/scatter").
- * For a rotation the canvas samples that touch a pixel lie in at most three consecutive detector bins; the plan holds, per
- * (angle, pixel), the first of them and the pixel's summed fp32 weight in each (the forward's own weights, summed over canvas
- * rows in ascending order): 16 bytes per (angle, pixel).  The backward adds ((W0 g[first] + W1 g[first+1]) + W2 g[first+2])
- * over the angles in ascending order: no atomics at any size, equal bits run to run, <= 1e-5 (of the largest value) from
- * ctpvae_rotate_bwd_f32(BILINEAR, EXACT) / the oracle's in-order scatter.  _bytes: the caller-owned plan buffer (16-byte
- * aligned); _build needs both tables; _overflowed (SYNCHRONISES): 1 if some pixel's samples span more than three bins (the rows
- * are not a rotation) -- keep ctpvae_rotate_bwd_f32 then.  Tinv8_dev places the cotangent segments a pixel tile stages. */
-long long ctpvae_rotate_exact_bilinear_plan_bytes(int H, int W, int A);
-int ctpvae_rotate_exact_bilinear_plan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
-                                                int py, int px, void *plan_dev, ctpvae_stream_t stream);
-int ctpvae_rotate_exact_bilinear_plan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream);
-int ctpvae_rotate_bwd_exact_bilinear_planned_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev,
-                                                 int H, int W, int py, int px, const void *plan_dev, float *gimg_dev,
-                                                 ctpvae_stream_t stream);
+/* Exact transpose as a deterministic gather through a plan of SUMMED WEIGHTS (round 5, ABI 3400; north_star: "bilinear
+ * sample/scatter").  For a rotation the canvas samples that touch a pixel lie in at most three consecutive detector bins; the
+ * plan holds, per (angle, pixel), the first of them and the pixel's summed fp32 weight in each (the forward's own weights,
+ * summed over canvas rows in ascending order; interp = NEAREST: the number of samples whose tap the pixel is): 16 bytes per
+ * (angle, pixel).  The backward adds ((W0 g[first] + W1 g[first+1]) + W2 g[first+2]) over the angles in ascending order: no
+ * atomics at any size, equal bits run to run, <= 1e-5 (of the largest value) from ctpvae_rotate_bwd_f32(mode EXACT) / the
+ * oracle's in-order scatter.  BILINEAR: the exact adjoint at every size; NEAREST: for geometries the byte plan above does not
+ * hold (PW > 255: 512 x 512).  _bytes: the caller-owned plan buffer (16-byte aligned); _build needs both tables; _overflowed
+ * (SYNCHRONISES): 1 if some pixel's samples span more than three bins (the rows are not a rotation) -- keep
+ * ctpvae_rotate_bwd_f32 then.  Tinv8_dev places the cotangent segments a pixel tile stages. */
+long long ctpvae_rotate_exact_wplan_bytes(int H, int W, int A);
+int ctpvae_rotate_exact_wplan_build_f32(const float *T8_dev, const float *Tinv8_dev, int A, int H, int W, int PH, int PW,
+                                        int py, int px, int interp, void *plan_dev, ctpvae_stream_t stream);
+int ctpvae_rotate_exact_wplan_overflowed(const void *plan_dev, int H, int W, int A, ctpvae_stream_t stream);
+int ctpvae_rotate_bwd_exact_wplan_f32(const float *gsino_dev, int S, int A, int PH, int PW, const float *Tinv8_dev,
+                                      int H, int W, int py, int px, const void *plan_dev, float *gimg_dev,
+                                      ctpvae_stream_t stream);
 
 /* ---- a7: TomoPy-style ray-driven projector --------------------------------------------------
  * Tables (host side, fp32): theta [dt] -> sin, cos of fmodf(theta, 2*pi) and libtomo's quadrant flag. */

@@ -251,3 +251,27 @@ def test_float64_pixels_are_projected_in_float64(oracle, interp, code):
         np.testing.assert_array_equal(to_np(got), want)
         got32 = fn(torch.from_numpy(x.astype(np.float32)).to(d), theta, pad=pad)
         assert got32.dtype == torch.float32 and rel_err(to_np(got32), want) <= REL
+
+
+def test_nearest_exact_adjoint_without_atomics_at_512(oracle):
+    """The byte plan of the nearest exact adjoint holds detectors of <= 255 bins; larger geometries (512 x 512: 728 bins) took
+    the scatter kernel -- 6 G global atomics at config 5's shape.  They now gather through the summed-weights plan (a pixel is
+    the tap of at most two samples of an angle): <= 1e-5 of the oracle's scatter, equal bits run to run, still the transpose."""
+    d = dev()
+    rng = np.random.default_rng(12)
+    H, S, A = 512, 3, 6
+    theta = np.concatenate([[0.0, np.pi / 2], rng.uniform(0, np.pi, A - 2)])
+    geom = oracle.Geometry(H, H, True)
+    plan = RotatePlan(theta, H, H, True, d, interp="nearest", backward="exact")
+    assert plan._exact_plan is None and plan._exact_bilin_plan is not None
+    img = rng.random((S, H, H)).astype(np.float32)
+    g = rng.standard_normal((S, A, geom.PW)).astype(np.float32)
+    gt = torch.from_numpy(g).to(d)
+    got = plan.backward(gt)
+    assert torch.equal(got, plan.backward(gt))
+    assert rel_err(to_np(got), oracle.rotate_bwd_exact(g, geom, oT(oracle, theta, plan), 0)) <= REL
+    lhs = float((to_np(plan.forward(torch.from_numpy(img).to(d))).astype(np.float64) * g).sum())
+    rhs = float((to_np(got).astype(np.float64) * img).sum())
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (lhs, rhs)
+    small = RotatePlan(theta, 128, 128, True, d, interp="nearest", backward="exact")      # the byte plan keeps what it holds
+    assert small._exact_plan is not None and small._exact_bilin_plan is None
