@@ -159,35 +159,52 @@ NODE_PATH = os.path.join(NODE_DIR, NODE_NAME + ".so")
 _node = False
 
 
+def _node_stamp(src, hdr):
+    """What a built node is good for: the ABI of this binding, a hash of its source and of the header it binds, torch's version."""
+    import hashlib
+    import torch
+    h = hashlib.sha256()
+    for path in (src, hdr):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return f"abi={ABI_VERSION} src={h.hexdigest()[:32]} torch={torch.__version__}\n"
+
+
 def build_torch_node(verbose=False):
     """Compile csrc/torch_node.cpp (host C++, no HIP) with torch's extension builder and put the module in-tree;
-    __graft_entry__.build() calls this.
+    __graft_entry__.build() calls this.  Returns nothing: torch_node() does the one import of the finished file.
+
+    Staleness is decided WITHOUT importing the existing .so (a stale module imported for the probe stays cached by
+    (name, path) in CPython and by path in dlopen, so the rebuilt file could never be loaded by this process): a sidecar
+    stamp next to the .so holds the ABI, a hash of the source + header and torch's version it was built for.
 
     The compile runs in a build directory of THIS process (a temporary sibling of NODE_DIR) and the finished .so is moved
     into NODE_DIR with os.replace(): no lock file is ever shared, so a build that was killed cannot leave a baton that a
     later build waits on forever (torch's FileBaton.wait() has no timeout), and two processes building at once each link
     their own file and the last rename wins -- both are the same module."""
-    import importlib.util
     import shutil
+    import subprocess
+    import sys
     import tempfile
-    from torch.utils.cpp_extension import load
     os.makedirs(NODE_DIR, exist_ok=True)
     src = os.path.join(_HERE, "csrc", "torch_node.cpp")
     hdr = os.path.join(os.path.dirname(_HERE), "include", "ctpvae_radon.h")
-    if os.path.exists(NODE_PATH) and os.path.getmtime(NODE_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        try:                                    # up to date (and loadable with this libtorch): nothing to compile
-            spec = importlib.util.spec_from_file_location(NODE_NAME, NODE_PATH)
-            mod = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(mod)
-            if mod.compiled_abi() == ABI_VERSION:   # (file times do not survive a copy of the tree: the ABI it was built for does)
-                return mod
-        except (ImportError, OSError, AttributeError):
-            pass
+    stamp_path = NODE_PATH + ".stamp"
+    stamp = _node_stamp(src, hdr)
+    if os.path.exists(NODE_PATH) and os.path.exists(stamp_path):
+        with open(stamp_path) as f:
+            if f.read() == stamp:
+                return                           # up to date: nothing to compile, nothing imported
     tmp = tempfile.mkdtemp(prefix=".build-", dir=os.path.dirname(NODE_DIR))
     try:
-        load(name=NODE_NAME, sources=[src], build_directory=tmp, extra_include_paths=[os.path.dirname(hdr)],
-             extra_cflags=["-O2"], extra_ldflags=["-ldl"], with_cuda=False, verbose=verbose, is_python_module=False)
+        # the compile (and the load torch's builder insists on) happen in a CHILD: this process never maps the temporary file
+        code = ("import sys; from torch.utils.cpp_extension import load; "
+                f"load(name={NODE_NAME!r}, sources=[{src!r}], build_directory={tmp!r}, extra_include_paths=[{os.path.dirname(hdr)!r}], "
+                f"extra_cflags=['-O2'], extra_ldflags=['-ldl'], with_cuda=False, verbose={bool(verbose)!r}, is_python_module=False)")
+        subprocess.run([sys.executable, "-c", code], check=True)
         os.replace(os.path.join(tmp, NODE_NAME + ".so"), NODE_PATH)
+        with open(stamp_path, "w") as f:
+            f.write(stamp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     for stale in ("lock", "build.ninja", ".ninja_log", ".ninja_deps"):   # leftovers of the round-2/3 in-place builds
@@ -195,10 +212,6 @@ def build_torch_node(verbose=False):
             os.remove(os.path.join(NODE_DIR, stale))
         except OSError:
             pass
-    spec = importlib.util.spec_from_file_location(NODE_NAME, NODE_PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
 
 
 def torch_node():

@@ -187,9 +187,16 @@ __device__ __forceinline__ bool arrived_last(unsigned *counter, unsigned expecte
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Round 5: the hand-off is ordered by the memory model, not by what the hardware happens to do -- the arrival
+        // add RELEASES this workgroup's partial stores at agent scope (they are behind the barrier above), and the workgroup
+        // whose add came last ACQUIRES before it re-reads the others' partials.  (The partials are also stored and re-read sc1,
+        // see store_part / object_sum_of_parts<true>: MI355X_MICROARCH.md's counter hand-off.)  This path is off by default.
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const bool last = old + 1u == expected;
-        if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         *flag = last ? 1 : 0;
     }
     __syncthreads();

@@ -1460,10 +1460,12 @@ TileSpec pick_tiles(int H, int W, int interp)
     // third of the partial sums less (91.9 us; profiles/r04_tile_heights.txt).  The shape is part of the result (association
     // of the sum): a function of (H, W) alone, reported by ctpvae_rotate_tile_shape.
     ts.th = ceil_div(H, ceil_div(H, kTileRowsMax));
-    {
-        const int v = knob(kKnobTiledTh);   // developer knob: another tile height (read when plans are built AND used)
+#ifdef CTPVAE_TUNE_TILED_TH   // timing builds only (tools/build_variant.sh ... -DCTPVAE_TUNE_TILED_TH): another tile height CHANGES the
+    {                         // association of the tiled sum, i.e. result bits -- not a switch of the product library (round 5)
+        const int v = knob(kKnobTiledTh);
         if (v >= 16 && v <= kTileRowsMax) ts.th = std::min(H, v);
     }
+#endif
     ts.ntx = ceil_div(W, ts.tw);
     ts.nty = ceil_div(H, ts.th);
     const float diag = sqrtf((float)(ts.tw * ts.tw + ts.th * ts.th));
@@ -2315,7 +2317,8 @@ int ctpvae_rotate_bwd_stepped_scaled_f32(const float *gsino_dev, int S, int A, i
                    "rotate_bwd_stepped: null pointer or empty sizes");
     if (int rc = check_geom("rotate_bwd_stepped", S, H, W, PH, PW, py, px, A, CTPVAE_NEAREST)) return rc;
     const StepLayout L = step_layout(H, W, A);
-    return for_slice_chunks(S, std::min(65532, max_slices_per_launch() / 4 * 4), [&](int s0, int n) {
+    // (>= 4: a MAX_SLICES knob of 1..3 must not make a chunk of 0 slices -- the chunk loop would never advance)
+    return for_slice_chunks(S, std::max(4, std::min(65532, max_slices_per_launch() / 4 * 4)), [&](int s0, int n) {
         const float *gs = gsino_dev + (size_t)s0 * A * PW;
         const float *sc = scale_dev ? scale_dev + (long long)s0 * scale_stride : nullptr;
         float *gi = gimg_dev + (size_t)s0 * H * W;

@@ -177,8 +177,12 @@ class RotatePlan:
     # wins the dense shapes of tools/time_compact_shapes.py (profiles/r04_time_compact_shapes.txt: A = 180: B = 50 20.6 vs 21.4 us,
     # B = 200 73 vs 78; A = 90, B = 400 79 vs 87), since round 4 also between 16 and 32 slices, where its angles are dealt to the
     # XCDs (A = 180, B = 16: 10.5 vs 12.2 us; the compact plan won that window in round 3: 12.1 vs 17.1).  Batch sizes inside
-    # COMPACT_DENSE_WINDOW (first, last) keep the compact plan for dense launches: empty today.
-    COMPACT_DENSE_WINDOW = (1, 0)
+    # COMPACT_DENSE_WINDOW (first, last) keep the compact plan for dense launches:
+    # Round 5: near-ties go to the format that moves fewer bytes.  At 180 angles the u16 plan streams 92 MB per launch through
+    # the fabric (9.3x the algorithmic bytes, profiles/r04_angles180_traffic_pmc.json), the compact one 28.5 MB (2.9x); where
+    # the two are within 3 % in time (profiles/r05_time_compact_shapes.txt: B = 40: 19.3 vs 19.6 us; B = 50: 22.2 vs 21.3 and
+    # B = 32: 16.2 vs 14.6 are not) the compact plan runs -- on one GPU the same time, under eight ranks' traffic the cheaper one.
+    COMPACT_DENSE_WINDOW = (36, 44)
 
     def __init__(self, theta, H, W, pad, device, interp="nearest", backward="tf_compat", use_plan=True, _tables=None,
                  plan_format="auto"):
@@ -230,6 +234,11 @@ class RotatePlan:
             if self._fwd_plan is None and self._lib.ctpvae_rotate_plan_supported(*geo, 0):
                 self._fwd_plan = self._build_plan(0)
             self._auto_dense_u16 = bool(plan_format == "auto" and self._compact and self._lib.ctpvae_rotate_plan_supported(*geo, 0))
+            if self._auto_dense_u16:
+                # built now, not on the first dense launch: a first launch inside a caller's HIP-graph capture would
+                # have captured the plan-build kernels and taken the plan's memory from the graph's pool.  A many-angle "auto"
+                # plan therefore holds BOTH forms: 2.35 MB compact + 17 MB u16 at 180 angles.
+                self._u16_plan = self._build_plan(0)
             self._want_bwd_plan = bool(self.mode == _lib.BWD_TF_COMPAT and
                                        self._lib.ctpvae_rotate_plan_supported(*geo, 1))
         # slices larger than LDS: the tiled forward walks compact TILE plans when they can be built (csrc/rotate.hip)
@@ -443,6 +452,9 @@ class RotatePlan:
         one stream, like its tile workspace)."""
         ws = self._part_ws.get((S, n, partition))
         if ws is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("the first per-object-sum call of a shape allocates and zeroes its workspace: run it once before "
+                                   "capturing a HIP graph (the zero fill must not be captured: the counters are zeroed ONCE)")
             nfl = self._lib.ctpvae_loglik_part_floats(S, n, self.PW, partition)
             _lib.check(nfl, "loglik_part_floats")
             if len(self._part_ws) >= 8:

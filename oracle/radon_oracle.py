@@ -141,6 +141,14 @@ def rotate_fwd(img, geom, T8, interp=NEAREST):
     return sino
 
 
+def tile_shape(H, W, interp=NEAREST):
+    """The tile shape the build's tiled forward uses for H x W slices (include/ctpvae_radon.h: the shape fixes the association
+    of the fp32 row sum, so it is part of the contract) -- RESTATED here, not read from the library under test:
+    64 wide (or W), th = ceil(H / ceil(H / R)) tall: equal rows of tiles, R = 128 (nearest), 96 (bilinear)."""
+    r = 128 if interp == NEAREST else 96
+    return (-(-H // -(-H // r)), min(W, 64))
+
+
 def rotate_fwd_f64(img, geom, T8, interp=NEAREST):
     """rotate_fwd on float64 pixels: fp32 coordinates and weights, float64 products and row sum (TF's T = double)."""
     img = np.ascontiguousarray(img, dtype=np.float64)

@@ -93,8 +93,8 @@ def test_bilinear_tiles_against_the_tiled_oracle(oracle, H, W, S, A):
     img = rng.random((S, H, W)).astype(np.float32)
     geom = oracle.Geometry(H, W, True)
     plan = RotatePlan(theta, H, W, True, d, interp="bilinear")
-    shape = _lib.tile_shape(H, W, 1)
-    assert plan.tiled and shape == (-(-H // -(-H // 96)), 64)
+    shape = oracle.tile_shape(H, W, 1)         # the checker's own statement of the rule ...
+    assert plan.tiled and _lib.tile_shape(H, W, 1) == shape == (-(-H // -(-H // 96)), 64)   # ... which the library reports too
     T = oT(oracle, theta, plan)
     got = to_np(plan.forward(torch.from_numpy(img).to(d)))
     np.testing.assert_array_equal(got, oracle.rotate_fwd_tiled(img, geom, T, shape, interp=1))
@@ -114,8 +114,8 @@ def test_bilinear_forced_tiles_on_small_unpadded_slices(oracle):
         geom = oracle.Geometry(H, W, pad)
         with _lib.tuned("TILED_FORCE", 1):
             plan = RotatePlan(theta, H, W, pad, d, interp="bilinear")
-            shape = _lib.tile_shape(H, W, 1)
-            assert shape is not None and plan.tiled
+            shape = oracle.tile_shape(H, W, 1)
+            assert _lib.tile_shape(H, W, 1) == shape and plan.tiled
             got = to_np(plan.forward(torch.from_numpy(img).to(d)))
         np.testing.assert_array_equal(got, oracle.rotate_fwd_tiled(img, geom, oT(oracle, theta, plan), shape, interp=1),
                                       err_msg=f"{H}x{W} pad={pad} tiles {shape}")

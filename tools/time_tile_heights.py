@@ -1,4 +1,6 @@
 """Developer timing: the 512 x 512 tile forward against the tile height (knob TILED_TH; the plan is built and used under it).
+Round 5: the knob is compiled into TIMING builds only -- bash tools/build_variant.sh th -DCTPVAE_TUNE_TILED_TH, then
+CTPVAE_VARIANT_LIB=tools/libctpvae_radon_th.bin python tools/time_tile_heights.py (the product library ignores it).
 512 rows in 96-row tiles (rounds 1-3) are five full rows of tiles and a 32-row remainder: 768 workgroups of unequal cost on
 256 CUs; 86 rows: 768 equal ones; 128 rows (the default since round 4): 512 equal ones.
    python tools/time_tile_heights.py [slices] [N] [heights, comma separated]"""
