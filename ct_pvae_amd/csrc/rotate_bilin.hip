@@ -155,7 +155,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
     const int off_cols = mirror ? (w - 2 + g.px) * CELL : -g.px * CELL;
     int off_v = pin_vgpr(off_rows + off_cols);   // (not const: a const int is not captured by the nested generic lambdas)
 
-    auto setup = [&](int a, int slot) -> BilinRay {
+    // one lane's ray: transform row of its angle, bin, conservative row range [ilo, ilo + cnt) through the unit
+    auto prepare = [&](int a, int slot, int &ilo, int &cnt) -> BilinRay {
         BilinRay q;
         const int ad = (t8_lds_off + 8 * a) * 4 + lds_base;
         const f32x4 u = lds_abs_vec<4>(ad);
@@ -175,9 +176,15 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         clip_rows(q.yj + q.t5, q.t4, (float)(g.py - 2), (float)(g.py + h + 1), lo, hi);
         lo = fminf(fmaxf(lo, 0.0f), (float)g.PH);
         hi = fminf(fmaxf(hi, -1.0f), (float)g.PH);
-        const int ilo = max((int)floorf(lo) - 1, 0);
+        ilo = max((int)floorf(lo) - 1, 0);
         const int ihi = min((int)ceilf(hi) + 2, g.PH);
-        const int cnt = q.live ? max(ihi - ilo, 0) : 0;
+        cnt = q.live ? max(ihi - ilo, 0) : 0;
+        return q;
+    };
+    // ... and the wave's common trip count: every lane walks kmax rows (+ the tail row) from its own first row
+    auto setup = [&](int a, int slot) -> BilinRay {
+        int ilo, cnt;
+        BilinRay q = prepare(a, slot, ilo, cnt);
         const int need = wave_max_nonneg(cnt);                  // wave-uniform trip count (SGPR)
         q.kmax = min((need + 1) & ~1, g.PH & ~1);               // whole row pairs ...
         q.tail = need > q.kmax;                                 // ... and the last row of an odd canvas alone
@@ -319,11 +326,85 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
     };
 
     __syncthreads();
-    // (angle, 64-slot block) tasks of this class, handed out through an LDS counter, the innermost blocks (longest rays) first;
-    // a wave takes two MIRRORED 32-slot runs of the slot range (equal chords: one trip count serves both)
     const int nbk = nb >> 6;
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
     int *next_task = cls_list + 1 + g.A;
+    if constexpr (TILED && NS == 4) {
+        // Tiles, four slices per cell: tasks of FOUR 16-SLOT BANDS of similar length, from any angles of the class.  A tile's
+        // chord profile over its ~117 ray slots is a trapezoid, so a wave that walks 64 neighbouring slots in lockstep spends
+        // 44 % of its lane-rows on rays that have already left the tile (tools/sim_bilin_tiles.py: 0.56 of the walked rows live
+        // with two mirrored 32-slot runs per wave, 0.76 with bands sorted by length over all the class's angles).  A
+        // ds_read_b128 is served in four hardware groups of 16 lanes -- lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
+        // the same + 32 -- so a band per hardware group keeps every group's addresses those of 16 neighbouring rays of one
+        // angle: no bank conflict is added.  The list is built HERE, per workgroup (~2 us of a ~150 us workgroup): every wave
+        // counts the rows of its share of (angle, band) pairs, a counting sort in LDS orders them, longest first.  Rays are
+        // independent: which task carries a ray does not touch its sum.  (One task group per class only: two workgroups
+        // sorting the same list could order equal lengths differently.)
+        unsigned char *bcnt = reinterpret_cast<unsigned char *>(next_task + 1);          // [ncls][nbands] rows of a band
+        const int nbands = nb >> 4, E = ncls * nbands;
+        int *hist = reinterpret_cast<int *>(bcnt + ((g.A * (nb >> 4) + 3) & ~3));        // [256] -> start offsets, descending
+        unsigned short *order = reinterpret_cast<unsigned short *>(hist + 256);          // [E] entries (angle index << 4 | band)
+        for (int p = threadIdx.x; p < 256; p += blockDim.x) hist[p] = 0;
+        for (int ai = wave; ai < ncls; ai += nwaves) {
+            const int a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
+            for (int half = 0; half < nbk; ++half) {
+                int ilo, cnt;
+                (void)prepare(a, half * 64 + lane, ilo, cnt);
+                cnt = min(cnt, 255);
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, false));   // row_shr:1 .. 8: the max of a row
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, false));   // of 16 lanes ends in its lane 15
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, false));
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, false));
+                if ((lane & 15) == 15) bcnt[ai * nbands + half * 4 + (lane >> 4)] = (unsigned char)cnt;
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(&hist[bcnt[e]], 1);
+        __syncthreads();
+        if (wave == 0) {   // hist[c] <- number of entries LONGER than c (their start in the descending order); 4 lengths per lane
+            const int c0 = 255 - 4 * lane;                    // this lane's lengths c0, c0 - 1, c0 - 2, c0 - 3 (descending)
+            const int h0 = hist[c0], h1 = hist[c0 - 1], h2 = hist[c0 - 2], h3 = hist[c0 - 3];
+            int run = h0 + h1 + h2 + h3, incl = run;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            const int base = incl - run;
+            hist[c0] = base;
+            hist[c0 - 1] = base + h0;
+            hist[c0 - 2] = base + h0 + h1;
+            hist[c0 - 3] = base + h0 + h1 + h2;
+        }
+        __syncthreads();
+        // (bands no ray of which meets the tile sort last and are still walked -- zero rows: their rays' partial sums must be
+        // stored, the reduce pass reads every slot of the span)
+        const int nlive = E;
+        for (int e = threadIdx.x; e < E; e += blockDim.x)
+            order[atomicAdd(&hist[bcnt[e]], 1)] = (unsigned short)(((e / nbands) << 4) | (e % nbands));
+        __syncthreads();
+        // lane -> (hardware group of a ds_read_b128, index within it)
+        const int l32 = lane & 31;
+        const int grp = (lane >> 5) * 2 + ((l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28 ? 1 : 0);
+        const int kin = (grp & 1) ? (l32 < 12 ? l32 - 4 : (l32 < 20 ? l32 - 8 : l32 - 16))
+                                  : (l32 < 4 ? l32 : (l32 < 16 ? l32 - 8 : l32 - 12));
+        const int ntask = (nlive + 3) >> 2;
+        for (;;) {
+            int m = 0;
+            if (lane == 0) m = atomicAdd(next_task, 1);
+            m = __builtin_amdgcn_readfirstlane(m);
+            if (m >= ntask) break;
+            const int idx = 4 * m + grp;
+            const int e = order[min(idx, nlive - 1)];
+            const int a = cls_list[1 + (e >> 4)];
+            const int slot = idx < nlive ? (e & 15) * 16 + kin : nb;      // (a task's missing bands: slots past the span, dead)
+            const BilinRay q = setup(a, slot);
+            if (mirror) walk(q, std::true_type{}); else walk(q, std::false_type{});
+        }
+        return;
+    }
+    // (angle, 64-slot block) tasks of this class, handed out through an LDS counter, the innermost blocks (longest rays) first;
+    // a wave takes two MIRRORED 32-slot runs of the slot range (equal chords: one trip count serves both)
     const int ntask = ncls * nbk;
     for (;;) {
         int m = 0;
@@ -734,7 +815,12 @@ __global__ __launch_bounds__(256) void rotate_bwd_exact_bilin_kernel(const float
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
-static size_t bilin_extra_bytes(int A) { return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16; }
+// behind the image: transform rows, class list + task counter, and (tiles of four slices) the band lengths [A][<= 16], the
+// counting sort's 256 offsets and the sorted (angle, band) entries
+static size_t bilin_extra_bytes(int A)
+{
+    return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16 + ((size_t)A * 16 + 4) + 256 * sizeof(int) + (size_t)A * 16 * sizeof(short);
+}
 static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
 
 bool bilin_fwd_whole_geometry(int H, int W) { return bilin_img_bytes(H, W, false, 1) + kBilinLdsReserve <= (size_t)kMaxLdsBytes; }
@@ -759,6 +845,7 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     int G = std::max(1, 256 / (2 * units));
     G = std::min(G, std::max(1, tasks / 8));
     if (knob(kKnobBw) > 0) G = knob(kKnobBw);
+    if (TILED && NS == 4) G = 1;     // the sorted band tasks are dealt by ONE workgroup per (tile, class)
     // >= 8 waves: a workgroup's fill is shared by its waves, and two waves per SIMD issue LDS reads and waits under each other's
     // vector instructions (tools/sweep_bilin.py, B = 50 x 128 x 128 x 20 angles, G = 5: 27.1 / 24.3 / 22.1 / 21.8 us at 4 / 6 / 8 / 16)
     int waves = std::min(16, std::max(8, ceil_div(tasks, 2 * G)));
@@ -782,6 +869,7 @@ static int bilin_fwd_ns(int S, int h, int w, bool tiled, int A)
     int ns = S >= 3 ? 4 : (S == 2 ? 2 : 1);
     if (knob(kKnobBns) == 1 || knob(kKnobBns) == 2 || knob(kKnobBns) == 4) ns = knob(kKnobBns);
     while (ns > 1 && bilin_img_bytes(h, w, tiled, ns) + bilin_extra_bytes(A) > (size_t)kMaxLdsBytes) ns >>= 1;
+    if (tiled && ns == 4 && A > 4095) ns = 2;    // (the band entries hold the angle's index in 12 bits)
     return ns;
 }
 
