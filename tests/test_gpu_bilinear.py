@@ -275,3 +275,44 @@ def test_nearest_exact_adjoint_without_atomics_at_512(oracle):
     assert abs(lhs - rhs) <= 1e-5 * abs(lhs), (lhs, rhs)
     small = RotatePlan(theta, 128, 128, True, d, interp="nearest", backward="exact")      # the byte plan keeps what it holds
     assert small._exact_plan is not None and small._exact_bilin_plan is None
+
+
+@pytest.mark.parametrize("H", [96, 512])
+def test_bilinear_dispatch_rows_angle_subsets_and_autograd(oracle, H):
+    """The bilinear rows of the dispatch matrix the host code can reach: dense / device-resident subset / host-resident subset,
+    forward and both backward modes, on a geometry that fits LDS and on 512 x 512 (tiles); and the drop-in call
+    project_tf_low_mem(...).backward() in the reference's [X][Y][Z] layout."""
+    import ct_pvae_amd as cp
+    d = dev()
+    rng = np.random.default_rng(H)
+    S, A = 3, 9
+    theta = rng.uniform(0, np.pi, A)
+    geom = oracle.Geometry(H, H, True)
+    img = rng.random((S, H, H)).astype(np.float32)
+    x = torch.from_numpy(img).to(d)
+    sub = np.array([7, 0, 3, 3, 8])
+    tiled = H == 512
+    for back in ("tf_compat", "exact"):
+        plan = RotatePlan(theta, H, H, True, d, interp="bilinear", backward=back)
+        T = oT(oracle, theta, plan)
+        assert plan.tiled == tiled
+        fwd = (lambda im, TT: oracle.rotate_fwd_tiled(im, geom, TT, oracle.tile_shape(H, H, 1), interp=1)) if tiled else \
+              (lambda im, TT: oracle.rotate_fwd(im, geom, TT, 1))
+        np.testing.assert_array_equal(to_np(plan.forward(x)), fwd(img, T), err_msg=f"dense {back}")
+        for where in ("device", "host"):
+            idx = cp.as_angle_index(sub, d, keep_host=(where == "host"))
+            np.testing.assert_array_equal(to_np(plan.forward(x, angles_i=idx)), fwd(img, T[sub]), err_msg=f"{where} subset fwd {back}")
+            g = rng.standard_normal((S, len(sub), geom.PW)).astype(np.float32)
+            got = to_np(plan.backward(torch.from_numpy(g).to(d), angles_i=idx))
+            if back == "tf_compat":
+                np.testing.assert_array_equal(got, oracle.rotate_bwd_tfcompat(g, geom, oracle.invert_transforms(T)[sub], 1))
+            else:
+                assert rel_err(got, oracle.rotate_bwd_exact(g, geom, T[sub], 1)) <= REL
+    # the drop-in call: [X][Y][Z] in, [A][P][Z] out, gradient through tf_compat (what tf.GradientTape computes)
+    xz = torch.from_numpy(np.ascontiguousarray(img.transpose(1, 2, 0))).to(d).requires_grad_(True)
+    out = cp.project_tf_low_mem(xz, theta, pad=True)
+    gz = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(gz).to(d))
+    T = oracle.rotate_transforms(theta.astype(np.float32), geom.PH, geom.PW)
+    want_g = oracle.rotate_bwd_tfcompat(np.ascontiguousarray(gz.transpose(2, 0, 1)), geom, oracle.invert_transforms(T), 1)
+    np.testing.assert_array_equal(to_np(xz.grad), want_g.transpose(1, 2, 0))
