@@ -530,7 +530,11 @@ __global__ __launch_bounds__(1024) void rotate_fwd_fast_kernel(const float *__re
 // ballot + popcount into a per-wave LDS list) -- the list depends on the angle and the bins only, so it is built ONCE and
 // serves all the workgroup's slices -- then adds their partial sums tile by tile, the slices' loads in flight together.
 // (One slice per workgroup made this pass wave-launch bound: 34.5 k waves of a dozen loads each at B=32, 27 us.)
+#ifdef CTPVAE_TUNE_REDUCE_S
+constexpr int kReduceSlices = CTPVAE_TUNE_REDUCE_S;   // timing builds only
+#else
 constexpr int kReduceSlices = 8;
+#endif
 // EPI 1: also write the log-probability of the measured sample under every ray-sum (loglik_math.h); EPI 2: the log-probabilities
 // are REDUCED -- one partial sum per (slice, angle, 64-bin block) into epi.part (LogLikEpilogue; partition 1 of
 // ctpvae_loglik_object_sums_f32), d lp / d ray-sum stored, ray-sums and log-probabilities only where buffers were given.
