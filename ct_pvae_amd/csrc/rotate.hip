@@ -2034,6 +2034,9 @@ long long ctpvae_rotate_fwd_tiled_workspace_bytes(int S, int H, int W, int PH, i
     if (S <= 0 || H <= 0 || W <= 0 || PH < H || PW < W || A <= 0) return fail(CTPVAE_EINVAL, "rotate_fwd_tiled_workspace_bytes: bad sizes");
     const TileSpec ts = pick_tiles(H, W, interp);
     if (ts.ntx == 0 || knob(kKnobForceGeneric) >= 0) return 0;
+    // (bilinear tiles keep their angles' tables in LDS: thousands of angles do not fit -- 0 = use ctpvae_rotate_fwd_f32, the
+    // global-memory kernel, for such a call)
+    if (interp != CTPVAE_NEAREST && !bilin_fwd_tiles_ok(ts, A)) return 0;
     const long long quads = (S + kPartialQuad - 1) / kPartialQuad;   // partial_index: whole slice quads
     return quads * kPartialQuad * ts.ntx * ts.nty * A * ts.nb * (long long)sizeof(float);
 }
@@ -2161,6 +2164,8 @@ int ctpvae_rotate_fwd_tiled_interp_f32(const float *img_dev, int S, int H, int W
     const TileSpec ts = pick_tiles(H, W, interp);
     CTPVAE_REQUIRE(ts.ntx > 0, "rotate_fwd_tiled: a %dx%d slice fits LDS whole; call ctpvae_rotate_fwd_f32", H, W);
     CTPVAE_REQUIRE(knob(kKnobForceGeneric) < 0, "rotate_fwd_tiled: not available with FORCE_GENERIC");
+    CTPVAE_REQUIRE(bilin_fwd_tiles_ok(ts, A), "rotate_fwd_tiled: the tables of %d angles do not fit LDS beside a tile (the workspace "
+                   "size reads 0 for such a call: use ctpvae_rotate_fwd_f32)", A);
     const int nt = ts.ntx * ts.nty;
     const int chunk = std::max(4, std::min(max_slices_per_launch(), 65535 / nt) / 4 * 4);
     return for_slice_chunks(S, chunk, [&](int s0, int n) {

@@ -823,6 +823,8 @@ static size_t bilin_extra_bytes(int A)
 }
 static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
 
+// the tile kernel takes this many angles (their transform rows, class list and band lists sit in LDS beside the tile)
+bool bilin_fwd_tiles_ok(const TileSpec &ts, int A) { return bilin_img_bytes(ts.th, ts.tw, true, 1) + bilin_extra_bytes(A) <= (size_t)kMaxLdsBytes; }
 bool bilin_fwd_whole_geometry(int H, int W) { return bilin_img_bytes(H, W, false, 1) + kBilinLdsReserve <= (size_t)kMaxLdsBytes; }
 bool bilin_fwd_whole_ok(int H, int W, int A)
 {

@@ -143,6 +143,7 @@ int launch_tile_reduce(const float *workspace_dev, const RotGeom &g, const TileS
 constexpr size_t kBilinLdsReserve = 16 * 1024;   // LDS kept free of the image for the transform copy and class list (A <= ~450)
 bool bilin_fwd_whole_geometry(int H, int W);          // (H, W) is projected whole (else: tiles)
 bool bilin_fwd_whole_ok(int H, int W, int A);         // ... and this many angles fit beside the image
+bool bilin_fwd_tiles_ok(const TileSpec &ts, int A);   // a tile and this many angles' tables fit LDS
 int bilin_fwd_whole(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev, int A,
                     float *sino_dev, ctpvae_stream_t stream);
 int bilin_fwd_tiles(const float *img_dev, int S, int H, int W, int PH, int PW, int py, int px, const float *T8_dev, int A,

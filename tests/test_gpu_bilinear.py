@@ -316,3 +316,17 @@ def test_bilinear_dispatch_rows_angle_subsets_and_autograd(oracle, H):
     T = oracle.rotate_transforms(theta.astype(np.float32), geom.PH, geom.PW)
     want_g = oracle.rotate_bwd_tfcompat(np.ascontiguousarray(gz.transpose(2, 0, 1)), geom, oracle.invert_transforms(T), 1)
     np.testing.assert_array_equal(to_np(xz.grad), want_g.transpose(1, 2, 0))
+
+
+def test_bilinear_very_many_angles_fall_back_correctly(oracle):
+    """The bilinear kernels keep their angles' transform rows and task lists in LDS: a call with thousands of angles does not
+    fit and takes round 1's kernels (whole slices) / the global-memory kernel (tiled geometries) -- same sums, bit for bit."""
+    d = dev()
+    rng = np.random.default_rng(9)
+    for H, W, A in ((40, 40, 2500), (300, 200, 2000)):
+        theta = rng.uniform(0, np.pi, A)
+        img = rng.random((1, H, W)).astype(np.float32)
+        geom = oracle.Geometry(H, W, True)
+        plan = RotatePlan(theta, H, W, True, d, interp="bilinear")
+        assert not plan.tiled
+        np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))), oracle.rotate_fwd(img, geom, oT(oracle, theta, plan), 1))
