@@ -330,20 +330,29 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
     int *next_task = cls_list + 1 + g.A;
     if constexpr (TILED && NS == 4) {
-        // Tiles, four slices per cell: tasks of FOUR 16-SLOT BANDS of similar length, from any angles of the class.  A tile's
+        // Tiles, four slices per cell: tasks of SIXTEEN 4-SLOT BANDS of similar length, from any angles of the class.  A tile's
         // chord profile over its ~117 ray slots is a trapezoid, so a wave that walks 64 neighbouring slots in lockstep spends
         // 44 % of its lane-rows on rays that have already left the tile (tools/sim_bilin_tiles.py: 0.56 of the walked rows live
-        // with two mirrored 32-slot runs per wave, 0.76 with bands sorted by length over all the class's angles).  A
-        // ds_read_b128 is served in four hardware groups of 16 lanes -- lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and
-        // the same + 32 -- so a band per hardware group keeps every group's addresses those of 16 neighbouring rays of one
-        // angle: no bank conflict is added.  The list is built HERE, per workgroup (~2 us of a ~150 us workgroup): every wave
-        // counts the rows of its share of (angle, band) pairs, a counting sort in LDS orders them, longest first.  Rays are
-        // independent: which task carries a ray does not touch its sum.  (One task group per class only: two workgroups
-        // sorting the same list could order equal lengths differently.)
+        // with two mirrored 32-slot runs per wave; bands sorted by length over all the class's angles: 0.75 at 16 slots per
+        // band, 0.83 at 8, 0.88 at 4).  A ds_read_b128 is served in four hardware groups of 16 lanes -- lanes {0-3, 12-15,
+        // 20-27}, {4-11, 16-19, 28-31} and the same + 32 --; whole bands sit inside one group, so the rays of a band keep the
+        // conflict-free pattern of neighbouring rays among themselves and only different bands of a group can collide.
+        // Measured at 32 x 512 x 512 x 90 angles on one box (the LDS array is ~50 % busy: the conflicts the narrower bands add
+        // are hidden): mirrored runs 436, 16-slot bands 347, 8-slot 325, 4-slot 311-318 us.  The list is built HERE, per
+        // workgroup (~2 us of a ~150 us workgroup): every wave counts the rows of its share of (angle, band) pairs, a counting
+        // sort in LDS orders them, longest first.  Rays are independent: which task carries a ray does not touch its sum.
+        // (One task group per class only: two workgroups sorting the same list could order equal lengths differently.)
+#ifdef CTPVAE_TUNE_BILIN_BAND
+        constexpr int BAND = CTPVAE_TUNE_BILIN_BAND;   // timing builds: slots per band (4, 8 or 16)
+#else
+        constexpr int BAND = 4;
+#endif
+        static_assert(BAND == 4 || BAND == 8 || BAND == 16, "the LDS lists below are sized for bands of >= 4 slots");
+        constexpr int BSH = BAND == 16 ? 4 : (BAND == 8 ? 3 : 2), PER = 64 / BAND;        // log2(BAND); bands per task
         unsigned char *bcnt = reinterpret_cast<unsigned char *>(next_task + 1);          // [ncls][nbands] rows of a band
-        const int nbands = nb >> 4, E = ncls * nbands;
-        int *hist = reinterpret_cast<int *>(bcnt + ((g.A * (nb >> 4) + 3) & ~3));        // [256] -> start offsets, descending
-        unsigned short *order = reinterpret_cast<unsigned short *>(hist + 256);          // [E] entries (angle index << 4 | band)
+        const int nbands = nb >> BSH, E = ncls * nbands;
+        int *hist = reinterpret_cast<int *>(bcnt + ((g.A * (nb >> 2) + 3) & ~3));        // [256] -> start offsets, descending
+        unsigned short *order = reinterpret_cast<unsigned short *>(hist + 256);          // [E] entries (angle index << 6 | band)
         for (int p = threadIdx.x; p < 256; p += blockDim.x) hist[p] = 0;
         for (int ai = wave; ai < ncls; ai += nwaves) {
             const int a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
@@ -351,11 +360,11 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
                 int ilo, cnt;
                 (void)prepare(a, half * 64 + lane, ilo, cnt);
                 cnt = min(cnt, 255);
-                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, false));   // row_shr:1 .. 8: the max of a row
-                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, false));   // of 16 lanes ends in its lane 15
-                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, false));
-                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, false));
-                if ((lane & 15) == 15) bcnt[ai * nbands + half * 4 + (lane >> 4)] = (unsigned char)cnt;
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, false));   // row_shr:1, 2, 4 (, 8): the max of a
+                if (BAND >= 4) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, false));   // band ends in its last lane
+                if (BAND >= 8) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, false));
+                if (BAND == 16) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, false));
+                if ((lane & (BAND - 1)) == BAND - 1) bcnt[ai * nbands + half * PER + (lane >> BSH)] = (unsigned char)cnt;
             }
         }
         __syncthreads();
@@ -381,23 +390,24 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         // stored, the reduce pass reads every slot of the span)
         const int nlive = E;
         for (int e = threadIdx.x; e < E; e += blockDim.x)
-            order[atomicAdd(&hist[bcnt[e]], 1)] = (unsigned short)(((e / nbands) << 4) | (e % nbands));
+            order[atomicAdd(&hist[bcnt[e]], 1)] = (unsigned short)(((e / nbands) << 6) | (e % nbands));
         __syncthreads();
         // lane -> (hardware group of a ds_read_b128, index within it)
         const int l32 = lane & 31;
         const int grp = (lane >> 5) * 2 + ((l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28 ? 1 : 0);
         const int kin = (grp & 1) ? (l32 < 12 ? l32 - 4 : (l32 < 20 ? l32 - 8 : l32 - 16))
                                   : (l32 < 4 ? l32 : (l32 < 16 ? l32 - 8 : l32 - 12));
-        const int ntask = (nlive + 3) >> 2;
+        const int sub = grp * (16 / BAND) + (kin >> BSH);      // this lane's band within the task
+        const int ntask = (nlive + PER - 1) / PER;
         for (;;) {
             int m = 0;
             if (lane == 0) m = atomicAdd(next_task, 1);
             m = __builtin_amdgcn_readfirstlane(m);
             if (m >= ntask) break;
-            const int idx = 4 * m + grp;
+            const int idx = PER * m + sub;
             const int e = order[min(idx, nlive - 1)];
-            const int a = cls_list[1 + (e >> 4)];
-            const int slot = idx < nlive ? (e & 15) * 16 + kin : nb;      // (a task's missing bands: slots past the span, dead)
+            const int a = cls_list[1 + (e >> 6)];
+            const int slot = idx < nlive ? ((e & 63) << BSH) + (kin & (BAND - 1)) : nb;   // (a task's missing bands: dead slots)
             const BilinRay q = setup(a, slot);
             if (mirror) walk(q, std::true_type{}); else walk(q, std::false_type{});
         }
@@ -816,10 +826,10 @@ __global__ __launch_bounds__(256) void rotate_bwd_exact_bilin_kernel(const float
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
 // behind the image: transform rows, class list + task counter, and (tiles of four slices) the band lengths [A][<= 16], the
-// counting sort's 256 offsets and the sorted (angle, band) entries
+// counting sort's 256 offsets and the sorted (angle, band) entries (sized for 4-slot bands)
 static size_t bilin_extra_bytes(int A)
 {
-    return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16 + ((size_t)A * 16 + 4) + 256 * sizeof(int) + (size_t)A * 16 * sizeof(short);
+    return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16 + ((size_t)A * 64 + 4) + 256 * sizeof(int) + (size_t)A * 64 * sizeof(short);
 }
 static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
 
@@ -871,7 +881,7 @@ static int bilin_fwd_ns(int S, int h, int w, bool tiled, int A)
     int ns = S >= 3 ? 4 : (S == 2 ? 2 : 1);
     if (knob(kKnobBns) == 1 || knob(kKnobBns) == 2 || knob(kKnobBns) == 4) ns = knob(kKnobBns);
     while (ns > 1 && bilin_img_bytes(h, w, tiled, ns) + bilin_extra_bytes(A) > (size_t)kMaxLdsBytes) ns >>= 1;
-    if (tiled && ns == 4 && A > 4095) ns = 2;    // (the band entries hold the angle's index in 12 bits)
+    if (tiled && ns == 4 && A > 1023) ns = 2;    // (the band entries hold the angle's index in 10 bits)
     return ns;
 }
 
