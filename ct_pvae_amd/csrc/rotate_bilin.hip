@@ -59,7 +59,7 @@ struct BilinRay {
     bool live, tail;      // tail: one more row behind the pairs (an odd canvas height walked whole)
 };
 
-template <int NS, bool TILED, bool PADDED>
+template <int NS, bool TILED, bool PADDED, bool SORTED>
 __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                 const float *__restrict__ T8, int t8_lds_off, float *__restrict__ out)
 {
@@ -325,107 +325,114 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         }
     };
 
-    __syncthreads();
-    const int nbk = nb >> 6;
+    // ---- tasks ------------------------------------------------------------------------------------------------------------------
+    // Lanes of a wave walk in lockstep: all 64 take the trip count of the longest ray.  A unit's chord profile over its ray slots
+    // is a trapezoid (tile) or worse (a square slice seen at 45 degrees), so a wave of 64 NEIGHBOURING slots spends 29 % (whole
+    // 128 x 128 slice) to 44 % (64 x 86 tile) of its lane-rows on rays that have left the unit (tools/sim_bilin_tiles.py).
+    // SORTED mode: the workgroup's (angle, band) pairs -- a band = 4 consecutive slots of one angle -- are sorted by length and
+    // dealt 16 at a time: 0.88 of the walked lane-rows are then live for tiles (1.3x fewer wave-rows for a slice at 180 angles).
+    // The hardware serves a ds_read_b32 / _b64 in two groups of 32 consecutive lanes and a ds_read_b128 in four groups of 16
+    // lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32): whole bands sit inside one group; the extra conflicts
+    // between a group's bands hide under the vector instructions (LDS array ~50 % busy).  Measured on one box at 32 x 512 x 512 x
+    // 90 angles: mirrored 32-slot runs of one angle per wave 436 us, 16-slot bands 347, 8-slot 325, 4-slot 311-318.
+    // The list is built HERE, per workgroup, for <= 2048 bands at a time (a chunk of the class's angles): every wave counts the
+    // rows of its share of bands, a counting sort in LDS orders them, longest first, and the waves take tasks from an LDS counter.
+    // Rays are independent: which task carries a ray does not touch its sum.  The G workgroups of a (unit, class) own DISJOINT
+    // bands -- band b of every angle belongs to workgroup b mod G: each samples every angle's profile evenly, none needs
+    // another's list.
+    // UNSORTED mode (few tasks per wave: the headline shape has 6 per workgroup of 8 waves): the launch ends with its longest
+    // ray whatever the other lanes do, and the sort's barriers would only delay the start (measured: B = 50 x 20 angles 24.5 us
+    // sorted against 21.8; B = 100 x 20: 36.8 against 35.2).  Then: (angle, 64-slot block) tasks over all the class's angles,
+    // every G-th to this workgroup, two MIRRORED 32-slot runs per wave (equal chords: one trip count serves both), the
+    // innermost blocks first.
+    constexpr int BSH = 2, BAND = 1 << BSH, PER = 64 / BAND;
+    const int nbk = nb >> 6, nbands = nb >> BSH;
+    __syncthreads();                                               // the image, the transform rows and the class list are staged
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
     int *next_task = cls_list + 1 + g.A;
-    if constexpr (TILED && NS == 4) {
-        // Tiles, four slices per cell: tasks of SIXTEEN 4-SLOT BANDS of similar length, from any angles of the class.  A tile's
-        // chord profile over its ~117 ray slots is a trapezoid, so a wave that walks 64 neighbouring slots in lockstep spends
-        // 44 % of its lane-rows on rays that have already left the tile (tools/sim_bilin_tiles.py: 0.56 of the walked rows live
-        // with two mirrored 32-slot runs per wave; bands sorted by length over all the class's angles: 0.75 at 16 slots per
-        // band, 0.83 at 8, 0.88 at 4).  A ds_read_b128 is served in four hardware groups of 16 lanes -- lanes {0-3, 12-15,
-        // 20-27}, {4-11, 16-19, 28-31} and the same + 32 --; whole bands sit inside one group, so the rays of a band keep the
-        // conflict-free pattern of neighbouring rays among themselves and only different bands of a group can collide.
-        // Measured at 32 x 512 x 512 x 90 angles on one box (the LDS array is ~50 % busy: the conflicts the narrower bands add
-        // are hidden): mirrored runs 436, 16-slot bands 347, 8-slot 325, 4-slot 311-318 us.  The list is built HERE, per
-        // workgroup (~2 us of a ~150 us workgroup): every wave counts the rows of its share of (angle, band) pairs, a counting
-        // sort in LDS orders them, longest first.  Rays are independent: which task carries a ray does not touch its sum.
-        // (One task group per class only: two workgroups sorting the same list could order equal lengths differently.)
-#ifdef CTPVAE_TUNE_BILIN_BAND
-        constexpr int BAND = CTPVAE_TUNE_BILIN_BAND;   // timing builds: slots per band (4, 8 or 16)
-#else
-        constexpr int BAND = 4;
-#endif
-        static_assert(BAND == 4 || BAND == 8 || BAND == 16, "the LDS lists below are sized for bands of >= 4 slots");
-        constexpr int BSH = BAND == 16 ? 4 : (BAND == 8 ? 3 : 2), PER = 64 / BAND;        // log2(BAND); bands per task
-        unsigned char *bcnt = reinterpret_cast<unsigned char *>(next_task + 1);          // [ncls][nbands] rows of a band
-        const int nbands = nb >> BSH, E = ncls * nbands;
-        int *hist = reinterpret_cast<int *>(bcnt + ((g.A * (nb >> 2) + 3) & ~3));        // [256] -> start offsets, descending
-        unsigned short *order = reinterpret_cast<unsigned short *>(hist + 256);          // [E] entries (angle index << 6 | band)
-        for (int p = threadIdx.x; p < 256; p += blockDim.x) hist[p] = 0;
-        for (int ai = wave; ai < ncls; ai += nwaves) {
-            const int a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
-            for (int half = 0; half < nbk; ++half) {
-                int ilo, cnt;
-                (void)prepare(a, half * 64 + lane, ilo, cnt);
-                cnt = min(cnt, 255);
-                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, false));   // row_shr:1, 2, 4 (, 8): the max of a
-                if (BAND >= 4) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, false));   // band ends in its last lane
-                if (BAND >= 8) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, false));
-                if (BAND == 16) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, false));
-                if ((lane & (BAND - 1)) == BAND - 1) bcnt[ai * nbands + half * PER + (lane >> BSH)] = (unsigned char)cnt;
-            }
-        }
-        __syncthreads();
-        for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(&hist[bcnt[e]], 1);
-        __syncthreads();
-        if (wave == 0) {   // hist[c] <- number of entries LONGER than c (their start in the descending order); 4 lengths per lane
-            const int c0 = 255 - 4 * lane;                    // this lane's lengths c0, c0 - 1, c0 - 2, c0 - 3 (descending)
-            const int h0 = hist[c0], h1 = hist[c0 - 1], h2 = hist[c0 - 2], h3 = hist[c0 - 3];
-            int run = h0 + h1 + h2 + h3, incl = run;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            const int base = incl - run;
-            hist[c0] = base;
-            hist[c0 - 1] = base + h0;
-            hist[c0 - 2] = base + h0 + h1;
-            hist[c0 - 3] = base + h0 + h1 + h2;
-        }
-        __syncthreads();
-        // (bands no ray of which meets the tile sort last and are still walked -- zero rows: their rays' partial sums must be
-        // stored, the reduce pass reads every slot of the span)
-        const int nlive = E;
-        for (int e = threadIdx.x; e < E; e += blockDim.x)
-            order[atomicAdd(&hist[bcnt[e]], 1)] = (unsigned short)(((e / nbands) << 6) | (e % nbands));
-        __syncthreads();
-        // lane -> (hardware group of a ds_read_b128, index within it)
+    unsigned char *bcnt = reinterpret_cast<unsigned char *>(next_task + 1);          // [<= 2048] rows of a band
+    int *hist = reinterpret_cast<int *>(bcnt + 2048);                                // [256] -> start offsets, descending
+    unsigned short *order = reinterpret_cast<unsigned short *>(hist + 256);          // [<= 2048] entries li * nmine + k
+    // lane -> (band of the task, slot within the band)
+    int sub, kin;
+    if constexpr (NS == 4) {
         const int l32 = lane & 31;
         const int grp = (lane >> 5) * 2 + ((l32 >= 4 && l32 < 12) || (l32 >= 16 && l32 < 20) || l32 >= 28 ? 1 : 0);
-        const int kin = (grp & 1) ? (l32 < 12 ? l32 - 4 : (l32 < 20 ? l32 - 8 : l32 - 16))
-                                  : (l32 < 4 ? l32 : (l32 < 16 ? l32 - 8 : l32 - 12));
-        const int sub = grp * (16 / BAND) + (kin >> BSH);      // this lane's band within the task
-        const int ntask = (nlive + PER - 1) / PER;
+        const int k16 = (grp & 1) ? (l32 < 12 ? l32 - 4 : (l32 < 20 ? l32 - 8 : l32 - 16)) : (l32 < 4 ? l32 : (l32 < 16 ? l32 - 8 : l32 - 12));
+        sub = grp * (16 >> BSH) + (k16 >> BSH);
+        kin = k16 & (BAND - 1);
+    } else {
+        sub = lane >> BSH;
+        kin = lane & (BAND - 1);
+    }
+    const int nmine = max(0, (nbands - gi + G - 1) / G);           // this workgroup's bands of an angle: gi, gi + G, ...
+    const int nkg = (nmine + PER - 1) / PER;                       // ... in groups of 16
+    const int CH = max(1, 2048 / max(nmine, 1));                   // angles per chunk
+    // (SORTED is the host's choice from the launch shape: about two tasks or more per wave; a workgroup with no band of its own
+    // has nothing to sort)
+    if (SORTED && nmine == 0) return;
+    for (int c0 = 0; c0 < ncls; c0 += (SORTED ? CH : ncls)) {
+        const int nch = SORTED ? min(CH, ncls - c0) : ncls, E = nch * nmine;
+        if constexpr (SORTED) {
+            __syncthreads();                                           // (every wave has left the previous chunk's lists)
+            for (int p = threadIdx.x; p < 256; p += blockDim.x) hist[p] = 0;
+            if (threadIdx.x == 0) *next_task = 0;
+            for (int it = wave; it < nch * nkg; it += nwaves) {        // (angle, 16 of this workgroup's bands) dealt to the waves
+                const int li = it / nkg, k = (it - li * nkg) * PER + (lane >> BSH);
+                const int a = __builtin_amdgcn_readfirstlane(cls_list[1 + c0 + li]);
+                int ilo, cnt;
+                (void)prepare(a, k < nmine ? ((gi + k * G) << BSH) + (lane & (BAND - 1)) : nb, ilo, cnt);
+                cnt = min(cnt, 255);
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, false));   // row_shr:1, 2: the max of a band
+                cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, false));   // of 4 lanes ends in its last lane
+                if ((lane & (BAND - 1)) == BAND - 1 && k < nmine) bcnt[li * nmine + k] = (unsigned char)cnt;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(&hist[bcnt[e]], 1);
+            __syncthreads();
+            if (wave == 0) {   // hist[c] <- number of bands LONGER than c (their start in the descending order); 4 lengths per lane
+                const int cc = 255 - 4 * lane;                    // this lane's lengths cc, cc - 1, cc - 2, cc - 3 (descending)
+                const int h0 = hist[cc], h1 = hist[cc - 1], h2 = hist[cc - 2], h3 = hist[cc - 3];
+                int run = h0 + h1 + h2 + h3, incl = run;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int up = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += up;
+                }
+                const int base = incl - run;
+                hist[cc] = base;
+                hist[cc - 1] = base + h0;
+                hist[cc - 2] = base + h0 + h1;
+                hist[cc - 3] = base + h0 + h1 + h2;
+            }
+            __syncthreads();
+            // (bands no ray of which meets the unit sort last and are still walked -- zero rows: their rays' sums must be stored)
+            for (int e = threadIdx.x; e < E; e += blockDim.x) order[atomicAdd(&hist[bcnt[e]], 1)] = (unsigned short)e;
+            __syncthreads();
+        }
+        const int ntask = SORTED ? (E + PER - 1) / PER : nch * nbk;
         for (;;) {
             int m = 0;
             if (lane == 0) m = atomicAdd(next_task, 1);
             m = __builtin_amdgcn_readfirstlane(m);
-            if (m >= ntask) break;
-            const int idx = PER * m + sub;
-            const int e = order[min(idx, nlive - 1)];
-            const int a = cls_list[1 + (e >> 6)];
-            const int slot = idx < nlive ? ((e & 63) << BSH) + (kin & (BAND - 1)) : nb;   // (a task's missing bands: dead slots)
+            int a, slot;
+            if constexpr (SORTED) {
+                if (m >= ntask) break;
+                const int idx = PER * m + sub;
+                const int e = order[min(idx, E - 1)];
+                const int li = e / nmine, k = e - li * nmine;
+                a = cls_list[1 + c0 + li];
+                slot = idx < E ? ((gi + k * G) << BSH) + kin : nb;   // (a last task's missing bands: slots past the span, dead)
+            } else {
+                m = m * G + gi;
+                if (m >= ntask) break;
+                const int bi = m / ncls, ai = m - bi * ncls, blk = nbk - 1 - bi;
+                a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
+                slot = lane < 32 ? blk * 32 + lane : nb - 32 * (blk + 1) + (lane - 32);
+            }
             const BilinRay q = setup(a, slot);
             if (mirror) walk(q, std::true_type{}); else walk(q, std::false_type{});
         }
-        return;
-    }
-    // (angle, 64-slot block) tasks of this class, handed out through an LDS counter, the innermost blocks (longest rays) first;
-    // a wave takes two MIRRORED 32-slot runs of the slot range (equal chords: one trip count serves both)
-    const int ntask = ncls * nbk;
-    for (;;) {
-        int m = 0;
-        if (lane == 0) m = atomicAdd(next_task, 1);
-        m = __builtin_amdgcn_readfirstlane(m) * G + gi;
-        if (m >= ntask) break;
-        const int bi = m / ncls, ai = m - bi * ncls;
-        const int a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]), blk = nbk - 1 - bi;
-        const int slot = lane < 32 ? blk * 32 + lane : nb - 32 * (blk + 1) + (lane - 32);
-        const BilinRay q = setup(a, slot);
-        if (mirror) walk(q, std::true_type{}); else walk(q, std::false_type{});
     }
 }
 
@@ -825,11 +832,11 @@ __global__ __launch_bounds__(256) void rotate_bwd_exact_bilin_kernel(const float
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------
-// behind the image: transform rows, class list + task counter, and (tiles of four slices) the band lengths [A][<= 16], the
-// counting sort's 256 offsets and the sorted (angle, band) entries (sized for 4-slot bands)
+// behind the image: transform rows, class list + task counter, and the band lists of one chunk of angles (lengths of <= 2048
+// bands, the counting sort's 256 offsets, the sorted band numbers)
 static size_t bilin_extra_bytes(int A)
 {
-    return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16 + ((size_t)A * 64 + 4) + 256 * sizeof(int) + (size_t)A * 64 * sizeof(short);
+    return (size_t)A * 8 * sizeof(float) + ((size_t)A + 2) * sizeof(int) + 16 + 2048 + 256 * sizeof(int) + 2048 * sizeof(short);
 }
 static size_t bilin_img_bytes(int h, int w, bool tiled, int ns) { return (bilin_lds_cells(h, w, tiled, ns) * 4 * ns + 15) & ~(size_t)15; }
 
@@ -857,12 +864,14 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     int G = std::max(1, 256 / (2 * units));
     G = std::min(G, std::max(1, tasks / 8));
     if (knob(kKnobBw) > 0) G = knob(kKnobBw);
-    if (TILED && NS == 4) G = 1;     // the sorted band tasks are dealt by ONE workgroup per (tile, class)
     // >= 8 waves: a workgroup's fill is shared by its waves, and two waves per SIMD issue LDS reads and waits under each other's
     // vector instructions (tools/sweep_bilin.py, B = 50 x 128 x 128 x 20 angles, G = 5: 27.1 / 24.3 / 22.1 / 21.8 us at 4 / 6 / 8 / 16)
     int waves = std::min(16, std::max(8, ceil_div(tasks, 2 * G)));
     if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
     const bool padded = g.px >= 1 && g.py >= 1;
+    // length-sorted band tasks from about two (angle, 64-slot block) tasks per wave on (the classes hold about half the angles each)
+    bool sorted = (long long)g.A * (nb / 64) >= 4ll * waves * G;
+    if (knob(kKnobBsort) >= 0) sorted = knob(kKnobBsort) != 0;
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_bilin_kernel", abs_ok);   // the all-zero block sits at LDS address 0
@@ -872,7 +881,8 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
         CTPVAE_LAUNCH_CHECK("rotate_fwd_bilin_kernel");
         return CTPVAE_OK;
     };
-    return padded ? launch(rotate_fwd_bilin_kernel<NS, TILED, true>) : launch(rotate_fwd_bilin_kernel<NS, TILED, false>);
+    if (sorted) return padded ? launch(rotate_fwd_bilin_kernel<NS, TILED, true, true>) : launch(rotate_fwd_bilin_kernel<NS, TILED, false, true>);
+    return padded ? launch(rotate_fwd_bilin_kernel<NS, TILED, true, false>) : launch(rotate_fwd_bilin_kernel<NS, TILED, false, false>);
 }
 
 // slices per LDS cell: as many as fit beside the transform copy (every one shares the sample's index instructions)
@@ -881,7 +891,6 @@ static int bilin_fwd_ns(int S, int h, int w, bool tiled, int A)
     int ns = S >= 3 ? 4 : (S == 2 ? 2 : 1);
     if (knob(kKnobBns) == 1 || knob(kKnobBns) == 2 || knob(kKnobBns) == 4) ns = knob(kKnobBns);
     while (ns > 1 && bilin_img_bytes(h, w, tiled, ns) + bilin_extra_bytes(A) > (size_t)kMaxLdsBytes) ns >>= 1;
-    if (tiled && ns == 4 && A > 1023) ns = 2;    // (the band entries hold the angle's index in 10 bits)
     return ns;
 }
 

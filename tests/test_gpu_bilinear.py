@@ -319,14 +319,20 @@ def test_bilinear_dispatch_rows_angle_subsets_and_autograd(oracle, H):
 
 
 def test_bilinear_very_many_angles_fall_back_correctly(oracle):
-    """The bilinear kernels keep their angles' transform rows and task lists in LDS: a call with thousands of angles does not
-    fit and takes round 1's kernels (whole slices) / the global-memory kernel (tiled geometries) -- same sums, bit for bit."""
+    """The bilinear kernels keep their angles' transform rows and class list in LDS (36 bytes per angle): a call with several
+    thousand angles does not fit and takes round 1's kernels (whole slices) / reports "not tiled" (tile geometries: the
+    global-memory kernel) -- same sums, bit for bit."""
     d = dev()
     rng = np.random.default_rng(9)
-    for H, W, A in ((40, 40, 2500), (300, 200, 2000)):
-        theta = rng.uniform(0, np.pi, A)
+    A = 4300
+    theta = rng.uniform(0, np.pi, A)
+    for H, W, force in ((40, 40, False), (64, 64, True)):
         img = rng.random((1, H, W)).astype(np.float32)
         geom = oracle.Geometry(H, W, True)
-        plan = RotatePlan(theta, H, W, True, d, interp="bilinear")
-        assert not plan.tiled
-        np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))), oracle.rotate_fwd(img, geom, oT(oracle, theta, plan), 1))
+        with _lib.tuned("TILED_FORCE", 1 if force else -1):
+            plan = RotatePlan(theta, H, W, True, d, interp="bilinear")
+            assert not plan.tiled
+            got = to_np(plan.forward(torch.from_numpy(img).to(d)))
+        np.testing.assert_array_equal(got, oracle.rotate_fwd(img, geom, oT(oracle, theta, plan), 1))
+    with _lib.tuned("TILED_FORCE", 1):          # ... while a few hundred angles are tiled
+        assert RotatePlan(theta[:300], 64, 64, True, d, interp="bilinear").tiled
