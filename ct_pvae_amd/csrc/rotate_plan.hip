@@ -343,14 +343,24 @@ __global__ __launch_bounds__(64) void rotate_class_list_kernel(int A, FwdLayout 
 // wave takes the (angle, bin block) tasks of its class round-robin.  A task streams its index groups four loads deep,
 // gathers the previous group's eight taps while the next indices are in flight, and adds in row order.
 #ifdef CTPVAE_TUNE_STAMPS
+// timing builds (tools/stamp_rounds.hip): per wave {s_memtime at start / fill issued / barrier passed / end, s_memrealtime (100 MHz)
+// at start / end, HW_ID | XCC_ID << 32}
 __device__ long long g_pstamps[8 * 65536];
+static int g_pshape[8];   // host: the last planned forward's {units, workgroups per unit, waves, slices per unit, affine}
 #define CTPVAE_PSTAMP(slot)                                                                                  \
     do {                                                                                                     \
         long long t_;                                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
-        if ((threadIdx.x & 63) == 0) g_pstamps[8 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + (slot)] = t_; \
-        if ((threadIdx.x & 63) == 0 && ((slot) == 0 || (slot) == 3))                                         \
-            g_pstamps[8 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
+        const size_t w_ = (size_t)q * (blockDim.x >> 6) + (threadIdx.x >> 6);   /* q: the piece */ \
+        if ((threadIdx.x & 63) == 0 && w_ < 65536) {                                                         \
+            g_pstamps[8 * w_ + (slot)] = t_;                                                                 \
+            if ((slot) == 0 || (slot) == 3) g_pstamps[8 * w_ + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
+            if ((slot) == 0) {                                                                               \
+                unsigned hw_, xcc_;                                                                          \
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+                g_pstamps[8 * w_ + 6] = (long long)hw_ | ((long long)xcc_ << 32);                            \
+            }                                                                                                \
+        }                                                                                                    \
     } while (0)
 #else
 #define CTPVAE_PSTAMP(slot)
@@ -373,7 +383,8 @@ template <int NS, bool EPI, bool SEL>
 __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *__restrict__ img, PlanGeom g, FwdLayout L,
                                                                   const char *__restrict__ plan, int wgs_per_slice,
                                                                   int g_S, float *__restrict__ sino, LogLikEpilogue epi,
-                                                                  const int *__restrict__ sel, int n_sel, int affine)
+                                                                  const int *__restrict__ sel, int n_sel, int affine,
+                                                                  int units1, int wgs2)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -384,23 +395,39 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     // launch (17 MB of u16 taps at 180 angles: streamed into all eight L2s otherwise), and every unit is staged through all of
     // them (3.3 MB x 8 at B = 50) -- the smaller stream by far at many angles.
     const int units = (g_S + NS - 1) / NS;
-    int u, wg;
+    // A launch is a list of PIECES (unit, class, task group), one workgroup each, dispatched in order: units1 * wgs_per_slice
+    // pieces of the first units1 units, then wgs2 pieces of every later unit (round 5: a coarse cut for whole rounds of
+    // workgroups, a finer one behind it so that the last, partial round spreads over all CUs; units1 == units otherwise).
+    // Inside either part pieces are numbered in octets of units, as above.
+    auto piece_of = [&](int q, int &u_, int &wg_, int &wgs_) {
+        int u0 = 0, nu = units1;
+        wgs_ = wgs_per_slice;
+        if (q >= units1 * wgs_per_slice) {
+            q -= units1 * wgs_per_slice;
+            u0 = units1;
+            nu = units - units1;
+            wgs_ = wgs2;
+        }
+        const int per8 = 8 * wgs_, octet = q / per8, rem = q - octet * per8;
+        if ((octet + 1) * 8 <= nu) {
+            wg_ = rem >> 3;
+            u_ = u0 + octet * 8 + (rem & 7);
+        } else {   // the last, partial octet is laid out unit-major
+            u_ = u0 + octet * 8 + rem / wgs_;
+            wg_ = rem % wgs_;
+        }
+    };
+    int u, wg, wgs = wgs_per_slice;
+    [[maybe_unused]] const int q = blockIdx.x;
     if (affine) {
         u = blockIdx.x / wgs_per_slice;
         wg = blockIdx.x - u * wgs_per_slice;
     } else {
-        const int per8 = 8 * wgs_per_slice, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
-        if ((octet + 1) * 8 <= units) {
-            wg = rem >> 3;
-            u = octet * 8 + (rem & 7);
-        } else {   // the last, partial octet is laid out unit-major
-            u = octet * 8 + rem / wgs_per_slice;
-            wg = rem % wgs_per_slice;
-        }
+        piece_of(q, u, wg, wgs);
     }
     const int s = u * NS;
     const bool has2 = NS == 2 && s + 1 < g_S;     // an odd batch ends with a half-empty pair (slice s staged twice)
-    const int c = wg & 1, gi = wg >> 1, G = wgs_per_slice >> 1;
+    const int c = wg & 1, gi = wg >> 1, G = wgs >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const float *im = img + (size_t)s * g.H * g.W;
     CTPVAE_PSTAMP(0);
@@ -1183,14 +1210,72 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     const int stage_waves = (int)std::min<size_t>(16, ceil_div((int)(shmem / 1024), 8));
     int waves = std::min(16, std::max(stage_waves, (T + 2 * G - 1) / (2 * G)));
     if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
-    const int wgs_per_slice = 2 * G;
+    int wgs_per_slice = 2 * G;
     CTPVAE_REQUIRE((long long)units * wgs_per_slice < (1ll << 31), "rotate_fwd_planned: too many slices");
+#ifdef CTPVAE_TUNE_STAMPS
+    g_pshape[0] = units, g_pshape[1] = wgs_per_slice, g_pshape[2] = waves, g_pshape[3] = ns, g_pshape[4] = affine;
+#endif
+    // Launches of more than one round of workgroups (round 5; tools/stamp_rounds.hip + tools/analyse_rounds.py, profiles/r05_rounds.txt):
+    // a CU's next workgroup starts 0.3-0.5 us after its previous one ended -- the dispatcher is not what a later round waits
+    // for -- and then spends 3.7-4.0 us before its unit is staged, as every workgroup does; what a launch of r.x rounds loses is
+    // QUANTISATION: 300 equal pieces on 256 CUs take two rounds for 1.17 rounds of work (B = 300 x 20 angles: 25 us against
+    // 14.5 at B = 256).  So the piece list gets TWO PARTS: G1 task groups per class for the first units1 units -- whole rounds
+    // of coarse pieces: one fill per unit and class, waves evenly loaded -- and G2 > G1 for the rest, so that the last round's
+    // work spreads over all CUs.  (G1, G2, units1) by list scheduling of the pieces, in order, on 256 CUs: a piece costs ~4.4 us
+    // from its CU falling free to its staged unit plus ceil(tasks / 16 waves) task rounds at ~0.19 us per row group (4.35 us at
+    // 128 x 128 with every CU busy).  A PERSISTENT form of the kernel -- 256 workgroups walking the list, the next unit's rows
+    // requested by the waves that run out of tasks first -- was built and measured: bit-equal, its hand-over no cheaper than a
+    // fresh workgroup (~3.4 us behind the slowest wave) and its task loop 5 % slower (127 registers, another schedule): removed.
+    int units1 = units, wgs2 = wgs_per_slice;
+    if (!affine && !sel_dev && (long long)units * wgs_per_slice > 256 && knob(kKnobMixG) != 0 && knob(kKnobG) <= 0) {
+        const double t_task = 0.19 * L.NG, t_fresh = 4.4;
+        const int Tc = (T + 1) / 2;     // tasks per unit and class
+        auto piece_us = [&](int Gx) { return t_fresh + std::ceil(std::ceil((double)Tc / Gx) / 16.0) * t_task; };
+        auto launch_us = [&](int G1, int G2, int u1) {   // pieces in order, each to the CU that falls free first
+            const long long Q1 = 2ll * u1 * G1, Q2 = 2ll * (units - u1) * G2;
+            const double t1 = piece_us(G1), t2 = piece_us(G2);
+            // part 1: r1 whole rounds + rem1 pieces; the CUs fall free in two groups, part 2's equal pieces go to whichever is earlier
+            const long long r1 = Q1 / 256, rem1 = Q1 % 256;
+            double t_free[2] = {r1 * t1, (r1 + 1) * t1};
+            long long n_cu[2] = {256 - rem1, rem1}, left = Q2;
+            double end = Q1 > 0 ? (rem1 ? t_free[1] : t_free[0]) : 0.0;
+            while (left > 0) {
+                const int k = n_cu[1] == 0 || t_free[0] <= t_free[1] ? 0 : 1;
+                left -= std::min(left, n_cu[k]);
+                t_free[k] += t2;
+                end = std::max(end, t_free[k]);
+            }
+            return end;
+        };
+        int G1 = G, G2 = G;
+        double best = launch_us(G, G, units);
+        const int gmax = std::min(12, std::max(1, Tc / 4));
+        for (int c1 = 1; c1 <= std::min(8, gmax); ++c1)
+            for (int c2 = c1; c2 <= gmax; ++c2)
+                for (int k = 0;; ++k) {   // first parts of (about) k whole rounds, and the whole launch
+                    const int u1 = std::min(units, (int)((256ll * k) / (2 * c1)));
+                    const double t = launch_us(c1, c2, u1);
+                    if (t < best * 0.97) best = t, G1 = c1, G2 = c2, units1 = u1;
+                    if (u1 == units) break;
+                }
+        if (units1 == units) G2 = G1;
+        if (knob(kKnobMixG2) > 0 && knob(kKnobMixU1) >= 0) G1 = G, G2 = knob(kKnobMixG2), units1 = std::min(units, knob(kKnobMixU1));
+        wgs_per_slice = 2 * G1;
+        wgs2 = 2 * G2;
+        waves = std::min(16, std::max(stage_waves, (T + 2 * G1 - 1) / (2 * G1)));
+        if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
+    }
+    const long long grid = (long long)units1 * wgs_per_slice + (long long)(units - units1) * wgs2;
+    CTPVAE_REQUIRE(grid < (1ll << 31), "rotate_fwd_planned: too many slices");
+#ifdef CTPVAE_TUNE_STAMPS
+    g_pshape[1] = wgs_per_slice, g_pshape[2] = waves, g_pshape[5] = units1, g_pshape[6] = wgs2;   // (timing builds: tools/stamp_rounds.hip)
+#endif
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
-        hipLaunchKernelGGL(kernel, dim3((unsigned)(units * wgs_per_slice)), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), shmem, (hipStream_t)stream,
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
     };

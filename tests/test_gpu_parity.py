@@ -277,6 +277,30 @@ def test_planned_equals_direct(oracle, shape, pad, A, S):
     np.testing.assert_array_equal(to_np(pa.backward(g)[:1]), oracle.rotate_bwd_tfcompat(to_np(g[:1]), geom, oTinv(oracle, theta, pa), 0))
 
 
+@pytest.mark.parametrize("A,S", [(20, 300), (20, 301), (90, 301), (7, 700)])
+def test_two_part_piece_lists_equal_one_cut(oracle, A, S):
+    """Launches of more than one round of workgroups cut their first units into coarse pieces and the rest into finer ones (round
+    5): which piece carries a ray does not touch its sum.  The library's own cut, one cut for the whole launch (knob MIXG=0) and
+    forced cuts -- part boundaries off the octets of units, a second part of one unit, an empty first part, odd batches --
+    give the same bits, and the oracle's."""
+    d = dev()
+    rng = np.random.default_rng(A + S)
+    theta = rng.uniform(-1.0, 4.0, A)
+    x = torch.from_numpy(rng.standard_normal((S, 128, 128)).astype(np.float32)).to(d)
+    plan = RotatePlan(theta, 128, 128, True, d, plan_format="u16")
+    auto = plan.forward(x)
+    with _lib.tuned("MIXG", 0):
+        one = plan.forward(x)
+    assert torch.equal(auto, one)
+    units = (S + 1) // 2
+    for g2, u1 in ((5, 128), (3, units - 1), (2, 0), (7, 13), (4, units)):
+        with _lib.tuned("NS", 2), _lib.tuned("MIXG_G2", g2), _lib.tuned("MIXG_U1", u1):
+            assert torch.equal(plan.forward(x), one), (g2, u1)
+    geom = oracle.Geometry(128, 128, True)
+    for k in (0, S // 2, S - 1):
+        np.testing.assert_array_equal(to_np(auto[k:k + 1]), oracle.rotate_fwd(to_np(x[k:k + 1]), geom, oT(oracle, theta, plan), 0))
+
+
 @pytest.mark.parametrize("shape,pad,A,S", [((128, 128), True, 20, 5), ((128, 128), True, 180, 51), ((40, 100), True, 33, 3),
                                           ((65, 31), False, 9, 1), ((2, 2), False, 2, 2), ((128, 128), True, 20, 17)])
 def test_paired_slices_equal_single_slices(oracle, shape, pad, A, S):
