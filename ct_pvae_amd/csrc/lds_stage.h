@@ -180,6 +180,66 @@ struct StagedRows {
     }
 };
 
+// A whole unit whose shape makes every index a shift: rows % 4 == 0, cols == 64 << cs, covered by NB blocks of 4 rows x 64
+// columns per wave (the host checks, and that the rows are 16-byte aligned).  `wave` must be WAVE-UNIFORM: block i of the wave is
+// pp = wave + i * nwaves -- scalar arithmetic --, a lane adds ONE offset of its own, the mirrored form is its own copy of the
+// code (no per-value selects).  ~150 instructions per wave where the general form above has ~270: the 16 waves of a workgroup
+// share 4 SIMDs, and the launch's prologue is bound by instructions issued per SIMD (tools/stamp_rounds.hip).
+// between(): called once, between the requests and the writes (work whose own loads should fly beside the rows).
+template <int NS, int NB, bool MIRROR, class F>
+__device__ __forceinline__ void stage_unit_pow2_m(float *lds, const float *const (&src)[NS], int rows, int cs, int src_stride, int pitch,
+                                                  int lane, int wave, int nwaves, F between)
+{
+    const int h = lane >> 5, k = (lane & 31) >> 3, m = lane & 7, cols = 64 << cs, nrq = rows >> 2;
+    const int lo_src = k * src_stride + (MIRROR ? -(32 * h + 4 * m) : 32 * h + 4 * m);
+    const int lo_dst = k * pitch + 32 * h + 4 * m;
+    float4 v[NB][NS];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pp = wave + i * nwaves, rq = pp >> cs, pc = pp & ((1 << cs) - 1);
+        const int so = rq < nrq ? 4 * rq * src_stride + (MIRROR ? cols - 4 - 64 * pc : 64 * pc) : (MIRROR ? cols - 4 : 0);   // (past the unit: block 0, dropped)
+#pragma unroll
+        for (int n = 0; n < NS; ++n) v[i][n] = *reinterpret_cast<const float4 *>(src[n] + so + lo_src);
+    }
+    between();
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pp = wave + i * nwaves, rq = pp >> cs, pc = pp & ((1 << cs) - 1);
+        if (rq >= nrq) continue;   // wave-uniform
+        const int cell = 4 * rq * pitch + 64 * pc + lo_dst;
+        if constexpr (NS == 1) {
+            float *d = lds + cell;
+            d[0] = MIRROR ? v[i][0].w : v[i][0].x;
+            d[1] = MIRROR ? v[i][0].z : v[i][0].y;
+            d[2] = MIRROR ? v[i][0].y : v[i][0].z;
+            d[3] = MIRROR ? v[i][0].x : v[i][0].w;
+        } else {
+            typedef float vec_t __attribute__((ext_vector_type(NS)));
+            vec_t *d = reinterpret_cast<vec_t *>(lds) + cell;
+            vec_t w0, w1, w2, w3;
+#pragma unroll
+            for (int n = 0; n < NS; ++n) {
+                w0[n] = MIRROR ? v[i][n].w : v[i][n].x;
+                w1[n] = MIRROR ? v[i][n].z : v[i][n].y;
+                w2[n] = MIRROR ? v[i][n].y : v[i][n].z;
+                w3[n] = MIRROR ? v[i][n].x : v[i][n].w;
+            }
+            d[0] = w0;
+            d[1] = w1;
+            d[2] = w2;
+            d[3] = w3;
+        }
+    }
+}
+// (mirror is wave-uniform: two copies of the code, no per-value selects)
+template <int NS, int NB, class F>
+__device__ __forceinline__ void stage_unit_pow2(float *lds, const float *const (&src)[NS], int rows, int cs, int src_stride, int pitch,
+                                                bool mirror, int lane, int wave, int nwaves, F between)
+{
+    if (mirror) stage_unit_pow2_m<NS, NB, true>(lds, src, rows, cs, src_stride, pitch, lane, wave, nwaves, between);
+    else stage_unit_pow2_m<NS, NB, false>(lds, src, rows, cs, src_stride, pitch, lane, wave, nwaves, between);
+}
+
 template <int NS>
 __device__ __forceinline__ void stage_rows_interleaved(float *lds, const float *const (&src)[NS], int rows, int cols,
                                                        int src_stride, int pitch, bool mirror, int lane, int wave, int nwaves)

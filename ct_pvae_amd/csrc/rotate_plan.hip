@@ -66,7 +66,7 @@ static FwdLayout fwd_layout(const PlanGeom &g)
     L.zero = g.H * L.pitch;
     L.off_cls = 0;
     L.off_clist = (long long)g.A * 4;                                     // two lists of (count, angles...)
-    L.off_first = (L.off_clist + 2ll * (g.A + 1) * 4 + 255) / 256 * 256;   // first live canvas row of every ray
+    L.off_first = (L.off_clist + 2ll * (g.A + 1) * 4 + 8 + 255) / 256 * 256;   // (+ the classes' division words: fwd_magic) first live canvas row of every ray
     L.off_rng = (L.off_first + (long long)g.A * L.PWpad * 4 + 255) / 256 * 256;
     L.off_idx = (L.off_rng + (long long)g.A * L.nJB * 8 + 255) / 256 * 256;
     L.bytes = L.off_idx + (long long)g.A * L.Galloc * L.PWpad * 16;
@@ -320,7 +320,15 @@ __device__ __forceinline__ void gather8(const float *lds, const uint4 q, float (
     v[7] = lds_at(lds, a7);
 }
 
-// clist[c] = (count, the angles of class c in ascending order): the planned kernels' task lists
+// x / d for the small operands of the launch's index arithmetic as ONE s_mul_hi_u32: magic = 2^32 / d + 1 is exact while
+// x * d < 2^32 (the callers check).  A 32-bit division costs a wave ~30 instructions, a workgroup's prologue had three of them in
+// front of its first loads, and that prologue is bound by the instructions its 16 waves issue.
+// (d = 1 has no 32-bit word -- and needs none: word 0 = "x itself"; d = 0 is never divided by)
+__host__ __device__ inline unsigned div_magic(unsigned d) { return d > 1 ? (unsigned)((1ull << 32) / d) + 1u : 0u; }
+__host__ __device__ inline unsigned div_by_magic(unsigned x, unsigned magic) { return magic ? (unsigned)(((unsigned long long)x * magic) >> 32) : x; }
+
+// clist[c] = (count, the angles of class c in ascending order): the planned kernels' task lists; behind the two lists the
+// division words of the two counts (div_magic)
 __global__ __launch_bounds__(64) void rotate_class_list_kernel(int A, FwdLayout L, char *__restrict__ plan)
 {
     const int *cls = reinterpret_cast<const int *>(plan + L.off_cls);
@@ -335,7 +343,10 @@ __global__ __launch_bounds__(64) void rotate_class_list_kernel(int A, FwdLayout 
             if (in) list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
             n += __popcll(m);
         }
-        if (lane == 0) list[0] = n;
+        if (lane == 0) {
+            list[0] = n;
+            reinterpret_cast<unsigned *>(clist + 2 * (A + 1))[c] = div_magic((unsigned)n);
+        }
     }
 }
 
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
                                                                   const char *__restrict__ plan, int wgs_per_slice,
                                                                   int g_S, float *__restrict__ sino, LogLikEpilogue epi,
                                                                   const int *__restrict__ sel, int n_sel, int affine,
-                                                                  int units1, int wgs2)
+                                                                  int units1, int wgs2, int stage_cs, unsigned inv_wgs1, unsigned inv_wgs2, int small_div)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -401,20 +412,24 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     // Inside either part pieces are numbered in octets of units, as above.
     auto piece_of = [&](int q, int &u_, int &wg_, int &wgs_) {
         int u0 = 0, nu = units1;
+        unsigned inv = inv_wgs1;
         wgs_ = wgs_per_slice;
         if (q >= units1 * wgs_per_slice) {
             q -= units1 * wgs_per_slice;
             u0 = units1;
             nu = units - units1;
             wgs_ = wgs2;
+            inv = inv_wgs2;
         }
-        const int per8 = 8 * wgs_, octet = q / per8, rem = q - octet * per8;
+        // q / (8 wgs) = (q / 8) / wgs, by multiplication (the host checked the range: small_div)
+        const int octet = small_div ? (int)div_by_magic((unsigned)q >> 3, inv) : q / (8 * wgs_), rem = q - octet * 8 * wgs_;
         if ((octet + 1) * 8 <= nu) {
             wg_ = rem >> 3;
             u_ = u0 + octet * 8 + (rem & 7);
         } else {   // the last, partial octet is laid out unit-major
-            u_ = u0 + octet * 8 + rem / wgs_;
-            wg_ = rem % wgs_;
+            const int ru = small_div ? (int)div_by_magic((unsigned)rem, inv) : rem / wgs_;
+            u_ = u0 + octet * 8 + ru;
+            wg_ = rem - ru * wgs_;
         }
     };
     int u, wg, wgs = wgs_per_slice;
@@ -463,6 +478,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     } else {
         ncls = clist[0];
     }
+    [[maybe_unused]] const unsigned inv_ncls = reinterpret_cast<const unsigned *>(plan + L.off_clist + 2ll * (g.A + 1) * 4)[c];
     // a workgroup's w-th task: round-robin over the class's (bin block, angle) list, or -- affine -- its own angles' blocks
     const int n_gi = affine ? max(0, (ncls - gi + G - 1) / G) : 0;
     const int ntask = affine ? n_gi * L.nJB : ncls * L.nJB;
@@ -495,7 +511,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
                 jb = m / n_gi;
                 ai = gi + G * (m - jb * n_gi);
             } else {
-                jb = m / ncls;
+                jb = !SEL && small_div ? (int)div_by_magic((unsigned)m, inv_ncls) : m / ncls;
                 ai = m - jb * ncls;
             }
             if constexpr (SEL) {
@@ -540,7 +556,13 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     if (threadIdx.x == 0) *next_task = nwaves;
 
     // Stage the slice(s): 16-byte loads, conflict-free ds_write_b32 (see stage_rows_v4).
-    if constexpr (NS == 1) {
+    if (stage_cs >= 0) {   // (the host's check: the unit's shape makes the lean form below possible)
+        const float *srcs[NS];
+        srcs[0] = im;
+        if constexpr (NS == 2) srcs[1] = im + (has2 ? (size_t)g.H * g.W : 0);
+        stage_unit_pow2<NS, 8 / NS>(lds, srcs, g.H, stage_cs, g.W, L.pitch, c == 0 && !L.skew0, lane,
+                                    __builtin_amdgcn_readfirstlane(wave), nwaves, [] {});   // (measured: the first task's set-up between requests and writes is no faster)
+    } else if constexpr (NS == 1) {
         stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0 && !L.skew0, lane, wave, nwaves);
     } else {   // both slices of the pair in one load round trip, written as float2
         const float *srcs[2] = {im, im + (has2 ? (size_t)g.H * g.W : 0)};
@@ -1274,8 +1296,16 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
+        // divisions by multiplication (div_magic): piece numbers / 8 by the pieces per unit, task numbers by a class's angle count
+        const int small_div = grid / 8 * 64 < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) ? 1 : 0;
+        // the lean staging form: W = 64, 128 or 256 columns, rows in fours, one batch of loads per lane, 16-byte aligned rows
+        int stage_cs = -1;
+        if ((H & 3) == 0 && (W == 64 || W == 128 || W == 256) && (H >> 2) * (W >> 6) <= (8 / ns) * waves &&
+            (reinterpret_cast<uintptr_t>(img_dev) & 15) == 0 && knob(kKnobLeanStage) != 0)
+            stage_cs = W == 64 ? 0 : (W == 128 ? 1 : 2);
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2);
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2, stage_cs,
+                           div_magic((unsigned)wgs_per_slice), div_magic((unsigned)wgs2), small_div);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
     };
