@@ -62,15 +62,6 @@ __device__ __forceinline__ void stage_rows_scalar(float *lds, const float *__res
         lds[(r * pitch + c) * es] = src[(size_t)r * src_stride + (mirror ? cols - 1 - c : c)];
     }
 }
-__device__ __forceinline__ void stage_rows(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
-                                           int pitch, bool mirror, int lane, int wave, int nwaves, int es = 1)
-{
-    if ((cols & 3) == 0 && (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
-        stage_rows_v4(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves, es);
-    else
-        stage_rows_scalar(lds, src, rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64, es);
-}
-
 // NS slices interleaved per LDS pixel (pixel (r, c) = NS consecutive floats, one per slice): the NS float4 loads of a
 // 4-pixel unit are issued together -- one load round trip for all slices, not one per slice -- and written as four
 // NS-wide vectors (ds_write_b64 / _b128), a quarter of the LDS instructions of per-slice dword writes.
@@ -240,6 +231,26 @@ __device__ __forceinline__ void stage_unit_pow2(float *lds, const float *const (
     else stage_unit_pow2_m<NS, NB, false>(lds, src, rows, cs, src_stride, pitch, lane, wave, nwaves, between);
 }
 
+// log2 of a unit's 64-column blocks per row if the lean form serves it (wave-uniform), else -1
+__device__ __forceinline__ int unit_pow2_cs(int rows, int cols, int src_stride, int nwaves, int nb)
+{
+#ifdef CTPVAE_TUNE_NO_LEAN_STAGE
+    return -1;
+#else
+    if ((rows & 3) != 0 || (src_stride & 3) != 0 || (cols != 64 && cols != 128 && cols != 256)) return -1;
+    const int cs = cols == 64 ? 0 : (cols == 128 ? 1 : 2);
+    return ((rows >> 2) << cs) <= nb * nwaves ? cs : -1;
+#endif
+}
+__device__ __forceinline__ void stage_rows(float *lds, const float *__restrict__ src, int rows, int cols, int src_stride,
+                                           int pitch, bool mirror, int lane, int wave, int nwaves, int es = 1)
+{
+    if ((cols & 3) == 0 && (src_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0)
+        stage_rows_v4(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves, es);
+    else
+        stage_rows_scalar(lds, src, rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64, es);
+}
+
 template <int NS>
 __device__ __forceinline__ void stage_rows_interleaved(float *lds, const float *const (&src)[NS], int rows, int cols,
                                                        int src_stride, int pitch, bool mirror, int lane, int wave, int nwaves)
@@ -253,6 +264,27 @@ __device__ __forceinline__ void stage_rows_interleaved(float *lds, const float *
 #pragma unroll
         for (int n = 0; n < NS; ++n)
             stage_rows_scalar(lds + n, src[n], rows, cols, src_stride, pitch, mirror, wave * 64 + lane, nwaves * 64, NS);
+    }
+}
+
+// A UNIT (a slice, a slice pair / quad, a tile) into LDS: the lean form where its shape allows (64 / 128 / 256 columns, rows in
+// fours, one batch of loads per lane, aligned rows), the general forms above otherwise.  For the forward kernels, whose units are
+// square slices and 64-column tiles; kernels that stage detector rows (184 or 728 bins) call the general forms directly -- with
+// the lean form compiled in beside them the planned backward ran 4 % slower (a longer prologue, another register allocation).
+template <int NS>
+__device__ __forceinline__ void stage_unit(float *lds, const float *const (&src)[NS], int rows, int cols, int src_stride, int pitch,
+                                           bool mirror, int lane, int wave, int nwaves)
+{
+    bool aligned = (reinterpret_cast<uintptr_t>(lds) & (4 * NS - 1)) == 0;
+#pragma unroll
+    for (int n = 0; n < NS; ++n) aligned = aligned && (reinterpret_cast<uintptr_t>(src[n]) & 15) == 0;
+    const int cs = aligned ? unit_pow2_cs(rows, cols, src_stride, nwaves, 8 / NS) : -1;
+    if (cs >= 0) {
+        stage_unit_pow2<NS, 8 / NS>(lds, src, rows, cs, src_stride, pitch, mirror, lane, __builtin_amdgcn_readfirstlane(wave), nwaves, [] {});
+    } else if constexpr (NS == 1) {
+        stage_rows(lds, src[0], rows, cols, src_stride, pitch, mirror, lane, wave, nwaves);
+    } else {
+        stage_rows_interleaved<NS>(lds, src, rows, cols, src_stride, pitch, mirror, lane, wave, nwaves);
     }
 }
 

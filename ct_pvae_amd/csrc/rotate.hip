@@ -1777,13 +1777,11 @@ __global__ __launch_bounds__(1024) void rotate_fwd_tile_compact_kernel(const flo
     cplan_zero_border<NS>(image, h, w, L.pitch);
     float *core = image + (size_t)(1 + L.pitch) * NS;
 #ifndef CTPVAE_TUNE_TILE_NOFILL   // (timing builds only: the walks over whatever LDS holds)
-    if constexpr (NS == 1) {
-        stage_rows(core, im, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
-    } else {
+    {
         const float *srcs[NS];
 #pragma unroll
         for (int n = 0; n < NS; ++n) srcs[n] = im + (size_t)(min(s + n, gfull.S - 1) - s) * gfull.H * gfull.W;
-        stage_rows_interleaved<NS>(core, srcs, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
+        stage_unit<NS>(core, srcs, h, w, gfull.W, L.pitch, cls == 0, lane, wave, nwaves);
     }
 #endif
     __syncthreads();

@@ -91,6 +91,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         vec_t *cells = reinterpret_cast<vec_t *>(lds);
         // LDS column of canvas column X0 + c (c = -1 .. w), relative to the row's first cell
         auto col_of = [&](int c) { return mirror ? w - 1 - c : c; };
+        // (the general forms: with the lean form of stage_unit the headline shape measured 1-2 % slower -- this kernel is bound
+        // by its walks, and its register allocation is the one thing the prologue can still spoil)
         if constexpr (NS == 1)
             stage_rows(lds + 2 * pitch, srcs[0], h, w, gfull.W, pitch, mirror, lane, wave, nwaves);
         else

@@ -248,11 +248,11 @@ __global__ __launch_bounds__(1024) void rotate_fwd_compact_kernel(const float *_
     cplan_init_lut<NS>(lds, L.pitch);
     cplan_zero_border<NS>(image, g.H, g.W, L.pitch);
     float *core = image + (size_t)(1 + L.pitch) * NS;   // cell of (iy = 0, column 0)
-    if constexpr (NS == 1) {
-        stage_rows(core, im, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
-    } else {   // both slices of the pair in one load round trip, written as float2
-        const float *srcs[2] = {im, im + (has2 ? (size_t)g.H * g.W : 0)};
-        stage_rows_interleaved<2>(core, srcs, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
+    {   // (both slices of a pair in one load round trip, written as float2; 64 / 128 / 256-column slices in the lean form)
+        const float *srcs[NS];
+        srcs[0] = im;
+        if constexpr (NS == 2) srcs[1] = im + (has2 ? (size_t)g.H * g.W : 0);
+        stage_unit<NS>(core, srcs, g.H, g.W, g.W, L.pitch, c == 0, lane, wave, nwaves);
     }
     __syncthreads();
 

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
                                                                   const char *__restrict__ plan, int wgs_per_slice,
                                                                   int g_S, float *__restrict__ sino, LogLikEpilogue epi,
                                                                   const int *__restrict__ sel, int n_sel, int affine,
-                                                                  int units1, int wgs2, int stage_cs, unsigned inv_wgs1, unsigned inv_wgs2, int small_div)
+                                                                  int units1, int wgs2, unsigned inv_wgs1, unsigned inv_wgs2, int small_div)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -556,17 +556,11 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     if (threadIdx.x == 0) *next_task = nwaves;
 
     // Stage the slice(s): 16-byte loads, conflict-free ds_write_b32 (see stage_rows_v4).
-    if (stage_cs >= 0) {   // (the host's check: the unit's shape makes the lean form below possible)
+    {   // (a pair in one load round trip, written as float2; units of 64 / 128 / 256 columns in the lean form: stage_unit)
         const float *srcs[NS];
         srcs[0] = im;
         if constexpr (NS == 2) srcs[1] = im + (has2 ? (size_t)g.H * g.W : 0);
-        stage_unit_pow2<NS, 8 / NS>(lds, srcs, g.H, stage_cs, g.W, L.pitch, c == 0 && !L.skew0, lane,
-                                    __builtin_amdgcn_readfirstlane(wave), nwaves, [] {});   // (measured: the first task's set-up between requests and writes is no faster)
-    } else if constexpr (NS == 1) {
-        stage_rows(lds, im, g.H, g.W, g.W, L.pitch, c == 0 && !L.skew0, lane, wave, nwaves);
-    } else {   // both slices of the pair in one load round trip, written as float2
-        const float *srcs[2] = {im, im + (has2 ? (size_t)g.H * g.W : 0)};
-        stage_rows_interleaved<2>(lds, srcs, g.H, g.W, g.W, L.pitch, c == 0 && !L.skew0, lane, wave, nwaves);
+        stage_unit<NS>(lds, srcs, g.H, g.W, g.W, L.pitch, c == 0 && !L.skew0, lane, wave, nwaves);
     }
     if (threadIdx.x < NS) lds[L.zero * NS + threadIdx.x] = 0.0f;
     CTPVAE_PSTAMP(1);
@@ -1298,13 +1292,8 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         // divisions by multiplication (div_magic): piece numbers / 8 by the pieces per unit, task numbers by a class's angle count
         const int small_div = grid / 8 * 64 < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) ? 1 : 0;
-        // the lean staging form: W = 64, 128 or 256 columns, rows in fours, one batch of loads per lane, 16-byte aligned rows
-        int stage_cs = -1;
-        if ((H & 3) == 0 && (W == 64 || W == 128 || W == 256) && (H >> 2) * (W >> 6) <= (8 / ns) * waves &&
-            (reinterpret_cast<uintptr_t>(img_dev) & 15) == 0 && knob(kKnobLeanStage) != 0)
-            stage_cs = W == 64 ? 0 : (W == 128 ? 1 : 2);
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), shmem, (hipStream_t)stream,
-                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2, stage_cs,
+                           img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2,
                            div_magic((unsigned)wgs_per_slice), div_magic((unsigned)wgs2), small_div);
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
