@@ -395,7 +395,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
     // sorted against 21.8; B = 100 x 20: 36.8 against 35.2).  Then: (angle, 64-slot block) tasks over all the class's angles,
     // every G-th to this workgroup, two MIRRORED 32-slot runs per wave (equal chords: one trip count serves both), the
     // innermost blocks first.
-    constexpr int BSH = 2, BAND = 1 << BSH, PER = 64 / BAND;
+#ifdef CTPVAE_TUNE_BILIN_BSH
+    constexpr int BSH = CTPVAE_TUNE_BILIN_BSH;   // timing builds: 8- or 16-slot bands
+#else
+    constexpr int BSH = 2;
+#endif
+    constexpr int BAND = 1 << BSH, PER = 64 / BAND;
     const int nbk = nb >> 6, nbands = nb >> BSH;
     __syncthreads();                                               // the image, the transform rows and the class list are staged
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
@@ -435,6 +440,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
                 cnt = min(cnt, 255);
                 cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x111, 0xf, 0xf, false));   // row_shr:1, 2: the max of a band
                 cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x112, 0xf, 0xf, false));   // of 4 lanes ends in its last lane
+                if constexpr (BSH >= 3) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x114, 0xf, 0xf, false));
+                if constexpr (BSH >= 4) cnt = max(cnt, __builtin_amdgcn_update_dpp(0, cnt, 0x118, 0xf, 0xf, false));
                 if ((lane & (BAND - 1)) == BAND - 1 && k < nmine) bcnt[li * nmine + k] = (unsigned char)cnt;
             }
             __syncthreads();
