@@ -724,7 +724,8 @@ __device__ __forceinline__ void gather8(const float *lds, unsigned w0, unsigned 
 template <int PPT, int MAXT, int NS, int DUP = 1, bool SHORT = false>
 __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *__restrict__ gsino, PlanGeom g, BwdLayout L,
                                                                  const uint4 *__restrict__ idx, int tiles_y, int g_S,
-                                                                 SliceScale scale, float *__restrict__ gimg)
+                                                                 SliceScale scale, float *__restrict__ gimg, unsigned inv_tiles,
+                                                                 unsigned inv_nxb)
 {
     typedef typename SliceVec<NS>::type vec_t;
     constexpr int kChunk = kBwdChunk / NS;
@@ -736,19 +737,22 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     // on one XCD so that its cotangent rows are fetched into one L2 -- block = (u / 8) * 8 * tiles + tile * 8 + u % 8.
     int u, tile;
     {
-        const int per8 = 8 * tiles, octet = blockIdx.x / per8, rem = blockIdx.x - octet * per8;
+        // (divisions by multiplication, div_magic: inv_tiles == 0 -- the host's "operands too large" -- divides)
+        const int per8 = 8 * tiles;
+        const int octet = inv_tiles ? (int)div_by_magic(blockIdx.x >> 3, inv_tiles) : (int)blockIdx.x / per8, rem = blockIdx.x - octet * per8;
         if ((octet + 1) * 8 <= units) {
             tile = rem >> 3;
             u = octet * 8 + (rem & 7);
         } else {   // the last, partial octet is laid out unit-major
-            u = octet * 8 + rem / tiles;
-            tile = rem - (rem / tiles) * tiles;
+            const int ru = inv_tiles ? (int)div_by_magic((unsigned)rem, inv_tiles) : rem / tiles;
+            u = octet * 8 + ru;
+            tile = rem - ru * tiles;
         }
     }
     const int s = u * NS;
     const bool has2 = NS == 2 && s + 1 < g_S;   // an odd batch ends with a half-empty pair (slice s staged twice)
     const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
-    const int xb = tile % L.nXB, ty = tile / L.nXB;
+    const int ty = inv_tiles ? (int)div_by_magic((unsigned)tile, inv_nxb) : tile / L.nXB, xb = tile - ty * L.nXB;
     const float *gs = gsino + (size_t)s * g.A * g.PW;
     const int xcol = xb * 64 + lane;
     const int y0 = ty * (nwaves * PPT) + wave;   // this wave's rows: y0, y0 + nwaves, ...
@@ -1399,12 +1403,16 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     const int tiles_y = ceil_div(H, rows_per_wg);
     const long long nblk = (long long)units * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
+    // (block numbers / 8 by the tiles per unit, by multiplication: exact while (nblk / 8) * tiles < 2^32; a unit of ONE tile
+    // divides as before: its word would be 0, which the kernel reads as "divide")
+    const bool small = (nblk / 8) * (long long)(L.nXB * tiles_y) < (1ll << 32) && L.nXB * tiles_y > 1;
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_bwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, L,
-                           (const uint4 *)bwd_plan_dev, tiles_y, S, SliceScale{scale_dev, scale_stride}, gimg_dev);
+                           (const uint4 *)bwd_plan_dev, tiles_y, S, SliceScale{scale_dev, scale_stride}, gimg_dev,
+                           small ? div_magic((unsigned)(L.nXB * tiles_y)) : 0u, div_magic((unsigned)L.nXB));
         return CTPVAE_OK;
     };
     int rc;
