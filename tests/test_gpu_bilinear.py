@@ -61,6 +61,9 @@ def test_bilinear_forward_random_geometries(oracle):
         for ns in (1, 2, 4):                       # slices per LDS cell, forced
             with _lib.tuned("BNS", ns):
                 np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"fwd BNS={ns} " + msg)
+                for bsort in (0, 1):               # ... with (angle, block) tasks and with length-sorted band tasks
+                    with _lib.tuned("BSORT", bsort):
+                        np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"fwd BNS={ns} BSORT={bsort} " + msg)
         with _lib.tuned("NO_PLAN", 1):             # round 1's direct kernel: a second implementation of the same sums
             np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg="fwd direct " + msg)
 
@@ -79,8 +82,9 @@ def test_bilinear_slice_independence_and_launch_shapes(oracle):
     for S in (1, 2, 3, 5, 9):
         np.testing.assert_array_equal(to_np(plan.forward(x[:S].contiguous())), want[:S], err_msg=f"S={S}")
     for G, waves in ((1, 16), (3, 5), (7, 2), (2, 1)):
-        with _lib.tuned("BW", G), _lib.tuned("WAVES", waves):
-            np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"G={G} waves={waves}")
+        for bsort in (0, 1):   # (sorted bands: band b of every angle belongs to task group b mod G)
+            with _lib.tuned("BW", G), _lib.tuned("WAVES", waves), _lib.tuned("BSORT", bsort):
+                np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"G={G} waves={waves} BSORT={bsort}")
 
 
 @pytest.mark.parametrize("H,W,S,A", [(512, 512, 3, 6), (300, 200, 5, 4), (190, 260, 2, 5)])
@@ -117,6 +121,9 @@ def test_bilinear_forced_tiles_on_small_unpadded_slices(oracle):
             shape = oracle.tile_shape(H, W, 1)
             assert _lib.tile_shape(H, W, 1) == shape and plan.tiled
             got = to_np(plan.forward(torch.from_numpy(img).to(d)))
+            for bsort in (0, 1):                   # both task forms of the tile kernel
+                with _lib.tuned("BSORT", bsort):
+                    np.testing.assert_array_equal(to_np(plan.forward(torch.from_numpy(img).to(d))), got, err_msg=f"BSORT={bsort}")
         np.testing.assert_array_equal(got, oracle.rotate_fwd_tiled(img, geom, oT(oracle, theta, plan), shape, interp=1),
                                       err_msg=f"{H}x{W} pad={pad} tiles {shape}")
 
