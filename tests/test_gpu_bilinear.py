@@ -87,6 +87,22 @@ def test_bilinear_slice_independence_and_launch_shapes(oracle):
                 np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"G={G} waves={waves} BSORT={bsort}")
 
 
+def test_bilinear_forward_at_many_angles(oracle):
+    """180 angles at 128 x 128: the launch the library itself runs with length-sorted band tasks (several chunks of bands per
+    workgroup, interiors of many rows) -- and forced onto (angle, block) tasks -- against the oracle, every bit."""
+    d = dev()
+    rng = np.random.default_rng(180)
+    theta = phantoms.dense_theta(180)
+    img = rng.standard_normal((7, 128, 128)).astype(np.float32)
+    plan = RotatePlan(theta, 128, 128, True, d, interp="bilinear")
+    want = oracle.rotate_fwd(img, oracle.Geometry(128, 128, True), oT(oracle, theta, plan), 1)
+    x = torch.from_numpy(img).to(d)
+    np.testing.assert_array_equal(to_np(plan.forward(x)), want)
+    for bsort, G in ((0, -1), (1, 1), (1, 5), (0, 3)):
+        with _lib.tuned("BSORT", bsort), _lib.tuned("BW", G):
+            np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"BSORT={bsort} G={G}")
+
+
 @pytest.mark.parametrize("H,W,S,A", [(512, 512, 3, 6), (300, 200, 5, 4), (190, 260, 2, 5)])
 def test_bilinear_tiles_against_the_tiled_oracle(oracle, H, W, S, A):
     """Slices larger than LDS: tiles with a one-pixel halo; a sample belongs to the tile of its floor tap, the tiles' partial
