@@ -917,9 +917,23 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     CTPVAE_REQUIRE(units <= 65535, "rotate_fwd (bilinear): at most 65535 units per launch (got %d)", units);
     const int nb = TILED ? ts.nb : ((g.PW + 63) & ~63);
     const int tasks = g.A * (nb / 64);
-    // task groups per class: fill the chip once, leave every workgroup >= 4 waves of tasks
-    int G = std::max(1, 256 / (2 * units));
-    G = std::min(G, std::max(1, tasks / 8));
+    // Task groups per class.  A workgroup of this kernel runs for tens to hundreds of microseconds behind ~6 us of fill and band
+    // sort, so the cut is chosen for WHOLE ROUNDS of workgroups on 256 CUs (round 5, second pass; profiles/r05_rounds.txt is the
+    // study): rounds(G) x (6 us + the class's tasks / G at ~1.3 us each for a 184-row canvas).  One group per class used to be
+    // taken from 128 units on -- 75 pairs x 2 classes = 150 workgroups on 256 CUs (B = 150 x 180 angles: 320 us; with G = 5,
+    // 750 workgroups in 3 rounds); 150 pairs = 300 workgroups = two rounds for 1.17 rounds of work (635 us; G = 5: 6 rounds of a
+    // fifth).  Near-ties go to fewer groups (every group stages the unit again).
+    // (Tiles keep the older rule -- fill the chip once: their workgroups are short, and a tile's bands sort worse in fewer hands:
+    // 8 x 512^2 x 90 measured 133 us with the rounds rule's G = 4 against 110.)
+    int G = std::min(std::max(1, 256 / (2 * units)), std::max(1, tasks / 8));
+    if (!TILED) {
+        const double t_task = 1.3 * (double)g.PH / 184.0 * (NS == 4 ? 1.25 : 1.0), tc = std::max(1, tasks / 2);
+        double best = 0.0;
+        for (int c = 1; c <= std::min(16, std::max(1, tasks / 8)); ++c) {
+            const double t = std::ceil(2.0 * units * c / 256.0) * (6.0 + t_task * tc / c);
+            if (best == 0.0 || t < best * 0.97) best = t, G = c;
+        }
+    }
     if (knob(kKnobBw) > 0) G = knob(kKnobBw);
     // >= 8 waves: a workgroup's fill is shared by its waves, and two waves per SIMD issue LDS reads and waits under each other's
     // vector instructions (tools/sweep_bilin.py, B = 50 x 128 x 128 x 20 angles, G = 5: 27.1 / 24.3 / 22.1 / 21.8 us at 4 / 6 / 8 / 16)
