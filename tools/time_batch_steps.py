@@ -1,3 +1,5 @@
+"""Forward and backward launch time of the rotate projector at 128 x 128 against the batch size (50 ... 600), nearest and bilinear,
+20 and 180 angles: where a launch steps from one round of workgroups to the next (profiles/r05_batch_steps.txt)."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
