@@ -1295,7 +1295,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         // divisions by multiplication (div_magic): piece numbers / 8 by the pieces per unit, task numbers by a class's angle count
-        const int small_div = grid / 8 * 64 < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) ? 1 : 0;
+        const int small_div = grid / 8 * 64 < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) && knob(kKnobNoMagic) <= 0 ? 1 : 0;
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), shmem, (hipStream_t)stream,
                            img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2,
                            div_magic((unsigned)wgs_per_slice), div_magic((unsigned)wgs2), small_div);
@@ -1405,7 +1405,7 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");
     // (block numbers / 8 by the tiles per unit, by multiplication: exact while (nblk / 8) * tiles < 2^32; a unit of ONE tile
     // divides as before: its word would be 0, which the kernel reads as "divide")
-    const bool small = (nblk / 8) * (long long)(L.nXB * tiles_y) < (1ll << 32) && L.nXB * tiles_y > 1;
+    const bool small = (nblk / 8) * (long long)(L.nXB * tiles_y) < (1ll << 32) && L.nXB * tiles_y > 1 && knob(kKnobNoMagic) <= 0;
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_bwd_planned_kernel", abs_ok);

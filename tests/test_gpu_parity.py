@@ -277,6 +277,25 @@ def test_planned_equals_direct(oracle, shape, pad, A, S):
     np.testing.assert_array_equal(to_np(pa.backward(g)[:1]), oracle.rotate_bwd_tfcompat(to_np(g[:1]), geom, oTinv(oracle, theta, pa), 0))
 
 
+def test_index_divisions_by_multiplication_equal_divisions(oracle):
+    """The planned kernels map block numbers to (unit, class, group / tile) and task numbers to (bin block, angle) with
+    multiplications by host- / plan-made reciprocal words where the operands are small (always, in practice); knob NO_MAGIC takes
+    the divisions: the same bits, forward and backward, on shapes with partial octets of units, one-angle classes, one-tile units."""
+    d = dev()
+    rng = np.random.default_rng(77)
+    for (H, W), pad, A, S in (((128, 128), True, 20, 53), ((40, 100), True, 33, 11), ((64, 64), False, 1, 9), ((128, 128), True, 180, 21)):
+        theta = rng.uniform(-1.0, 4.0, A)
+        x = torch.from_numpy(rng.standard_normal((S, H, W)).astype(np.float32)).to(d)
+        plan = RotatePlan(theta, H, W, pad, d, plan_format="u16")
+        f = plan.forward(x)
+        g = torch.from_numpy(rng.standard_normal(tuple(f.shape)).astype(np.float32)).to(d)
+        b = plan.backward(g)
+        with _lib.tuned("NO_MAGIC", 1):
+            assert torch.equal(plan.forward(x), f) and torch.equal(plan.backward(g), b), (H, W, A, S)
+        geom = oracle.Geometry(H, W, pad)
+        np.testing.assert_array_equal(to_np(f[-1:]), oracle.rotate_fwd(to_np(x[-1:]), geom, oT(oracle, theta, plan), 0))
+
+
 @pytest.mark.parametrize("A,S", [(20, 300), (20, 301), (90, 301), (7, 700)])
 def test_two_part_piece_lists_equal_one_cut(oracle, A, S):
     """Launches of more than one round of workgroups cut their first units into coarse pieces and the rest into finer ones (round
