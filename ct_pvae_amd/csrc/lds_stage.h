@@ -77,18 +77,27 @@ __device__ __forceinline__ void stage_rows_interleaved_v4(float *lds, const floa
     constexpr int NB = 8 / NS;   // units in flight per lane: 8 float4 loads, as in stage_rows_v4
     const int d_rq = nwaves / npc, d_pc = nwaves - d_rq * npc;
     int rq = wave / npc, pc = wave - rq * npc;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // (the units a wave has left to stage: a scalar count)
     for (int p0 = wave; p0 < npairs; p0 += NB * nwaves) {
         float4 v[NB][NS];
         int r_[NB], c_[NB];
+        const int left = npairs - (wave_u + (p0 - wave));        // units of this wave from p0 on: 1 + (left - 1) / nwaves of them
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             r_[u] = 4 * rq + k;
             c_[u] = 32 * (2 * pc + h) + 4 * m;
             const bool ok = rq < nrq && r_[u] < rows && c_[u] < cols;
-            const int rl = min(r_[u], rows - 1), cl = min(c_[u], cols - 4);   // unconditional, clamped loads
+            const int rl = min(r_[u], rows - 1), cl = min(c_[u], cols - 4);   // per lane: unconditional, clamped loads
+            // ... but whole units past the block are not requested at all (wave-uniform: a small block -- 20 detector rows of a
+            // short launch -- is one unit per wave, and the other NB - 1 were loads of the last row over and over)
+            if (u * nwaves < left) {
 #pragma unroll
-            for (int n = 0; n < NS; ++n)
-                v[u][n] = *reinterpret_cast<const float4 *>(src[n] + (size_t)rl * src_stride + (mirror ? cols - 4 - cl : cl));
+                for (int n = 0; n < NS; ++n)
+                    v[u][n] = *reinterpret_cast<const float4 *>(src[n] + (size_t)rl * src_stride + (mirror ? cols - 4 - cl : cl));
+            } else {
+#pragma unroll
+                for (int n = 0; n < NS; ++n) v[u][n] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
             if (!ok) r_[u] = -1;
             rq += d_rq;
             pc += d_pc;
