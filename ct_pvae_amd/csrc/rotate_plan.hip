@@ -1242,15 +1242,19 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     // 14.5 at B = 256).  So the piece list gets TWO PARTS: G1 task groups per class for the first units1 units -- whole rounds
     // of coarse pieces: one fill per unit and class, waves evenly loaded -- and G2 > G1 for the rest, so that the last round's
     // work spreads over all CUs.  (G1, G2, units1) by list scheduling of the pieces, in order, on 256 CUs: a piece costs ~4.4 us
-    // from its CU falling free to its staged unit plus ceil(tasks / 16 waves) task rounds at ~0.19 us per row group (4.35 us at
+    // from its CU falling free to its staged unit plus ceil(tasks / 16 waves) task rounds at 0.12-0.19 us per row group (2.7 us with 6 waves gathering, 4.35 us at
     // 128 x 128 with every CU busy).  A PERSISTENT form of the kernel -- 256 workgroups walking the list, the next unit's rows
     // requested by the waves that run out of tasks first -- was built and measured: bit-equal, its hand-over no cheaper than a
     // fresh workgroup (~3.4 us behind the slowest wave) and its task loop 5 % slower (127 registers, another schedule): removed.
     int units1 = units, wgs2 = wgs_per_slice;
     if (!affine && !sel_dev && (long long)units * wgs_per_slice > 256 && knob(kKnobMixG) != 0 && knob(kKnobG) <= 0) {
-        const double t_task = 0.19 * L.NG, t_fresh = 4.4;
+        // (a task round is the faster the fewer waves of the CU gather at once: 2.7 us with 6 waves, 4.35 with all 16, at 23 row groups)
+        const double t_fresh = 4.4;
         const int Tc = (T + 1) / 2;     // tasks per unit and class
-        auto piece_us = [&](int Gx) { return t_fresh + std::ceil(std::ceil((double)Tc / Gx) / 16.0) * t_task; };
+        auto piece_us = [&](int Gx) {
+            const int tp = (Tc + Gx - 1) / Gx;
+            return t_fresh + std::ceil(tp / 16.0) * (0.072 + 0.0073 * std::min(16, tp)) * L.NG;
+        };
         auto launch_us = [&](int G1, int G2, int u1) {   // pieces in order, each to the CU that falls free first
             const long long Q1 = 2ll * u1 * G1, Q2 = 2ll * (units - u1) * G2;
             const double t1 = piece_us(G1), t2 = piece_us(G2);
@@ -1279,7 +1283,8 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
                     if (u1 == units) break;
                 }
         if (units1 == units) G2 = G1;
-        if (knob(kKnobMixG2) > 0 && knob(kKnobMixU1) >= 0) G1 = G, G2 = knob(kKnobMixG2), units1 = std::min(units, knob(kKnobMixU1));
+        if (knob(kKnobMixG2) > 0 && knob(kKnobMixU1) >= 0)
+            G1 = knob(kKnobMixG1) > 0 ? knob(kKnobMixG1) : G, G2 = knob(kKnobMixG2), units1 = std::min(units, knob(kKnobMixU1));
         wgs_per_slice = 2 * G1;
         wgs2 = 2 * G2;
         waves = std::min(16, std::max(stage_waves, (T + 2 * G1 - 1) / (2 * G1)));
