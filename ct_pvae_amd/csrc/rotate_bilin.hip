@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         }
         if (lane == 0) {
             cls_list[0] = n;
-            cls_list[1 + g.A] = 0;
+            cls_list[1 + g.A] = SORTED ? 0 : (int)(blockDim.x >> 6);   // the task counter (unsorted: the waves' first tasks are fixed)
         }
     }
 
@@ -468,10 +468,21 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
             __syncthreads();
         }
         const int ntask = SORTED ? (E + PER - 1) / PER : nch * nbk;
+        // UNSORTED: a wave's FIRST task is fixed, dealt to the SIMDs like a snake -- waves w and w + 4 share a SIMD (HW_ID of the
+        // stamped launches: tools/stamp_rounds.hip), the tasks come longest first, and this kernel is bound by the vector unit: two
+        // waves of one SIMD take turns.  In arrival order the headline shape's six tasks fell 2 long + 2 short on two SIMDs and
+        // one short each on the other two; the snake gives the long ones a SIMD each and pairs the short ones.
+        bool first = !SORTED;
         for (;;) {
             int m = 0;
-            if (lane == 0) m = atomicAdd(next_task, 1);
-            m = __builtin_amdgcn_readfirstlane(m);
+            if (first) {
+                const int lo = wave & ~3, hi = min(lo + 3, nwaves - 1);      // the wave's quad of SIMDs (a last quad may be short)
+                m = (wave & 4) ? lo + (hi - wave) : wave;                     // odd quads run backwards: a bijection of 0 .. nwaves - 1
+            } else {
+                if (lane == 0) m = atomicAdd(next_task, 1);
+                m = __builtin_amdgcn_readfirstlane(m);
+            }
+            first = false;
             int a, slot;
             if constexpr (SORTED) {
                 if (m >= ntask) break;

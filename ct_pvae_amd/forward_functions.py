@@ -18,6 +18,7 @@ gets implicitly from TensorFlow:
                                         the inverted transform); "exact" is the true transpose of the forward.
 """
 import math
+import os
 
 import ctypes
 import weakref
@@ -38,6 +39,19 @@ _BACKWARD = {"tf_compat": _lib.BWD_TF_COMPAT, "exact": _lib.BWD_EXACT}
 # ---------------------------------------------------------------------------------------------------------
 # a1: size rule of pad_phantom (host arithmetic, ctvae/forward_functions.py:29-36)
 # ---------------------------------------------------------------------------------------------------------
+
+# Test aid: outputs the kernels must fill completely come NaN-poisoned instead of uninitialised (tests/conftest.py switches it
+# on).  torch's caching allocator hands a freshly freed block straight back, so a launch that SKIPS part of its output would
+# otherwise be "checked" against the previous, correct result still lying in that memory.
+POISON_OUTPUTS = bool(os.environ.get("CTPVAE_POISON_OUTPUTS"))
+
+
+def _new_output(shape, dtype, device):
+    if POISON_OUTPUTS:
+        return torch.full(tuple(shape), float("nan"), dtype=dtype, device=device)
+    return torch.empty(tuple(shape), dtype=dtype, device=device)
+
+
 def num_proj_pix(img_size_x, img_size_y):
     """P = int(ceil((sqrt(float64(Nx^2 + Ny^2)) + 2) / 2) * 2)."""
     return int(math.ceil((math.sqrt(float(img_size_x ** 2 + img_size_y ** 2)) + 2.0) / 2.0) * 2)
@@ -403,7 +417,7 @@ class RotatePlan:
             return self.subset(angles_i).forward_loglik_sums(img, mask, meas, pnm, eps, with_dlp=with_dlp)
         with torch.cuda.device(self._dev_index):
             S = img.shape[0]
-            sums = torch.empty((S,), dtype=torch.float32, device=self._tdev)
+            sums = _new_output((S,), torch.float32, self._tdev)
             ws = self._tile_workspace(S) if angles_i is None else None
             if ws is not None:      # tiled geometry: the reduce pass of the tiled forward reduces the log-probabilities too
                 self._check(img, (self.H, self.W), "img")
@@ -411,7 +425,7 @@ class RotatePlan:
                 self._check(mask, (self.A,), "mask")
                 if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
                     raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
-                dlp = torch.empty((S, self.A, self.PW), dtype=torch.float32, device=self._tdev) if with_dlp else None
+                dlp = _new_output((S, self.A, self.PW), torch.float32, self._tdev) if with_dlp else None
                 part = self._part_workspace(S, self.A, 1)
                 rc = self._lib.ctpvae_rotate_fwd_tiled_compact_f32(
                     img.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.py, self.px, self.T8.data_ptr(), self.A,
@@ -437,7 +451,7 @@ class RotatePlan:
             self._check(mask, (n_in,), "mask")
             if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
                 raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
-            dlp = torch.empty((S, n, self.PW), dtype=torch.float32, device=self._tdev) if with_dlp else None
+            dlp = _new_output((S, n, self.PW), torch.float32, self._tdev) if with_dlp else None
             part = self._part_workspace(S, n, 0)
             rc = self._run_compact(img.data_ptr(), S, None, angles_i, n if angles_i is not None else 0, mask, meas,
                                    1 if dense_inputs else 0, pnm, eps, None, dlp.data_ptr() if dlp is not None else None,
@@ -504,7 +518,7 @@ class RotatePlan:
             raise ValueError(f"img must be a contiguous float64 tensor [S][{self.H}][{self.W}] on {self._tdev} "
                              f"(got {tuple(img.shape)}, {img.dtype}, {img.device})")
         S = img.shape[0]
-        out = torch.empty((S, self.A, self.PW), dtype=torch.float64, device=img.device)
+        out = _new_output((S, self.A, self.PW), torch.float64, img.device)
         if S == 0:
             return out
         with torch.cuda.device(self._dev_index):
@@ -599,7 +613,7 @@ class RotatePlan:
         S = img.shape[0]
         n = self.A if angles_i is None else self._check_sel(angles_i)
         if out is None:
-            out = torch.empty((S, n, self.PW), dtype=torch.float32, device=img.device)
+            out = _new_output((S, n, self.PW), torch.float32, img.device)
         else:
             self._check(out, (n, self.PW), "out")
             if out.shape[0] != S:
@@ -653,18 +667,18 @@ class RotatePlan:
         if meas.shape[0] != S or mask.shape[0] != S or pnm.numel() != 1 or pnm.dtype != torch.float32 or pnm.device != img.device:
             raise ValueError("mask [S][A], meas [S][A][PW] and a one-element float32 pnm on the same device are needed")
         if out is None:
-            out = torch.empty((S, n, self.PW), dtype=torch.float32, device=img.device)
+            out = _new_output((S, n, self.PW), torch.float32, img.device)
         else:
             self._check(out, (n, self.PW), "out")
         if out_lp is None:
-            out_lp = torch.empty_like(out)
+            out_lp = _new_output(out.shape, out.dtype, out.device)
         else:
             self._check(out_lp, (n, self.PW), "out_lp")
         if out.shape[0] != S or out_lp.shape[0] != S:
             raise ValueError("out / out_lp must hold one sinogram per slice")
         if with_dlp or out_dlp is not None:
             if out_dlp is None:
-                out_dlp = torch.empty_like(out)
+                out_dlp = _new_output(out.shape, out.dtype, out.device)
             else:
                 self._check(out_dlp, (n, self.PW), "out_dlp")
                 if out_dlp.shape[0] != S:
@@ -746,7 +760,7 @@ class RotatePlan:
                                  f"(got {tuple(scale.shape)}, {scale.dtype}, {scale.device})")
             sc_ptr, sc_stride = scale.data_ptr(), scale.stride(0)
         if out is None:
-            out = torch.empty((S, self.H, self.W), dtype=torch.float32, device=gsino.device)
+            out = _new_output((S, self.H, self.W), torch.float32, gsino.device)
         else:
             self._check(out, (self.H, self.W), "out")
             if out.shape[0] != S:
@@ -809,7 +823,7 @@ class RotatePlan:
                 or _current_device() != self._dev_index):
             return None
         S = x4.shape[0]
-        out = torch.empty((S, self.A, self.PW, 1), dtype=torch.float32, device=self._tdev)
+        out = _new_output((S, self.A, self.PW, 1), torch.float32, self._tdev)
         fplan, compact = self.dense_plan(S)
         if compact:
             rc = self._run_compact(x4.data_ptr(), S, out.data_ptr())
@@ -828,7 +842,7 @@ class RotatePlan:
             return None
         if self._bwd_plan is None:
             self._bwd_plan = self._build_plan(1)
-        out = torch.empty((S, self.H, self.W, 1), dtype=torch.float32, device=self._tdev)
+        out = _new_output((S, self.H, self.W, 1), torch.float32, self._tdev)
         rc = self._lib.ctpvae_rotate_bwd_planned_scaled_f32(g4.data_ptr(), S, self.H, self.W, self.PH, self.PW, self.A,
                                                             self._bwd_plan.data_ptr(), None, 0, out.data_ptr(),
                                                             _stream_ptr(self._dev_index))

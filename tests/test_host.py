@@ -140,3 +140,12 @@ def test_cpp_autograd_node_loads_and_binds(torch_node):
         node.rotate_vae(torch.zeros(2, 8, 8, 1, dtype=torch.float64), plan, plan, 8, 8, 14, 14, 3, 0, 0)
     with pytest.raises(RuntimeError, match="expected a contiguous float32"):
         node.rotate_vae(torch.zeros(2, 8, 9, 1), plan, plan, 8, 8, 14, 14, 3, 0, 0)
+
+
+def test_test_sessions_poison_the_projector_outputs():
+    """tests/conftest.py: every output the kernels must fill starts as NaN, so a launch that skips part of it cannot pass on the
+    previous call's values in recycled memory."""
+    import torch
+    from ct_pvae_amd import forward_functions
+    assert forward_functions.POISON_OUTPUTS
+    assert bool(torch.isnan(forward_functions._new_output((3, 2), torch.float32, torch.device("cpu"))).all())
