@@ -7,6 +7,8 @@ Re(ifft(filter_1d)) inside one HIP kernel (see csrc/fbp.hip)."""
 import numpy as np
 import torch
 
+from . import forward_functions as _fwd  # noqa: E402  (NaN-poisoned outputs in test sessions)
+
 from . import _lib
 from .forward_functions import _stream_ptr
 
@@ -81,8 +83,8 @@ def _iradon_forward(sinogram, hker, cos_t, sin_t, X, Y, geom):
     B, A, P = sinogram.shape
     dev = sinogram.device
     sino = sinogram.to(torch.float64).contiguous()
-    filtered = torch.empty_like(sino)
-    recon = torch.empty((B, X, Y), dtype=torch.float64, device=dev)
+    filtered = _fwd._new_output(sino.shape, sino.dtype, sino.device)
+    recon = _fwd._new_output((B, X, Y), torch.float64, dev)
     with torch.cuda.device(dev):
         _lib.check(lib.ctpvae_fbp_filter_f64(sino.data_ptr(), B * A, P, hker.data_ptr(), filtered.data_ptr(),
                                              _stream_ptr()), "fbp_filter")
@@ -108,8 +110,8 @@ class _IRadon(torch.autograd.Function):
         hker_t, cos_t, sin_t = ctx.saved_tensors
         (B, A, P), X, Y = ctx.shape
         g = grecon.to(torch.float64).contiguous()
-        gfilt = torch.empty((B, A, P), dtype=torch.float64, device=g.device)
-        gsino = torch.empty_like(gfilt)
+        gfilt = _fwd._new_output((B, A, P), torch.float64, g.device)
+        gsino = _fwd._new_output(gfilt.shape, gfilt.dtype, gfilt.device)
         with torch.cuda.device(g.device):
             _lib.check(lib.ctpvae_fbp_backproject_bwd_f64(g.data_ptr(), B, A, P, cos_t.data_ptr(), sin_t.data_ptr(), X, Y,
                                                           ctx.geom[0], ctx.geom[1], ctx.geom[2], gfilt.data_ptr(), _stream_ptr()),

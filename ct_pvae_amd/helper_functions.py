@@ -9,6 +9,8 @@ import ctypes
 import numpy as np
 import torch
 
+from . import forward_functions as _fwd  # noqa: E402  (NaN-poisoned outputs in test sessions)
+
 from . import _lib, forward_functions
 from .forward_functions import _cached_plan, _current_device, _stream_ptr, as_angle_index, project_tf_fast
 
@@ -57,7 +59,7 @@ def _siddon_forward(obj, tables, dx, meas=None, rn2=None, out=None):
     oy, ox, oz = obj.shape
     dt = sin_t.numel()
     if out is None:
-        out = torch.empty((oy, dt, dx), dtype=torch.float32, device=obj.device)
+        out = _fwd._new_output((oy, dt, dx), torch.float32, obj.device)
     need = lib.ctpvae_siddon_fwd_workspace_bytes(oy, ox, oz)
     _lib.check(need, "siddon_fwd_workspace_bytes")
     ws = torch.empty(int(need), dtype=torch.uint8, device=obj.device) if need else None
@@ -111,7 +113,7 @@ class _GaussianPoissonLogProb(torch.autograd.Function):
             if t.dtype is not torch.float32 or not t.is_contiguous():
                 raise TypeError(f"{name} must be contiguous float32 (got {t.dtype}, contiguous={t.is_contiguous()})")
         B, A, P = proj.shape
-        out = torch.empty_like(proj)
+        out = _fwd._new_output(proj.shape, proj.dtype, proj.device)
         with torch.cuda.device(proj.device):
             _lib.check(lib.ctpvae_loglik_fwd_f32(proj.data_ptr(), mask.data_ptr(), x.data_ptr(), B, A, P,
                                                  pnm.data_ptr(), ctypes.c_float(eps), out.data_ptr(),
@@ -126,8 +128,8 @@ class _GaussianPoissonLogProb(torch.autograd.Function):
         proj, mask, x, pnm = ctx.saved_tensors
         B, A, P = proj.shape
         gout = gout.contiguous()
-        gproj = torch.empty_like(proj)
-        gpnm = torch.empty((), dtype=torch.float32, device=proj.device) if ctx.needs_input_grad[3] else None
+        gproj = _fwd._new_output(proj.shape, proj.dtype, proj.device)
+        gpnm = _fwd._new_output((), torch.float32, proj.device) if ctx.needs_input_grad[3] else None
         with torch.cuda.device(proj.device):
             _lib.check(lib.ctpvae_loglik_bwd_f32(proj.data_ptr(), mask.data_ptr(), x.data_ptr(), gout.data_ptr(),
                                                  B, A, P, pnm.data_ptr(), ctypes.c_float(ctx.eps),
@@ -213,8 +215,8 @@ class _ProjectLogLik(torch.autograd.Function):
         sino, mask, x, pnm = ctx.saved_tensors
         B, A, P = sino.shape
         gout = gout.contiguous()
-        gproj = torch.empty_like(sino)
-        gpnm = torch.empty((), dtype=torch.float32, device=sino.device) if ctx.needs_input_grad[4] else None
+        gproj = _fwd._new_output(sino.shape, sino.dtype, sino.device)
+        gpnm = _fwd._new_output((), torch.float32, sino.device) if ctx.needs_input_grad[4] else None
         with torch.cuda.device(sino.device):
             _lib.check(lib.ctpvae_loglik_bwd_f32(sino.data_ptr(), mask.data_ptr(), x.data_ptr(), gout.data_ptr(),
                                                  B, A, P, pnm.data_ptr(), ctypes.c_float(ctx.eps),
@@ -256,7 +258,7 @@ class _ObjectSums(torch.autograd.Function):
         lib = _lib.load()
         lp = lp4.reshape(lp4.shape[0], lp4.shape[1], lp4.shape[2]).to(torch.float32).contiguous()
         ctx.shape, ctx.dtype = tuple(lp4.shape), lp4.dtype
-        out = torch.empty((lp.shape[0],), dtype=torch.float32, device=lp.device)
+        out = _fwd._new_output((lp.shape[0],), torch.float32, lp.device)
         if lp.shape[0]:
             with torch.cuda.device(lp.device):
                 _lib.check(lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), lp.shape[0], lp.shape[1], lp.shape[2], partition,

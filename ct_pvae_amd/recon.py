@@ -32,6 +32,8 @@ import ctypes
 import numpy as np
 import torch
 
+from . import forward_functions as _fwd  # noqa: E402  (NaN-poisoned outputs in test sessions)
+
 from . import _lib
 from .dataset_io import compare, crop
 from .fbp import iradon, ramp_filter
@@ -70,7 +72,7 @@ def _gridrec(data, theta, gx, gy, filter_name, filter_par):
     need = lib.ctpvae_gridrec_workspace_bytes(oy, dt, dx)
     _lib.check(need, "gridrec_workspace_bytes")
     ws = torch.empty(int(need), dtype=torch.uint8, device=data.device)
-    out = torch.empty((oy, gx, gy), dtype=torch.float32, device=data.device)
+    out = _fwd._new_output((oy, gx, gy), torch.float32, data.device)
     _lib.check(lib.ctpvae_gridrec_f32(data.data_ptr(), oy, dt, dx, tab.data_ptr(), gx, gy, ws.data_ptr(), out.data_ptr(),
                                       _stream_ptr()), "gridrec")
     return out
@@ -119,7 +121,7 @@ def _backproject(data, tables, gx, gy, ws=None, colsum=None, out=None):
     if ws is None:
         ws = _bp_workspace(tables, oy, gx, gy, dt, dx, data.device)
     if out is None:
-        out = torch.empty((oy, gx, gy), dtype=torch.float32, device=data.device)
+        out = _fwd._new_output((oy, gx, gy), torch.float32, data.device)
     _lib.check(lib.ctpvae_siddon_bwd_prepared_f32(data.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(),
                                                   dt, dx, ctypes.c_float(dx / 2.0), ws.data_ptr(),
                                                   colsum.data_ptr() if colsum is not None else None, out.data_ptr(),
@@ -149,13 +151,13 @@ def _sirt(data, tables, gx, gy, num_iter, init):
     lib = _lib.load()
     sin_t, cos_t, quad = tables
     oy, dt, dx = data.shape
-    rn2 = torch.empty((dt, dx), dtype=torch.float32, device=data.device)
+    rn2 = _fwd._new_output((dt, dx), torch.float32, data.device)
     _lib.check(lib.ctpvae_siddon_rownorm_f32(gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), dt, dx,
                                              ctypes.c_float(dx / 2.0), rn2.data_ptr(), _stream_ptr()), "siddon_rownorm")
     ws = _bp_workspace(tables, oy, gx, gy, dt, dx, data.device)
     colsum = _backproject(torch.ones((1, dt, dx), dtype=torch.float32, device=data.device), tables, gx, gy, ws=ws)[0]   # sum_dist
     x = init.contiguous().clone()
-    upd = torch.empty_like(data)
+    upd = _fwd._new_output(data.shape, data.dtype, data.device)
     for _ in range(int(num_iter)):
         _siddon_forward(x, tables, dx, meas=data, rn2=rn2, out=upd)
         _backproject(upd, tables, gx, gy, ws=ws, colsum=colsum, out=x)
@@ -191,9 +193,9 @@ def _tv(data, tables, gx, gy, num_iter, init, lam):
     _lib.check(need, "siddon_fwd_workspace_bytes")
     fws = torch.empty(int(need), dtype=torch.uint8, device=dev) if need else None
     x = init.contiguous().clone()
-    xbar, xbar2 = x.clone(), torch.empty_like(x)
+    xbar, xbar2 = x.clone(), _fwd._new_output(x.shape, x.dtype, x.device)
     p = torch.zeros_like(data)
-    qx, qy, qx2, qy2 = torch.zeros_like(x), torch.zeros_like(x), torch.empty_like(x), torch.empty_like(x)
+    qx, qy, qx2, qy2 = torch.zeros_like(x), torch.zeros_like(x), _fwd._new_output(x.shape, x.dtype, x.device), _fwd._new_output(x.shape, x.dtype, x.device)
     center, sp = ctypes.c_float(dx / 2.0), _stream_ptr()
     for _ in range(int(num_iter)):
         _lib.check(lib.ctpvae_siddon_fwd_ws_tv_dual_f32(xbar.data_ptr(), oy, gx, gy, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(),
