@@ -951,8 +951,10 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     int waves = std::min(16, std::max(8, ceil_div(tasks, 2 * G)));
     if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
     const bool padded = g.px >= 1 && g.py >= 1;
-    // length-sorted band tasks from about two (angle, 64-slot block) tasks per wave on (the classes hold about half the angles each)
-    bool sorted = (long long)g.A * (nb / 64) >= 4ll * waves * G;
+    // length-sorted band tasks from ~22 (angle, 64-slot block) tasks per workgroup on (the classes hold about half the angles each);
+    // measured, B x 128^2 x angles, sorted against plain: 50 x 30 (9 tasks per workgroup) 28.5 / 23.6 us, 50 x 60 (18) 35.9 / 35.9,
+    // 50 x 90 (27) 45.1 / 50.6, 100 x 45 (34) 62.3 / 65.0, 50 x 120 (36) 55.5 / 65.5, 10 x 180 (17) 36.8 / 34.0
+    bool sorted = (long long)g.A * (nb / 64) >= 44ll * G;
     if (knob(kKnobBsort) >= 0) sorted = knob(kKnobBsort) != 0;
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};
