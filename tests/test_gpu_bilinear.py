@@ -103,6 +103,24 @@ def test_bilinear_forward_at_many_angles(oracle):
             np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"BSORT={bsort} G={G}")
 
 
+@pytest.mark.parametrize("S,A", [(151, 180), (300, 20), (257, 45)])
+def test_bilinear_forward_long_launches(oracle, S, A):
+    """Batches whose workgroups come in several rounds: the task groups the library picks for whole rounds (and their snake deal /
+    sorted bands) against one group per class and against the oracle on a few slices -- every output NaN before the launch."""
+    d = dev()
+    rng = np.random.default_rng(S + A)
+    theta = phantoms.dense_theta(180)[:: 180 // A][:A]
+    img = rng.standard_normal((S, 128, 128)).astype(np.float32)
+    plan = RotatePlan(theta, 128, 128, True, d, interp="bilinear")
+    x = torch.from_numpy(img).to(d)
+    got = plan.forward(x)
+    assert not bool(torch.isnan(got).any())
+    with _lib.tuned("BW", 1):
+        assert torch.equal(plan.forward(x), got)
+    pick = [0, S // 2, S - 1]
+    np.testing.assert_array_equal(to_np(got[pick]), oracle.rotate_fwd(img[pick], oracle.Geometry(128, 128, True), oT(oracle, theta, plan), 1))
+
+
 @pytest.mark.parametrize("H,W,S,A", [(512, 512, 3, 6), (300, 200, 5, 4), (190, 260, 2, 5)])
 def test_bilinear_tiles_against_the_tiled_oracle(oracle, H, W, S, A):
     """Slices larger than LDS: tiles with a one-pixel halo; a sample belongs to the tile of its floor tap, the tiles' partial
