@@ -362,7 +362,7 @@ static int g_pshape[8];   // host: the last planned forward's {units, workgroups
     do {                                                                                                     \
         long long t_;                                                                                        \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
-        const size_t w_ = (size_t)q * (blockDim.x >> 6) + (threadIdx.x >> 6);   /* q: the piece */ \
+        const size_t w_ = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                       \
         if ((threadIdx.x & 63) == 0 && w_ < 65536) {                                                         \
             g_pstamps[8 * w_ + (slot)] = t_;                                                                 \
             if ((slot) == 0 || (slot) == 3) g_pstamps[8 * w_ + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
@@ -751,6 +751,7 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
     }
     const int s = u * NS;
     const bool has2 = NS == 2 && s + 1 < g_S;   // an odd batch ends with a half-empty pair (slice s staged twice)
+    CTPVAE_PSTAMP(0);
     const float k0 = scale.at(s), k1 = has2 ? scale.at(s + 1) : 1.0f;
     const int ty = inv_tiles ? (int)div_by_magic((unsigned)tile, inv_nxb) : tile / L.nXB, xb = tile - ty * L.nXB;
     const float *gs = gsino + (size_t)s * g.A * g.PW;
@@ -825,7 +826,9 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
                 ahead_valid = true;
             }
         }
+        if (acv == 0) CTPVAE_PSTAMP(1);
         __syncthreads();
+        if (acv == 0) CTPVAE_PSTAMP(2);
         // up to four (eight with DUP = 2) groups of sixteen virtual angles, unrolled so that every row offset is an immediate
         auto group = [&](auto al_tag) {
             constexpr int AL = decltype(al_tag)::value;
@@ -915,6 +918,7 @@ __global__ __launch_bounds__(MAXT) void rotate_bwd_planned_kernel(const float *_
             }
         }
     }
+    CTPVAE_PSTAMP(3);
 }
 
 // ---- angle-selecting planned backward ("bwd4" plan) ---------------------------------------------------------------------
@@ -1405,6 +1409,9 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has
     if (knob(kKnobBw) > 0) waves = std::min(16, knob(kKnobBw));
     const int rows_per_wg = waves * ppt;
+#ifdef CTPVAE_TUNE_STAMPS
+    g_pshape[0] = units, g_pshape[1] = L.nXB * ceil_div(H, waves * ppt), g_pshape[2] = waves, g_pshape[3] = ns, g_pshape[4] = 0, g_pshape[5] = units, g_pshape[6] = g_pshape[1];
+#endif
     const int tiles_y = ceil_div(H, rows_per_wg);
     const long long nblk = (long long)units * L.nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned: too many slices");

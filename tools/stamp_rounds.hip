@@ -34,7 +34,21 @@ int main(int argc, char **argv)
     void *fp;
     CK(hipMalloc(&fp, ctpvae_rotate_plan_bytes(N, N, P, P, A, 0)));
     if (ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, fp, nullptr, nullptr)) { printf("%s\n", ctpvae_last_error()); return 1; }
-    auto run = [&] { if (ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); } };
+    // CTPVAE_STAMP_BWD=1: the planned backward instead (the cotangents = the forward's sinograms)
+    const bool bwd = getenv("CTPVAE_STAMP_BWD") != nullptr;
+    void *bp = nullptr;
+    float *d_gimg = nullptr;
+    if (bwd) {
+        CK(hipMalloc(&bp, ctpvae_rotate_plan_bytes(N, N, P, P, A, 1)));
+        CK(hipMalloc(&d_gimg, img.size() * 4));
+        if (ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, nullptr, bp, nullptr)) { printf("%s\n", ctpvae_last_error()); return 1; }
+        if (ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); return 1; }
+    }
+    auto run = [&] {
+        const int rc = bwd ? ctpvae_rotate_bwd_planned_f32(d_sino, S, N, N, P, P, A, bp, d_gimg, nullptr)
+                           : ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr);
+        if (rc) { printf("%s\n", ctpvae_last_error()); exit(1); }
+    };
     for (int i = 0; i < 20; ++i) run();
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
