@@ -1304,7 +1304,8 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         // divisions by multiplication (div_magic): piece numbers / 8 by the pieces per unit, task numbers by a class's angle count
-        const int small_div = grid / 8 * 64 < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) && knob(kKnobNoMagic) <= 0 ? 1 : 0;
+        const int small_div = (grid / 8 + 1) * (long long)std::max(wgs_per_slice, wgs2) < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) &&
+                                      knob(kKnobNoMagic) <= 0 ? 1 : 0;
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), shmem, (hipStream_t)stream,
                            img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2,
                            div_magic((unsigned)wgs_per_slice), div_magic((unsigned)wgs2), small_div);
