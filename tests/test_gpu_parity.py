@@ -32,6 +32,11 @@ def rel_err(got, want):
     return float(np.abs(np.asarray(got, np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
 
 
+def nan_out(shape, device, dtype=torch.float32):
+    """An output buffer for a raw launch: NaN, so that an element the launch skips cannot pass on recycled memory."""
+    return torch.full(tuple(shape) if not isinstance(shape, int) else (shape,), float("nan"), dtype=dtype, device=device)
+
+
 def to_np(t):
     return t.detach().cpu().numpy()
 
@@ -1556,7 +1561,7 @@ def test_ray_driven_pair_with_a_shifted_rotation_centre(oracle, shift):
     sin_t, cos_t, quad = _siddon_tables(theta, d)
     sp = torch.cuda.current_stream().cuda_stream
     t = torch.from_numpy(obj).to(d)
-    sino = torch.empty((S, A, dx), device=d)
+    sino = nan_out((S, A, dx), d)
     fws = torch.empty(int(lib.ctpvae_siddon_fwd_workspace_bytes(S, n, n)), dtype=torch.uint8, device=d)
     _lib.check(lib.ctpvae_siddon_fwd_ws_f32(t.data_ptr(), S, n, n, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), A, dx,
                                             ctypes.c_float(center), None, None, fws.data_ptr(), sino.data_ptr(), sp), "siddon_fwd_ws")
@@ -1566,7 +1571,7 @@ def test_ray_driven_pair_with_a_shifted_rotation_centre(oracle, shift):
     y = rng.standard_normal((S, A, dx)).astype(np.float32)
     yt = torch.from_numpy(y).to(d)
     ws = torch.empty(int(lib.ctpvae_siddon_bwd_workspace_bytes(S, n, n, A, dx)), dtype=torch.uint8, device=d)
-    rec = torch.empty((S, n, n), device=d)
+    rec = nan_out((S, n, n), d)
     _lib.check(lib.ctpvae_siddon_bwd_f32(yt.data_ptr(), S, n, n, sin_t.data_ptr(), cos_t.data_ptr(), quad.data_ptr(), A, dx,
                                          ctypes.c_float(center), ws.data_ptr(), rec.data_ptr(), sp), "siddon_bwd")
     want_r = np.zeros((S, n, n), np.float32)
@@ -1585,7 +1590,7 @@ def test_launches_are_graph_capturable():
     plan = RotatePlan(theta, 128, 128, True, d)
     x = torch.rand((6, 128, 128), device=d)
     g = torch.rand((6, 20, 184), device=d)
-    sino, gimg = torch.empty((6, 20, 184), device=d), torch.empty_like(x)
+    sino, gimg = nan_out((6, 20, 184), d), nan_out(x.shape, d)
 
     def step():
         plan.forward(x, out=sino)
@@ -2046,7 +2051,7 @@ def test_per_object_loglik_sums_are_the_ordered_sum_of_the_two_step_path(oracle,
     np.testing.assert_array_equal(to_np(sums), want)
     assert torch.equal(dlp2, dlp)
     lib = _lib.load()
-    out = torch.empty(S, device=d)
+    out = nan_out(S, d)
     assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), S, lp.shape[1], plan.PW, 0, out.data_ptr(), None) == 0
     np.testing.assert_array_equal(to_np(out), want)
     assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), S, lp.shape[1], plan.PW, 1, out.data_ptr(), None) == 0
@@ -2062,7 +2067,7 @@ def test_object_sums_of_many_angles_and_host_subsets_past_the_argument_list(orac
     rng = np.random.default_rng(21)
     lib = _lib.load()
     lp = torch.from_numpy(rng.standard_normal((2, 600, 2048)).astype(np.float32)).to(d)       # 600 x 32 tasks = 19200
-    out = torch.empty(2, device=d)
+    out = nan_out(2, d)
     for part in (0, 1):
         assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), 2, 600, 2048, part, out.data_ptr(), None) == 0
         np.testing.assert_array_equal(to_np(out), oracle.loglik_object_sums(to_np(lp), part))
@@ -2248,7 +2253,7 @@ def test_operand_checks_see_a_tensor_whose_storage_was_swapped():
     d = dev()
     plan = RotatePlan(phantoms.dense_theta(180)[::9], 128, 128, True, d)
     x = torch.rand((4, 128, 128), device=d)
-    out = torch.empty((4, 20, plan.PW), device=d)
+    out = nan_out((4, 20, plan.PW), d)
     plan.forward(x, out=out)
     x.data = torch.rand((4, 64, 64), device=d)             # same object, a quarter of the storage
     with pytest.raises(ValueError, match="img must be"):
@@ -2393,7 +2398,7 @@ def test_round3_operators_against_golden(golden_dir):
                                num_gridy=44)), z["g_ramlak_40x44"]) <= REL
     lib = _lib.load()
     lp = torch.from_numpy(z["s_lp"]).to(d)
-    out = torch.empty(lp.shape[0], device=d)
+    out = nan_out(lp.shape[0], d)
     for part, key in ((0, "s_sums_bands"), (1, "s_sums_blocks")):
         assert lib.ctpvae_loglik_object_sums_f32(lp.data_ptr(), lp.shape[0], lp.shape[1], lp.shape[2], part, out.data_ptr(), None) == 0
         np.testing.assert_array_equal(to_np(out), z[key])
