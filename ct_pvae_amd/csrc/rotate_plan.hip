@@ -357,7 +357,7 @@ __global__ __launch_bounds__(64) void rotate_class_list_kernel(int A, FwdLayout 
 // timing builds (tools/stamp_rounds.hip): per wave {s_memtime at start / fill issued / barrier passed / end, s_memrealtime (100 MHz)
 // at start / end, HW_ID | XCC_ID << 32}
 __device__ long long g_pstamps[8 * 65536];
-static int g_pshape[8];   // host: the last planned forward's {units, workgroups per unit, waves, slices per unit, affine}
+static int g_pshape[10];   // host: the last planned forward's {units, workgroups per unit, waves, slices per unit, affine}
 #define CTPVAE_PSTAMP(slot)                                                                                  \
     do {                                                                                                     \
         long long t_;                                                                                        \
@@ -395,7 +395,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
                                                                   const char *__restrict__ plan, int wgs_per_slice,
                                                                   int g_S, float *__restrict__ sino, LogLikEpilogue epi,
                                                                   const int *__restrict__ sel, int n_sel, int affine,
-                                                                  int units1, int wgs2, unsigned inv_wgs1, unsigned inv_wgs2, int small_div)
+                                                                  int units1, int wgs2, unsigned inv_wgs1, unsigned inv_wgs2, int small_div,
+                                                                  int units2, int wgs3, unsigned inv_wgs3)
 {
     typedef typename SliceVec<NS>::type vec_t;
     extern __shared__ float lds[];
@@ -410,14 +411,22 @@ __global__ __launch_bounds__(1024) void rotate_fwd_planned_kernel(const float *_
     // pieces of the first units1 units, then wgs2 pieces of every later unit (round 5: a coarse cut for whole rounds of
     // workgroups, a finer one behind it so that the last, partial round spreads over all CUs; units1 == units otherwise).
     // Inside either part pieces are numbered in octets of units, as above.
+    // (... and, from unit units2 on, wgs3 pieces per unit: a third, finer part where it fills the last round better)
     auto piece_of = [&](int q, int &u_, int &wg_, int &wgs_) {
         int u0 = 0, nu = units1;
         unsigned inv = inv_wgs1;
         wgs_ = wgs_per_slice;
-        if (q >= units1 * wgs_per_slice) {
-            q -= units1 * wgs_per_slice;
+        const int Q1 = units1 * wgs_per_slice, Q2 = (units2 - units1) * wgs2;
+        if (q >= Q1 + Q2) {
+            q -= Q1 + Q2;
+            u0 = units2;
+            nu = units - units2;
+            wgs_ = wgs3;
+            inv = inv_wgs3;
+        } else if (q >= Q1) {
+            q -= Q1;
             u0 = units1;
-            nu = units - units1;
+            nu = units2 - units1;
             wgs_ = wgs2;
             inv = inv_wgs2;
         }
@@ -1250,7 +1259,7 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
     // 128 x 128 with every CU busy).  A PERSISTENT form of the kernel -- 256 workgroups walking the list, the next unit's rows
     // requested by the waves that run out of tasks first -- was built and measured: bit-equal, its hand-over no cheaper than a
     // fresh workgroup (~3.4 us behind the slowest wave) and its task loop 5 % slower (127 registers, another schedule): removed.
-    int units1 = units, wgs2 = wgs_per_slice;
+    int units1 = units, wgs2 = wgs_per_slice, units2 = units, wgs3 = wgs_per_slice;
     if (!affine && !sel_dev && (long long)units * wgs_per_slice > 256 && knob(kKnobMixG) != 0 && knob(kKnobG) <= 0) {
         // (a task round is the faster the fewer waves of the CU gather at once: 2.7 us with 6 waves, 4.35 with all 16, at 23 row groups)
         const double t_fresh = 4.4;
@@ -1287,28 +1296,62 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
                     if (u1 == units) break;
                 }
         if (units1 == units) G2 = G1;
+        // a THIRD part, finer again, for the end of the second: its pieces fill the CUs that the second part's last round leaves
+        // idle (B = 400 x 180 angles: [128 units x 1][40 x 3][32 x 4] 113-115 us against [128 x 1][72 x 3] 117-118)
+        int G3 = G2;
+        if (units1 < units && knob(kKnobMixG3) != 0) {
+            auto launch3_us = [&](int c3, int u2) {
+                struct Free { double t; long long n; } f[16] = {{0.0, 256}};
+                int nf = 1;
+                const long long cnt[3] = {2ll * units1 * G1, 2ll * (u2 - units1) * G2, 2ll * (units - u2) * c3};
+                const double cost[3] = {piece_us(G1), piece_us(G2), piece_us(c3)};
+                double end = 0.0;
+                for (int part = 0; part < 3; ++part)
+                    for (long long left = cnt[part]; left > 0;) {
+                        int k = 0;
+                        for (int i = 1; i < nf; ++i) if (f[i].t < f[k].t) k = i;
+                        const long long n = std::min(left, f[k].n);
+                        if (n < f[k].n && nf < 16) f[nf++] = {f[k].t, f[k].n - n}, f[k].n = n;
+                        f[k].t += cost[part];
+                        end = std::max(end, f[k].t);
+                        left -= n;
+                    }
+                return end;
+            };
+            double best3 = launch3_us(G2, units);
+            for (int c3 = G2 + 1; c3 <= std::min(gmax, G2 + 3); ++c3)
+                for (int u2 = units1 + 4; u2 < units; u2 += 4) {
+                    const double t = launch3_us(c3, u2);
+                    if (t < best3 * 0.98) best3 = t, G3 = c3, units2 = u2;
+                }
+            if (G3 == G2) units2 = units;
+        }
         if (knob(kKnobMixG2) > 0 && knob(kKnobMixU1) >= 0)
             G1 = knob(kKnobMixG1) > 0 ? knob(kKnobMixG1) : G, G2 = knob(kKnobMixG2), units1 = std::min(units, knob(kKnobMixU1));
         wgs_per_slice = 2 * G1;
-        wgs2 = 2 * G2;
+        wgs2 = 2 * G2, wgs3 = 2 * G3;
+        if (knob(kKnobMixG2) > 0 && knob(kKnobMixU1) >= 0) wgs3 = wgs2, units2 = units;
+        if (knob(kKnobMixG3) > 0 && knob(kKnobMixU2) >= 0)
+            wgs3 = 2 * knob(kKnobMixG3), units2 = std::max(units1, std::min(units, knob(kKnobMixU2)));
         waves = std::min(16, std::max(stage_waves, (T + 2 * G1 - 1) / (2 * G1)));
         if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
     }
-    const long long grid = (long long)units1 * wgs_per_slice + (long long)(units - units1) * wgs2;
+    units2 = std::max(units1, std::min(units2, units));
+    const long long grid = (long long)units1 * wgs_per_slice + (long long)(units2 - units1) * wgs2 + (long long)(units - units2) * wgs3;
     CTPVAE_REQUIRE(grid < (1ll << 31), "rotate_fwd_planned: too many slices");
 #ifdef CTPVAE_TUNE_STAMPS
-    g_pshape[1] = wgs_per_slice, g_pshape[2] = waves, g_pshape[5] = units1, g_pshape[6] = wgs2;   // (timing builds: tools/stamp_rounds.hip)
+    g_pshape[1] = wgs_per_slice, g_pshape[2] = waves, g_pshape[5] = units1, g_pshape[6] = wgs2, g_pshape[7] = units2, g_pshape[8] = wgs3;   // (timing builds: tools/stamp_rounds.hip)
 #endif
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};   // per kernel instantiation: devices done
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_planned_kernel", abs_ok);
         CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);
         // divisions by multiplication (div_magic): piece numbers / 8 by the pieces per unit, task numbers by a class's angle count
-        const int small_div = (grid / 8 + 1) * (long long)std::max(wgs_per_slice, wgs2) < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) &&
+        const int small_div = (grid / 8 + 1) * (long long)std::max(wgs_per_slice, std::max(wgs2, wgs3)) < (1ll << 32) && (long long)A * L.nJB * A < (1ll << 32) &&
                                       knob(kKnobNoMagic) <= 0 ? 1 : 0;
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(64 * waves), shmem, (hipStream_t)stream,
                            img_dev, g, L, (const char *)fwd_plan_dev, wgs_per_slice, S, sino_dev, epi, sel_dev, n_sel, affine, units1, wgs2,
-                           div_magic((unsigned)wgs_per_slice), div_magic((unsigned)wgs2), small_div);
+                           div_magic((unsigned)wgs_per_slice), div_magic((unsigned)wgs2), small_div, units2, wgs3, div_magic((unsigned)wgs3));
         CTPVAE_LAUNCH_CHECK("rotate_fwd_planned_kernel");
         return CTPVAE_OK;
     };

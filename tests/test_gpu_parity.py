@@ -301,10 +301,11 @@ def test_index_divisions_by_multiplication_equal_divisions(oracle):
         np.testing.assert_array_equal(to_np(f[-1:]), oracle.rotate_fwd(to_np(x[-1:]), geom, oT(oracle, theta, plan), 0))
 
 
-@pytest.mark.parametrize("A,S", [(20, 300), (20, 301), (90, 301), (7, 700)])
+@pytest.mark.parametrize("A,S", [(20, 300), (20, 301), (90, 301), (7, 700), (90, 388)])
 def test_two_part_piece_lists_equal_one_cut(oracle, A, S):
     """Launches of more than one round of workgroups cut their first units into coarse pieces and the rest into finer ones (round
-    5): which piece carries a ray does not touch its sum.  The library's own cut, one cut for the whole launch (knob MIXG=0) and
+    5; a still finer third part where it fills the last round, S = 388 x 90 angles): which piece carries a ray does not touch its
+    sum.  The library's own cut, one cut for the whole launch (knob MIXG=0) and
     forced cuts -- part boundaries off the octets of units, a second part of one unit, an empty first part, odd batches --
     give the same bits, and the oracle's."""
     d = dev()
@@ -320,6 +321,11 @@ def test_two_part_piece_lists_equal_one_cut(oracle, A, S):
     for g2, u1 in ((5, 128), (3, units - 1), (2, 0), (7, 13), (4, units)):
         with _lib.tuned("NS", 2), _lib.tuned("MIXG_G2", g2), _lib.tuned("MIXG_U1", u1):
             assert torch.equal(plan.forward(x), one), (g2, u1)
+    # ... and a third part, finer again, behind the second: boundaries off the octets, an empty second part, a third of one unit
+    for g1, g2, u1, g3, u2 in ((1, 3, 64, 4, 101), (2, 3, 13, 5, 13), (1, 2, 0, 7, units - 1), (1, 3, 128, 4, 140), (3, 2, 7, 1, 90)):
+        with _lib.tuned("NS", 2), _lib.tuned("MIXG_G1", g1), _lib.tuned("MIXG_G2", g2), _lib.tuned("MIXG_U1", u1), \
+                _lib.tuned("MIXG_G3", g3), _lib.tuned("MIXG_U2", u2):
+            assert torch.equal(plan.forward(x), one), (g1, g2, u1, g3, u2)
     geom = oracle.Geometry(128, 128, True)
     for k in (0, S // 2, S - 1):
         np.testing.assert_array_equal(to_np(auto[k:k + 1]), oracle.rotate_fwd(to_np(x[k:k + 1]), geom, oT(oracle, theta, plan), 0))

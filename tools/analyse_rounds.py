@@ -51,8 +51,9 @@ def analyse(path):
     span = end.max()
     cut = f"{meta['units']} units x {meta['wgs_per_unit']} per unit"
     if int(meta.get("units1", meta["units"])) < int(meta["units"]):
-        cut = (f"the first {meta['units1']} units x {meta['wgs_per_unit']} per unit, the other {int(meta['units']) - int(meta['units1'])} x "
-               f"{meta['wgs_per_unit2']}")
+        u2 = int(meta.get("units2", meta["units"]))
+        cut = (f"the first {meta['units1']} units x {meta['wgs_per_unit']} per unit, the next {u2 - int(meta['units1'])} x "
+               f"{meta['wgs_per_unit2']}, the last {int(meta['units']) - u2} x {meta.get('wgs_per_unit3', meta['wgs_per_unit2'])}")
     print(f"== {path}: S {meta['S']} A {meta['A']}: {nwg} workgroups of {wpw} waves ({cut}, "
           f"{meta['ns']} slices per unit), {len(per_cu)} CUs used, {cyc_per_us:.0f} shader cycles per us")
     print(f"   launch span (first wave start -> last wave end) {span:.2f} us; stamped build, back to back: {meta['us_per_launch_stamped_build']} us per launch")

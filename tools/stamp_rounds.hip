@@ -67,8 +67,8 @@ int main(int argc, char **argv)
     int nw = 0;
     while (nw < 65536 && st[8 * nw + 4] != 0) ++nw;
     FILE *f = fopen(argv[3], "w");
-    fprintf(f, "# S %d A %d waves %d us_per_launch_stamped_build %.2f units %d wgs_per_unit %d waves_per_wg %d ns %d affine %d units1 %d wgs_per_unit2 %d\n", S, A, nw, ms * 1000.0 / 50,
-            ctpvae::g_pshape[0], ctpvae::g_pshape[1], ctpvae::g_pshape[2], ctpvae::g_pshape[3], ctpvae::g_pshape[4], ctpvae::g_pshape[5], ctpvae::g_pshape[6]);
+    fprintf(f, "# S %d A %d waves %d us_per_launch_stamped_build %.2f units %d wgs_per_unit %d waves_per_wg %d ns %d affine %d units1 %d wgs_per_unit2 %d units2 %d wgs_per_unit3 %d\n", S, A, nw, ms * 1000.0 / 50,
+            ctpvae::g_pshape[0], ctpvae::g_pshape[1], ctpvae::g_pshape[2], ctpvae::g_pshape[3], ctpvae::g_pshape[4], ctpvae::g_pshape[5], ctpvae::g_pshape[6], ctpvae::g_pshape[7], ctpvae::g_pshape[8]);
     fprintf(f, "# wave start_rt end_rt start_cyc fill_cyc barrier_cyc end_cyc hwid xcc issued_cyc\n");
     for (int w = 0; w < nw; ++w)
         fprintf(f, "%d %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", w, st[8 * w + 4], st[8 * w + 5], st[8 * w], st[8 * w + 1], st[8 * w + 2], st[8 * w + 3],
