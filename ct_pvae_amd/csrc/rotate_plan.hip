@@ -1284,21 +1284,38 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
             }
             return end;
         };
-        int G1 = G, G2 = G;
+        int G1 = G, G2 = G, G3 = G;
+        // The search below costs 2-15 us of host time at a few hundred units (it was 0.9 ms at 2000 units before its first parts were
+        // limited to the last whole rounds): the last few shapes' cuts are kept per thread.
+        struct CutKey { int units, T, NG, G, mix3; };
+        struct Cut { CutKey key; int G1, G2, G3, units1, units2; };
+        static thread_local Cut cut_cache[8];
+        static thread_local unsigned cut_next = 0;
+        const CutKey key{units, T, L.NG, G, knob(kKnobMixG3) != 0 ? 1 : 0};
+        const Cut *hit = nullptr;
+        for (const Cut &c : cut_cache)
+            if (c.key.units == key.units && c.key.T == key.T && c.key.NG == key.NG && c.key.G == key.G && c.key.mix3 == key.mix3) hit = &c;
+        if (hit) {
+            G1 = hit->G1, G2 = hit->G2, G3 = hit->G3, units1 = hit->units1, units2 = hit->units2;
+        } else {
         double best = launch_us(G, G, units);
         const int gmax = std::min(12, std::max(1, Tc / 4));
-        for (int c1 = 1; c1 <= std::min(8, gmax); ++c1)
+        for (int c1 = 1; c1 <= std::min(8, gmax); ++c1) {
+            // first parts of (about) k whole rounds -- the last four such boundaries: a finer rest of more rounds than that never
+            // won -- and the whole launch
+            const int kmax = (int)((2ll * c1 * units) / 256);
             for (int c2 = c1; c2 <= gmax; ++c2)
-                for (int k = 0;; ++k) {   // first parts of (about) k whole rounds, and the whole launch
+                for (int k = std::max(0, kmax - 3);; ++k) {
                     const int u1 = std::min(units, (int)((256ll * k) / (2 * c1)));
                     const double t = launch_us(c1, c2, u1);
                     if (t < best * 0.97) best = t, G1 = c1, G2 = c2, units1 = u1;
                     if (u1 == units) break;
                 }
+        }
         if (units1 == units) G2 = G1;
         // a THIRD part, finer again, for the end of the second: its pieces fill the CUs that the second part's last round leaves
         // idle (B = 400 x 180 angles: [128 units x 1][40 x 3][32 x 4] 113-115 us against [128 x 1][72 x 3] 117-118)
-        int G3 = G2;
+        G3 = G2;
         if (units1 < units && knob(kKnobMixG3) != 0) {
             auto launch3_us = [&](int c3, int u2) {
                 struct Free { double t; long long n; } f[16] = {{0.0, 256}};
@@ -1325,6 +1342,8 @@ static int launch_fwd_planned(const float *img_dev, int S, int H, int W, int PH,
                     if (t < best3 * 0.98) best3 = t, G3 = c3, units2 = u2;
                 }
             if (G3 == G2) units2 = units;
+        }
+        cut_cache[cut_next++ % 8] = Cut{key, G1, G2, G3, units1, units2};
         }
         if (knob(kKnobMixG2) > 0 && knob(kKnobMixU1) >= 0)
             G1 = knob(kKnobMixG1) > 0 ? knob(kKnobMixG1) : G, G2 = knob(kKnobMixG2), units1 = std::min(units, knob(kKnobMixU1));
