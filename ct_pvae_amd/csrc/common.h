@@ -93,7 +93,7 @@ struct SliceScale {
 enum Knob {
     kKnobNoPlan, kKnobForceGeneric, kKnobNs, kKnobG, kKnobWaves, kKnobBns, kKnobBw, kKnobSegNs, kKnobSegChunk,
     kKnobSegPpt, kKnobTiledNs, kKnobTiledG, kKnobSiddonNs, kKnobSiddonThreads, kKnobSiddonPpb, kKnobMaxSlices,
-    kKnobSiddonBwdNs, kKnobSiddonBwdChunks, kKnobNoCompact, kKnobSkew0, kKnobTiledSort, kKnobTiledPair, kKnobAffine, kKnobFakeStaticLds, kKnobFoldSums, kKnobTiledXcd, kKnobTiledWaves, kKnobTiledTh, kKnobReduceWaves, kKnobStepNs, kKnobStepLdsKb, kKnobTiledForce, kKnobBsort, kKnobMixG, kKnobMixG2, kKnobMixU1, kKnobNoMagic, kKnobMixG1, kKnobMixG3, kKnobMixU2, kKnobCount
+    kKnobSiddonBwdNs, kKnobSiddonBwdChunks, kKnobNoCompact, kKnobSkew0, kKnobTiledSort, kKnobTiledPair, kKnobAffine, kKnobFakeStaticLds, kKnobFoldSums, kKnobTiledXcd, kKnobTiledWaves, kKnobTiledTh, kKnobReduceWaves, kKnobStepNs, kKnobStepLdsKb, kKnobTiledForce, kKnobBsort, kKnobMixG, kKnobMixG2, kKnobMixU1, kKnobNoMagic, kKnobMixG1, kKnobMixG3, kKnobMixU2, kKnobBrsplit, kKnobCount
 };
 int knob(Knob k);
 

@@ -24,7 +24,7 @@ int fail(int code, const char *fmt, ...)
 // ---- developer knobs ---------------------------------------------------------------------------------------------
 static const char *const kKnobNames[kKnobCount] = {
     "NO_PLAN", "FORCE_GENERIC", "NS", "G", "WAVES", "BNS", "BW", "SEG_NS", "SEG_CHUNK", "SEG_PPT", "TILED_NS", "TILED_G",
-    "SIDDON_NS", "SIDDON_THREADS", "SIDDON_PPB", "MAX_SLICES", "SIDDON_BWD_NS", "SIDDON_BWD_CHUNKS", "NO_COMPACT", "SKEW0", "TILED_SORT", "TILED_PAIR", "AFFINE", "FAKE_STATIC_LDS", "FOLD_SUMS", "TILED_XCD", "TILED_WAVES", "TILED_TH", "REDUCE_WAVES", "STEP_NS", "STEP_LDS_KB", "TILED_FORCE", "BSORT", "MIXG", "MIXG_G2", "MIXG_U1", "NO_MAGIC", "MIXG_G1", "MIXG_G3", "MIXG_U2"};
+    "SIDDON_NS", "SIDDON_THREADS", "SIDDON_PPB", "MAX_SLICES", "SIDDON_BWD_NS", "SIDDON_BWD_CHUNKS", "NO_COMPACT", "SKEW0", "TILED_SORT", "TILED_PAIR", "AFFINE", "FAKE_STATIC_LDS", "FOLD_SUMS", "TILED_XCD", "TILED_WAVES", "TILED_TH", "REDUCE_WAVES", "STEP_NS", "STEP_LDS_KB", "TILED_FORCE", "BSORT", "MIXG", "MIXG_G2", "MIXG_U1", "NO_MAGIC", "MIXG_G1", "MIXG_G3", "MIXG_U2", "BRSPLIT"};
 static std::atomic<int> g_knobs[kKnobCount];
 static int find_knob(const char *name)
 {

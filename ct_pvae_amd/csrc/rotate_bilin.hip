@@ -24,6 +24,7 @@
 #include "loglik_math.h"
 #include "rotate_plan.h"
 #include "rotate_dev.h"
+#include "tune_stamps.h"
 
 namespace ctpvae {
 
@@ -55,13 +56,14 @@ __host__ __device__ inline size_t bilin_lds_cells(int h, int w, bool tiled, int 
 
 struct BilinRay {
     float t1, t2, t4, t5, xj, yj;
-    int ray, ilo, kmax;   // kmax: rows walked in pairs (even)
-    int ka, kb;           // wave-uniform, even: on rows [ka, kb) of the walk EVERY live lane's sample is owned by the unit
-    bool live, tail;      // tail: one more row behind the pairs (an odd canvas height walked whole)
+    int ray, ilo, kmax;   // kmax: rows walked in pairs (even; row-split walks: in fours)
+    int ka, kb;           // wave-uniform, even (fours): on rows [ka, kb) of the walk EVERY live lane's sample is owned by the unit
+    bool live;
+    int tail;             // rows behind the pairs (an odd canvas height walked whole: 1; row-split walks: up to 3)
     bool none;            // the ray misses the unit: whatever its lane walks on the interior, its sum is zero
 };
 
-template <int NS, bool TILED, bool PADDED, bool SORTED>
+template <int NS, bool TILED, bool PADDED, bool SORTED, bool RS = false>
 __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__restrict__ img, RotGeom gfull, TileSpec ts,
                                                                 const float *__restrict__ T8, int t8_lds_off, float *__restrict__ out)
 {
@@ -88,7 +90,17 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
 #pragma unroll
     for (int n = 0; n < NS; ++n) srcs[n] = img + ((size_t)min(s + n, gfull.S - 1) * gfull.H + y0) * gfull.W + x0;
 
+    CTPVAE_PSTAMP(0);
     // ---- stage ---------------------------------------------------------------------------------------------------------------
+    // (the transform rows this thread copies to LDS and the first 64 angles' class tests are requested BEFORE the unit's rows: behind
+    // them each was another round trip to memory in front of the barrier -- loads return in order, the rows' wait covers them)
+    const float t8_first = (int)threadIdx.x < 8 * g.A ? T8[threadIdx.x] : 0.0f;
+    float cls_t0 = 0.0f, cls_t3 = 0.0f;
+    if (threadIdx.x < 64) {
+        const float *tm = T8 + 8 * min(lane, g.A - 1);
+        cls_t0 = tm[0];
+        cls_t3 = tm[3];
+    }
     {
         vec_t *cells = reinterpret_cast<vec_t *>(lds);
         // LDS column of canvas column X0 + c (c = -1 .. w), relative to the row's first cell
@@ -131,12 +143,14 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
 
     // behind the image: a copy of the transform rows, the ascending list of this class's angles ([0] = their count), a task counter
     int *cls_list = reinterpret_cast<int *>(lds + t8_lds_off + 8 * g.A);
-    for (int p = threadIdx.x; p < 8 * g.A; p += blockDim.x) lds[t8_lds_off + p] = T8[p];
+    if ((int)threadIdx.x < 8 * g.A) lds[t8_lds_off + threadIdx.x] = t8_first;
+    for (int p = threadIdx.x + blockDim.x; p < 8 * g.A; p += blockDim.x) lds[t8_lds_off + p] = T8[p];
     if (threadIdx.x < 64) {
         int n = 0;
         for (int a0 = 0; a0 < g.A; a0 += 64) {
             const float *tm = T8 + 8 * min(a0 + lane, g.A - 1);
-            const bool in_cls = a0 + lane < g.A && ((((tm[0] >= 0.0f) == (tm[3] >= 0.0f)) ? 0 : 1) == cls);
+            const float c0 = a0 == 0 ? cls_t0 : tm[0], c3 = a0 == 0 ? cls_t3 : tm[3];
+            const bool in_cls = a0 + lane < g.A && ((((c0 >= 0.0f) == (c3 >= 0.0f)) ? 0 : 1) == cls);
             const unsigned long long m = __ballot(in_cls);
             if (in_cls) cls_list[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = a0 + lane;
             n += __popcll(m);
@@ -147,6 +161,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         }
     }
 
+    CTPVAE_PSTAMP(1);
     const int nb = TILED ? ts.nb : ((g.PW + 63) & ~63);   // ray slots per angle
     const int span = TILED ? ts.span : g.PW;
     const float tile_cx = (float)g.px + 0.5f * (float)(w - 1), tile_cy = (float)g.py + 0.5f * (float)(h - 1);
@@ -190,9 +205,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         int ilo, cnt;
         BilinRay q = prepare(a, slot, ilo, cnt);
         const int need = wave_max_nonneg(cnt);                  // wave-uniform trip count (SGPR)
-        q.kmax = min((need + 1) & ~1, g.PH & ~1);               // whole row pairs ...
-        q.tail = need > q.kmax;                                 // ... and the last row of an odd canvas alone
-        q.ilo = max(min(ilo, g.PH - q.kmax - (q.tail ? 1 : 0)), 0);   // only legitimate rows are visited
+        constexpr int RM = RS ? 3 : 1;                          // rows per step of the walk - 1
+        q.kmax = min((need + RM) & ~RM, g.PH & ~RM);            // whole row pairs (fours) ...
+        q.tail = need > q.kmax ? g.PH - q.kmax : 0;             // ... and the last rows of a canvas walked whole alone
+        q.ilo = max(min(ilo, g.PH - q.kmax - q.tail), 0);       // only legitimate rows are visited
         // The INTERIOR of the walk: rows on which the floor tap of every live lane's sample lies inside the unit's ownership
         // window need no ownership test (12 -> 6 vector instructions for floor, test and address; see walk).  Per lane from the
         // ray's line, conservatively: the window shrunk by 0.01 px (the walk's own coordinates are fp32 sums, off by ~1e-5),
@@ -218,8 +234,8 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
             ka_l = min(max(ia - q.ilo, 0), q.kmax);
             kb_l = max(min(ib - q.ilo, q.kmax), ka_l);
         }
-        q.ka = (wave_max_nonneg(ka_l) + 1) & ~1;
-        q.kb = (q.kmax - wave_max_nonneg(q.kmax - kb_l)) & ~1;
+        q.ka = (wave_max_nonneg(ka_l) + RM) & ~RM;
+        q.kb = (q.kmax - wave_max_nonneg(q.kmax - kb_l)) & ~RM;
         if (q.kb <= q.ka) q.ka = q.kb = q.kmax;                  // no interior: the whole walk with tests
         return q;
     };
@@ -228,7 +244,10 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         constexpr bool MIRROR = decltype(mirror_tag)::value;
         const f32x2 basex = {q.xj, q.xj}, basey = {q.yj, q.yj}, stepx = {q.t1, q.t1}, stepy = {q.t4, q.t4};
         const f32x2 shiftx = {q.t2, q.t2}, shifty = {q.t5, q.t5};
-        f32x2 fi = {(float)q.ilo, (float)q.ilo + 1.0f};
+        // (row-split walks: lanes 32-63 carry the SAME rays as lanes 0-31, two rows further on -- four rows of a ray per step;
+        // the sums are kept, and stored, by lanes 32-63)
+        const float fi0 = (float)(q.ilo + (RS ? (lane >> 5) * 2 : 0));
+        f32x2 fi = {fi0, fi0 + 1.0f};
         vec_t acc = vec_t(0.0f);
         const int offv = off_v;     // (named here: an outer variable used only inside an asm operand of a nested lambda is not captured)
         struct Pair {               // two consecutive rows of one ray
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
         auto issue = [&](Pair &P, auto test_tag) {
             const f32x2 x = (basex + stepx * fi) + shiftx;
             const f32x2 y = (basey + stepy * fi) + shifty;
-            fi += 2.0f;
+            fi += RS ? 4.0f : 2.0f;
             f32x2 wx0, wx1;
             if constexpr (PADDED) {
                 wx1 = f32x2{__builtin_amdgcn_fractf(x.x), __builtin_amdgcn_fractf(x.y)};
@@ -301,13 +320,45 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
             __builtin_amdgcn_sched_barrier(0);
         };
         auto consume = [&](const Pair &P) {
+            vec_t val[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float wl = r ? P.wl.y : P.wl.x, wh = r ? P.wh.y : P.wh.x;
                 const float w0 = r ? P.wy0.y : P.wy0.x, w1 = r ? P.wy1.y : P.wy1.x;
                 const vec_t v_yf = wl * P.tp[r][0] + wh * P.tp[r][1];
                 const vec_t v_yc = wl * P.tp[r][2] + wh * P.tp[r][3];
-                acc += w0 * v_yf + w1 * v_yc;
+                val[r] = w0 * v_yf + w1 * v_yc;
+                if constexpr (!RS) acc += val[r];
+            }
+            if constexpr (RS) {
+                // the ray's four rows in order, in lanes 32-63: the two of lanes 0-31, then their own.  v_permlane32_swap: lanes 32-63 of
+                // its first operand change places with lanes 0-31 of its second -- the first operand is a dead tap register (its upper
+                // half receives the other half's value), the second keeps its upper half, which is all that is read of it afterwards.
+                // What lanes 0-31 accumulate is never stored.  (Inline: hipcc's builtin returns the first operand's register for BOTH
+                // results on ROCm 7.2 and copies the second operand first.  Two wait states between a vector write and the swap.)
+                vec_t oth[2];
+                if constexpr (NS == 1) {
+                    oth[0] = P.tp[0][0], oth[1] = P.tp[1][0];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3"
+                                 : "+v"(oth[0]), "+v"(oth[1]), "+v"(val[0]), "+v"(val[1]));
+                } else if constexpr (NS == 2) {
+                    oth[0] = P.tp[0][0], oth[1] = P.tp[1][0];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                                 "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
+                                 : "+v"(oth[0].x), "+v"(oth[0].y), "+v"(oth[1].x), "+v"(oth[1].y), "+v"(val[0].x), "+v"(val[0].y), "+v"(val[1].x), "+v"(val[1].y));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        oth[r] = P.tp[r][0];
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\t"
+                                     "v_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7"
+                                     : "+v"(oth[r].x), "+v"(oth[r].y), "+v"(oth[r].z), "+v"(oth[r].w), "+v"(val[r].x), "+v"(val[r].y), "+v"(val[r].z), "+v"(val[r].w));
+                    }
+                }
+                acc += oth[0];
+                acc += oth[1];
+                acc += val[0];
+                acc += val[1];
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -340,11 +391,12 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
                 }
             }
         };
-        stretch(q.ka >> 1, std::true_type{});
-        stretch((q.kb - q.ka) >> 1, std::false_type{});
-        stretch((q.kmax - q.kb) >> 1, std::true_type{});
-        if (q.tail) {               // an odd canvas height walked whole: its last row
-            const float fr = fi.x;
+        constexpr int RSH = RS ? 2 : 1;
+        stretch(q.ka >> RSH, std::true_type{});
+        stretch((q.kb - q.ka) >> RSH, std::false_type{});
+        stretch((q.kmax - q.kb) >> RSH, std::true_type{});
+        for (int tr = 0; tr < q.tail; ++tr) {   // an odd canvas height walked whole: its last row (row-split walks: up to three, every lane all of them)
+            const float fr = (float)(q.ilo + q.kmax + tr);
             const float x = (q.xj + q.t1 * fr) + q.t2, y = (q.yj + q.t4 * fr) + q.t5;
             const float xf = floorf(x), yf = floorf(y), xc = xf + 1.0f, yc = yf + 1.0f;
             const int ixr = cvt_flr(x), iyr = cvt_flr(y);
@@ -358,7 +410,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
             acc += (yc - y) * v_yf + (y - yf) * v_yc;
         }
         if (q.none) acc = vec_t(0.0f);
-        if (q.live) {
+        if (q.live && (!RS || lane >= 32)) {
             if constexpr (TILED) {
                 const size_t nrays = (size_t)g.A * nb;
                 float *dst = out + partial_index(s, nt, t, nrays, (size_t)q.ray);
@@ -403,6 +455,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
     constexpr int BAND = 1 << BSH, PER = 64 / BAND;
     const int nbk = nb >> 6, nbands = nb >> BSH;
     __syncthreads();                                               // the image, the transform rows and the class list are staged
+    CTPVAE_PSTAMP(2);
     const int ncls = __builtin_amdgcn_readfirstlane(cls_list[0]);
     int *next_task = cls_list + 1 + g.A;
     unsigned char *bcnt = reinterpret_cast<unsigned char *>(next_task + 1);          // [<= 2048] rows of a band
@@ -467,7 +520,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
             for (int e = threadIdx.x; e < E; e += blockDim.x) order[atomicAdd(&hist[bcnt[e]], 1)] = (unsigned short)e;
             __syncthreads();
         }
-        const int ntask = SORTED ? (E + PER - 1) / PER : nch * nbk;
+        const int ntask = SORTED ? (E + PER - 1) / PER : nch * nbk * (RS ? 2 : 1);
         // UNSORTED: a wave's FIRST task is fixed, dealt to the SIMDs like a snake -- waves w and w + 4 share a SIMD (HW_ID of the
         // stamped launches: tools/stamp_rounds.hip), the tasks come longest first, and this kernel is bound by the vector unit: two
         // waves of one SIMD take turns.  In arrival order the headline shape's six tasks fell 2 long + 2 short on two SIMDs and
@@ -496,12 +549,17 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
                 if (m >= ntask) break;
                 const int bi = m / ncls, ai = m - bi * ncls, blk = nbk - 1 - bi;
                 a = __builtin_amdgcn_readfirstlane(cls_list[1 + ai]);
+                if constexpr (RS) {   // 32-slot runs, both halves of the wave on the same one; the innermost first, either side in turn
+                    const int pr = bi >> 1;
+                    slot = ((bi & 1) ? nbk + pr : nbk - 1 - pr) * 32 + (lane & 31);
+                } else
                 slot = lane < 32 ? blk * 32 + lane : nb - 32 * (blk + 1) + (lane - 32);
             }
             const BilinRay q = setup(a, slot);
             if (mirror) walk(q, std::true_type{}); else walk(q, std::false_type{});
         }
     }
+    CTPVAE_PSTAMP(3);
 }
 
 // ---- backward, TensorFlow-compatible ------------------------------------------------------------------------------------------
@@ -949,13 +1007,26 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     // >= 8 waves: a workgroup's fill is shared by its waves, and two waves per SIMD issue LDS reads and waits under each other's
     // vector instructions (tools/sweep_bilin.py, B = 50 x 128 x 128 x 20 angles, G = 5: 27.1 / 24.3 / 22.1 / 21.8 us at 4 / 6 / 8 / 16)
     int waves = std::min(16, std::max(8, ceil_div(tasks, 2 * G)));
-    if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
     const bool padded = g.px >= 1 && g.py >= 1;
     // length-sorted band tasks from ~22 (angle, 64-slot block) tasks per workgroup on (the classes hold about half the angles each);
     // measured, B x 128^2 x angles, sorted against plain: 50 x 30 (9 tasks per workgroup) 28.5 / 23.6 us, 50 x 60 (18) 35.9 / 35.9,
     // 50 x 90 (27) 45.1 / 50.6, 100 x 45 (34) 62.3 / 65.0, 50 x 120 (36) 55.5 / 65.5, 10 x 180 (17) 36.8 / 34.0
     bool sorted = (long long)g.A * (nb / 64) >= 44ll * G;
     if (knob(kKnobBsort) >= 0) sorted = knob(kKnobBsort) != 0;
+    // ROW-SPLIT walks for the unsorted launches of whole slices (few tasks per workgroup: the headline shape has 6 on a CU of 4 SIMDs, and
+    // a lone wave issues one instruction of ANY kind per ~4.4 cycles -- its LDS reads, waits and scalar steps are not hidden under anything):
+    // a task is a run of 32 slots, lanes 32-63 walk the same rays two rows further on, so twice the tasks of half the length
+    // -- up to ~10 tasks per workgroup (tools/ab_rsplit.py, plain / row-split in us: 50 x 128^2 x 20 angles [6 tasks per workgroup] 20.97 /
+    // 19.05, 5 x 128^2 x 20 [4] 17.2 / 15.5, 3 x 100^2 x 7 16.9 / 12.5, 256 x 64^2 x 20 [10] 25.5 / 22.0, 50 x 128^2 x 30 [9] 23.4 / 23.7,
+    // 76 x 128^2 x 20 [10] 26.9 / 26.8; 100 x 128^2 x 20 [15] 31.9 / 34.1, 50 x 128^2 x 60 [18] 35.6 / 38.4: with many tasks per SIMD the
+    // plain walk's longer stretches and half as many task set-ups win)
+    bool rsplit = !TILED && !sorted && tasks <= 20 * G;
+    if (knob(kKnobBrsplit) >= 0) rsplit = !TILED && !sorted && knob(kKnobBrsplit) != 0;
+    if (rsplit) waves = std::min(16, std::max(8, ceil_div(2 * tasks, 2 * G)));
+    if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
+#ifdef CTPVAE_TUNE_STAMPS
+    g_pshape[0] = units, g_pshape[1] = 2 * G, g_pshape[2] = waves, g_pshape[3] = NS, g_pshape[4] = 0, g_pshape[5] = units, g_pshape[6] = 2 * G, g_pshape[7] = units, g_pshape[8] = 2 * G;
+#endif
     auto launch = [&](auto kernel) -> int {
         static std::atomic<unsigned long long> attr_set{0}, abs_ok{0};
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_fwd_bilin_kernel", abs_ok);   // the all-zero block sits at LDS address 0
@@ -966,6 +1037,8 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
         return CTPVAE_OK;
     };
     if (sorted) return padded ? launch(rotate_fwd_bilin_kernel<NS, TILED, true, true>) : launch(rotate_fwd_bilin_kernel<NS, TILED, false, true>);
+    if constexpr (!TILED)
+        if (rsplit) return padded ? launch(rotate_fwd_bilin_kernel<NS, false, true, false, true>) : launch(rotate_fwd_bilin_kernel<NS, false, false, false, true>);
     return padded ? launch(rotate_fwd_bilin_kernel<NS, TILED, true, false>) : launch(rotate_fwd_bilin_kernel<NS, TILED, false, false>);
 }
 

@@ -35,6 +35,7 @@
 #include "lds_stage.h"
 #include "loglik_math.h"
 #include "rotate_plan.h"
+#include "tune_stamps.h"
 
 namespace ctpvae {
 
@@ -353,30 +354,6 @@ __global__ __launch_bounds__(64) void rotate_class_list_kernel(int A, FwdLayout 
 // Forward.  Workgroup = (slice s, class c, group gi): stages the slice once (LDS-DMA, mirrored for class 0), then each
 // wave takes the (angle, bin block) tasks of its class round-robin.  A task streams its index groups four loads deep,
 // gathers the previous group's eight taps while the next indices are in flight, and adds in row order.
-#ifdef CTPVAE_TUNE_STAMPS
-// timing builds (tools/stamp_rounds.hip): per wave {s_memtime at start / fill issued / barrier passed / end, s_memrealtime (100 MHz)
-// at start / end, HW_ID | XCC_ID << 32}
-__device__ long long g_pstamps[8 * 65536];
-static int g_pshape[10];   // host: the last planned forward's {units, workgroups per unit, waves, slices per unit, affine}
-#define CTPVAE_PSTAMP(slot)                                                                                  \
-    do {                                                                                                     \
-        long long t_;                                                                                        \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                           \
-        const size_t w_ = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                       \
-        if ((threadIdx.x & 63) == 0 && w_ < 65536) {                                                         \
-            g_pstamps[8 * w_ + (slot)] = t_;                                                                 \
-            if ((slot) == 0 || (slot) == 3) g_pstamps[8 * w_ + 4 + (slot) / 3] = __builtin_amdgcn_s_memrealtime(); \
-            if ((slot) == 0) {                                                                               \
-                unsigned hw_, xcc_;                                                                          \
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
-                g_pstamps[8 * w_ + 6] = (long long)hw_ | ((long long)xcc_ << 32);                            \
-            }                                                                                                \
-        }                                                                                                    \
-    } while (0)
-#else
-#define CTPVAE_PSTAMP(slot)
-#endif
-
 // NS = 2: two slices per workgroup, interleaved as float2 in LDS -- ONE index stream and ONE ds_read_b64 per tap serve
 // both slices (the index stream is what binds the kernel, section 6 of DESIGN.md).  Used when a launch has enough
 // tasks to keep every CU busy with half as many workgroups.

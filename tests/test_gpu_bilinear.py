@@ -64,6 +64,9 @@ def test_bilinear_forward_random_geometries(oracle):
                 for bsort in (0, 1):               # ... with (angle, block) tasks and with length-sorted band tasks
                     with _lib.tuned("BSORT", bsort):
                         np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"fwd BNS={ns} BSORT={bsort} " + msg)
+                for rsplit in (0, 1):              # ... (angle, block) tasks of 64 rays, and of 32 rays with four rows of a ray per step
+                    with _lib.tuned("BSORT", 0), _lib.tuned("BRSPLIT", rsplit):
+                        np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"fwd BNS={ns} BRSPLIT={rsplit} " + msg)
         with _lib.tuned("NO_PLAN", 1):             # round 1's direct kernel: a second implementation of the same sums
             np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg="fwd direct " + msg)
 
@@ -85,6 +88,28 @@ def test_bilinear_slice_independence_and_launch_shapes(oracle):
         for bsort in (0, 1):   # (sorted bands: band b of every angle belongs to task group b mod G)
             with _lib.tuned("BW", G), _lib.tuned("WAVES", waves), _lib.tuned("BSORT", bsort):
                 np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"G={G} waves={waves} BSORT={bsort}")
+        for rsplit in (0, 1):  # (row-split walks: 32-ray tasks, lanes 32-63 two rows further on)
+            with _lib.tuned("BW", G), _lib.tuned("WAVES", waves), _lib.tuned("BSORT", 0), _lib.tuned("BRSPLIT", rsplit):
+                np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"G={G} waves={waves} BRSPLIT={rsplit}")
+
+
+@pytest.mark.parametrize("H,W,pad", [(65, 40, False), (66, 31, False), (67, 128, False), (3, 50, False), (2, 2, False), (33, 47, True), (128, 128, True)])
+def test_bilinear_row_split_walks(oracle, H, W, pad):
+    """Row-split walks (launches of few tasks per workgroup: lanes 32-63 of a wave carry the rays of lanes 0-31 two rows further on,
+    the sums kept in ray-row order through v_permlane32_swap) against the plain walk and the oracle: canvas heights that leave 0, 1,
+    2 and 3 rows behind the steps of four, canvases shorter than one step, 1 / 2 / 4 slices per cell, axis-aligned angles."""
+    d = dev()
+    rng = np.random.default_rng(H * 1000 + W)
+    theta = np.concatenate([rng.uniform(-np.pi, np.pi, 5), [0.0, np.pi / 2, np.pi / 4]])
+    img = rng.standard_normal((5, H, W)).astype(np.float32)
+    geom = oracle.Geometry(H, W, pad)
+    plan = RotatePlan(theta, H, W, pad, d, interp="bilinear")
+    want = oracle.rotate_fwd(img, geom, oT(oracle, theta, plan), 1)
+    x = torch.from_numpy(img).to(d)
+    for ns in (1, 2, 4):
+        for G in (-1, 1, 3):
+            with _lib.tuned("BNS", ns), _lib.tuned("BW", G), _lib.tuned("BSORT", 0), _lib.tuned("BRSPLIT", 1):
+                np.testing.assert_array_equal(to_np(plan.forward(x)), want, err_msg=f"BNS={ns} G={G}")
 
 
 def test_bilinear_forward_at_many_angles(oracle):

@@ -44,7 +44,12 @@ int main(int argc, char **argv)
         if (ctpvae_rotate_plan_build_f32(d_T, d_Ti, A, N, N, P, P, pad, pad, nullptr, bp, nullptr)) { printf("%s\n", ctpvae_last_error()); return 1; }
         if (ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); return 1; }
     }
+    const bool bilin = getenv("CTPVAE_STAMP_BILIN") != nullptr;   // the bilinear forward of whole slices instead
     auto run = [&] {
+        if (bilin) {
+            if (ctpvae_rotate_fwd_f32(d_img, S, N, N, P, P, pad, pad, d_T, A, CTPVAE_BILINEAR, d_sino, nullptr)) { printf("%s\n", ctpvae_last_error()); exit(1); }
+            return;
+        }
         const int rc = bwd ? ctpvae_rotate_bwd_planned_f32(d_sino, S, N, N, P, P, A, bp, d_gimg, nullptr)
                            : ctpvae_rotate_fwd_planned_f32(d_img, S, N, N, P, P, A, fp, d_sino, nullptr);
         if (rc) { printf("%s\n", ctpvae_last_error()); exit(1); }
