@@ -581,7 +581,7 @@ __global__ __launch_bounds__(1024) void rotate_fwd_bilin_kernel(const float *__r
 // Every pixel adds its angles in ascending order: bit-identical to the oracle whatever the class.
 constexpr int kBSegBins = 80, kBSegPitch = kBSegBins + 1;
 template <int PPT, int NS>
-__global__ __launch_bounds__(256) void rotate_bwd_bilin_seg_kernel(const float *__restrict__ gsino, RotGeom g,
+__global__ __launch_bounds__(PPT == 1 ? 1024 : (PPT == 2 ? 512 : 256)) void rotate_bwd_bilin_seg_kernel(const float *__restrict__ gsino, RotGeom g,
                                                                    const float *__restrict__ Tinv8, int chunk_a,
                                                                    float *__restrict__ gimg)
 {
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(64) void rotate_exact_bilin_plan_kernel(RotGeom g, 
 }
 
 template <int PPT, int NS>
-__global__ __launch_bounds__(256) void rotate_bwd_exact_bilin_kernel(const float *__restrict__ gsino, RotGeom g,
+__global__ __launch_bounds__(PPT == 1 ? 1024 : (PPT == 2 ? 512 : 256)) void rotate_bwd_exact_bilin_kernel(const float *__restrict__ gsino, RotGeom g,
                                                                      const float *__restrict__ Tinv8, int chunk_a,
                                                                      const float4 *__restrict__ plan, float *__restrict__ gimg)
 {
@@ -1086,25 +1086,33 @@ int bilin_bwd_tfcompat(const float *gsino_dev, int S, int A, int PH, int PW, con
         const RotGeom g{n, H, W, PH, PW, py, px, A};
         const float *gs = gsino_dev + (size_t)s0 * A * PW;
         float *gi = gimg_dev + (size_t)s0 * H * W;
-        // slices per cell and rows per lane: the most sharing that still puts about two workgroups on every CU
-        const long long tiles8 = (long long)ceil_div(W, 64) * ceil_div(H, 32), tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
-        int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 8;
-        while (ns > 1 && ceil_div(n, ns) * tiles4 < 400) ns >>= 1;
-        if (ceil_div(n, ns) * tiles8 < 400) ppt = 4;
+        // Slices per cell: the most sharing that still leaves ~200 workgroups.  Rows per lane: TWO -- eight waves on a workgroup's
+        // 64 x 16 pixels and its segments (four waves of four rows, round 5's first form, left one or two waves on a SIMD, and a lone
+        // wave issues one instruction of any kind per ~4.4 cycles: tools/sweep_bilin_bwd.py, B x 128^2 x angles, us with 4 / 2 / 1
+        // rows per lane: 50 x 20 [four slices per cell] 10.3 / 8.6 / 8.6, 50 x 180 77.6 / 59.9 / 53.7, 100 x 20 14.1 / 12.8 / 14.3,
+        // 400 x 180 286 / 271 / -, 32 x 512^2 x 90 163.8 / 160.0 / 208; 25 x 20 [pairs] 9.0 / 7.1 / 7.1, 12 x 20 [singles] 7.8 / 6.8 /
+        // 6.9) -- ONE row, sixteen waves, for launches of one round of workgroups at many angles.
+        const long long tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
+        int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 2;
+        while (ns > 1 && ceil_div(n, ns) * tiles4 < 200) ns >>= 1;
+        if (ceil_div(n, ns) * tiles4 <= 256 && A >= 64) ppt = 1;
         if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
         if (ns == 3) ns = 2;
-        if (knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
-        if (ns == 4) ppt = 4;                     // (eight rows of four slices: the taps of an angle alone are 64 registers)
+        if (knob(kKnobSegPpt) == 1 || knob(kKnobSegPpt) == 2 || knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
+        if (ns == 4 && ppt == 8) ppt = 4;         // (eight rows of four slices: the taps of an angle alone are 64 registers)
         // ~48 KiB of segments per chunk of angles: three 4-wave workgroups per CU
         int chunk_a = std::max(1, std::min(A, (48 * 1024) / (kBSegPitch * 4 * ns + 40)));
         if (knob(kKnobSegChunk) > 0) chunk_a = std::max(1, std::min(A, std::min(knob(kKnobSegChunk), chunk_a)));
         const size_t shmem = (((size_t)chunk_a * (kBSegPitch * ns + 2) + 3) & ~(size_t)3) * 4 + (size_t)chunk_a * 32 + 16;
-        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), ceil_div(n, ns)), block(256);
+        // (two rows per lane: EIGHT waves on the same 64 x 16 pixels and the same segments)
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, ppt <= 2 ? 16 : 4 * ppt), ceil_div(n, ns)), block(ppt == 1 ? 1024 : (ppt == 2 ? 512 : 256));
         auto launch = [&](auto kernel) -> int {
             hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a, gi);
             CTPVAE_LAUNCH_CHECK("rotate_bwd_bilin_seg_kernel");
             return CTPVAE_OK;
         };
+        if (ppt == 1) return ns == 4 ? launch(rotate_bwd_bilin_seg_kernel<1, 4>) : (ns == 2 ? launch(rotate_bwd_bilin_seg_kernel<1, 2>) : launch(rotate_bwd_bilin_seg_kernel<1, 1>));
+        if (ppt == 2) return ns == 4 ? launch(rotate_bwd_bilin_seg_kernel<2, 4>) : (ns == 2 ? launch(rotate_bwd_bilin_seg_kernel<2, 2>) : launch(rotate_bwd_bilin_seg_kernel<2, 1>));
         if (ns == 4) return launch(rotate_bwd_bilin_seg_kernel<4, 4>);
         if (ns == 2) return ppt == 8 ? launch(rotate_bwd_bilin_seg_kernel<8, 2>) : launch(rotate_bwd_bilin_seg_kernel<4, 2>);
         return ppt == 8 ? launch(rotate_bwd_bilin_seg_kernel<8, 1>) : launch(rotate_bwd_bilin_seg_kernel<4, 1>);
@@ -1144,24 +1152,34 @@ int exact_bilin_bwd(const float *gsino_dev, int S, int A, int PH, int PW, const 
         const RotGeom g{n, H, W, PH, PW, py, px, A};
         const float *gs = gsino_dev + (size_t)s0 * A * PW;
         float *gi = gimg_dev + (size_t)s0 * H * W;
-        // every slice of a cell shares the 16-byte plan word of its (angle, pixel): as many slices per cell as the batch has
+        // Every slice of a cell shares the 16-byte plan word of its (angle, pixel): four slices per cell from ~200 workgroups on, pairs
+        // below.  Rows per lane: the kernel waits for its plan words, so the more waves the better while the plan is cache-resident
+        // -- ONE row per lane (sixteen waves on 64 x 16 pixels) for a launch of one round of workgroups, TWO (eight waves) above;
+        // four rows (round 5's first form) where the plan streams from memory (512 x 512 x 90 angles: 377 MB).
+        // tools/sweep_bilin_bwd.py with BWD=exact, us at 4 / 2 / 1 rows per lane: 50 x 128^2 x 20 angles [four slices] 14.0 / 10.3 / 8.9,
+        // 25 x 20 [pairs] 13.7 / 7.9 / 7.5, 5 x 20 [pairs] 13.5 / 7.6 / 7.2, 50 x 180 [four] 131 / 97 / 80, 100 x 20 17.1 / 14.0 / 15.3,
+        // 400 x 180 399 / 323 / -, 32 x 512^2 x 90 302 / 340 / 566.
         const long long tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
-        int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 4;
-        if (ceil_div(n, ns) * tiles4 >= 1024) ppt = 8;
+        int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 2;
+        while (ns > 2 && ceil_div(n, ns) * tiles4 < 200) ns >>= 1;
+        if (ceil_div(n, ns) * tiles4 <= 256) ppt = 1;
+        if ((long long)A * H * W * 16 > (128ll << 20)) ppt = 4;
         if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
         if (ns == 3) ns = 2;
-        if (knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
-        if (ns == 4) ppt = 4;
+        if (knob(kKnobSegPpt) == 1 || knob(kKnobSegPpt) == 2 || knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
+        if (ns == 4 && ppt == 8) ppt = 4;
         int chunk_a = std::max(1, std::min(A, (48 * 1024) / (kXSegPitch * 4 * ns + 8)));
         if (knob(kKnobSegChunk) > 0) chunk_a = std::max(1, std::min(A, std::min(knob(kKnobSegChunk), chunk_a)));
         const size_t shmem = (size_t)chunk_a * (kXSegPitch * ns * 4 + 8) + 16;
-        const dim3 grid(ceil_div(W, 64), ceil_div(H, 4 * ppt), ceil_div(n, ns)), block(256);
+        const dim3 grid(ceil_div(W, 64), ceil_div(H, ppt <= 2 ? 16 : 4 * ppt), ceil_div(n, ns)), block(ppt == 1 ? 1024 : (ppt == 2 ? 512 : 256));
         auto launch = [&](auto kernel) -> int {
             hipLaunchKernelGGL(kernel, grid, block, shmem, (hipStream_t)stream, gs, g, Tinv8_dev, chunk_a,
                                reinterpret_cast<const float4 *>(plan_dev), gi);
             CTPVAE_LAUNCH_CHECK("rotate_bwd_exact_bilin_kernel");
             return CTPVAE_OK;
         };
+        if (ppt == 1) return ns == 4 ? launch(rotate_bwd_exact_bilin_kernel<1, 4>) : (ns == 2 ? launch(rotate_bwd_exact_bilin_kernel<1, 2>) : launch(rotate_bwd_exact_bilin_kernel<1, 1>));
+        if (ppt == 2) return ns == 4 ? launch(rotate_bwd_exact_bilin_kernel<2, 4>) : (ns == 2 ? launch(rotate_bwd_exact_bilin_kernel<2, 2>) : launch(rotate_bwd_exact_bilin_kernel<2, 1>));
         if (ns == 4) return launch(rotate_bwd_exact_bilin_kernel<4, 4>);
         if (ns == 2) return ppt == 8 ? launch(rotate_bwd_exact_bilin_kernel<8, 2>) : launch(rotate_bwd_exact_bilin_kernel<4, 2>);
         return ppt == 8 ? launch(rotate_bwd_exact_bilin_kernel<8, 1>) : launch(rotate_bwd_exact_bilin_kernel<4, 1>);
