@@ -13,20 +13,47 @@ constexpr float kHalfLog2Pi = 0.91893853320467274178f;
 // -- with its three IEEE divisions as they stand: where x and loc nearly cancel, the value IS the rounding of those two large
 // quotients (x / scale ~ 1e2 .. 1e4, so ~1e-5 absolute), and only the same operations on the same bits reproduce it (taken as
 // products with 1 / scale the golden log-probabilities moved by 6e-6 of their largest value, 2e-5 in single samples: reverted).
+//
+// The divisions are IEEE quotients WITHOUT hipcc's twelve-instruction sequence per quotient: that sequence is (v_div_scale x 2,
+// v_rcp, two Newton steps on the reciprocal, quotient, two residual corrections -- the last through v_div_fmas --, v_div_fixup), and
+// for operands it does not have to rescale (finite, the quotient far from the denormals: every quotient here -- scale >= eps > 0,
+// pnm > 0) scale / fmas / fixup are the identity.  div_by() is the rest of it, verbatim, with the refined reciprocal of the
+// denominator taken ONCE for the quotients that share it (x / scale and loc / scale; loc / pnm of every sample of a kernel): the
+// same bits (tools/ab_loglik_div.py: 2^26 samples against the compiler's sequence, 0 differ), 5 instead of 12 instructions per quotient.
+struct Recip {
+    float d, r;   // a denominator and its reciprocal, v_rcp_f32 + one Newton step (the IEEE sequence's r1)
+};
+__device__ __forceinline__ Recip recip_refined(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return Recip{d, r};
+}
+__device__ __forceinline__ float div_by(float a, const Recip &k)
+{
+    float q = a * k.r;
+    float e = __builtin_fmaf(-k.d, q, a);
+    q = __builtin_fmaf(e, k.r, q);
+    e = __builtin_fmaf(-k.d, q, a);
+    return __builtin_fmaf(e, k.r, q);
+}
 struct GaussPoisson {
     float loc, root, scale;
+    Recip rscale;
 };
 __device__ __forceinline__ GaussPoisson gaussian_poisson_terms(float proj, float m, float pnm, float eps)
 {
     GaussPoisson t;
     t.loc = proj * m;
-    t.root = sqrtf(t.loc / pnm + eps);
+    t.root = sqrtf(div_by(t.loc, recip_refined(pnm)) + eps);
     t.scale = eps + t.root;
+    t.rscale = recip_refined(t.scale);
     return t;
 }
 __device__ __forceinline__ float gaussian_poisson_logp(const GaussPoisson &t, float x)
 {
-    const float z = x / t.scale - t.loc / t.scale;
+    const float z = div_by(x, t.rscale) - div_by(t.loc, t.rscale);
     return -0.5f * (z * z) - (kHalfLog2Pi + logf(t.scale));
 }
 __device__ __forceinline__ float gaussian_poisson_logp(float proj, float m, float x, float pnm, float eps)
@@ -36,17 +63,17 @@ __device__ __forceinline__ float gaussian_poisson_logp(float proj, float m, floa
 
 // d logp / d proj (the mask factor included) and d logp / d pnm of the same sample: what the backward multiplies the
 // upstream gradient by.  One expression for loglik_bwd_kernel and for the projector epilogue that stores dlp.  Nothing pins
-// its bits (the tests hold it to float64 autograd at 1e-4), so its quotients are products with TWO reciprocals, 1 / scale and
-// 1 / root, and with the caller's 1 / pnm (once per kernel) -- written with a division per quotient (round 2) the derivative
+// its bits (the tests hold it to float64 autograd at 1e-4), so its quotients are products with TWO reciprocals, 1 / scale (the log-probability's refined one) and
+// 1 / root (v_rcp_f32), and with the caller's 1 / pnm (once per kernel) -- written with a division per quotient (round 2) the derivative
 // was six divisions and a second root, ~110 of the ~180 vector instructions a sample cost.  (Measured on one box: config 5's
 // forward + likelihood + sums 122.4 -> 122.2 us, the training call 9.9 -> 9.85 us -- the epilogues' arithmetic hides under
 // their memory traffic; kept because it is less code, not because it is faster.)
 __device__ __forceinline__ float gaussian_poisson_dlogp(const GaussPoisson &t, float m, float x, float inv_pnm, float &dpnm)
 {
-    const float rs = 1.0f / t.scale;
+    const float rs = t.rscale.r;                         // (the refined reciprocal: within an ulp of 1 / scale)
     const float z = (x - t.loc) * rs;
     const float dscale = (z * z - 1.0f) * rs;            // d logp / d scale
-    const float dscale_du = 0.5f * (1.0f / t.root);      // d scale / d (loc/pnm + eps)
+    const float dscale_du = 0.5f * __builtin_amdgcn_rcpf(t.root);   // d scale / d (loc/pnm + eps)
     dpnm = dscale * dscale_du * (-t.loc * (inv_pnm * inv_pnm));
     return (z * rs + dscale * dscale_du * inv_pnm) * m;
 }
