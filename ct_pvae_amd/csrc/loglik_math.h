@@ -145,10 +145,34 @@ struct LogLikEpilogue {
 
 // The fixed order of a 64-lane task's partial sum: xor butterfly, every lane ends with the same value (a + b == b + a bit
 // for bit, so both partners of a step compute the same sum).  oracle/radon_oracle.py loglik_object_sums restates it.
+// (round 5: the partners' values arrive through the vector unit -- v_permlane32_swap / v_permlane16_swap for the distances 32 and 16,
+// DPP row rotations and quad permutations below -- instead of six dependent ds_bpermute round trips through the LDS queue; the same
+// six sums a + b, the same bits: a copy pair swapped half against half holds both partners of every lane, and a + b == b + a.)
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ float wave_sum_dpp(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    {   // xor 32: lanes 32-63 of the first copy change places with lanes 0-31 of the second: a = {lo, lo}, b = {hi, hi}
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // (two wait states behind the write of v)
+        v = a + b;
+    }
+    {   // xor 16: odd rows of the first copy change places with even rows of the second: a = rows {0, 0, 2, 2}, b = rows {1, 1, 3, 3}
+        float a = v, b = v;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        v = a + b;
+    }
+    v = v + wave_sum_dpp<0x128>(v, v);              // row_ror:8 = xor 8 inside a row of 16
+    {
+        float p = wave_sum_dpp<0x104, 0x5>(v, v);   // row_shl:4: lanes with bit 2 clear (banks 0, 2) take lane + 4
+        p = wave_sum_dpp<0x114, 0xa>(p, v);         // row_shr:4: the others take lane - 4
+        v = v + p;
+    }
+    v = v + wave_sum_dpp<0x4e>(v, v);               // quad_perm [2, 3, 0, 1]
+    v = v + wave_sum_dpp<0xb1>(v, v);               // quad_perm [1, 0, 3, 2]
     return v;
 }
 
