@@ -77,7 +77,7 @@ int ctpvae_device_count(void);
  * path never reads the environment: the registry is filled once, when the library is loaded, from CTPVAE_TUNE_<NAME>
  * (and CTPVAE_NO_PLAN / CTPVAE_FORCE_GENERIC), and changed afterwards only here.  name: "NS", "G", "WAVES", "BNS",
  * "BW", "SEG_NS", "SEG_CHUNK", "SEG_PPT", "TILED_NS", "TILED_G", "SIDDON_NS", "SIDDON_THREADS", "SIDDON_PPB",
- * "SIDDON_BWD_NS", "SIDDON_BWD_CHUNKS", "MAX_SLICES", "NO_PLAN", "NO_COMPACT", "FORCE_GENERIC"; value < 0 unsets; name "*" unsets every knob.
+ * "SIDDON_BWD_NS", "SIDDON_BWD_CHUNKS", "MAX_SLICES", "NO_PLAN", "NO_COMPACT", "FORCE_GENERIC", ... (every name: DESIGN.md section 8); value < 0 unsets; name "*" unsets every knob.
  * _active: how many knobs are set (bench.py prints it next to its numbers). */
 int ctpvae_tune_set(const char *name, int value);
 int ctpvae_tune_active(void);
