@@ -204,7 +204,7 @@ def test_bilinear_tfcompat_backward_random_geometries(oracle):
         gt = torch.from_numpy(g).to(d)
         msg = f"case {case}: {H}x{W} pad={pad} A={len(theta)} S={S}"
         np.testing.assert_array_equal(to_np(plan.backward(gt)), want, err_msg="bwd " + msg)
-        for ns, ppt in ((1, 4), (1, 8), (2, 4), (2, 8), (4, 4)):
+        for ns, ppt in ((1, 4), (1, 8), (2, 4), (2, 8), (4, 4), (1, 1), (2, 1), (4, 1), (1, 2), (2, 2), (4, 2)):   # (1 / 2 rows per lane: 16 / 8 waves per tile)
             with _lib.tuned("SEG_NS", ns), _lib.tuned("SEG_PPT", ppt):
                 np.testing.assert_array_equal(to_np(plan.backward(gt)), want, err_msg=f"bwd SEG_NS={ns} SEG_PPT={ppt} " + msg)
         with _lib.tuned("SEG_CHUNK", 3):           # several chunks of angles
@@ -247,7 +247,7 @@ def test_bilinear_exact_adjoint_random_geometries(oracle):
         got = plan.backward(gt)
         assert rel_err(to_np(got), want) <= REL, msg
         assert torch.equal(got, plan.backward(gt)), "run to run " + msg
-        for ns, ppt in ((1, 4), (1, 8), (2, 4), (2, 8), (4, 4)):
+        for ns, ppt in ((1, 4), (1, 8), (2, 4), (2, 8), (4, 4), (1, 1), (2, 1), (4, 1), (1, 2), (2, 2), (4, 2)):   # (1 / 2 rows per lane: 16 / 8 waves per tile)
             with _lib.tuned("SEG_NS", ns), _lib.tuned("SEG_PPT", ppt):
                 assert torch.equal(got, plan.backward(gt)), f"SEG_NS={ns} SEG_PPT={ppt} " + msg
         with _lib.tuned("SEG_CHUNK", 3):
