@@ -998,7 +998,9 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     if (!TILED) {
         const double t_task = 1.3 * (double)g.PH / 184.0 * (NS == 4 ? 1.25 : 1.0), tc = std::max(1, tasks / 2);
         double best = 0.0;
-        for (int c = 1; c <= std::min(16, std::max(1, tasks / 8)); ++c) {
+        // (up to a group per four tasks: with row-split walks -- below -- the small launches keep gaining up to 16 groups: 1 .. 12 x 128^2 x
+        // 20 angles 14.7 us at 7 groups, 12.3 at 16; tools/sweep_bilin_modes.py, profiles/r05_bilin_fwd_rules.txt)
+        for (int c = 1; c <= std::min(16, std::max(1, tasks / 4)); ++c) {
             const double t = std::ceil(2.0 * units * c / 256.0) * (6.0 + t_task * tc / c);
             if (best == 0.0 || t < best * 0.97) best = t, G = c;
         }
@@ -1016,11 +1018,11 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     // ROW-SPLIT walks for the unsorted launches of whole slices (few tasks per workgroup: the headline shape has 6 on a CU of 4 SIMDs, and
     // a lone wave issues one instruction of ANY kind per ~4.4 cycles -- its LDS reads, waits and scalar steps are not hidden under anything):
     // a task is a run of 32 slots, lanes 32-63 walk the same rays two rows further on, so twice the tasks of half the length
-    // -- up to ~10 tasks per workgroup (tools/ab_rsplit.py, plain / row-split in us: 50 x 128^2 x 20 angles [6 tasks per workgroup] 20.97 /
+    // -- up to ~14 tasks per workgroup (tools/ab_rsplit.py, plain / row-split in us: 50 x 128^2 x 20 angles [6 tasks per workgroup] 20.97 /
     // 19.05, 5 x 128^2 x 20 [4] 17.2 / 15.5, 3 x 100^2 x 7 16.9 / 12.5, 256 x 64^2 x 20 [10] 25.5 / 22.0, 50 x 128^2 x 30 [9] 23.4 / 23.7,
-    // 76 x 128^2 x 20 [10] 26.9 / 26.8; 100 x 128^2 x 20 [15] 31.9 / 34.1, 50 x 128^2 x 60 [18] 35.6 / 38.4: with many tasks per SIMD the
+    // 76 x 128^2 x 20 [10] 26.9 / 26.8, 50 x 128^2 x 45 [13.5] 32.2 / 30.7; 100 x 128^2 x 20 [15] 31.9 / 34.1, 50 x 128^2 x 60 [18] 35.6 / 38.4: with many tasks per SIMD the
     // plain walk's longer stretches and half as many task set-ups win)
-    bool rsplit = !TILED && !sorted && tasks <= 20 * G;
+    bool rsplit = !TILED && !sorted && tasks <= 28 * G;
     if (knob(kKnobBrsplit) >= 0) rsplit = !TILED && !sorted && knob(kKnobBrsplit) != 0;
     if (rsplit) waves = std::min(16, std::max(8, ceil_div(2 * tasks, 2 * G)));
     if (knob(kKnobWaves) > 0) waves = std::min(16, knob(kKnobWaves));
