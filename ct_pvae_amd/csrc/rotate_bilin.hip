@@ -1096,8 +1096,8 @@ int bilin_bwd_tfcompat(const float *gsino_dev, int S, int A, int PH, int PW, con
         // 6.9) -- ONE row, sixteen waves, for launches of one round of workgroups at many angles.
         const long long tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
         int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 2;
-        while (ns > 1 && ceil_div(n, ns) * tiles4 < 200) ns >>= 1;
-        if (ceil_div(n, ns) * tiles4 <= 256 && A >= 64) ppt = 1;
+        while (ns > 1 && ceil_div(n, ns) * tiles4 < 160) ns >>= 1;   // (20 x 128^2 x 90 angles: pairs, 160 workgroups, 20.5 us; singles, 320: 27)
+        if (ceil_div(n, ns) * tiles4 <= 256 && A >= 32) ppt = 1;
         if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
         if (ns == 3) ns = 2;
         if (knob(kKnobSegPpt) == 1 || knob(kKnobSegPpt) == 2 || knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
@@ -1163,9 +1163,12 @@ int exact_bilin_bwd(const float *gsino_dev, int S, int A, int PH, int PW, const 
         // 400 x 180 399 / 323 / -, 32 x 512^2 x 90 302 / 340 / 566.
         const long long tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
         int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 2;
-        while (ns > 2 && ceil_div(n, ns) * tiles4 < 200) ns >>= 1;
-        if (ceil_div(n, ns) * tiles4 <= 256) ppt = 1;
-        if ((long long)A * H * W * 16 > (128ll << 20)) ppt = 4;
+        // (second look, library against the best forced launch over 19 shapes: at >= 64 angles pairs in up to 512 sixteen-wave
+        // workgroups beat quads in ~200 -- 50 x 180 angles 79.8 -> 75.0 us --, and the streaming plan's four rows per lane pay from
+        // ~700 workgroups on -- 8 x 512^2 x 90 (512): 92.9 us with four rows, 82.0 with two)
+        while (ns > 2 && ceil_div(n, ns) * tiles4 < (A >= 64 ? 256 : 200)) ns >>= 1;
+        if (ceil_div(n, ns) * tiles4 <= (A >= 64 ? 512 : 256)) ppt = 1;
+        if ((long long)A * H * W * 16 > (128ll << 20)) ppt = ceil_div(n, ns) * tiles4 >= 700 ? 4 : 2;   // (one row: 145 us at 8 x 512^2 x 90; 12 slices, 768 workgroups: 99 us with four rows, 109 with two)
         if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
         if (ns == 3) ns = 2;
         if (knob(kKnobSegPpt) == 1 || knob(kKnobSegPpt) == 2 || knob(kKnobSegPpt) == 4 || knob(kKnobSegPpt) == 8) ppt = knob(kKnobSegPpt);
