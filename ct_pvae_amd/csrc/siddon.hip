@@ -867,7 +867,13 @@ static int siddon_fwd_ws(const float *obj_dev, int oy, int ox, int oz, const flo
     CTPVAE_REQUIRE(obj_dev && data_dev && sin_dev && cos_dev && quad_dev && oy > 0 && ox > 0 && oz > 0 && dt > 0 && dx > 0,
                    "siddon_fwd: null pointer or empty sizes");
     CTPVAE_REQUIRE((meas_dev == nullptr) == (rn2_dev == nullptr), "siddon_fwd: meas and the per-ray weights go together");
-    const int ns = siddon_packed_ns(oy, ox, oz);
+    int ns = siddon_packed_ns(oy, ox, oz);
+    // A launch of few waves takes as long as ONE walk -- 55-70 us with eight slices behind a ray (packed, objects through the L2),
+    // 43-47 us with the slice pair in LDS: up to ~750 waves of pairs the LDS kernels are the faster ones (16 x 128^2 x 20 angles: 47.4
+    // against 67.6 us, 24 x 20: 47.4 against 67.6; 32 x 20, 920 waves of pairs: 75.6 against 66-69; tools/sweep_siddon_ns.py)
+    if (ns != 0 && knob(kKnobSiddonNs) < 0 && 2 * (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float) <= (size_t)kMaxLdsBytes &&
+        (long long)ceil_div(oy, 2) * dt * dx <= 750ll * 64)
+        ns = 0;
     if (ns == 0)
         return siddon_fwd_chunks(obj_dev, oy, ox, oz, sin_dev, cos_dev, quad_dev, dt, dx, center, meas_dev, rn2_dev, mode, data_dev, stream);
     CTPVAE_REQUIRE(workspace_dev, "siddon_fwd: %d slices need the workspace", oy);
@@ -918,7 +924,8 @@ static int siddon_fwd_one(const float *obj_dev, int oy, int ox, int oz, const fl
     const size_t lds_one = (size_t)ox * (oz + ((1 - (oz & 31)) & 31)) * sizeof(float);
     const bool use_lds = lds_one <= (size_t)kMaxLdsBytes;
     // two slices per workgroup when the pair fits LDS and the call has slices to pair
-    int ns = (oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
+    // (... and up to ~500 waves single slices: more workgroups of the same walk -- 8 x 128^2 x 20 angles 43.8 us single, 47.1 paired)
+    int ns = (oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes && (long long)oy * dt * dx > 500ll * 64) ? 2 : 1;
     if (knob(kKnobSiddonNs) >= 0) ns = (knob(kKnobSiddonNs) == 2 && oy >= 2 && 2 * lds_one <= (size_t)kMaxLdsBytes) ? 2 : 1;
     const int units = ceil_div(oy, ns);
     const size_t lds_bytes = lds_one * ns;
