@@ -992,10 +992,20 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     // taken from 128 units on -- 75 pairs x 2 classes = 150 workgroups on 256 CUs (B = 150 x 180 angles: 320 us; with G = 5,
     // 750 workgroups in 3 rounds); 150 pairs = 300 workgroups = two rounds for 1.17 rounds of work (635 us; G = 5: 6 rounds of a
     // fifth).  Near-ties go to fewer groups (every group stages the unit again).
-    // (Tiles keep the older rule -- fill the chip once: their workgroups are short, and a tile's bands sort worse in fewer hands:
-    // 8 x 512^2 x 90 measured 133 us with the rounds rule's G = 4 against 110.)
+    // (Tiles: the whole-slice constants over-split them -- a tile's walk is ~150 rows, not the canvas's 728: 8 x 512^2 x 90 measured 133 us
+    // with G = 4 against 110 -- so they get the rule with their own constants, below.)
     int G = std::min(std::max(1, 256 / (2 * units)), std::max(1, tasks / 8));
-    if (!TILED) {
+    if (TILED) {
+        // (tiles, second look -- tools/sweep_tile_rules.py, profiles/r05_tile_rules.txt: the same rounds rule with a tile's own walk
+        // length and ~20 us of fill and band sorts per workgroup (12 us took four groups at 8 x 512^2 x 90: 123.5 us against 108.7 with one);
+        // 16 x 512^2 x 90 angles: one group 202 us in 1.5 rounds, two 182)
+        const double t_task = 1.3 * (double)(ts.th + ts.tw) / 184.0 * (NS == 4 ? 1.25 : 1.0), tc = std::max(1, tasks / 2);
+        double best = 0.0;
+        for (int c = 1; c <= std::min(16, std::max(1, tasks / 8)); ++c) {
+            const double t = std::ceil(2.0 * units * c / 256.0) * (20.0 + t_task * tc / c);
+            if (best == 0.0 || t < best * 0.97) best = t, G = c;
+        }
+    } else {
         const double t_task = 1.3 * (double)g.PH / 184.0 * (NS == 4 ? 1.25 : 1.0), tc = std::max(1, tasks / 2);
         double best = 0.0;
         // (up to a group per four tasks: with row-split walks -- below -- the small launches keep gaining up to 16 groups: 1 .. 12 x 128^2 x
@@ -1013,7 +1023,8 @@ static int launch_bilin_fwd(const float *img_dev, const RotGeom &g, const TileSp
     // length-sorted band tasks from ~22 (angle, 64-slot block) tasks per workgroup on (the classes hold about half the angles each);
     // measured, B x 128^2 x angles, sorted against plain: 50 x 30 (9 tasks per workgroup) 28.5 / 23.6 us, 50 x 60 (18) 35.9 / 35.9,
     // 50 x 90 (27) 45.1 / 50.6, 100 x 45 (34) 62.3 / 65.0, 50 x 120 (36) 55.5 / 65.5, 10 x 180 (17) 36.8 / 34.0
-    bool sorted = (long long)g.A * (nb / 64) >= 44ll * G;
+    // (tiles from ~12 on: their chord profiles are the worse ones -- 8 x 512^2 x 20 angles 46.0 us plain, 42.2 sorted)
+    bool sorted = (long long)g.A * (nb / 64) >= (TILED ? 24ll : 44ll) * G;
     if (knob(kKnobBsort) >= 0) sorted = knob(kKnobBsort) != 0;
     // ROW-SPLIT walks for the unsorted launches of whole slices (few tasks per workgroup: the headline shape has 6 on a CU of 4 SIMDs, and
     // a lone wave issues one instruction of ANY kind per ~4.4 cycles -- its LDS reads, waits and scalar steps are not hidden under anything):
