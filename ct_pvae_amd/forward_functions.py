@@ -730,17 +730,24 @@ class RotatePlan:
     def backward_uses_step_plan(self, S):
         """The segment backward over the step plan (ctpvae_rotate_bwd_stepped_scaled_f32; below 512 tiles of 64 x 32 that entry
         point runs the direct segment kernel itself): always for slices too large for the planned backward; for slices that fit
-        LDS from 160 slices on, and from 80 slices at <= 64 angles -- round 3, 128 x 128, planned vs this entry point:
+        LDS where _segments_win says so -- round 3, 128 x 128, planned vs this entry point:
         B=400 A=180 142.7 vs 111.9 us, B=400 A=20 30.0 vs 20.0, B=200 A=90 47.0 vs 39.4, B=160 A=180 62.4 vs 58.9; the planned
         kernel keeps B=128 A=180 (42.5 vs 49.7) and everything smaller at many angles.  The three paths give the same bits."""
         if self._step_plan is None:
             return False
-        return (not self._want_bwd_plan) or S >= 160 or (S >= 80 and self.A <= 64)
+        return (not self._want_bwd_plan) or self._segments_win(S)
+
+    def _segments_win(self, S):
+        """Where the segment kernels beat the planned gather at sizes that fit LDS (round 5, both paths forced over 9 batch sizes x 6 angle
+        counts, tools/sweep_bwd_paths_grid.py, profiles/r05_nearest_rules.txt): from 200 slices on; from 80 at <= 24 angles; from 128 at
+        <= 45.  (Round 3's rule -- 160, or 80 at <= 64 angles -- sent 80 .. 160 slices x 45 .. 64 angles to the segments: 100 x 64 angles 20.8 us
+        against the planned gather's 14.7.)"""
+        return S >= 200 or (S >= 80 and self.A <= 24) or (S >= 128 and self.A <= 45)
 
     def backward_uses_plan(self, S):
         """The planned gather backward: slices that fit LDS, except where the segment kernels are faster (see above; without a
-        step plan -- unpadded canvases -- the direct segment kernel still takes S >= 80 at <= 64 angles)."""
-        return self._want_bwd_plan and not self.backward_uses_step_plan(S) and not (S >= 80 and self.A <= 64)
+        step plan -- unpadded canvases -- the direct segment kernel still takes the shapes of _segments_win)."""
+        return self._want_bwd_plan and not self.backward_uses_step_plan(S) and not self._segments_win(S)
 
     def backward_kernel_name(self, S):
         if self.backward_uses_step_plan(S):
