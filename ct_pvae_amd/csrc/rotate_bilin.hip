@@ -596,9 +596,10 @@ __global__ __launch_bounds__(PPT == 1 ? 1024 : (PPT == 2 ? 512 : 256)) void rota
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
-    const float fx = (float)(c + g.px);
-    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + 63.0f;
-    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)(nwaves * PPT - 1);
+    // (ragged tiles: the rectangle clipped to the image, the lanes / rows past it repeating its last column / row -- rotate.hip's segment kernel)
+    const float fx = (float)(min(c, g.W - 1) + g.px);
+    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + (float)min(63, g.W - 1 - (int)blockIdx.x * 64);
+    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)min(nwaves * PPT - 1, g.H - 1 - (int)blockIdx.y * (nwaves * PPT));
     const float x_hi = (float)g.PW - 0.5f, y_hi = (float)g.PH - 0.5f;
     const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
     size_t soff[NS];                                   // slices past the batch re-read the last one (never stored)
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(PPT == 1 ? 1024 : (PPT == 2 ? 512 : 256)) void rota
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         acc[k] = vec_t(0.0f);
-        fy[k] = (float)(r0 + k * nwaves + g.py);
+        fy[k] = (float)(min(r0 + k * nwaves, g.H - 1) + g.py);
     }
 
     for (int ac = 0; ac < g.A; ac += chunk_a) {
@@ -839,8 +840,8 @@ __global__ __launch_bounds__(PPT == 1 ? 1024 : (PPT == 2 ? 512 : 256)) void rota
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int c = blockIdx.x * 64 + lane, cl = min(c, g.W - 1);
     const int r0 = blockIdx.y * (nwaves * PPT) + wave;   // rows r0, r0 + nwaves, ...
-    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + 63.0f;
-    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)(nwaves * PPT - 1);
+    const float X0 = (float)(blockIdx.x * 64 + g.px), X1 = X0 + (float)min(63, g.W - 1 - (int)blockIdx.x * 64);
+    const float Y0 = (float)(blockIdx.y * (nwaves * PPT) + g.py), Y1 = Y0 + (float)min(nwaves * PPT - 1, g.H - 1 - (int)blockIdx.y * (nwaves * PPT));
     const int lds_base = (int)(uintptr_t)(lds_cptr)lds;
     size_t soff[NS];
 #pragma unroll
