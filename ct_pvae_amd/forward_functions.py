@@ -738,10 +738,17 @@ class RotatePlan:
         return (not self._want_bwd_plan) or self._segments_win(S)
 
     def _segments_win(self, S):
-        """Where the segment kernels beat the planned gather at sizes that fit LDS (round 5, both paths forced over 9 batch sizes x 6 angle
-        counts, tools/sweep_bwd_paths_grid.py, profiles/r05_nearest_rules.txt): from 200 slices on; from 80 at <= 24 angles; from 128 at
-        <= 45.  (Round 3's rule -- 160, or 80 at <= 64 angles -- sent 80 .. 160 slices x 45 .. 64 angles to the segments: 100 x 64 angles 20.8 us
-        against the planned gather's 14.7.)"""
+        """Where the segment kernels beat the planned gather at sizes that fit LDS (round 5, both paths forced over batch sizes x angle
+        counts x image sizes, tools/sweep_bwd_paths_grid.py, profiles/r05_nearest_rules.txt).  128 x 128: from 200 slices on; from 80 at
+        <= 24 angles; from 128 at <= 45 (round 3's rule -- 160, or 80 at <= 64 angles -- sent 80 .. 160 slices x 45 .. 64 angles to the
+        segments: 100 x 64 angles 20.8 us against the planned gather's 14.7).  LARGER slices (160 x 160: the planned tiles stage detector
+        rows of 230 bins): always -- 50 x 160^2 x 180 angles 42.5 us against 77.9.  SMALLER ones (no step plan below 128 x 128: the
+        direct segment kernel): only long launches at few angles -- 128 x 100^2 x 45 angles had run 47.2 us there against 12.5 planned."""
+        area = self.H * self.W
+        if area > 128 * 128:
+            return True
+        if area < 128 * 128:
+            return S >= 200 and self.A <= 24 and area >= 64 * 64
         return S >= 200 or (S >= 80 and self.A <= 24) or (S >= 128 and self.A <= 45)
 
     def backward_uses_plan(self, S):
