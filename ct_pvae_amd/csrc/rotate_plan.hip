@@ -1418,6 +1418,11 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     // A=20, 16.5 -> 13.8 us at A=90, 28.3 -> 25.4 us at A=180.  Small batches pair up too, in short 4-wave tiles
     // (tools/sweep_bwd.py: 4.7 -> 4.1 us at S=2..16, 5.3 -> 4.8 us at S=24, A=20; even at A=90).
     int ns = S >= 2 ? 2 : 1;
+    // (slices of ONE column of tiles, 33 .. 64 pixels wide, make few workgroups, and every workgroup of a pair stages both slices' rows:
+    // single slices in 16-row tiles until the launch has ~512 of them; tools/sweep_nearest_rules.py with N=64: 50 x 90 angles 11.7 ->
+    // 9.4 us, 20 x 180: 21.0 -> 16.0, 50 x 20: 5.5 -> 4.8; N=48: 50 x 90 10.9 -> 8.8; at 32 x 32 the pairs stay ahead)
+    const bool narrow = L.nXB == 1 && H > 32 && (long long)S * ceil_div(H, 16) < 512;
+    if (narrow) ns = 1;
     if (knob(kKnobBns) >= 0) ns = (knob(kKnobBns) == 2 && S >= 2) ? 2 : 1;
     const int ppt = ns == 2 ? 2 : 4;
     const int units = ceil_div(S, ns);
@@ -1444,7 +1449,7 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
                 waves = w_more;
         }
     }
-    if (ns != 2 && Aeff >= 32)
+    if (ns != 2 && Aeff >= 32 && !narrow)
         while (waves < 16 && (long long)units * L.nXB * ceil_div(H, 2 * waves * ppt) >= 200 && waves * ppt < H) waves *= 2;
     while (waves > 1 && (waves / 2) * ppt >= H) waves /= 2;   // tiny slices: no more rows per tile than the slice has
     if (knob(kKnobBw) > 0) waves = std::min(16, knob(kKnobBw));

@@ -12,10 +12,11 @@ d = torch.device('cuda', 0)
 shapes = [(1, 20), (5, 20), (12, 20), (25, 20), (50, 20), (76, 20), (100, 20), (200, 20), (50, 10), (50, 45), (50, 90), (20, 90), (10, 180), (25, 180), (50, 180), (100, 90)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-x0 = torch.rand((400, 128, 128), device=d)
+N = int(os.environ.get('N', 128))     # N=100 python tools/sweep_nearest_rules.py ...: another image size
+x0 = torch.rand((400, N, N), device=d)
 for B, A in shapes:
     theta = np.pi * (np.arange(A) + 0.37) / A
-    plans = {f: RotatePlan(theta, 128, 128, True, d, plan_format=f) for f in ("auto", "u16", "compact")}
+    plans = {f: RotatePlan(theta, N, N, True, d, plan_format=f) for f in ("auto", "u16", "compact")}
     x = x0[:B]
     out = torch.empty((B, A, plans["auto"].PW), device=d)
     n = 100 if B * A <= 4000 else 30
@@ -33,8 +34,8 @@ for B, A in shapes:
                         continue
                 res.append((t, f"{f} NS={ns} G={G}"))
     res.sort()
-    print(f"fwd B={B} A={A}: library ({'compact' if plans['auto']._compact else 'u16'}) {lib:.2f} us | best " + " ; ".join(f"{nm} {t:.2f}" for t, nm in res[:3]) + f" | library / best {lib / res[0][0]:.3f}", flush=True)
-    g = torch.rand((B, A, plans["auto"].PW), device=d); gi = torch.empty((B, 128, 128), device=d)
+    print(f"fwd N={N} B={B} A={A}: library ({'compact' if plans['auto']._compact else 'u16'}) {lib:.2f} us | best " + " ; ".join(f"{nm} {t:.2f}" for t, nm in res[:3]) + f" | library / best {lib / res[0][0]:.3f}", flush=True)
+    g = torch.rand((B, A, plans["auto"].PW), device=d); gi = torch.empty((B, N, N), device=d)
     p = plans["auto"]
     for _ in range(3): graph_time(lambda: p.backward(g, out=gi), n)
     lib = min(graph_time(lambda: p.backward(g, out=gi), n) for _ in range(3)) * 1e6
@@ -45,4 +46,4 @@ for B, A in shapes:
                 t = min(graph_time(lambda: p.backward(g, out=gi), n) for _ in range(2)) * 1e6
             res.append((t, f"BNS={ns} BW={w}"))
     res.sort()
-    print(f"bwd B={B} A={A}: library {lib:.2f} us | best " + " ; ".join(f"{nm} {t:.2f}" for t, nm in res[:3]) + f" | library / best {lib / res[0][0]:.3f}", flush=True)
+    print(f"bwd N={N} B={B} A={A}: library {lib:.2f} us | best " + " ; ".join(f"{nm} {t:.2f}" for t, nm in res[:3]) + f" | library / best {lib / res[0][0]:.3f}", flush=True)
