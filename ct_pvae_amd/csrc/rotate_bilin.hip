@@ -1166,7 +1166,7 @@ int exact_bilin_bwd(const float *gsino_dev, int S, int A, int PH, int PW, const 
         const RotGeom g{n, H, W, PH, PW, py, px, A};
         const float *gs = gsino_dev + (size_t)s0 * A * PW;
         float *gi = gimg_dev + (size_t)s0 * H * W;
-        // Every slice of a cell shares the 16-byte plan word of its (angle, pixel): four slices per cell from ~200 workgroups on, pairs
+        // Every slice of a cell shares the 16-byte plan word of its (angle, pixel): four slices per cell from ~160 workgroups on, pairs
         // below.  Rows per lane: the kernel waits for its plan words, so the more waves the better while the plan is cache-resident
         // -- ONE row per lane (sixteen waves on 64 x 16 pixels) for a launch of one round of workgroups, TWO (eight waves) above;
         // four rows (round 5's first form) where the plan streams from memory (512 x 512 x 90 angles: 377 MB).
@@ -1175,11 +1175,12 @@ int exact_bilin_bwd(const float *gsino_dev, int S, int A, int PH, int PW, const 
         // 400 x 180 399 / 323 / -, 32 x 512^2 x 90 302 / 340 / 566.
         const long long tiles4 = (long long)ceil_div(W, 64) * ceil_div(H, 16);
         int ns = n >= 3 ? 4 : (n == 2 ? 2 : 1), ppt = 2;
-        // (second look, library against the best forced launch over 19 shapes: at >= 64 angles pairs in up to 512 sixteen-wave
-        // workgroups beat quads in ~200 -- 50 x 180 angles 79.8 -> 75.0 us --, and the streaming plan's four rows per lane pay from
-        // ~700 workgroups on -- 8 x 512^2 x 90 (512): 92.9 us with four rows, 82.0 with two)
-        while (ns > 2 && ceil_div(n, ns) * tiles4 < (A >= 64 ? 256 : 200)) ns >>= 1;
-        if (ceil_div(n, ns) * tiles4 <= (A >= 64 ? 512 : 256)) ppt = 1;
+        // (second look, library against the best forced launch over 19 shapes and other image sizes: sixteen-wave workgroups only while
+        // they make ONE round -- 50 x 160^2 x 90 angles, 390 of them: 87 us against 57 with eight waves; pairs in 400 sixteen-wave
+        // workgroups were 6 % ahead at 50 x 128^2 x 180 and are not worth a rule of their own -- and the streaming plan's four rows per
+        // lane pay from ~700 workgroups on -- 8 x 512^2 x 90 (512): 92.9 us with four rows, 82.0 with two)
+        while (ns > 2 && ceil_div(n, ns) * tiles4 < 160) ns >>= 1;   // (50 x 100^2 x 20 angles: quads in 182 workgroups 8.8 us, pairs in 350: 10.1)
+        if (ceil_div(n, ns) * tiles4 <= 256) ppt = 1;
         if ((long long)A * H * W * 16 > (128ll << 20)) ppt = ceil_div(n, ns) * tiles4 >= 700 ? 4 : 2;   // (one row: 145 us at 8 x 512^2 x 90; 12 slices, 768 workgroups: 99 us with four rows, 109 with two)
         if (knob(kKnobSegNs) == 1 || knob(kKnobSegNs) == 2 || knob(kKnobSegNs) == 4) ns = std::min(knob(kKnobSegNs), n >= 3 ? 4 : n);
         if (ns == 3) ns = 2;
