@@ -1436,6 +1436,10 @@ static int launch_bwd_planned(const float *gsino_dev, int S, int H, int W, int P
     int waves = 4;
     if (ns == 2) {   // pairs: 64 x 16-row tiles for few angles, 64 x 32 for many; half as tall below 32 slices (sweeps)
         waves = Aeff >= 64 ? (S >= 32 ? 16 : 8) : (S > 16 ? 8 : 4);
+        // (32 .. 63 angles, second look at other image sizes -- at 20 angles the short tiles win whatever the rounds: 16-row tiles that need a second round of workgroups where 32-row tiles fit in
+        // one lose it all -- 64 x 96^2 x 45 angles: 384 workgroups 13.2 us, 192 of twice the height 9.9)
+        if (Aeff >= 32 && Aeff < 64 && waves == 8 && (long long)units * L.nXB * ceil_div(H, 8 * ppt) > 256 && (long long)units * L.nXB * ceil_div(H, 16 * ppt) <= 256)
+            waves = 16;
         // Many angles (round 4, tools/sweep_bwd_waves.py, profiles/r04_sweep_bwd_waves.txt): a workgroup's cost is mostly the
         // staging of ALL its pair's cotangent rows (~14 of 18 us at 180 angles), whatever its height -- so (a) while 16-row tiles
         // are at most one workgroup per CU they win (B=32: 15.2 vs 17.3 us), and (b) one more row of tiles (26-row tiles of 13
