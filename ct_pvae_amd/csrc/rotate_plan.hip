@@ -941,8 +941,8 @@ __global__ __launch_bounds__(64) void rotate_bwd4_plan_kernel(PlanGeom g, const 
 // reads 0.0f); row k of the cotangent belongs to plan angle sel[k] and the sum runs over k ascending -- the order of
 // ctpvae_rotate_bwd_sel_scaled_f32 and of the oracle on the gathered table.
 // HOSTSEL: the subset arrived in host memory and travels in the kernel arguments (selh) instead of device memory (sel).
-template <int NS, bool HOSTSEL>
-__global__ __launch_bounds__(256) void rotate_bwd_planned_sel_kernel(const float *__restrict__ gsino, PlanGeom g, int Wpad,
+template <int NS, bool HOSTSEL, int MAXT = 256>
+__global__ __launch_bounds__(MAXT) void rotate_bwd_planned_sel_kernel(const float *__restrict__ gsino, PlanGeom g, int Wpad,
                                                                      int HQ, const unsigned *__restrict__ idx4,
                                                                      const int *__restrict__ sel, int n_sel, int tiles_y,
                                                                      int g_S, SliceScale scale, float *__restrict__ gimg,
@@ -1546,9 +1546,13 @@ int ctpvae_rotate_bwd_planned_sel_scaled_f32(const float *gsino_dev, int S, int 
     if (knob(kKnobBns) >= 0) ns = (knob(kKnobBns) == 2 && S >= 2) ? 2 : 1;
     const int units = ceil_div(S, ns);
     // tile = 64 columns x 4 * waves rows.  Four waves: every workgroup stages all n cotangent rows of its unit, and fewer waves
-    // would need more than one batch of loads per lane for it (20 rows of a pair = 29 KB = 7 loads per lane of 256 threads)
+    // would need more than one batch of loads per lane for it (20 rows of a pair = 29 KB = 7 loads per lane of 256 threads).  MORE
+    // waves for larger subsets in LONG launches (round 5): every workgroup stages all n rows again, and from ~768 four-wave workgroups
+    // on that redundancy is what the launch costs -- 100 x 128^2, 90 of 180 angles: 40.3 us with four waves, 25.2 with sixteen (256 x:
+    // 81 -> 53); in short launches the small workgroups win (5 x, 90 of 180: 18.9 us against 24.2)
     int waves = std::min(4, HQ);
-    if (knob(kKnobBw) > 0) waves = std::min(4, std::max(1, knob(kKnobBw)));
+    if ((long long)units * nXB * ceil_div(HQ, 4) >= 768) waves = std::min(n_idx >= 48 ? 16 : (n_idx >= 24 ? 8 : 4), HQ);
+    if (knob(kKnobBw) > 0) waves = std::min(16, std::max(1, knob(kKnobBw)));
     const int tiles_y = ceil_div(HQ, waves);
     const long long nblk = (long long)units * nXB * tiles_y;
     CTPVAE_REQUIRE(nblk < (1ll << 31), "rotate_bwd_planned_sel: too many slices");
@@ -1559,15 +1563,21 @@ int ctpvae_rotate_bwd_planned_sel_scaled_f32(const float *gsino_dev, int S, int 
         angle_idx_dev = nullptr;
     }
     auto launch = [&](auto kernel) -> int {
-        static std::atomic<unsigned long long> abs_ok{0};   // per kernel instantiation: devices checked
+        static std::atomic<unsigned long long> abs_ok{0}, attr_set{0};   // per kernel instantiation: devices checked
         CTPVAE_REQUIRE_NO_STATIC_LDS(kernel, "rotate_bwd_planned_sel_kernel", abs_ok);
+        CTPVAE_SET_MAX_LDS_ONCE(kernel, attr_set);   // (a full chunk is 256 bytes over 64 KB)
         hipLaunchKernelGGL(kernel, dim3((unsigned)nblk), dim3(64 * waves), shmem, (hipStream_t)stream, gsino_dev, g, nXB * 64, HQ,
                            (const unsigned *)bwd4_plan_dev, angle_idx_dev, n_idx, tiles_y, S, SliceScale{scale_dev, scale_stride},
                            gimg_dev, selh);
         return CTPVAE_OK;
     };
     int rc;
-    if (idx_on_host)
+    if (waves > 4) {
+        if (idx_on_host)
+            rc = ns == 2 ? launch(rotate_bwd_planned_sel_kernel<2, true, 1024>) : launch(rotate_bwd_planned_sel_kernel<1, true, 1024>);
+        else
+            rc = ns == 2 ? launch(rotate_bwd_planned_sel_kernel<2, false, 1024>) : launch(rotate_bwd_planned_sel_kernel<1, false, 1024>);
+    } else if (idx_on_host)
         rc = ns == 2 ? launch(rotate_bwd_planned_sel_kernel<2, true>) : launch(rotate_bwd_planned_sel_kernel<1, true>);
     else
         rc = ns == 2 ? launch(rotate_bwd_planned_sel_kernel<2, false>) : launch(rotate_bwd_planned_sel_kernel<1, false>);
