@@ -149,3 +149,20 @@ def test_test_sessions_poison_the_projector_outputs():
     from ct_pvae_amd import forward_functions
     assert forward_functions.POISON_OUTPUTS
     assert bool(torch.isnan(forward_functions._new_output((3, 2), torch.float32, torch.device("cpu"))).all())
+
+
+def test_nearest_backward_dispatch_rule_by_image_area_and_padding():
+    """The nearest tf_compat backward's choice between the planned gather and the segment kernels (forward_functions.py _segments_win;
+    measured, profiles/r05_nearest_rules.txt): tuned thresholds at 128 x 128, always the segments for larger LDS-resident slices, the
+    planned gather for smaller ones except long launches at few angles, and never the segments on an unpadded canvas."""
+    from types import SimpleNamespace
+    from ct_pvae_amd.forward_functions import RotatePlan
+
+    def wins(H, W, A, S, pad=28):
+        return RotatePlan._segments_win(SimpleNamespace(H=H, W=W, A=A, py=pad, px=pad), S)
+
+    assert not wins(128, 128, 20, 50) and wins(128, 128, 20, 80) and wins(128, 128, 180, 200)
+    assert not wins(128, 128, 64, 100) and not wins(128, 128, 180, 160) and wins(128, 128, 45, 128)
+    assert wins(160, 160, 180, 8) and wins(144, 150, 20, 2)
+    assert not wins(100, 100, 45, 128) and wins(100, 100, 20, 256) and not wins(32, 32, 20, 256)
+    assert not wins(128, 128, 20, 400, pad=0) and not wins(160, 160, 20, 400, pad=0)
